@@ -1,0 +1,206 @@
+/*
+ * sina_hip.h -- C ABI of the MI355X (gfx950) implementation of SINA's per-query
+ * hot path: k-mer reference search and partial-order ("mesh") DP alignment.
+ *
+ * The reference (epruesse/SINA) has no FFI; this is the boundary its stage
+ * functors would bind.  Each entry point names the reference code it replaces
+ * (paths under the SINA source tree).  Conventions:
+ *   - plain pointers + sizes, caller-owned host buffers unless stated;
+ *   - every function returns 0 on success, non-zero on error, and
+ *     sina_hip_last_error() (thread-local) describes the failure -- the C++
+ *     stage functors turn that into SINA's exception / tray.log conventions;
+ *   - no C++ types, exceptions or torch types cross this line;
+ *   - a context may be used from several host threads; calls on one context
+ *     serialise on an internal mutex (one HIP stream per context).
+ *
+ * Sequences use SINA's own packed form (src/aligned_base.h:287-319):
+ *   aligned base = uint32: (column & 0xFFFFFF) | iupac_mask << 24
+ *   iupac mask   = A 1, G 2, C 4, T/U 8, lower-case bit 16 (src/aligned_base.h:47-52)
+ */
+#ifndef SINA_HIP_H
+#define SINA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SINA_HIP_ABI_VERSION 1
+
+typedef struct sina_hip_ctx sina_hip_ctx;
+
+/* ------------------------------------------------------------------ lifecycle */
+
+int sina_hip_abi_version(void);
+const char *sina_hip_last_error(void);
+
+/* Creates a context on HIP device `device` (own stream). */
+int sina_hip_init(int device, sina_hip_ctx **ctx);
+void sina_hip_destroy(sina_hip_ctx *ctx);
+/* Blocks until all work queued on the context's stream has finished. */
+int sina_hip_sync(sina_hip_ctx *ctx);
+
+/* ------------------------------------------------------- reference store + index
+ * Replaces: the in-memory sequence cache famfinder/kmer_search read through
+ * query_arb::getCseq (src/kmer_search.cpp:417, src/query_arb.cpp:742-755) and
+ * kmer_search::impl::build / try_load (src/kmer_search.cpp:245-351).
+ */
+
+/* Copies n_refs packed aligned references (concatenated `ab`, offsets `off`
+ * [n_refs+1]) of common alignment width `width` into HBM. */
+int sina_hip_upload_refs(sina_hip_ctx *ctx, const uint32_t *ab, const uint64_t *off,
+                         uint32_t n_refs, uint32_t width);
+
+/* Builds the device k-mer index from the uploaded references, on the GPU:
+ * posting list of k-mer v = ascending ids of references containing v at least
+ * once (unique_prefix_kmers / unique_kmers + IndexBuilder,
+ * src/kmer_search.cpp:152-211,245-276).  Stored as plain
+ * CSR (u32 offsets [4^k+1], u32 ids); SINA's list inversion (src/idset.h:367-384)
+ * is a storage optimisation with identical scores and is not reproduced. */
+int sina_hip_build_index(sina_hip_ctx *ctx, unsigned k, int nofast);
+
+/* Alternative to build_index: adopt a host-built CSR index. */
+int sina_hip_upload_index(sina_hip_ctx *ctx, unsigned k, int nofast, const uint32_t *offsets,
+                          const uint32_t *ids, uint64_t n_postings);
+
+/* Device-pointer view of the index and reference store, for the one-off
+ * start-up broadcast over RCCL (torch.distributed) described in INTEGRATION.md:
+ * rank 0 builds, every rank allocates with sina_hip_alloc_like, then the
+ * buffers are broadcast in place. */
+typedef struct sina_hip_store_view {
+    void *ref_ab;       uint64_t ref_ab_bytes;    /* u32[total bases]           */
+    void *ref_off;      uint64_t ref_off_bytes;   /* u64[n_refs+1]              */
+    void *idx_offsets;  uint64_t idx_offsets_bytes; /* u32[4^k+1]               */
+    void *idx_ids;      uint64_t idx_ids_bytes;   /* u32[n_postings]            */
+    uint32_t n_refs, width, k, nofast;
+    uint64_t n_postings, total_bases;
+} sina_hip_store_view;
+int sina_hip_store_view_get(sina_hip_ctx *ctx, sina_hip_store_view *view);
+/* Allocates (uninitialised) device buffers of the sizes in `shape` so that a
+ * broadcast can fill them; afterwards the context behaves as if it had built
+ * the store itself. Pointer members of `shape` are ignored on input and
+ * overwritten with the new device pointers. */
+int sina_hip_store_alloc_like(sina_hip_ctx *ctx, sina_hip_store_view *shape);
+
+/* ------------------------------------------------------------- k-mer search
+ * Replaces kmer_search::impl::find (src/kmer_search.cpp:366-420) for a batch:
+ * for every query, count shared k-mers against every reference
+ * (prefix_kmers/all_kmers, duplicates counted, final k-mer dropped:
+ * src/kmer.h:188-201) and return the top-`max` by (score desc, id desc)
+ * (std::greater<std::pair<int16_t,int>>, src/kmer_search.cpp:412).
+ *
+ *   qmask/qoff : concatenated iupac masks of the queries' bases, offsets [nq+1]
+ *   max        : results wanted per query (clamped to n_refs)
+ *   out_ids    : [nq * max] reference ids, out_scores: [nq * max] as float
+ *                (result_item.score is float, src/search.h:57-60)
+ *   out_n      : [nq] number of valid results per query
+ */
+int sina_hip_kmer_topk(sina_hip_ctx *ctx, const uint8_t *qmask, const uint64_t *qoff, uint32_t nq,
+                       uint32_t max, uint32_t *out_ids, float *out_scores, uint32_t *out_n);
+
+/* Full score vector (score+offset of src/kmer_search.cpp:405-409) of one query
+ * against every reference; for tests and the search_filter stage. */
+int sina_hip_kmer_scores(sina_hip_ctx *ctx, const uint8_t *qmask, uint32_t qlen, int16_t *scores);
+
+/* ------------------------------------------------------------- alignment
+ * Replaces, for a batch of queries: mseq::mseq + sort + reduce_edges
+ * (src/mseq.cpp:47-118, src/graph.h:451-488) when given family ids, compute()
+ * with compute_node_simple<transition_simple|transition_aspace_aware> over
+ * scoring_scheme_simple|weighted (src/mesh.h:263-528, src/scoring_schemes.h:
+ * 102-241) and the walk of backtrack() (src/mesh.h:535-721).
+ */
+enum { SINA_OVERHANG_ATTACH = 0, SINA_OVERHANG_REMOVE = 1, SINA_OVERHANG_EDGE = 2 };
+enum { SINA_LOWERCASE_NONE = 0, SINA_LOWERCASE_ORIGINAL = 1, SINA_LOWERCASE_UNALIGNED = 2 };
+enum { SINA_INSERTION_SHIFT = 0, SINA_INSERTION_FORBID = 1, SINA_INSERTION_REMOVE = 2 };
+
+typedef struct sina_hip_align_params {
+    float match_score;      /* --match-score    (2)  src/align.cpp:250-252 */
+    float mismatch_score;   /* --mismatch-score (-1) */
+    float gap_penalty;      /* --pen-gap        (5)  */
+    float gap_ext_penalty;  /* --pen-gapext     (2)  */
+    float fs_weight;        /* --fs-weight      (1)  src/align.cpp:247-249 */
+    int32_t overhang;       /* SINA_OVERHANG_*  */
+    int32_t lowercase;      /* SINA_LOWERCASE_* */
+    int32_t insertion;      /* SINA_INSERTION_* */
+    const float *weights;   /* posvar weights => scoring_scheme_weighted, or NULL */
+    uint32_t n_weights;
+} sina_hip_align_params;
+void sina_hip_align_params_default(sina_hip_align_params *p);
+
+/* A batch of family DAGs in CSR form (node id == topological rank == mesh row).
+ * All arrays are concatenated over the nq queries of the batch. */
+typedef struct sina_hip_graph_batch {
+    uint32_t nq;
+    const uint64_t *node_off;  /* [nq+1] into the node arrays                      */
+    const uint64_t *edge_off;  /* [nq+1] into pred                                 */
+    const uint32_t *node_pos;  /* alignment column of each node                    */
+    const uint8_t *node_mask;  /* iupac mask of each node                          */
+    const float *node_weight;  /* mseq_node::weight (src/mseq.cpp:113)             */
+    const uint32_t *pred_off;  /* per query N+1 entries, relative to edge_off[q];
+                                  stored at node_off[q] + q                        */
+    const uint32_t *pred;      /* predecessor node ids, ascending per node         */
+    const uint32_t *succ_minpos; /* min column over successors, 1000000 if none
+                                  (src/mesh.h:480-484); may be NULL unless FORBID  */
+    uint32_t width;            /* alignment width (mseq::getWidth)                 */
+} sina_hip_graph_batch;
+
+/* Per-query result of DP + backtrack walk, before the cseq container steps
+ * (append rule, setWidth, reverse, fix_duplicate_positions) that the host-side
+ * aligner applies (src/mesh.h:723-726). */
+typedef struct sina_hip_align_out {
+    uint32_t end_m, end_s;   /* start cell of the backtrack (src/mesh.h:567-592)   */
+    float raw;               /* value at the end cell  (rval, :618)                */
+    float sum_weight;        /* (:621,637,683)                                     */
+    int32_t aligned_bases;   /* (:622)                                             */
+    int32_t cutoff_head, cutoff_tail;
+    uint32_t n_out;          /* number of appended bases written to pos[]          */
+    int32_t status;          /* 0 ok; <0 device-side failure                       */
+} sina_hip_align_out;
+
+/* Aligns nq queries (upper-cased or not is the caller's business: masks are
+ * used as given) against their DAGs.
+ *   qmask/qoff : concatenated query iupac masks, offsets [nq+1]
+ *   out        : [nq]
+ *   out_pos    : concatenated like qmask; for query q, out_pos[qoff[q] + i] is
+ *                the column handed to the i-th cseq::append() call of
+ *                backtrack() (i.e. in reverse query order, tail overhang first).
+ */
+int sina_hip_align_graphs(sina_hip_ctx *ctx, const sina_hip_graph_batch *g, const uint8_t *qmask,
+                          const uint64_t *qoff, const sina_hip_align_params *p,
+                          sina_hip_align_out *out, uint32_t *out_pos);
+
+/* Same, but the DAGs are built on the GPU from family member ids into the
+ * uploaded reference store (order of ids = family order = mseq input order).
+ *   fam_ids/fam_off : concatenated reference ids, offsets [nq+1]
+ */
+int sina_hip_align_families(sina_hip_ctx *ctx, const uint32_t *fam_ids, const uint64_t *fam_off,
+                            uint32_t nq, const uint8_t *qmask, const uint64_t *qoff,
+                            const sina_hip_align_params *p, sina_hip_align_out *out,
+                            uint32_t *out_pos);
+
+/* Test hook: DP planes of ONE query for bit-exact comparison with the oracle.
+ * tb_vm/tb_vs: [N*L] value_midx / value_sidx; value: [N*L] float (may be NULL). */
+int sina_hip_debug_mesh(sina_hip_ctx *ctx, const sina_hip_graph_batch *g, const uint8_t *qmask,
+                        uint32_t qlen, const sina_hip_align_params *p, uint32_t *tb_vm,
+                        uint32_t *tb_vs, float *value);
+
+/* Statistics of the most recent sina_hip_align_* / kmer_topk call on this
+ * context (kernel time from HIP events on the context's stream). */
+typedef struct sina_hip_stats {
+    double dp_ms;          /* mesh DP fill kernel(s)                  */
+    double backtrack_ms;   /* backtrack walk kernel                   */
+    double graph_ms;       /* device DAG build                        */
+    double kmer_count_ms;  /* k-mer count kernel                      */
+    double kmer_select_ms; /* top-k select kernel                     */
+    uint64_t dp_cells;     /* sum of N*L over the batch               */
+    uint64_t postings;     /* postings visited by the count kernel    */
+    uint32_t dp_launches, kmer_launches;
+} sina_hip_stats;
+int sina_hip_get_stats(sina_hip_ctx *ctx, sina_hip_stats *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SINA_HIP_H */

@@ -1,0 +1,123 @@
+// Shared declarations for the gfx950 kernels behind include/sina_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sina_hip.h"
+
+namespace sina_hip {
+
+void set_error(const std::string &msg);
+
+#define SH_CHECK(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            ::sina_hip::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));       \
+            return 1;                                                                       \
+        }                                                                                   \
+    } while (0)
+
+#define SH_FAIL(msg)                   \
+    do {                               \
+        ::sina_hip::set_error(msg);    \
+        return 1;                      \
+    } while (0)
+
+// Growable device buffer (never shrinks): batches reuse their scratch.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        SH_CHECK(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ---------------------------------------------------------------- mesh DP
+
+// Per-query descriptor of one DP problem inside a batch.
+struct QDesc {
+    uint64_t node_off;   // into node arrays
+    uint64_t edge_off;   // into pred
+    uint64_t poff_off;   // into pred_off (N+1 entries)
+    uint64_t q_off;      // into qmask / out_pos
+    uint64_t tb_off;     // into traceback plane (u32 cells), row stride = Lp
+    uint64_t spill_off;  // into spill rows (row units)
+    uint32_t N, L;
+    uint32_t n_spill, pad;
+};
+
+struct DpResult {
+    uint32_t end_m, end_s;
+    float raw;
+    int32_t status;
+};
+
+struct DpArgs {
+    const QDesc *qd;
+    const uint32_t *node_pos;
+    const uint8_t *node_mask;
+    const float *node_weight;
+    const uint32_t *pred_off;
+    const uint32_t *pred;
+    const uint32_t *succ_minpos;
+    const uint32_t *spill_idx;  // per node: spill row index or 0xFFFFFFFF
+    const uint8_t *node_flags;  // per node: bit0 = sink (no successors)
+    const uint8_t *qmask;
+    uint32_t *tb;               // (value_midx << 16) | value_sidx
+    float *dbg_value;           // optional [N*Lp] plane of the first query
+    float *spill;               // spill rows: value[Lp] | gm[Lp] | gmi(u32)[Lp]
+    DpResult *res;
+    const float *weights;       // posvar weights (device) or nullptr
+    uint32_t n_weights;
+    float ms, mms, gp, gpe;     // scheme ctor args: -match, -mismatch, gap, gapext
+    int W;                      // ring slots in LDS
+};
+
+struct BtArgs {
+    const QDesc *qd;
+    const uint32_t *node_pos;
+    const float *node_weight;
+    const uint32_t *pred_off;
+    const uint32_t *tb;
+    const DpResult *res;
+    const float *weights;
+    uint32_t n_weights;
+    sina_hip_align_out *out;
+    uint32_t *out_pos;
+    uint32_t nq, width, Lp_T, Lp_B;  // Lp = Lp_T * Lp_B
+    float ms;
+    int overhang;
+};
+
+// Picks the (threads, cells per thread) geometry for the longest query of a batch.
+struct DpGeom {
+    int T, B;
+    int Lp() const { return T * B; }
+};
+bool pick_geom(uint32_t maxL, DpGeom *g);
+size_t dp_slot_bytes(const DpGeom &g);
+size_t dp_fixed_lds_bytes(const DpGeom &g);
+int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
+                   size_t lds_bytes, hipStream_t s);
+int launch_backtrack(const BtArgs &a, hipStream_t s);
+
+}  // namespace sina_hip

@@ -1,0 +1,561 @@
+// K-mer reference search on gfx950: device index build, shared-k-mer counting,
+// top-k selection.
+//
+// What it computes (reference src/kmer.h, src/idset.h, src/kmer_search.cpp:
+// 152-276,366-420; spec in SURVEY.md Appendix A.1):
+//   K(seq)  = k-mers over windows of k unambiguous bases ending at base index
+//             e, k-1 <= e <= len-2 (the window ending on the last base is never
+//             produced, kmer.h:188-201); "fast" keeps windows starting with A.
+//   index   : reference r is in postings(v) iff v in set(K(r)); ids ascending.
+//   score   = sum over K(query) WITH multiplicity of [r in postings(v)], int16.
+//   top-k   : (score desc, id desc), i.e. std::greater<pair<int16,int>>.
+//
+// How it maps to the hardware: both kernels are HBM-bound integer work.
+//   count : grid (ref tile, query).  A workgroup keeps the tile's int16 score
+//           histogram in LDS (two counters per 32-bit word), finds each query
+//           k-mer's posting sub-range for the tile by binary search (lists are
+//           ascending) and streams the u32 postings with coalesced loads into
+//           LDS atomics; the tile is written out once.
+//   select: one workgroup per query: LDS histogram over score values -> cut
+//           score -> ordered compaction (ties keep the LARGEST ids) -> bitonic
+//           sort of the <= 4096 survivors.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+
+#include "common.h"
+#include "ctx.h"
+
+namespace sina_hip {
+namespace {
+
+constexpr int kCountThreads = 256;
+constexpr int kTileRefs = 32768;            // refs per LDS histogram tile (64 KiB)
+constexpr int kMaxQueryLen = 8192;          // k-mer list capacity in LDS (32 KiB)
+constexpr int kSelThreads = 256;
+constexpr int kSelMax = 4096;               // candidates sortable in LDS
+
+__device__ __forceinline__ bool ambig(uint32_t m) { return __popc(m & 0xfu) > 1; }
+
+// k-mer ending at base e of a sequence of iupac masks (bases must be unambiguous
+// and non-gap).  Returns false if the window is not a valid k-mer.
+__device__ __forceinline__ bool kmer_at(const uint8_t *m, uint32_t len, uint32_t e, unsigned k, bool fast,
+                                        uint32_t *out) {
+    if (e + 1 < k || e + 2 > len) return false;  // need k bases and e <= len-2
+    uint32_t v = 0;
+    for (unsigned i = 0; i < k; i++) {
+        const uint32_t b = m[e + 1 - k + i] & 0xfu;
+        if (__popc(b) != 1) return false;
+        v = (v << 2) | (uint32_t)(__ffs(b) - 1);
+    }
+    if (fast && (v >> (2 * (k - 1))) != 0) return false;  // prefix_filter(k, 1, BASE_A)
+    *out = v;
+    return true;
+}
+
+// ---------------------------------------------------------------- index build
+
+// one (kmer << 32 | ref) key per valid window of every reference; invalid
+// windows emit ~0 (sorted to the end, dropped).
+__global__ void ref_kmer_keys(const uint32_t *ref_ab, const uint64_t *ref_off, uint32_t n_refs, unsigned k,
+                              bool fast, uint64_t *keys) {
+    const uint32_t r = blockIdx.x;
+    const uint64_t b = ref_off[r], e = ref_off[r + 1];
+    const uint32_t len = (uint32_t)(e - b);
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+        uint64_t key = ~0ull;
+        if (i + 1 >= k && i + 2 <= len) {
+            uint32_t v = 0;
+            bool ok = true;
+            for (unsigned x = 0; x < k; x++) {
+                const uint32_t m = (ref_ab[b + i + 1 - k + x] >> 24) & 0xfu;
+                if (__popc(m) != 1) {
+                    ok = false;
+                    break;
+                }
+                v = (v << 2) | (uint32_t)(__ffs(m) - 1);
+            }
+            if (ok && fast && (v >> (2 * (k - 1))) != 0) ok = false;
+            if (ok) key = ((uint64_t)v << 32) | r;
+        }
+        keys[b + i] = key;
+    }
+}
+
+// after sorting: flag first occurrence of each (kmer, ref) key
+__global__ void mark_unique(const uint64_t *keys, uint64_t n, uint32_t *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t kx = keys[i];
+    flag[i] = (kx != ~0ull && (i == 0 || keys[i - 1] != kx)) ? 1u : 0u;
+}
+
+__global__ void scatter_unique(const uint64_t *keys, const uint32_t *flag, const uint32_t *pos, uint64_t n,
+                               uint32_t *ids, uint32_t *counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const uint64_t kx = keys[i];
+    ids[pos[i]] = (uint32_t)kx;
+    atomicAdd(&counts[(uint32_t)(kx >> 32)], 1u);
+}
+
+// ---------------------------------------------------------------- count
+
+struct CountArgs {
+    const uint8_t *qmask;
+    const uint64_t *qoff;
+    const uint32_t *idx_off;
+    const uint32_t *idx_ids;
+    int16_t *scores;  // [nq][n_refs]
+    unsigned long long *postings;
+    uint32_t n_refs;
+    unsigned k;
+    int fast;
+};
+
+__global__ void __launch_bounds__(kCountThreads) kmer_count_kernel(CountArgs a) {
+    __shared__ uint32_t hist[kTileRefs / 2];
+    __shared__ uint32_t kmers[kMaxQueryLen];
+    __shared__ uint32_t n_kmers;
+    const uint32_t q = blockIdx.y;
+    const uint32_t tile_lo = blockIdx.x * kTileRefs;
+    const uint32_t tile_hi = min(tile_lo + (uint32_t)kTileRefs, a.n_refs);
+    const uint8_t *qm = a.qmask + a.qoff[q];
+    const uint32_t len = (uint32_t)(a.qoff[q + 1] - a.qoff[q]);
+    if (threadIdx.x == 0) n_kmers = 0;
+    for (uint32_t i = threadIdx.x; i < kTileRefs / 2; i += kCountThreads) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < len; e += kCountThreads) {
+        uint32_t v;
+        if (kmer_at(qm, len, e, a.k, a.fast != 0, &v)) kmers[atomicAdd(&n_kmers, 1u)] = v;
+    }
+    __syncthreads();
+    const uint32_t nk = n_kmers;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long visited = 0;
+    for (uint32_t i = wave; i < nk; i += kCountThreads / 64) {
+        const uint32_t v = kmers[i];
+        uint32_t lo = a.idx_off[v], hi = a.idx_off[v + 1];
+        if (lo == hi) continue;
+        // first posting >= tile_lo, first posting >= tile_hi (ids ascending)
+        uint32_t b = lo, e = hi;
+        if (tile_lo > 0) {
+            uint32_t l = lo, h = hi;
+            while (l < h) {
+                const uint32_t mid = (l + h) >> 1;
+                if (a.idx_ids[mid] < tile_lo) l = mid + 1; else h = mid;
+            }
+            b = l;
+        }
+        if (tile_hi < a.n_refs) {
+            uint32_t l = b, h = hi;
+            while (l < h) {
+                const uint32_t mid = (l + h) >> 1;
+                if (a.idx_ids[mid] < tile_hi) l = mid + 1; else h = mid;
+            }
+            e = l;
+        }
+        for (uint32_t x = b + lane; x < e; x += 64) {
+            const uint32_t id = a.idx_ids[x] - tile_lo;
+            atomicAdd(&hist[id >> 1], 1u << (16 * (id & 1)));
+        }
+        if (lane == 0) visited += e - b;
+    }
+    __syncthreads();
+    int16_t *dst = a.scores + (size_t)q * a.n_refs + tile_lo;
+    const uint32_t cnt = tile_hi - tile_lo;
+    for (uint32_t i = threadIdx.x; i < cnt; i += kCountThreads)
+        dst[i] = (int16_t)((hist[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+    if (lane == 0 && visited) atomicAdd(a.postings, visited);
+}
+
+// ---------------------------------------------------------------- select
+
+struct SelectArgs {
+    const int16_t *scores;  // [nq][n_refs]
+    uint32_t *out_ids;      // [nq][max]
+    float *out_scores;
+    uint32_t *out_n;
+    uint32_t n_refs, max;
+};
+
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, uint32_t *total) {
+    // exclusive scan over the workgroup (kSelThreads), wave64 ballot-free version
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int w = 0; w < kSelThreads / 64; w++) {
+        if (w < wave) base += wsum[w];
+        tot += wsum[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + x - v;
+}
+
+__global__ void __launch_bounds__(kSelThreads) kmer_select_kernel(SelectArgs a) {
+    __shared__ uint32_t hist[kMaxQueryLen + 1];
+    __shared__ unsigned long long cand[kSelMax];
+    __shared__ uint32_t wsum[kSelThreads / 64];
+    __shared__ uint32_t sh_cut, sh_need_eq, sh_skip_eq, sh_ncand;
+    const uint32_t q = blockIdx.x;
+    const int16_t *sc = a.scores + (size_t)q * a.n_refs;
+    const uint32_t M = min(a.max, a.n_refs);
+    for (uint32_t i = threadIdx.x; i <= kMaxQueryLen; i += kSelThreads) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < a.n_refs; i += kSelThreads) {
+        int v = sc[i];
+        v = v < 0 ? 0 : (v > kMaxQueryLen ? kMaxQueryLen : v);
+        atomicAdd(&hist[v], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        int t = kMaxQueryLen;
+        for (; t >= 0; t--) {
+            if (acc + hist[t] >= M) break;
+            acc += hist[t];
+        }
+        if (t < 0) t = 0;
+        sh_cut = (uint32_t)t;                 // scores > cut: all taken (acc of them)
+        sh_need_eq = M - acc;                 // ties at the cut still needed
+        sh_skip_eq = hist[t] - (M - acc);     // ties to skip (smallest ids)
+        sh_ncand = 0;
+    }
+    __syncthreads();
+    const int cut = (int)sh_cut;
+    const uint32_t skip_eq = sh_skip_eq;
+    uint32_t eq_seen = 0, out_base = 0;  // running totals (uniform)
+    for (uint32_t base = 0; base < a.n_refs; base += kSelThreads) {
+        const uint32_t i = base + threadIdx.x;
+        int v = -1;
+        if (i < a.n_refs) v = sc[i];
+        const uint32_t is_eq = (i < a.n_refs && v == cut) ? 1u : 0u;
+        uint32_t tot_eq;
+        const uint32_t eq_rank = eq_seen + block_excl_scan(is_eq, wsum, &tot_eq);
+        const uint32_t take = (i < a.n_refs && (v > cut || (is_eq && eq_rank >= skip_eq))) ? 1u : 0u;
+        uint32_t tot_take;
+        const uint32_t slot = out_base + block_excl_scan(take, wsum, &tot_take);
+        if (take && slot < kSelMax) {
+            // sort key: score (biased) high, id low -> descending order = (score desc, id desc)
+            cand[slot] = ((unsigned long long)(uint32_t)(v + 32768) << 32) | i;
+        }
+        eq_seen += tot_eq;
+        out_base += tot_take;
+    }
+    __syncthreads();
+    const uint32_t n = min(out_base, (uint32_t)kSelMax);
+    uint32_t P = 1;
+    while (P < n) P <<= 1;
+    for (uint32_t i = n + threadIdx.x; i < P; i += kSelThreads) cand[i] = 0ull;
+    __syncthreads();
+    // bitonic sort, descending
+    for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
+        for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (uint32_t i = threadIdx.x; i < P; i += kSelThreads) {
+                const uint32_t ixj = i ^ j2;
+                if (ixj > i) {
+                    const unsigned long long x = cand[i], y = cand[ixj];
+                    const bool desc = ((i & k2) == 0);
+                    if (desc ? (x < y) : (x > y)) {
+                        cand[i] = y;
+                        cand[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < M; i += kSelThreads) {
+        if (i < n) {
+            const unsigned long long c = cand[i];
+            a.out_ids[(size_t)q * a.max + i] = (uint32_t)c;
+            a.out_scores[(size_t)q * a.max + i] = (float)((int)(uint32_t)(c >> 32) - 32768);
+        }
+    }
+    if (threadIdx.x == 0) a.out_n[q] = n < M ? n : M;
+}
+
+}  // namespace
+
+static int index_ready(sina_hip_ctx *c) {
+    if (!c->have_refs) SH_FAIL("k-mer search: no references uploaded");
+    if (!c->have_index) SH_FAIL("k-mer search: no index (call sina_hip_build_index / upload_index)");
+    return 0;
+}
+
+// counts + selects for nq queries whose masks are already on the device
+static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint64_t *d_qoff, uint32_t nq,
+                            uint32_t max, bool want_scores_only) {
+    hipStream_t s = c->stream;
+    if (c->k_scores.reserve((size_t)nq * c->n_refs * 2) || c->k_tmp2.reserve(8)) return 1;
+    SH_CHECK(hipMemsetAsync(c->k_tmp2.p, 0, 8, s));
+    CountArgs ca;
+    ca.qmask = d_qmask;
+    ca.qoff = d_qoff;
+    ca.idx_off = c->idx_off.as<uint32_t>();
+    ca.idx_ids = c->idx_ids.as<uint32_t>();
+    ca.scores = c->k_scores.as<int16_t>();
+    ca.postings = c->k_tmp2.as<unsigned long long>();
+    ca.n_refs = c->n_refs;
+    ca.k = c->k;
+    ca.fast = c->nofast ? 0 : 1;
+    const uint32_t tiles = (c->n_refs + kTileRefs - 1) / kTileRefs;
+    SH_CHECK(hipEventRecord(c->ev[3], s));
+    hipLaunchKernelGGL(kmer_count_kernel, dim3(tiles, nq), dim3(kCountThreads), 0, s, ca);
+    SH_CHECK(hipGetLastError());
+    SH_CHECK(hipEventRecord(c->ev[4], s));
+    if (!want_scores_only) {
+        if (c->k_out_ids.reserve((size_t)nq * max * 4) || c->k_out_scores.reserve((size_t)nq * max * 4) ||
+            c->k_out_n.reserve((size_t)nq * 4))
+            return 1;
+        SelectArgs sa;
+        sa.scores = ca.scores;
+        sa.out_ids = c->k_out_ids.as<uint32_t>();
+        sa.out_scores = c->k_out_scores.as<float>();
+        sa.out_n = c->k_out_n.as<uint32_t>();
+        sa.n_refs = c->n_refs;
+        sa.max = max;
+        hipLaunchKernelGGL(kmer_select_kernel, dim3(nq), dim3(kSelThreads), 0, s, sa);
+        SH_CHECK(hipGetLastError());
+    }
+    SH_CHECK(hipEventRecord(c->ev[5], s));
+    return 0;
+}
+
+}  // namespace sina_hip
+
+using namespace sina_hip;
+
+extern "C" {
+
+int sina_hip_upload_index(sina_hip_ctx *c, unsigned k, int nofast, const uint32_t *offsets, const uint32_t *ids,
+                          uint64_t n_postings) {
+    if (!c || !offsets || (!ids && n_postings)) SH_FAIL("upload_index: null argument");
+    if (k < 1 || k > 12) SH_FAIL("upload_index: k must be in 1..12");
+    std::lock_guard<std::mutex> lk(c->mu);
+    SH_CHECK(hipSetDevice(c->device));
+    const uint64_t nk = 1ull << (2 * k);
+    if (c->idx_off.reserve(4 * (nk + 1)) || c->idx_ids.reserve(4 * std::max<uint64_t>(n_postings, 1))) return 1;
+    SH_CHECK(hipMemcpyAsync(c->idx_off.p, offsets, 4 * (nk + 1), hipMemcpyHostToDevice, c->stream));
+    if (n_postings)
+        SH_CHECK(hipMemcpyAsync(c->idx_ids.p, ids, 4 * n_postings, hipMemcpyHostToDevice, c->stream));
+    SH_CHECK(hipStreamSynchronize(c->stream));
+    c->k = k;
+    c->nofast = nofast ? 1 : 0;
+    c->n_postings = n_postings;
+    c->have_index = true;
+    return 0;
+}
+
+int sina_hip_build_index(sina_hip_ctx *c, unsigned k, int nofast) {
+    if (!c) SH_FAIL("build_index: null ctx");
+    if (k < 1 || k > 12) SH_FAIL("build_index: k must be in 1..12");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_refs) SH_FAIL("build_index: upload references first");
+    SH_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint64_t n = c->total_bases;
+    const uint64_t nk = 1ull << (2 * k);
+    if (n >= (1ull << 32)) SH_FAIL("build_index: more than 2^32 reference bases");
+    DevBuf keys_in, keys_out, flag, pos, tmp;
+    int rc = 1;
+    do {
+        if (keys_in.reserve(8 * std::max<uint64_t>(n, 1)) || keys_out.reserve(8 * std::max<uint64_t>(n, 1)) ||
+            flag.reserve(4 * std::max<uint64_t>(n, 1)) || pos.reserve(4 * std::max<uint64_t>(n, 1)))
+            break;
+        if (c->n_refs)
+            hipLaunchKernelGGL(ref_kmer_keys, dim3(c->n_refs), dim3(256), 0, s, c->ref_ab.as<uint32_t>(),
+                               c->ref_off.as<uint64_t>(), c->n_refs, k, nofast == 0, keys_in.as<uint64_t>());
+        size_t tb = 0;
+        const int end_bit = 32 + 2 * (int)k;
+        if (hipcub::DeviceRadixSort::SortKeys(nullptr, tb, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(),
+                                              (int)n, 0, 64, s) != hipSuccess)
+            break;
+        (void)end_bit;
+        if (tmp.reserve(tb + 16)) break;
+        if (n && hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(),
+                                                   (int)n, 0, 64, s) != hipSuccess)
+            break;
+        const unsigned blocks = (unsigned)((n + 255) / 256);
+        if (n) hipLaunchKernelGGL(mark_unique, dim3(blocks), dim3(256), 0, s, keys_out.as<uint64_t>(), n,
+                                  flag.as<uint32_t>());
+        size_t tb2 = 0;
+        if (hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, flag.as<uint32_t>(), pos.as<uint32_t>(), (int)n, s) !=
+            hipSuccess)
+            break;
+        if (tmp.reserve(tb2 + 16)) break;
+        if (n && hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, flag.as<uint32_t>(), pos.as<uint32_t>(), (int)n, s) !=
+                     hipSuccess)
+            break;
+        uint32_t last_flag = 0, last_pos = 0;
+        if (n) {
+            if (hipMemcpyAsync(&last_flag, flag.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipMemcpyAsync(&last_pos, pos.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                break;
+        }
+        const uint64_t np = (uint64_t)last_flag + last_pos;
+        DevBuf counts;
+        if (counts.reserve(4 * (nk + 1)) || c->idx_off.reserve(4 * (nk + 1)) ||
+            c->idx_ids.reserve(4 * std::max<uint64_t>(np, 1))) {
+            counts.release();
+            break;
+        }
+        bool ok = hipMemsetAsync(counts.p, 0, 4 * (nk + 1), s) == hipSuccess;
+        if (ok && n)
+            hipLaunchKernelGGL(scatter_unique, dim3(blocks), dim3(256), 0, s, keys_out.as<uint64_t>(),
+                               flag.as<uint32_t>(), pos.as<uint32_t>(), n, c->idx_ids.as<uint32_t>(),
+                               counts.as<uint32_t>());
+        size_t tb3 = 0;
+        ok = ok && hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, counts.as<uint32_t>(), c->idx_off.as<uint32_t>(),
+                                                    (int)(nk + 1), s) == hipSuccess;
+        ok = ok && tmp.reserve(tb3 + 16) == 0;
+        ok = ok && hipcub::DeviceScan::ExclusiveSum(tmp.p, tb3, counts.as<uint32_t>(), c->idx_off.as<uint32_t>(),
+                                                    (int)(nk + 1), s) == hipSuccess;
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+        counts.release();
+        if (!ok) break;
+        c->k = k;
+        c->nofast = nofast ? 1 : 0;
+        c->n_postings = np;
+        c->have_index = true;
+        rc = 0;
+    } while (0);
+    keys_in.release();
+    keys_out.release();
+    flag.release();
+    pos.release();
+    tmp.release();
+    if (rc) {
+        hipError_t e = hipGetLastError();
+        set_error(std::string("build_index failed: ") + hipGetErrorString(e));
+    }
+    return rc;
+}
+
+int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qoff, uint32_t nq, uint32_t max,
+                       uint32_t *out_ids, float *out_scores, uint32_t *out_n) {
+    if (!c || !qmask || !qoff || !out_ids || !out_scores || !out_n) SH_FAIL("kmer_topk: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (index_ready(c)) return 1;
+    if (nq == 0) return 0;
+    SH_CHECK(hipSetDevice(c->device));
+    if (max > c->n_refs) max = c->n_refs;
+    if (max == 0) {
+        memset(out_n, 0, sizeof(uint32_t) * nq);
+        return 0;
+    }
+    if (max > (uint32_t)kSelMax) SH_FAIL("kmer_topk: max > 4096 not supported by the LDS select kernel");
+    for (uint32_t q = 0; q < nq; q++)
+        if (qoff[q + 1] - qoff[q] > (uint64_t)kMaxQueryLen) SH_FAIL("kmer_topk: query longer than 8192 bases");
+    hipStream_t s = c->stream;
+    const uint64_t nqm = qoff[nq] - qoff[0];
+    // sub-batches bound the [nq][n_refs] int16 score matrix to ~2 GiB
+    const uint32_t per = (uint32_t)std::max<uint64_t>(1, ((uint64_t)2 << 30) / (2ull * std::max<uint32_t>(c->n_refs, 1)));
+    c->stats.kmer_count_ms = c->stats.kmer_select_ms = 0;
+    c->stats.postings = 0;
+    c->stats.kmer_launches = 0;
+    if (c->qmask.reserve(std::max<uint64_t>(nqm, 1)) || c->k_qoff.reserve(8 * ((uint64_t)nq + 1))) return 1;
+    std::vector<uint64_t> rel(nq + 1);
+    for (uint32_t q = 0; q <= nq; q++) rel[q] = qoff[q] - qoff[0];
+    SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qoff[0], nqm, hipMemcpyHostToDevice, s));
+    SH_CHECK(hipMemcpyAsync(c->k_qoff.p, rel.data(), 8 * ((uint64_t)nq + 1), hipMemcpyHostToDevice, s));
+    for (uint32_t q0 = 0; q0 < nq; q0 += per) {
+        const uint32_t bq = std::min(per, nq - q0);
+        if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>() + q0, bq, max, false)) return 1;
+        SH_CHECK(hipMemcpyAsync(out_ids + (size_t)q0 * max, c->k_out_ids.p, (size_t)bq * max * 4, hipMemcpyDeviceToHost, s));
+        SH_CHECK(hipMemcpyAsync(out_scores + (size_t)q0 * max, c->k_out_scores.p, (size_t)bq * max * 4, hipMemcpyDeviceToHost, s));
+        SH_CHECK(hipMemcpyAsync(out_n + q0, c->k_out_n.p, (size_t)bq * 4, hipMemcpyDeviceToHost, s));
+        unsigned long long visited = 0;
+        SH_CHECK(hipMemcpyAsync(&visited, c->k_tmp2.p, 8, hipMemcpyDeviceToHost, s));
+        SH_CHECK(hipStreamSynchronize(s));
+        float ms = 0;
+        SH_CHECK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+        c->stats.kmer_count_ms += ms;
+        SH_CHECK(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
+        c->stats.kmer_select_ms += ms;
+        c->stats.postings += visited;
+        c->stats.kmer_launches++;
+    }
+    return 0;
+}
+
+int sina_hip_kmer_scores(sina_hip_ctx *c, const uint8_t *qmask, uint32_t qlen, int16_t *scores) {
+    if (!c || !qmask || !scores) SH_FAIL("kmer_scores: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (index_ready(c)) return 1;
+    if (qlen > (uint32_t)kMaxQueryLen) SH_FAIL("kmer_scores: query longer than 8192 bases");
+    SH_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint64_t rel[2] = {0, qlen};
+    if (c->qmask.reserve(std::max<uint32_t>(qlen, 1)) || c->k_qoff.reserve(16)) return 1;
+    SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask, qlen, hipMemcpyHostToDevice, s));
+    SH_CHECK(hipMemcpyAsync(c->k_qoff.p, rel, 16, hipMemcpyHostToDevice, s));
+    if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>(), 1, 1, true)) return 1;
+    SH_CHECK(hipMemcpyAsync(scores, c->k_scores.p, (size_t)c->n_refs * 2, hipMemcpyDeviceToHost, s));
+    SH_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int sina_hip_store_view_get(sina_hip_ctx *c, sina_hip_store_view *v) {
+    if (!c || !v) SH_FAIL("store_view_get: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_refs) SH_FAIL("store_view_get: no references uploaded");
+    memset(v, 0, sizeof(*v));
+    v->ref_ab = c->ref_ab.p;
+    v->ref_ab_bytes = 4 * c->total_bases;
+    v->ref_off = c->ref_off.p;
+    v->ref_off_bytes = 8 * ((uint64_t)c->n_refs + 1);
+    v->n_refs = c->n_refs;
+    v->width = c->width;
+    v->total_bases = c->total_bases;
+    if (c->have_index) {
+        v->idx_offsets = c->idx_off.p;
+        v->idx_offsets_bytes = 4 * ((1ull << (2 * c->k)) + 1);
+        v->idx_ids = c->idx_ids.p;
+        v->idx_ids_bytes = 4 * c->n_postings;
+        v->k = c->k;
+        v->nofast = c->nofast;
+        v->n_postings = c->n_postings;
+    }
+    return 0;
+}
+
+int sina_hip_store_alloc_like(sina_hip_ctx *c, sina_hip_store_view *v) {
+    if (!c || !v) SH_FAIL("store_alloc_like: null argument");
+    if (v->k < 1 || v->k > 12) SH_FAIL("store_alloc_like: k must be in 1..12");
+    std::lock_guard<std::mutex> lk(c->mu);
+    SH_CHECK(hipSetDevice(c->device));
+    const uint64_t nk = 1ull << (2 * v->k);
+    if (c->ref_ab.reserve(4 * std::max<uint64_t>(v->total_bases, 1)) ||
+        c->ref_off.reserve(8 * ((uint64_t)v->n_refs + 1)) || c->idx_off.reserve(4 * (nk + 1)) ||
+        c->idx_ids.reserve(4 * std::max<uint64_t>(v->n_postings, 1)))
+        return 1;
+    c->n_refs = v->n_refs;
+    c->width = v->width;
+    c->total_bases = v->total_bases;
+    c->k = v->k;
+    c->nofast = v->nofast;
+    c->n_postings = v->n_postings;
+    c->have_refs = c->have_index = true;
+    v->ref_ab = c->ref_ab.p;
+    v->ref_ab_bytes = 4 * v->total_bases;
+    v->ref_off = c->ref_off.p;
+    v->ref_off_bytes = 8 * ((uint64_t)v->n_refs + 1);
+    v->idx_offsets = c->idx_off.p;
+    v->idx_offsets_bytes = 4 * (nk + 1);
+    v->idx_ids = c->idx_ids.p;
+    v->idx_ids_bytes = 4 * v->n_postings;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from sina_amd import capi, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _family(oracle, refs, cs, idx, qs, qi):
+    q = util.query_cseq(qs, qi)
+    ids, sc, _ = idx.famfinder(q)
+    fam = [cs[i] for i in ids]
+    return q, fam, ids
+
+
+@pytest.fixture(scope="module")
+def small(oracle):
+    refs = synth.make_refs(400, length=300, width=3000, seed=11, amb_rate=0.01, lower_rate=0.02)
+    qs = synth.make_queries(refs, 12, seed=12, amb_rate=0.01)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    return refs, qs, cs, idx
+
+
+@pytest.mark.parametrize("mode", ["simple", "weighted", "forbid", "weighted_forbid"])
+def test_mesh_planes_bit_exact(oracle, gpu_ctx, small, mode):
+    refs, qs, cs, idx = small
+    rng = np.random.default_rng(5)
+    weights = rng.uniform(0.2, 1.5, size=refs.width).astype(np.float32) if "weighted" in mode else None
+    ins = 1 if "forbid" in mode else 0
+    for qi in range(4):
+        q, fam, _ = _family(oracle, refs, cs, idx, qs, qi)
+        oo = oracle.align_opts(weights=weights, insertion=ins)
+        cells = oracle.mesh_compute(fam, q, oo)
+        g = util.graph_dict(fam)
+        gb = gpu_ctx.graph_batch([g], refs.width)
+        qm = (q.packed() >> 24).astype(np.uint8)
+        vm, vs, val = gpu_ctx.debug_mesh(gb, qm, gpu_ctx.params(weights=weights, insertion=ins))
+        assert (util.f32_bits(val) == util.f32_bits(cells["value"])).all()
+        assert (vm == cells["value_midx"]).all()
+        assert (vs == cells["value_sidx"]).all()
+
+
+@pytest.mark.parametrize("overhang,lowercase", [(0, 0), (1, 0), (2, 2), (0, 2)])
+def test_align_matches_oracle(oracle, gpu_ctx, small, overhang, lowercase):
+    refs, qs, cs, idx = small
+    graphs, qms, fams, qcs = [], [], [], []
+    for qi in range(qs.n):
+        q, fam, _ = _family(oracle, refs, cs, idx, qs, qi)
+        if not fam:
+            continue
+        graphs.append(util.graph_dict(fam))
+        qms.append((q.packed() >> 24).astype(np.uint8))
+        fams.append(fam)
+        qcs.append(q)
+    qoff = np.zeros(len(qms) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(m) for m in qms])
+    gb = gpu_ctx.graph_batch(graphs, refs.width)
+    out, pos = gpu_ctx.align_graphs(gb, np.concatenate(qms), qoff, gpu_ctx.params(overhang=overhang))
+    for i, (fam, q) in enumerate(zip(fams, qcs)):
+        ref = oracle.align(fam, q, oracle.align_opts(overhang=overhang, lowercase=lowercase, realign=1))
+        assert ref["status"] == 0
+        o = out[i]
+        assert o["status"] == 0
+        assert o["cutoff_head"] == ref["head"] and o["cutoff_tail"] == ref["tail"]
+        score = np.float32(o["raw"]) / np.float32(o["sum_weight"])
+        assert util.f32_bits(score) == util.f32_bits(ref["score"])
+        aligned, log = util.finish_alignment(qms[i], o, pos[int(qoff[i]):int(qoff[i + 1])], refs.width,
+                                             lowercase_unaligned=(lowercase == 2))
+        assert aligned == ref["aligned"]
+
+
+def test_full_length_16s_geometry(oracle, gpu_ctx):
+    """One full-length 16S-shaped problem (T=256,B=6 geometry, ~4.5 M cells)."""
+    refs = synth.make_refs(600, length=1500, width=50000, seed=21)
+    qs = synth.make_queries(refs, 2, seed=22)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    for qi in range(2):
+        q, fam, _ = _family(oracle, refs, cs, idx, qs, qi)
+        cells = oracle.mesh_compute(fam, q)
+        g = util.graph_dict(fam)
+        gb = gpu_ctx.graph_batch([g], refs.width)
+        qm = (q.packed() >> 24).astype(np.uint8)
+        vm, vs, val = gpu_ctx.debug_mesh(gb, qm)
+        assert (util.f32_bits(val) == util.f32_bits(cells["value"])).all()
+        assert (vm == cells["value_midx"]).all() and (vs == cells["value_sidx"]).all()
+
+
+def test_kmer_scores_and_topk(oracle, gpu_ctx, small):
+    refs, qs, cs, idx = small
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    off, ids = idx.csr()
+    gpu_ctx.upload_index(10, False, off, ids)
+    for qi in range(qs.n):
+        q = util.query_cseq(qs, qi)
+        assert (gpu_ctx.kmer_scores(qs.seq(qi)) == idx.scores(q)).all()
+    for mx in (1, 41, 400, 5000):
+        gi, gs, gn = gpu_ctx.kmer_topk(qs.mask, qs.off, mx)
+        for qi in range(qs.n):
+            oi, os_ = idx.find(util.query_cseq(qs, qi), mx)
+            assert gn[qi] == len(oi)
+            assert (gi[qi, :gn[qi]] == oi).all()
+            assert (gs[qi, :gn[qi]] == os_).all()
+
+
+def test_device_index_build_equals_oracle_csr(oracle, gpu_ctx, small):
+    refs, qs, cs, idx = small
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    for nofast in (False, True):
+        oidx = oracle.Index(cs, k=8, nofast=nofast)
+        gpu_ctx.build_index(8, nofast)
+        for qi in range(qs.n):
+            q = util.query_cseq(qs, qi)
+            assert (gpu_ctx.kmer_scores(qs.seq(qi)) == oidx.scores(q)).all()

@@ -1,0 +1,76 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import ctypes as C
+
+import numpy as np
+
+from oracle import pyoracle as po
+from sina_amd import synth
+
+
+def cseqs_from_refs(refs, idxs=None):
+    idxs = range(refs.n) if idxs is None else idxs
+    return [po.Cseq.from_packed("r%d" % i, refs.seq(i), refs.width) for i in idxs]
+
+
+def query_cseq(qs, i, upper=True):
+    m = qs.seq(i)
+    if upper:
+        m = m & 0x0f
+    ab = np.arange(len(m), dtype=np.uint32) | (m.astype(np.uint32) << 24)
+    return po.Cseq.from_packed("q%d" % i, ab, len(m))
+
+
+def graph_dict(fam, weight=1.0):
+    """Oracle-built family DAG in the layout sina_hip_graph_batch wants."""
+    g = po.mseq_build(fam, weight)
+    n = g["n"]
+    succ_min = np.full(n, 1000000, np.uint32)
+    for m in range(n):
+        s = g["succ"][g["succ_off"][m]:g["succ_off"][m + 1]]
+        if len(s):
+            succ_min[m] = g["pos"][s].min()
+    g["succ_minpos"] = succ_min
+    return g
+
+
+def finish_alignment(q_masks, out, pos, width, lowercase_unaligned=False, insertion_remove=False):
+    """Applies the cseq container steps of backtrack() (mesh.h:603-726) to the device's
+    per-append columns, using the oracle's cseq ops.  Returns (aligned string, log)."""
+    L = po.lib()
+    c = po.Cseq("out")
+    n = int(out["n_out"])
+    qlen = len(q_masks)
+    tail, head = int(out["cutoff_tail"]), int(out["cutoff_head"])
+    n_al = int(out["aligned_bases"])
+    # append order: tail overhang (unless overhang=remove), aligned bases from end_s
+    # downwards, head overhang
+    if n == n_al:
+        kept_tail = kept_head = 0
+    else:
+        kept_tail, kept_head = tail, head
+    assert n == n_al + kept_tail + kept_head, (n, n_al, tail, head)
+    idx = []
+    if kept_tail:
+        idx += [qlen - 1 - i for i in range(tail)]
+    s_end = int(out["end_s"])
+    idx += [s_end - i for i in range(n_al)]
+    if kept_head:
+        idx += [head - 1 - i for i in range(head)]
+    assert len(idx) == n
+    for i, qi in enumerate(idx):
+        m = int(q_masks[qi])
+        unaligned = (i < kept_tail) or (i >= kept_tail + n_al)
+        if lowercase_unaligned and unaligned:
+            m |= 16
+        L.so_cseq_append_base(c.h, int(pos[i]) & 0xFFFFFF | (m << 24), None)
+    lg = po.new_log()
+    assert L.so_cseq_set_width(c.h, width) == 0
+    L.so_cseq_reverse(c.h)
+    rc = L.so_cseq_fix_duplicate_positions(c.h, C.byref(lg), int(lowercase_unaligned), int(insertion_remove))
+    txt = po.log_text(lg)
+    L.so_log_free(C.byref(lg))
+    return (c.aligned() if rc == 0 else None), txt
+
+
+def f32_bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
