@@ -259,7 +259,7 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
     c->device = device;
     SH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
-    c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 128) * 1024;
+    c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 80) * 1024;
     c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 24) << 30;
     memset(&c->stats, 0, sizeof(c->stats));
     *ctx = c;

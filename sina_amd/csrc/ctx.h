@@ -21,7 +21,7 @@ struct sina_hip_ctx {
     sina_hip::DevBuf k_qoff, k_scores, k_out_ids, k_out_scores, k_out_n, k_tmp0, k_tmp1, k_tmp2;
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes;
 
-    size_t lds_budget = 128 * 1024;
+    size_t lds_budget = 80 * 1024;
     uint64_t tb_budget_bytes = (uint64_t)24 << 30;
     sina_hip_stats stats;
 
