@@ -127,6 +127,9 @@ def lib():
                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(Log)]
         L.so_align.argtypes = [C.POINTER(vp), C.c_uint32, vp, C.POINTER(AlignOpts), vp,
                                C.POINTER(AlignResult), C.POINTER(Log)]
+        L.so_score_op.restype = C.c_float
+        L.so_score_op.argtypes = [C.c_int, C.c_float, C.c_uint32, C.c_int, C.c_float, C.c_int, C.c_int,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, f32p, C.c_uint32]
         L.so_log_init.argtypes = [C.POINTER(Log)]
         L.so_log_free.argtypes = [C.POINTER(Log)]
         _lib = L

@@ -943,6 +943,23 @@ static void scheme_from_opts(scheme *s, const so_align_opts *o) {
     s->nw = o->n_weights;
 }
 
+/* single scoring op, for cross-checks with the real scoring_schemes.h (oracle/_ref):
+ * op 0 insertion, 1 insertion_ext, 2 deletion, 3 deletion_ext, 4 match */
+float so_score_op(int op, float prev, uint32_t mpos, int mmask, float mweight, int smask, int offset,
+                  float ms, float mms, float gp, float gpe, const float *weights, uint32_t nw) {
+    scheme s;
+    s.ms = ms; s.mms = mms; s.gp = gp; s.gpe = gpe;
+    s.w = (weights && nw) ? weights : NULL;
+    s.nw = nw;
+    switch (op) {
+    case 0: return s_insertion(&s, prev, mpos);
+    case 1: return s_insertion_ext(&s, prev, mpos, offset);
+    case 2: return s_deletion(&s, prev, mpos);
+    case 3: return s_deletion_ext(&s, prev, mpos);
+    default: return s_match(&s, prev, (uint8_t)mmask, (uint8_t)smask, mpos, mweight);
+    }
+}
+
 /* mesh.h:455-502 compute_node_simple::calc with transition_simple (:307-374) or
  * transition_aspace_aware::insertion (:403-437); mesh.h:512-528 compute(). */
 void so_mesh_compute(const so_graph *g, const uint32_t *q, uint32_t L, const so_align_opts *o,

@@ -172,6 +172,9 @@ typedef struct so_align_opts {
 } so_align_opts;
 void so_align_opts_default(so_align_opts *o);
 
+float so_score_op(int op, float prev, uint32_t mpos, int mmask, float mweight, int smask, int offset,
+                  float ms, float mms, float gp, float gpe, const float *weights, uint32_t nw);
+
 /* cells: caller-allocated g->n * L array */
 void so_mesh_compute(const so_graph *g, const uint32_t *query_ab, uint32_t L,
                      const so_align_opts *o, so_cell *cells);

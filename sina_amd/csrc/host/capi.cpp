@@ -1,0 +1,290 @@
+// Plain-C driver over the C++ stage mirror, for pytest / bench.py (ctypes).
+// Not part of the drop-in boundary (that is include/sina_hip.h below the stages
+// and the famfinder/aligner classes above it); this only lets Python feed trays
+// through the stages and read the results back.
+#include <atomic>
+#include <chrono>
+#include <cstring>
+
+#include "stages.h"
+
+using namespace sina;
+
+namespace {
+thread_local std::string g_err;
+int fail(const std::exception &e) {
+    g_err = e.what();
+    return 1;
+}
+
+struct result {
+    int status = 2;  // 0 aligned by DP, 1 alignment copied from a reference, 2 not aligned
+    int head = 0, tail = 0, qual = 0;
+    uint32_t width = 0;
+    std::vector<uint32_t> ab;
+    std::string log, family;
+};
+
+struct pipeline {
+    famfinder ff;
+    aligner al;
+    std::vector<result> results;
+    double wall_s = 0, ff_s = 0, al_s = 0;
+};
+}  // namespace
+
+extern "C" {
+
+const char *sina_host_last_error(void) { return g_err.c_str(); }
+
+int sina_host_store_from_packed(const char *key, const uint32_t *ab, const uint64_t *off, uint32_t n, uint32_t width,
+                                int device) {
+    try {
+        auto s = reference_store::from_packed(key, ab, off, n, width);
+        s->set_device(device);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+int sina_host_store_close(const char *key) {
+    try {
+        for (int k = 1; k <= 12; k++)
+            for (int nf = 0; nf < 2; nf++) kmer_search::release_kmer_search(key, k, nf != 0);
+        reference_store::close(key);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+int sina_host_add_filter(const char *key, const char *name, const float *weights, uint32_t n) {
+    try {
+        reference_store::get(key)->getAlignmentStats().emplace_back(std::string(name),
+                                                                    std::vector<float>(weights, weights + n));
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+int sina_host_reset_options(void) {
+    famfinder::reset_options();
+    aligner::reset_options();
+    return 0;
+}
+
+int sina_host_set_option(const char *stage, const char *name, const char *value) {
+    try {
+        if (!strcmp(stage, "famfinder")) famfinder::set_option(name, value);
+        else if (!strcmp(stage, "aligner")) aligner::set_option(name, value);
+        else if (!strcmp(stage, "host") && !strcmp(name, "threads")) set_host_threads((unsigned)atoi(value));
+        else throw std::logic_error(std::string("unknown stage ") + stage);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+void *sina_host_pipeline_create(void) {
+    try {
+        famfinder::validate_options();
+        aligner::validate_options();
+        return new pipeline();
+    } catch (const std::exception &e) {
+        fail(e);
+        return nullptr;
+    }
+}
+void sina_host_pipeline_destroy(void *p) { delete (pipeline *)p; }
+
+// Feeds nq unaligned queries (iupac masks) through famfinder -> aligner in batches
+// of `batch`, with `inflight` batches being worked on concurrently (host stages of
+// one batch overlap GPU work of another).
+int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff, uint32_t nq, uint32_t batch,
+                           uint32_t inflight) {
+    pipeline *p = (pipeline *)pp;
+    try {
+        p->results.assign(nq, result());
+        if (batch == 0) batch = nq ? nq : 1;
+        if (inflight == 0) inflight = 1;
+        std::atomic<uint32_t> next{0};
+        std::atomic<uint64_t> ff_ns{0}, al_ns{0};
+        std::exception_ptr err;
+        std::mutex err_mu;
+        const auto t0 = std::chrono::steady_clock::now();
+        auto worker = [&]() {
+            try {
+                for (;;) {
+                    const uint32_t b0 = next.fetch_add(batch);
+                    if (b0 >= nq) break;
+                    const uint32_t b1 = std::min(nq, b0 + batch);
+                    std::vector<tray> trays(b1 - b0);
+                    for (uint32_t q = b0; q < b1; q++) {
+                        tray &t = trays[q - b0];
+                        t.seqno = q;
+                        const std::string name = "query" + std::to_string(q);
+                        t.input_sequence = new cseq(name.c_str());
+                        for (uint64_t x = qoff[q]; x < qoff[q + 1]; x++)
+                            t.input_sequence->append(
+                                aligned_base((uint32_t)(x - qoff[q]), base_iupac::from_mask(qmask[x])));
+                        t.input_sequence->setWidth((uint32_t)(qoff[q + 1] - qoff[q]));
+                    }
+                    const auto a = std::chrono::steady_clock::now();
+                    p->ff(trays);
+                    const auto b = std::chrono::steady_clock::now();
+                    p->al(trays);
+                    const auto c = std::chrono::steady_clock::now();
+                    ff_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
+                    al_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(c - b).count();
+                    for (uint32_t q = b0; q < b1; q++) {
+                        tray &t = trays[q - b0];
+                        result &r = p->results[q];
+                        r.log = t.log.str();
+                        r.family = t.input_sequence->get_attr<std::string>(fn::family);
+                        if (t.aligned_sequence) {
+                            const cseq &c = *t.aligned_sequence;
+                            r.qual = c.get_attr<int>(fn::qual);
+                            r.head = c.get_attr<int>(fn::head);
+                            r.tail = c.get_attr<int>(fn::tail);
+                            r.width = c.getWidth();
+                            r.ab.assign(c.packed(), c.packed() + c.size());
+                            r.status = (r.log.find("copied alignment from") != std::string::npos) ? 1 : 0;
+                        }
+                        t.destroy();
+                    }
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(err_mu);
+                if (!err) err = std::current_exception();
+            }
+        };
+        std::vector<std::thread> th;
+        for (uint32_t i = 1; i < inflight; i++) th.emplace_back(worker);
+        worker();
+        for (auto &t : th) t.join();
+        p->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        p->ff_s = ff_ns.load() * 1e-9;
+        p->al_s = al_ns.load() * 1e-9;
+        if (err) std::rethrow_exception(err);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+int sina_host_result(void *pp, uint32_t q, int *status, int *head, int *tail, int *qual, uint32_t *width,
+                     uint32_t *n_bases) {
+    pipeline *p = (pipeline *)pp;
+    if (q >= p->results.size()) return 1;
+    const result &r = p->results[q];
+    *status = r.status;
+    *head = r.head;
+    *tail = r.tail;
+    *qual = r.qual;
+    *width = r.width;
+    *n_bases = (uint32_t)r.ab.size();
+    return 0;
+}
+const uint32_t *sina_host_result_bases(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].ab.data(); }
+const char *sina_host_result_log(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].log.c_str(); }
+const char *sina_host_result_family(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].family.c_str(); }
+void sina_host_timings(void *pp, double *wall_s, double *famfinder_s, double *aligner_s) {
+    pipeline *p = (pipeline *)pp;
+    *wall_s = p->wall_s;
+    *famfinder_s = p->ff_s;
+    *aligner_s = p->al_s;
+}
+
+// host DAG build exposed for tests (compares with the oracle's mseq)
+int sina_host_build_graph(const char *key, const uint32_t *ids, uint32_t F, float fs_weight, uint32_t *n_nodes,
+                          uint32_t *n_edges, uint32_t *pos, uint8_t *mask, float *weight, uint32_t *pred_off,
+                          uint32_t *pred, uint32_t *succ_minpos, uint32_t cap_nodes, uint32_t cap_edges) {
+    try {
+        auto st = reference_store::get(key);
+        std::vector<const cseq *> fam;
+        for (uint32_t i = 0; i < F; i++) fam.push_back(&st->getCseq(ids[i]));
+        host_graph g;
+        build_family_graph(fam, fs_weight, &g);
+        *n_nodes = (uint32_t)g.pos.size();
+        *n_edges = (uint32_t)g.pred.size();
+        if (g.pos.size() > cap_nodes || g.pred.size() > cap_edges) throw std::runtime_error("graph buffers too small");
+        std::copy(g.pos.begin(), g.pos.end(), pos);
+        std::copy(g.mask.begin(), g.mask.end(), mask);
+        std::copy(g.weight.begin(), g.weight.end(), weight);
+        std::copy(g.pred_off.begin(), g.pred_off.end(), pred_off);
+        std::copy(g.pred.begin(), g.pred.end(), pred);
+        std::copy(g.succ_minpos.begin(), g.succ_minpos.end(), succ_minpos);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+// cseq container ops exposed for CPU-only tests against the reference's cseq_test KATs.
+// op: 0 none, 1 setWidth(arg), 2 reverse, 3 complement, 4 upperCaseAll
+// what: 0 getAligned(nodots), 1 getAligned(dots), 2 getAligned(nodots, dna), 3 getBases
+int sina_host_cseq_op(const char *aligned, int op, uint32_t arg, int what, char *out, uint32_t cap,
+                      uint32_t *size, uint32_t *width) {
+    try {
+        cseq c("", aligned);
+        switch (op) {
+        case 1: c.setWidth(arg); break;
+        case 2: c.reverse(); break;
+        case 3: c.complement(); break;
+        case 4: c.upperCaseAll(); break;
+        default: break;
+        }
+        std::string s;
+        switch (what) {
+        case 0: s = c.getAligned(true, false); break;
+        case 1: s = c.getAligned(false, false); break;
+        case 2: s = c.getAligned(true, true); break;
+        default: s = c.getBases(); break;
+        }
+        if (s.size() + 1 > cap) throw std::runtime_error("buffer too small");
+        memcpy(out, s.c_str(), s.size() + 1);
+        *size = c.size();
+        *width = c.getWidth();
+        return 0;
+    } catch (const base_iupac::bad_character_exception &e) {
+        g_err = e.what();
+        return 3;
+    } catch (const std::runtime_error &e) {
+        g_err = e.what();
+        return 2;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+// NAST fix-up exposed for CPU-only property tests against the oracle
+int sina_host_fix_duplicates(uint32_t *ab, uint32_t n, uint32_t width, int lowercase, int remove, char *log,
+                             uint32_t log_cap) {
+    try {
+        cseq c("");
+        std::vector<aligned_base> v;
+        for (uint32_t i = 0; i < n; i++) v.push_back(aligned_base::from_raw(ab[i]));
+        c.setAlignedBases(v);
+        c.setWidth(width);
+        std::stringstream ss;
+        int rc = 0;
+        try {
+            c.fix_duplicate_positions(ss, lowercase != 0, remove != 0);
+        } catch (const std::runtime_error &) {
+            rc = 2;  // "no space to left and right"
+        }
+        memcpy(ab, c.packed(), 4 * (size_t)n);
+        const std::string s = ss.str();
+        if (log && log_cap) {
+            strncpy(log, s.c_str(), log_cap - 1);
+            log[log_cap - 1] = 0;
+        }
+        return rc;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+}  // extern "C"

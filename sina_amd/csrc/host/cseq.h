@@ -1,0 +1,190 @@
+// Host-side sequence container with the interface SINA's stages use
+// (reference: src/aligned_base.h, src/cseq.h, src/cseq.cpp).  Written from the
+// behavioural spec in SURVEY.md (sections 8a, A.4-A.6); the packed layout of an
+// aligned base is the reference's own (aligned_compact, src/aligned_base.h:287-319)
+// because that is what crosses the C ABI.
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <ostream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <variant>
+#include <vector>
+
+namespace sina {
+
+enum base_types { BASE_A = 0, BASE_G = 1, BASE_C = 2, BASE_TU = 3, BASE_MAX = 4, BASE_LC = 4 };
+
+// IUPAC base as a bit mask: A 1, G 2, C 4, T/U 8, lower-case 16 (src/aligned_base.h:47-52).
+class base_iupac {
+public:
+    using value_type = unsigned char;
+    class bad_character_exception : public std::exception {
+    public:
+        explicit bad_character_exception(value_type c) noexcept : character(c) {}
+        const char *what() const noexcept override { return "Character not IUPAC encoded base or gap"; }
+        value_type character;
+    };
+    base_iupac() = default;
+    base_iupac(unsigned char c) : _data(from_char(c)) {}
+    static base_iupac from_mask(value_type m) {
+        base_iupac b;
+        b._data = m;
+        return b;
+    }
+    static value_type from_char(unsigned char c);  // throws bad_character_exception
+    operator unsigned char() const { return iupac_rna(); }
+    unsigned char iupac_rna() const;
+    unsigned char iupac_dna() const;
+    value_type mask() const { return _data; }
+    base_types getBaseType() const { return static_cast<base_types>(__builtin_ctz(_data & 0xf)); }
+    base_iupac &complement();
+    base_iupac &setLowerCase() { _data |= 16; return *this; }
+    base_iupac &setUpperCase() { _data &= ~16; return *this; }
+    bool isLowerCase() const { return (_data & 16) != 0; }
+    int ambig_order() const { return __builtin_popcount(_data & 0xf); }
+    bool is_ambig() const { return ambig_order() > 1; }
+    bool comp(const base_iupac &rhs) const { return (0xf & _data & rhs._data) != 0; }
+    bool comp_exact(const base_iupac &rhs) const { return (0xf & _data) == (0xf & rhs._data); }
+
+private:
+    value_type _data{0};
+};
+
+// 24-bit column + 8-bit base in one uint32 -- identical bits to the reference's
+// aligned_compact<base_iupac>, so vectors of these can be handed to the C ABI.
+class aligned_base {
+public:
+    using idx_type = uint32_t;
+    using base_type = base_iupac;
+    aligned_base(idx_type pos = 0, unsigned char c = '-') : raw((pos & 0xFFFFFFu) | ((uint32_t)base_iupac::from_char(c) << 24)) {}
+    aligned_base(idx_type pos, base_iupac b) : raw((pos & 0xFFFFFFu) | ((uint32_t)b.mask() << 24)) {}
+    static aligned_base from_raw(uint32_t r) {
+        aligned_base a;
+        a.raw = r;
+        return a;
+    }
+    base_iupac getBase() const { return base_iupac::from_mask((unsigned char)(raw >> 24)); }
+    void setBase(const base_iupac &b) { raw = (raw & 0xFFFFFFu) | ((uint32_t)b.mask() << 24); }
+    idx_type getPosition() const { return raw & 0xFFFFFFu; }
+    void setPosition(idx_type pos) { raw = (pos & 0xFFFFFFu) | (raw & 0xFF000000u); }
+    void setLowerCase() { raw |= (uint32_t)16 << 24; }
+    void setUpperCase() { raw &= ~((uint32_t)16 << 24); }
+    void complement() {
+        base_iupac b = getBase();
+        b.complement();
+        setBase(b);
+    }
+    bool operator<(const aligned_base &rhs) const { return getPosition() < rhs.getPosition(); }
+    bool operator==(const aligned_base &rhs) const { return raw == rhs.raw; }
+    bool operator!=(const aligned_base &rhs) const { return raw != rhs.raw; }
+    uint32_t raw;
+};
+static_assert(sizeof(aligned_base) == 4, "aligned_base must stay 4 bytes");
+
+class cseq_base {
+public:
+    using idx_type = unsigned int;
+    using vidx_type = aligned_base::idx_type;
+    using value_type = aligned_base;
+    using iterator = std::vector<aligned_base>::iterator;
+    using const_iterator = std::vector<aligned_base>::const_iterator;
+    using const_reverse_iterator = std::vector<aligned_base>::const_reverse_iterator;
+
+    cseq_base() = default;
+    cseq_base(const char *_name, const char *_data = nullptr);
+
+    void clearSequence();
+    cseq_base &append(const char *str);
+    cseq_base &append(const std::string &str) { return append(str.c_str()); }
+    cseq_base &append(const aligned_base &ab);
+
+    vidx_type size() const { return (vidx_type)bases.size(); }
+    const std::vector<aligned_base> &getAlignedBases() const { return bases; }
+    void setAlignedBases(const std::vector<aligned_base> &vab) { bases = vab; }
+    vidx_type getWidth() const { return alignment_width; }
+    void setWidth(vidx_type newWidth);
+    void fix_duplicate_positions(std::ostream &log, bool lowercase, bool remove);
+    static void sort() {}
+    void reverse();
+    void complement();
+    void upperCaseAll();
+    std::string getAligned(bool nodots = false, bool dna = false) const;
+    std::string getBases() const;
+    std::string getName() const { return name; }
+    void setName(std::string n) { name = std::move(n); }
+
+    iterator begin() { return bases.begin(); }
+    const_iterator begin() const { return bases.begin(); }
+    iterator end() { return bases.end(); }
+    const_iterator end() const { return bases.end(); }
+    const_reverse_iterator rbegin() const { return bases.rbegin(); }
+    const_reverse_iterator rend() const { return bases.rend(); }
+    const aligned_base &getById(idx_type i) const { return bases[i]; }
+    char operator[](vidx_type i) const;
+
+    bool operator==(const cseq_base &rhs) const { return name == rhs.name && bases == rhs.bases; }
+    bool operator!=(const cseq_base &rhs) const { return !(*this == rhs); }
+    bool operator<(const cseq_base &rhs) const { return name < rhs.name; }
+
+    // raw view for the C ABI
+    const uint32_t *packed() const { return reinterpret_cast<const uint32_t *>(bases.data()); }
+
+private:
+    std::string name;
+    std::vector<aligned_base> bases;
+    unsigned int alignment_width{0};
+};
+
+std::ostream &operator<<(std::ostream &out, const cseq_base &c);
+
+// attribute map of annotated_cseq (src/cseq.h:233-272); boost::variant -> std::variant
+class annotated_cseq : public cseq_base {
+public:
+    using variant = std::variant<std::string, char, int, float>;
+    annotated_cseq(const char *_name, const char *_data = nullptr) : cseq_base(_name, _data) {}
+    annotated_cseq() = default;
+
+    template <typename T> void set_attr(const std::string &key, T val) { attributes[key] = variant(val); }
+    void set_attr(const std::string &key, const char *val) { attributes[key] = variant(std::string(val)); }
+    bool has_attr(const std::string &key) const { return attributes.find(key) != attributes.end(); }
+    template <typename T> T get_attr(const std::string &attr) const { return get_attr<T>(attr, T()); }
+    template <typename T> T get_attr(const std::string &attr, T dflt) const {
+        const auto it = attributes.find(attr);
+        if (it == attributes.end()) return dflt;
+        return std::visit([&](const auto &v) { return convert<T>(v); }, it->second);
+    }
+    const std::map<std::string, variant> &get_attrs() const { return attributes; }
+
+private:
+    template <typename T, typename S> static T convert(const S &s) {
+        if constexpr (std::is_same<T, S>::value) {
+            return s;
+        } else {  // boost::lexical_cast semantics: stream out, stream in, default on failure
+            std::stringstream ss;
+            ss << s;
+            T t{};
+            if constexpr (std::is_same<T, std::string>::value) {
+                return ss.str();
+            } else {
+                ss >> t;
+                if (ss.fail()) return T();
+                return t;
+            }
+        }
+    }
+    std::map<std::string, variant> attributes;
+};
+
+typedef annotated_cseq cseq;
+
+// field names used by the stages (src/query_arb.cpp:83-107)
+namespace fn {
+extern const char *turn, *acc, *start, *cutoff_head, *cutoff_tail, *date, *qual, *head, *tail, *idty, *family,
+    *filter, *align_log, *used_rels, *fullname;
+}
+
+}  // namespace sina

@@ -1,0 +1,1054 @@
+// Host side of the boundary: reference_store, kmer_search, famfinder, aligner.
+// Behaviour follows the reference stage by stage (citations inline); the heavy
+// lifting goes through the C ABI (include/sina_hip.h).  No CPU fallback: if the
+// HIP library reports an error, the stage throws.
+#include "stages.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cctype>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <map>
+
+namespace sina {
+
+static void hip_check(int rc, const char *what) {
+    if (rc != 0) throw std::runtime_error(std::string(what) + ": " + sina_hip_last_error());
+}
+
+// ================================================================ thread pool
+
+namespace {
+class pool {
+public:
+    static pool &get() {
+        static pool p;
+        return p;
+    }
+    void resize(unsigned n) {
+        shutdown();
+        start(n);
+    }
+    unsigned size() const { return (unsigned)workers.size() + 1; }
+    void run(size_t n, const std::function<void(size_t)> &fn) {
+        if (n == 0) return;
+        if (workers.empty() || n == 1) {
+            for (size_t i = 0; i < n; i++) fn(i);
+            return;
+        }
+        std::unique_lock<std::mutex> lk(mu);
+        job_fn = &fn;
+        job_n = n;
+        next.store(0);
+        pending = workers.size();
+        error = nullptr;
+        ++generation;
+        cv.notify_all();
+        lk.unlock();
+        work();  // the caller helps
+        lk.lock();
+        done_cv.wait(lk, [this] { return pending == 0; });
+        job_fn = nullptr;
+        if (error) std::rethrow_exception(error);
+    }
+    ~pool() { shutdown(); }
+
+private:
+    pool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        start(hw > 1 ? std::min(hw, 64u) : 1);
+    }
+    void start(unsigned n) {
+        stop = false;
+        for (unsigned i = 1; i < n; i++) workers.emplace_back([this] { loop(); });
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            ++generation;
+        }
+        cv.notify_all();
+        for (auto &w : workers) w.join();
+        workers.clear();
+    }
+    void work() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= job_n) break;
+            try {
+                (*job_fn)(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!error) error = std::current_exception();
+            }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return generation != seen; });
+            seen = generation;
+            if (stop) return;
+            lk.unlock();
+            work();
+            lk.lock();
+            if (--pending == 0) done_cv.notify_all();
+        }
+    }
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    const std::function<void(size_t)> *job_fn = nullptr;
+    size_t job_n = 0, pending = 0;
+    std::atomic<size_t> next{0};
+    uint64_t generation = 0;
+    bool stop = false;
+    std::exception_ptr error;
+};
+std::mutex pool_user_mu;  // one parallel_for at a time
+}  // namespace
+
+void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
+    std::lock_guard<std::mutex> lk(pool_user_mu);
+    pool::get().run(n, fn);
+}
+void set_host_threads(unsigned n) {
+    std::lock_guard<std::mutex> lk(pool_user_mu);
+    pool::get().resize(n < 1 ? 1 : n);
+}
+unsigned host_threads() { return pool::get().size(); }
+
+// ================================================================ tray (src/tray.cpp)
+
+tray::tray(const tray &o)
+    : seqno(o.seqno), input_sequence(o.input_sequence), aligned_sequence(o.aligned_sequence),
+      alignment_reference(o.alignment_reference), search_result(o.search_result), astats(o.astats) {
+    log.str(o.log.str());
+    log.seekp(0, std::ios_base::end);
+}
+tray &tray::operator=(const tray &o) {
+    seqno = o.seqno;
+    input_sequence = o.input_sequence;
+    aligned_sequence = o.aligned_sequence;
+    alignment_reference = o.alignment_reference;
+    search_result = o.search_result;
+    log.str(o.log.str());
+    log.seekp(0, std::ios_base::end);
+    astats = o.astats;
+    return *this;
+}
+void tray::destroy() {
+    delete input_sequence;
+    delete aligned_sequence;
+    delete alignment_reference;
+    delete search_result;
+    delete astats;
+    input_sequence = aligned_sequence = nullptr;
+    alignment_reference = search_result = nullptr;
+    astats = nullptr;
+}
+
+// ================================================================ reference_store
+
+namespace {
+std::mutex stores_mu;
+std::map<std::string, std::shared_ptr<reference_store>> stores;
+}  // namespace
+
+std::shared_ptr<reference_store> reference_store::get(const std::string &path) {
+    {
+        std::lock_guard<std::mutex> lk(stores_mu);
+        auto it = stores.find(path);
+        if (it != stores.end()) return it->second;
+    }
+    return open(path);
+}
+void reference_store::close(const std::string &path) {
+    std::lock_guard<std::mutex> lk(stores_mu);
+    stores.erase(path);
+}
+
+std::shared_ptr<reference_store> reference_store::from_packed(const std::string &key, const uint32_t *ab,
+                                                              const uint64_t *off, uint32_t n, uint32_t width,
+                                                              const char *const *names) {
+    std::shared_ptr<reference_store> s(new reference_store());
+    s->path = key;
+    s->width = width;
+    s->seqs.reserve(n);
+    std::vector<aligned_base> tmp;
+    for (uint32_t i = 0; i < n; i++) {
+        std::string nm = names ? std::string(names[i]) : ("ref" + std::to_string(i));
+        s->seqs.emplace_back(nm.c_str());
+        cseq &c = s->seqs.back();
+        tmp.clear();
+        for (uint64_t x = off[i]; x < off[i + 1]; x++) tmp.push_back(aligned_base::from_raw(ab[x]));
+        c.setAlignedBases(tmp);
+        c.setWidth(width);
+        c.set_attr(fn::acc, nm);
+    }
+    std::lock_guard<std::mutex> lk(stores_mu);
+    stores[key] = s;
+    return s;
+}
+
+// Minimal aligned-FASTA reader ('>' name [description], sequence lines; '-'/'.' are gaps).
+std::shared_ptr<reference_store> reference_store::open(const std::string &path) {
+    std::ifstream in(path);
+    if (!in) throw std::logic_error("Reference database file " + path + " does not exist");
+    std::shared_ptr<reference_store> s(new reference_store());
+    s->path = path;
+    std::string line, name, data;
+    auto flush = [&]() {
+        if (name.empty()) return;
+        s->seqs.emplace_back(name.c_str(), data.c_str());
+        s->seqs.back().set_attr(fn::acc, name);
+        data.clear();
+    };
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '>') {
+            flush();
+            size_t e = line.find_first_of(" \t", 1);
+            name = line.substr(1, e == std::string::npos ? std::string::npos : e - 1);
+        } else {
+            data += line;
+        }
+    }
+    flush();
+    for (const auto &c : s->seqs) s->width = std::max(s->width, c.getWidth());
+    for (auto &c : s->seqs) c.setWidth(s->width);
+    std::lock_guard<std::mutex> lk(stores_mu);
+    stores[path] = s;
+    return s;
+}
+
+reference_store::~reference_store() {
+    if (ctx) sina_hip_destroy(ctx);
+}
+
+const cseq &reference_store::getCseq(const std::string &name) const {
+    for (const auto &c : seqs)
+        if (c.getName() == name) return c;
+    throw std::runtime_error("no such sequence: " + name);
+}
+std::vector<std::string> reference_store::getSequenceNames() const {
+    std::vector<std::string> v;
+    v.reserve(seqs.size());
+    for (const auto &c : seqs) v.push_back(c.getName());
+    return v;
+}
+void reference_store::loadKey(const cseq &, const std::string &) const {
+    // attributes of FASTA-backed references are loaded eagerly (acc := name); nothing to fetch
+}
+
+sina_hip_ctx *reference_store::device() {
+    std::lock_guard<std::mutex> lk(gpu_mu);
+    if (ctx) return ctx;
+    hip_check(sina_hip_init(device_id, &ctx), "sina_hip_init");
+    std::vector<uint32_t> ab;
+    std::vector<uint64_t> off(seqs.size() + 1, 0);
+    size_t total = 0;
+    for (const auto &c : seqs) total += c.size();
+    ab.reserve(total);
+    for (size_t i = 0; i < seqs.size(); i++) {
+        const uint32_t *p = seqs[i].packed();
+        ab.insert(ab.end(), p, p + seqs[i].size());
+        off[i + 1] = ab.size();
+    }
+    hip_check(sina_hip_upload_refs(ctx, ab.data(), off.data(), (uint32_t)seqs.size(), width), "upload_refs");
+    return ctx;
+}
+
+void reference_store::ensure_index(unsigned k, bool nofast) {
+    sina_hip_ctx *c = device();
+    std::lock_guard<std::mutex> lk(gpu_mu);
+    if (idx_k == (int)k && idx_nofast == nofast) return;
+    hip_check(sina_hip_build_index(c, k, nofast ? 1 : 0), "build_index");
+    idx_k = (int)k;
+    idx_nofast = nofast;
+}
+
+// ================================================================ kmer_search
+
+class kmer_search::impl {
+public:
+    std::shared_ptr<reference_store> store;
+    unsigned k;
+    bool nofast;
+    impl(std::shared_ptr<reference_store> s, unsigned k_, bool nofast_) : store(std::move(s)), k(k_), nofast(nofast_) {
+        store->ensure_index(k, nofast);
+    }
+};
+
+namespace {
+struct idx_key {
+    std::string path;
+    int k;
+    bool nofast;
+    bool operator<(const idx_key &o) const { return std::tie(path, k, nofast) < std::tie(o.path, o.k, o.nofast); }
+};
+std::mutex indices_mu;
+std::map<idx_key, std::shared_ptr<kmer_search::impl>> indices;
+}  // namespace
+
+// src/kmer_search.cpp:118-144
+kmer_search *kmer_search::get_kmer_search(const std::string &filename, int k, bool nofast) {
+    std::lock_guard<std::mutex> lk(indices_mu);
+    idx_key key{filename, k, nofast};
+    auto it = indices.find(key);
+    if (it == indices.end())
+        it = indices.emplace(key, std::make_shared<impl>(reference_store::get(filename), (unsigned)k, nofast)).first;
+    return new kmer_search(it->second);
+}
+void kmer_search::release_kmer_search(const std::string &filename, int k, bool nofast) {
+    std::lock_guard<std::mutex> lk(indices_mu);
+    indices.erase(idx_key{filename, k, nofast});
+}
+kmer_search::kmer_search(std::shared_ptr<impl> p) : pimpl(std::move(p)) {}
+kmer_search::~kmer_search() = default;
+unsigned int kmer_search::size() const { return pimpl->store->size(); }
+
+double kmer_search::match(result_vector &, const cseq &, int, int, float, float, reference_store *, bool, int, int,
+                          int, int, bool) {
+    throw std::runtime_error("Legacy family composition not implemented for internal search");
+}
+
+void kmer_search::find(const cseq &query, result_vector &results, unsigned int max) {
+    std::vector<const cseq *> q{&query};
+    std::vector<result_vector> r;
+    find_batch(q, r, max);
+    results = std::move(r[0]);
+}
+
+// src/kmer_search.cpp:366-420 for a batch of queries
+void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vector<result_vector> &results,
+                             unsigned int max) {
+    reference_store &st = *pimpl->store;
+    const unsigned n = st.size();
+    results.assign(queries.size(), result_vector());
+    if (max > n) max = n;
+    if (max == 0 || queries.empty()) return;
+    st.ensure_index(pimpl->k, pimpl->nofast);
+    std::vector<uint64_t> qoff(queries.size() + 1, 0);
+    for (size_t i = 0; i < queries.size(); i++) qoff[i + 1] = qoff[i] + queries[i]->size();
+    std::vector<uint8_t> qmask(qoff.back() ? qoff.back() : 1);
+    for (size_t i = 0; i < queries.size(); i++) {
+        const auto &b = queries[i]->getAlignedBases();
+        for (size_t x = 0; x < b.size(); x++) qmask[qoff[i] + x] = b[x].getBase().mask();
+    }
+    sina_hip_ctx *ctx = st.device();
+    if (max <= 4096) {
+        std::vector<uint32_t> ids((size_t)queries.size() * max), cnt(queries.size());
+        std::vector<float> sc((size_t)queries.size() * max);
+        hip_check(sina_hip_kmer_topk(ctx, qmask.data(), qoff.data(), (uint32_t)queries.size(), max, ids.data(),
+                                     sc.data(), cnt.data()),
+                  "kmer_topk");
+        for (size_t i = 0; i < queries.size(); i++) {
+            results[i].reserve(cnt[i]);
+            for (uint32_t x = 0; x < cnt[i]; x++)
+                results[i].emplace_back(sc[i * max + x], &st.getCseq(ids[i * max + x]));
+        }
+    } else {
+        // rare escalation (famfinder asks for >4096 candidates): the GPU still does the
+        // counting; ranking the full score vector is the reference's own partial_sort
+        // (src/kmer_search.cpp:405-418).
+        std::vector<int16_t> scores(n);
+        using pair = std::pair<int16_t, int>;
+        std::vector<pair> ranks(n);
+        for (size_t i = 0; i < queries.size(); i++) {
+            hip_check(sina_hip_kmer_scores(ctx, qmask.data() + qoff[i], (uint32_t)(qoff[i + 1] - qoff[i]),
+                                           scores.data()),
+                      "kmer_scores");
+            for (unsigned r = 0; r < n; r++) ranks[r] = pair(scores[r], (int)r);
+            std::partial_sort(ranks.begin(), ranks.begin() + max, ranks.end(), std::greater<pair>());
+            results[i].reserve(max);
+            for (unsigned x = 0; x < max; x++) results[i].emplace_back(ranks[x].first, &st.getCseq(ranks[x].second));
+        }
+    }
+}
+
+// ================================================================ famfinder
+
+namespace {
+struct ff_options {
+    TURN_TYPE turn_which;
+    ENGINE_TYPE engine;
+    std::string posvar_filter;
+    unsigned int fs_min, fs_max;
+    float fs_msc, fs_msc_max;
+    bool fs_leave_query_out;
+    unsigned int fs_req, fs_req_full, fs_full_len, fs_req_gaps;
+    bool fs_no_fast;
+    unsigned int fs_kmer_len, fs_min_len, fs_cover_gene;
+    std::string database;
+};
+ff_options ff_defaults() {  // src/famfinder.cpp:144-203
+    ff_options o;
+    o.turn_which = TURN_NONE;
+    o.engine = ENGINE_SINA_KMER;
+    o.fs_min = 40;
+    o.fs_max = 40;
+    o.fs_msc = .7f;
+    o.fs_msc_max = 2;
+    o.fs_leave_query_out = false;
+    o.fs_req = 1;
+    o.fs_req_full = 1;
+    o.fs_full_len = 1400;
+    o.fs_req_gaps = 10;
+    o.fs_no_fast = false;
+    o.fs_kmer_len = 10;
+    o.fs_min_len = 150;
+    o.fs_cover_gene = 0;
+    return o;
+}
+ff_options ff_opts = ff_defaults();
+
+bool to_bool(const std::string &v) { return !(v.empty() || v == "0" || v == "false" || v == "no" || v == "off"); }
+std::string lower(std::string s) {
+    for (auto &c : s) c = (char)tolower((unsigned char)c);
+    return s;
+}
+
+// cseq_comparator(CMP_IUPAC_OPTIMISTIC, CMP_DIST_NONE, CMP_COVER_QUERY, false)
+// (src/cseq_comparator.cpp:59-117,211-295): column-wise merge walk
+float identity_cover_query(const cseq &A, const cseq &B) {
+    const auto &a = A.getAlignedBases();
+    const auto &b = B.getAlignedBases();
+    size_t i = 0, j = 0;
+    const size_t ae = a.size(), be = b.size();
+    if (ae == 0 || be == 0) return 0.f;
+    int match = 0, mismatch = 0, only_a = 0, only_a_over = 0;
+    if (a[0].getPosition() < b[0].getPosition()) {
+        while (i != ae && a[i].getPosition() < b[j].getPosition()) { ++only_a_over; ++i; }
+    } else {
+        while (j != be && a[i].getPosition() > b[j].getPosition()) ++j;
+    }
+    while (i != ae && j != be) {
+        const int diff = (int)a[i].getPosition() - (int)b[j].getPosition();
+        if (diff > 0) ++j;
+        else if (diff < 0) { ++only_a; ++i; }
+        else {
+            if (a[i].getBase().comp(b[j].getBase())) ++match; else ++mismatch;
+            ++i; ++j;
+        }
+    }
+    only_a_over += (int)(ae - i);
+    const int base = match + mismatch + only_a + only_a_over;
+    return (float)match / base;
+}
+}  // namespace
+
+void famfinder::reset_options() { ff_opts = ff_defaults(); }
+
+void famfinder::set_option(const std::string &name, const std::string &value) {
+    ff_options &o = ff_opts;
+    if (name == "db" || name == "ptdb") o.database = value;
+    else if (name == "turn") {
+        const std::string v = lower(value);
+        if (v == "none") o.turn_which = TURN_NONE;
+        else if (v == "revcomp" || v.empty()) o.turn_which = TURN_REVCOMP;
+        else if (v == "all") o.turn_which = TURN_ALL;
+        else throw std::logic_error("invalid value for --turn: " + value);
+    } else if (name == "fs-engine") {
+        if (lower(value) == "internal") o.engine = ENGINE_SINA_KMER;
+        else throw std::logic_error("only the internal k-mer engine is available");
+    } else if (name == "fs-kmer-len") o.fs_kmer_len = (unsigned)std::stoul(value);
+    else if (name == "fs-req") o.fs_req = (unsigned)std::stoul(value);
+    else if (name == "fs-min") o.fs_min = (unsigned)std::stoul(value);
+    else if (name == "fs-max") o.fs_max = (unsigned)std::stoul(value);
+    else if (name == "fs-msc") o.fs_msc = std::stof(value);
+    else if (name == "fs-req-full") o.fs_req_full = (unsigned)std::stoul(value);
+    else if (name == "fs-full-len") o.fs_full_len = (unsigned)std::stoul(value);
+    else if (name == "fs-req-gaps") o.fs_req_gaps = (unsigned)std::stoul(value);
+    else if (name == "fs-min-len") o.fs_min_len = (unsigned)std::stoul(value);
+    else if (name == "fs-kmer-no-fast") o.fs_no_fast = to_bool(value);
+    else if (name == "fs-msc-max") o.fs_msc_max = std::stof(value);
+    else if (name == "fs-leave-query-out") o.fs_leave_query_out = to_bool(value);
+    else if (name == "fs-cover-gene") o.fs_cover_gene = (unsigned)std::stoul(value);
+    else if (name == "filter") o.posvar_filter = value;
+    else throw std::logic_error("famfinder: unknown option " + name);
+}
+
+void famfinder::validate_options() {  // src/famfinder.cpp:213-239
+    if (ff_opts.database.empty()) throw std::logic_error("Family Finder: Must have reference database (--db/-r)");
+    if (ff_opts.fs_req < 1) throw std::logic_error("Family Finder: fs-req must be >= 1");
+    if (ff_opts.fs_kmer_len < 1 || ff_opts.fs_kmer_len > 12)
+        throw std::logic_error("Family Finder: fs-kmer-len must be in 1..12 on this engine");
+}
+ENGINE_TYPE famfinder::get_engine() { return ff_opts.engine; }
+
+class famfinder::impl {
+public:
+    kmer_search *index{nullptr};
+    std::shared_ptr<reference_store> arb;
+    impl() : arb(reference_store::get(ff_opts.database)) {
+        index = kmer_search::get_kmer_search(ff_opts.database, (int)ff_opts.fs_kmer_len, ff_opts.fs_no_fast);
+    }
+    ~impl() { delete index; }
+    int turn_check(const cseq &query, bool all);
+    void do_turn_check(cseq &c);
+    void select_astats(tray &t);
+    void run(std::vector<tray *> &batch);
+};
+
+famfinder::famfinder() : pimpl(new impl()) {}
+famfinder::famfinder(const famfinder &o) = default;
+famfinder &famfinder::operator=(const famfinder &o) = default;
+famfinder::~famfinder() = default;
+
+int famfinder::turn_check(const cseq &query, bool all) { return pimpl->turn_check(query, all); }
+
+// src/famfinder.cpp:344-378
+int famfinder::impl::turn_check(const cseq &query, bool all) {
+    search::result_vector matches;
+    double score[4];
+    index->find(query, matches, 1);
+    score[0] = matches.empty() ? 0 : matches[0].score;
+    cseq turn(query);
+    turn.reverse();
+    if (all) {
+        index->find(turn, matches, 1);
+        score[1] = matches.empty() ? 0 : matches[0].score;
+        cseq comp(query);
+        comp.complement();
+        index->find(comp, matches, 1);
+        score[2] = matches.empty() ? 0 : matches[0].score;
+    } else {
+        score[1] = score[2] = 0;
+    }
+    turn.complement();
+    index->find(turn, matches, 1);
+    score[3] = matches.empty() ? 0 : matches[0].score;
+    double max = 0;
+    int best = 0;
+    for (int i = 0; i < 4; i++)
+        if (max < score[i]) max = score[i], best = i;
+    return best;
+}
+
+// src/famfinder.cpp:312-341
+void famfinder::impl::do_turn_check(cseq &c) {
+    if (ff_opts.turn_which != TURN_NONE) {
+        switch (turn_check(c, ff_opts.turn_which == TURN_ALL)) {
+        case 0: c.set_attr(fn::turn, "none"); break;
+        case 1: c.set_attr(fn::turn, "reversed"); c.reverse(); break;
+        case 2: c.set_attr(fn::turn, "complemented"); c.complement(); break;
+        case 3: c.set_attr(fn::turn, "reversed and complemented"); c.reverse(); c.complement(); break;
+        }
+    } else {
+        c.set_attr(fn::turn, "turn-check disabled");
+    }
+}
+
+// src/famfinder.cpp:381-436 without the auto-filter (needs ARB fields)
+void famfinder::impl::select_astats(tray &t) {
+    alignment_stats *astats = nullptr;
+    if (!ff_opts.posvar_filter.empty()) {
+        for (alignment_stats &as : arb->getAlignmentStats()) {
+            if (as.getName() == ff_opts.posvar_filter || as.getName() == ff_opts.posvar_filter + ":ALL" ||
+                as.getName() == ff_opts.posvar_filter + ":all")
+                astats = new alignment_stats(as);  // trays own (and delete) their astats
+        }
+    }
+    if (astats == nullptr) astats = new alignment_stats();
+    t.astats = astats;
+}
+
+// One pass of the filter cascade of famfinder::impl::match over ranked candidates
+// (src/famfinder.cpp:497-612). Returns true when the loop condition
+// says "enough".
+namespace {
+struct match_state {
+    size_t have = 0, have_full = 0, have_cover_left = 0, have_cover_right = 0;
+};
+bool match_pass(search::result_vector &results, const cseq &query, match_state &st) {
+    const ff_options &o = ff_opts;
+    const size_t range_begin = 0, range_end = 0;
+    st = match_state();
+    auto remove = [&](const search::result_item &r) {
+        const cseq &s = *r.sequence;
+        const bool is_full = s.size() >= o.fs_full_len;
+        const bool is_left = s.size() && s.begin()->getPosition() <= range_begin;
+        const bool is_right = s.size() && s.getById(s.size() - 1).getPosition() >= range_end;
+        if (s.size() < o.fs_min_len) return true;
+        if (o.fs_leave_query_out && query.getName() == s.getName()) return true;
+        if (o.fs_msc_max <= 2 && o.fs_msc_max < 1 && identity_cover_query(query, s) > o.fs_msc_max) return true;
+        const bool min_reached = st.have >= o.fs_min, max_reached = st.have >= o.fs_max;
+        const bool score_good = r.score < o.fs_msc;  // sic (src/famfinder.cpp:565-567)
+        const bool adds_to_full = o.fs_req_full && st.have_full < o.fs_req_full && is_full;
+        const bool adds_to_range = (o.fs_cover_gene && st.have_cover_right < o.fs_cover_gene && is_right) ||
+                                   (o.fs_cover_gene && st.have_cover_left < o.fs_cover_gene && is_left);
+        if (min_reached && (max_reached || !score_good) && !adds_to_full && !adds_to_range) return true;
+        ++st.have;
+        if (o.fs_req_full && is_full) ++st.have_full;
+        if (o.fs_cover_gene && is_right) ++st.have_cover_right;
+        if (o.fs_cover_gene && is_left) ++st.have_cover_left;
+        return false;
+    };
+    results.erase(std::remove_if(results.begin(), results.end(), remove), results.end());
+    return !(st.have < o.fs_max || st.have_full < o.fs_req_full || st.have_cover_left < o.fs_cover_gene ||
+             st.have_cover_right < o.fs_cover_gene);
+}
+}  // namespace
+
+// src/famfinder.cpp:439-494 for a batch; the k-mer search of every escalation
+// round is ONE launch over all queries still looking for relatives.
+void famfinder::impl::run(std::vector<tray *> &batch) {
+    const ff_options &o = ff_opts;
+    std::vector<tray *> todo;
+    for (tray *t : batch) {
+        t->alignment_reference = new search::result_vector();
+        do_turn_check(*t->input_sequence);
+        todo.push_back(t);
+    }
+    size_t max_results = (size_t)o.fs_max + 1;
+    const unsigned isize = index->size();
+    while (!todo.empty()) {
+        std::vector<const cseq *> qs;
+        for (tray *t : todo) qs.push_back(t->input_sequence);
+        std::vector<search::result_vector> found;
+        index->find_batch(qs, found, (unsigned)std::min<size_t>(max_results, isize));
+        std::vector<char> done(todo.size(), 0);
+        parallel_for(todo.size(), [&](size_t i) {
+            search::result_vector &res = *todo[i]->alignment_reference;
+            res = std::move(found[i]);
+            if (res.empty()) {
+                done[i] = 1;
+                return;
+            }
+            match_state st;
+            const bool enough = match_pass(res, *todo[i]->input_sequence, st);
+            done[i] = (enough || max_results >= isize) ? 1 : 0;
+        });
+        std::vector<tray *> next;
+        for (size_t i = 0; i < todo.size(); i++)
+            if (!done[i]) next.push_back(todo[i]);
+        todo.swap(next);
+        max_results *= 10;
+    }
+    parallel_for(batch.size(), [&](size_t i) {
+        tray &t = *batch[i];
+        auto &vc = *t.alignment_reference;
+        cseq &c = *t.input_sequence;
+        std::string fam;
+        char buf[64];
+        for (auto &r : vc) {
+            arb->loadKey(*r.sequence, fn::acc);
+            arb->loadKey(*r.sequence, fn::start);
+            snprintf(buf, sizeof(buf), ":%.2f ", (double)r.score);
+            fam += r.sequence->get_attr<std::string>(fn::acc) + "." +
+                   r.sequence->get_attr<std::string>(fn::start, "0") + buf;
+        }
+        c.set_attr(fn::family, fam);
+        if (o.fs_req_gaps != 0) {  // :472-480
+            auto too_few_gaps = [&](search::result_item &it) {
+                return 0 == it.sequence->size() ||
+                       it.sequence->rbegin()->getPosition() - it.sequence->size() + 1 < o.fs_req_gaps;
+            };
+            vc.erase(std::remove_if(vc.begin(), vc.end(), too_few_gaps), vc.end());
+        }
+        select_astats(t);
+        if (vc.size() < o.fs_req) {  // :486-491
+            t.log << "unable to align: too few relatives (" << vc.size() << ");";
+            delete t.alignment_reference;
+            t.alignment_reference = nullptr;
+        }
+    });
+}
+
+tray famfinder::operator()(const tray &t) {
+    tray r(t);
+    std::vector<tray *> b{&r};
+    pimpl->run(b);
+    return r;
+}
+void famfinder::operator()(std::vector<tray> &batch) {
+    std::vector<tray *> b;
+    for (auto &t : batch) b.push_back(&t);
+    pimpl->run(b);
+}
+
+// ================================================================ host DAG build
+
+// src/mseq.cpp:47-118 + src/graph.h:332-357,466-488, flat arrays.
+void build_family_graph(const std::vector<const cseq *> &fam, float fs_weight, host_graph *g) {
+    const size_t F = fam.size();
+    g->pos.clear(); g->mask.clear(); g->weight.clear();
+    g->pred_off.assign(1, 0); g->pred.clear(); g->succ_minpos.clear();
+    g->width = F ? fam[0]->getWidth() : 0;
+    for (const cseq *c : fam)
+        if (c->getWidth() != g->width)
+            throw std::runtime_error("Aligned sequences to be stored in mseq of differ in length!");
+    std::vector<uint32_t> cur(F, 0);
+    std::vector<int32_t> last(F, -1);
+    std::vector<float> count;
+    struct ed { uint32_t b, a; };
+    std::vector<ed> col_edges;
+    int32_t node_of_mask[32];
+    uint32_t next_col = 0xFFFFFFFFu;
+    for (size_t j = 0; j < F; j++)
+        if (fam[j]->size()) next_col = std::min(next_col, fam[j]->getById(0).getPosition());
+    while (next_col != 0xFFFFFFFFu) {
+        const uint32_t col = next_col;
+        next_col = 0xFFFFFFFFu;
+        for (int &x : node_of_mask) x = -1;
+        const uint32_t first_node = (uint32_t)g->pos.size();
+        col_edges.clear();
+        for (size_t j = 0; j < F; j++) {
+            const auto &b = fam[j]->getAlignedBases();
+            if (cur[j] < b.size() && b[cur[j]].getPosition() == col) {
+                const uint8_t m = b[cur[j]].getBase().mask() & 31;
+                int32_t node = node_of_mask[m];
+                if (node < 0) {
+                    node = (int32_t)g->pos.size();
+                    node_of_mask[m] = node;
+                    g->pos.push_back(col);
+                    g->mask.push_back(m);
+                    count.push_back(1.f);
+                    g->succ_minpos.push_back(1000000u);
+                } else {
+                    count[node] += 1.f;
+                }
+                if (last[j] >= 0) {
+                    col_edges.push_back({(uint32_t)node, (uint32_t)last[j]});
+                    if (col < g->succ_minpos[last[j]]) g->succ_minpos[last[j]] = col;
+                }
+                last[j] = node;
+                ++cur[j];
+            }
+            if (cur[j] < b.size()) next_col = std::min(next_col, b[cur[j]].getPosition());
+        }
+        // reduce_edges: per node ascending unique predecessor ids
+        std::sort(col_edges.begin(), col_edges.end(),
+                  [](const ed &x, const ed &y) { return x.b != y.b ? x.b < y.b : x.a < y.a; });
+        size_t e = 0;
+        for (uint32_t node = first_node; node < g->pos.size(); node++) {
+            uint32_t prev = 0xFFFFFFFFu;
+            while (e < col_edges.size() && col_edges[e].b == node) {
+                if (col_edges[e].a != prev) g->pred.push_back(prev = col_edges[e].a);
+                ++e;
+            }
+            g->pred_off.push_back((uint32_t)g->pred.size());
+        }
+    }
+    g->weight.resize(count.size());
+    for (size_t i = 0; i < count.size(); i++)  // mseq.cpp:113: double reciprocal + float product
+        g->weight[i] = (float)(1.0 / (double)(fs_weight + 1) + (double)(fs_weight * (count[i] / (float)(unsigned)F)));
+}
+
+// ================================================================ aligner
+
+aligner::options *aligner::opts = nullptr;
+
+static aligner::options al_defaults() {  // src/align.cpp:231-274
+    aligner::options o;
+    o.realign = false;
+    o.overhang = OVERHANG_ATTACH;
+    o.lowercase = LOWERCASE_NONE;
+    o.insertion = INSERTION_SHIFT;
+    o.calc_idty = false;
+    o.fs_no_graph = false;
+    o.fs_weight = 1;
+    o.match_score = 2;
+    o.mismatch_score = -1;
+    o.gap_penalty = 5.0f;
+    o.gap_ext_penalty = 2.0f;
+    o.debug_graph = o.write_used_rels = o.use_subst_matrix = false;
+    o.device_graph = false;  // flipped to true once sina_hip_align_families is the faster path
+    return o;
+}
+static aligner::options &al_opts() {
+    if (!aligner::opts) aligner::opts = new aligner::options(al_defaults());
+    return *aligner::opts;
+}
+void aligner::reset_options() { al_opts() = al_defaults(); }
+
+void aligner::set_option(const std::string &name, const std::string &value) {
+    options &o = al_opts();
+    const std::string v = lower(value);
+    if (name == "realign") o.realign = to_bool(value);
+    else if (name == "overhang") {
+        if (v == "attach") o.overhang = OVERHANG_ATTACH;
+        else if (v == "remove") o.overhang = OVERHANG_REMOVE;
+        else if (v == "edge") o.overhang = OVERHANG_EDGE;
+        else throw std::logic_error("invalid value for --overhang: " + value);
+    } else if (name == "lowercase") {
+        if (v == "none") o.lowercase = LOWERCASE_NONE;
+        else if (v == "original") o.lowercase = LOWERCASE_ORIGINAL;
+        else if (v == "unaligned") o.lowercase = LOWERCASE_UNALIGNED;
+        else throw std::logic_error("invalid value for --lowercase: " + value);
+    } else if (name == "insertion") {
+        if (v == "shift") o.insertion = INSERTION_SHIFT;
+        else if (v == "forbid") o.insertion = INSERTION_FORBID;
+        else if (v == "remove") o.insertion = INSERTION_REMOVE;
+        else throw std::logic_error("invalid value for --insertion: " + value);
+    } else if (name == "fs-weight") o.fs_weight = std::stof(value);
+    else if (name == "match-score") o.match_score = std::stof(value);
+    else if (name == "mismatch-score") o.mismatch_score = std::stof(value);
+    else if (name == "pen-gap") o.gap_penalty = std::stof(value);
+    else if (name == "pen-gapext") o.gap_ext_penalty = std::stof(value);
+    else if (name == "write-used-rels") o.write_used_rels = to_bool(value);
+    else if (name == "fs-no-graph" || name == "use-subst-matrix" || name == "debug-graph" || name == "calc-idty") {
+        if (to_bool(value)) throw std::logic_error("aligner: --" + name + " is outside the accelerated path");
+    } else if (name == "device-graph") o.device_graph = to_bool(value);
+    else if (name == "db") o.database = value;
+    else throw std::logic_error("aligner: unknown option " + name);
+}
+void aligner::validate_options() {}
+
+aligner::aligner() { al_opts(); }
+aligner::~aligner() = default;
+aligner::aligner(const aligner &) = default;
+aligner &aligner::operator=(const aligner &) = default;
+
+static std::string make_datetime() {  // src/align.cpp:287-299
+    time_t t;
+    struct tm tmv;
+    char buf[50];
+    time(&t);
+    gmtime_r(&t, &tmv);
+    strftime(buf, 50, "%F %T", &tmv);
+    return std::string(buf);
+}
+
+namespace {
+// case-insensitive substring search on base strings (boost::algorithm::icontains /
+// ifind_first as used at src/align.cpp:329-333,364-369)
+std::string upper_copy(const std::string &s) {
+    std::string r(s);
+    for (auto &c : r) c = (char)toupper((unsigned char)c);
+    return r;
+}
+
+struct dp_job {
+    tray *t;
+    cseq *c;                           // working copy (becomes aligned_sequence)
+    std::vector<const cseq *> family;  // mseq input order
+};
+}  // namespace
+
+tray aligner::operator()(tray t) {
+    std::vector<tray> b{t};
+    (*this)(b);
+    return b[0];
+}
+
+// src/align.cpp:307-460 for a batch of trays.
+void aligner::operator()(std::vector<tray> &batch) {
+    const options &o = al_opts();
+    std::vector<dp_job> jobs(batch.size());
+    std::vector<char> need_dp(batch.size(), 0);
+
+    parallel_for(batch.size(), [&](size_t i) {
+        tray &t = batch[i];
+        if (t.input_sequence == nullptr || t.alignment_reference == nullptr || t.astats == nullptr) return;  // :310-318
+        cseq &c = *(new cseq(*t.input_sequence));
+        search::result_vector &vc = *t.alignment_reference;
+        const std::string bases = c.getBases();
+        const std::string ubases = upper_copy(bases);
+        if (o.lowercase != LOWERCASE_ORIGINAL) c.upperCaseAll();
+
+        auto not_contains_query = [&](search::result_item &item) {
+            return upper_copy(item.sequence->getBases()).find(ubases) == std::string::npos;
+        };
+        auto begin_containing = std::partition(vc.begin(), vc.end(), not_contains_query);
+        if (begin_containing != vc.end()) {
+            if (o.realign) {  // :337-348
+                t.log << "sequences ";
+                for (auto it = begin_containing; it != vc.end(); ++it)
+                    t.log << it->sequence->get_attr<std::string>(fn::acc) << " ";
+                t.log << "containing exact candidate removed from family;";
+                vc.erase(begin_containing, vc.end());
+                if (vc.empty()) {
+                    t.log << "that's ALL of them. skipping sequence;";
+                    delete &c;
+                    return;
+                }
+            } else {  // :349-388 steal the alignment
+                auto same_as_query = [&](search::result_item &item) {
+                    return upper_copy(item.sequence->getBases()) == ubases;
+                };
+                auto exact = std::find_if(begin_containing, vc.end(), same_as_query);
+                if (exact != vc.end()) {
+                    c.setAlignedBases(exact->sequence->getAlignedBases());
+                    t.log << "copied alignment from identical template sequence "
+                          << exact->sequence->get_attr<std::string>(fn::acc) << ":"
+                          << exact->sequence->get_attr<std::string>(fn::start, "0") << "; ";
+                } else {
+                    const auto &refal = begin_containing->sequence->getAlignedBases();
+                    const size_t at = upper_copy(begin_containing->sequence->getBases()).find(ubases);
+                    std::vector<aligned_base> sub(refal.begin() + at, refal.begin() + at + bases.size());
+                    c.setAlignedBases(sub);
+                    t.log << "copied alignment from (longer) template sequence "
+                          << begin_containing->sequence->get_attr<std::string>(fn::acc) << ":"
+                          << begin_containing->sequence->get_attr<std::string>(fn::start, "0") << "; ";
+                }
+                c.setWidth(begin_containing->sequence->getWidth());
+                c.set_attr(fn::date, make_datetime());
+                c.set_attr(fn::qual, 100);
+                if (o.calc_idty) c.set_attr(fn::idty, 100.f);
+                c.set_attr(fn::head, 0);
+                c.set_attr(fn::tail, 0);
+                c.set_attr(fn::filter, "");
+                t.aligned_sequence = &c;
+                return;
+            }
+        }
+        jobs[i].t = &t;
+        jobs[i].c = &c;
+        for (auto &r : vc) jobs[i].family.push_back(r.sequence);
+        need_dp[i] = 1;
+    });
+
+    // group DP jobs by scoring scheme: default-constructed astats (width 0) => simple
+    // scheme, otherwise weighted with that tray's weights (src/align.cpp:404-416)
+    std::map<std::vector<float>, std::vector<size_t>> groups;
+    for (size_t i = 0; i < batch.size(); i++)
+        if (need_dp[i]) groups[batch[i].astats->getWeights()].push_back(i);
+
+    std::shared_ptr<reference_store> store;
+    if (!groups.empty()) {
+        const std::string db = o.database.empty() ? ff_opts.database : o.database;
+        store = reference_store::get(db);
+    }
+    for (auto &grp : groups) {
+        const std::vector<float> &weights = grp.first;
+        const std::vector<size_t> &idx = grp.second;
+        const size_t nq = idx.size();
+        sina_hip_align_params p;
+        sina_hip_align_params_default(&p);
+        p.match_score = o.match_score;
+        p.mismatch_score = o.mismatch_score;
+        p.gap_penalty = o.gap_penalty;
+        p.gap_ext_penalty = o.gap_ext_penalty;
+        p.fs_weight = o.fs_weight;
+        p.overhang = (int)o.overhang;
+        p.lowercase = (int)o.lowercase;
+        p.insertion = (int)o.insertion;
+        p.weights = weights.empty() ? nullptr : weights.data();
+        p.n_weights = (uint32_t)weights.size();
+
+        std::vector<uint64_t> qoff(nq + 1, 0);
+        for (size_t x = 0; x < nq; x++) qoff[x + 1] = qoff[x] + jobs[idx[x]].c->size();
+        std::vector<uint8_t> qmask(qoff.back() ? qoff.back() : 1);
+        for (size_t x = 0; x < nq; x++) {
+            const auto &b = jobs[idx[x]].c->getAlignedBases();
+            for (size_t y = 0; y < b.size(); y++) qmask[qoff[x] + y] = b[y].getBase().mask();
+        }
+        std::vector<sina_hip_align_out> out(nq);
+        std::vector<uint32_t> out_pos(qoff.back() ? qoff.back() : 1);
+        sina_hip_ctx *ctx = store->device();
+        uint32_t width = 0;
+
+        if (o.device_graph) {
+            std::vector<uint64_t> foff(nq + 1, 0);
+            for (size_t x = 0; x < nq; x++) foff[x + 1] = foff[x] + jobs[idx[x]].family.size();
+            std::vector<uint32_t> fids(foff.back() ? foff.back() : 1);
+            for (size_t x = 0; x < nq; x++)
+                for (size_t y = 0; y < jobs[idx[x]].family.size(); y++)
+                    fids[foff[x] + y] = store->id_of(jobs[idx[x]].family[y]);
+            width = store->getAlignmentWidth();
+            hip_check(sina_hip_align_families(ctx, fids.data(), foff.data(), (uint32_t)nq, qmask.data(), qoff.data(),
+                                              &p, out.data(), out_pos.data()),
+                      "align_families");
+        } else {
+            std::vector<host_graph> gs(nq);
+            parallel_for(nq, [&](size_t x) { build_family_graph(jobs[idx[x]].family, o.fs_weight, &gs[x]); });
+            sina_hip_graph_batch gb;
+            std::vector<uint64_t> node_off(nq + 1, 0), edge_off(nq + 1, 0);
+            for (size_t x = 0; x < nq; x++) {
+                node_off[x + 1] = node_off[x] + gs[x].pos.size();
+                edge_off[x + 1] = edge_off[x] + gs[x].pred.size();
+            }
+            std::vector<uint32_t> npos(node_off.back()), pred(edge_off.back() ? edge_off.back() : 1),
+                poff(node_off.back() + nq), smin(node_off.back());
+            std::vector<uint8_t> nmask(node_off.back());
+            std::vector<float> nw(node_off.back());
+            parallel_for(nq, [&](size_t x) {
+                const host_graph &g = gs[x];
+                std::copy(g.pos.begin(), g.pos.end(), npos.begin() + node_off[x]);
+                std::copy(g.mask.begin(), g.mask.end(), nmask.begin() + node_off[x]);
+                std::copy(g.weight.begin(), g.weight.end(), nw.begin() + node_off[x]);
+                std::copy(g.succ_minpos.begin(), g.succ_minpos.end(), smin.begin() + node_off[x]);
+                std::copy(g.pred_off.begin(), g.pred_off.end(), poff.begin() + node_off[x] + x);
+                std::copy(g.pred.begin(), g.pred.end(), pred.begin() + edge_off[x]);
+            });
+            width = gs[0].width;
+            gb.nq = (uint32_t)nq;
+            gb.node_off = node_off.data();
+            gb.edge_off = edge_off.data();
+            gb.node_pos = npos.data();
+            gb.node_mask = nmask.data();
+            gb.node_weight = nw.data();
+            gb.pred_off = poff.data();
+            gb.pred = pred.data();
+            gb.succ_minpos = smin.data();
+            gb.width = width;
+            hip_check(sina_hip_align_graphs(ctx, &gb, qmask.data(), qoff.data(), &p, out.data(), out_pos.data()),
+                      "align_graphs");
+        }
+
+        // cseq container steps of backtrack() (src/mesh.h:603-736) + do_align attrs (:507-509)
+        parallel_for(nq, [&](size_t x) {
+            dp_job &jb = jobs[idx[x]];
+            tray &t = *jb.t;
+            cseq &c = *jb.c;
+            const sina_hip_align_out &r = out[x];
+            if (r.status != 0) throw std::runtime_error("device alignment failed for " + c.getName());
+            const std::vector<aligned_base> q = c.getAlignedBases();  // query bases (maybe upper-cased)
+            const uint32_t L = (uint32_t)q.size();
+            const uint32_t *pos = out_pos.data() + qoff[x];
+            c.clearSequence();
+            const bool keep_over = (o.overhang != OVERHANG_REMOVE);
+            const uint32_t tail = keep_over ? (uint32_t)r.cutoff_tail : 0;
+            const uint32_t head = keep_over ? (uint32_t)r.cutoff_head : 0;
+            uint32_t n = 0;
+            for (uint32_t k = 0; k < tail; k++, n++) {  // it = slave.rbegin()
+                base_iupac b = q[L - 1 - k].getBase();
+                if (o.lowercase == LOWERCASE_UNALIGNED) b.setLowerCase();
+                c.append(aligned_base(pos[n], b));
+            }
+            for (int k = 0; k < r.aligned_bases; k++, n++) c.append(aligned_base(pos[n], q[r.end_s - k].getBase()));
+            if (o.overhang == OVERHANG_ATTACH) {
+                for (uint32_t k = 0; k < head; k++, n++) {
+                    aligned_base ab(pos[n], q[(uint32_t)r.cutoff_head - 1 - k].getBase());
+                    if (o.lowercase == LOWERCASE_UNALIGNED) ab.setLowerCase();
+                    c.append(ab);
+                }
+            } else if (o.overhang == OVERHANG_EDGE) {
+                for (uint32_t k = 0; k < head; k++, n++) {
+                    aligned_base ab(pos[n], q[(uint32_t)r.cutoff_head - 1 - k].getBase());
+                    if (o.lowercase == LOWERCASE_UNALIGNED) ab.setLowerCase();
+                    c.append(ab);
+                }
+            }
+            c.setWidth(width);
+            c.reverse();
+            c.fix_duplicate_positions(t.log, o.lowercase == LOWERCASE_UNALIGNED, o.insertion == INSERTION_REMOVE);
+            if (c.getWidth() > width) t.log << "warning: result sequence too wide!";
+            const float rval = r.raw, sum_weight = r.sum_weight;
+            const float score = rval / sum_weight;
+            t.log << "scoring: raw=" << rval << ", weight=" << sum_weight << ", query-len=" << L
+                  << ", aligned-bases=" << r.aligned_bases << ", score=" << score << "; ";
+            c.set_attr(fn::head, r.cutoff_head);
+            c.set_attr(fn::tail, r.cutoff_tail);
+            c.set_attr(fn::qual, (int)std::min(100.f, std::max(0.f, 100.f * score)));
+            if (o.write_used_rels) {
+                std::string s;
+                for (const cseq *f : jb.family) s += f->getName() + " ";
+                c.set_attr(fn::used_rels, s);
+            }
+            c.set_attr(fn::date, make_datetime());
+            c.set_attr(fn::filter, t.astats->getName());
+            t.aligned_sequence = &c;
+        });
+    }
+}
+
+}  // namespace sina

@@ -1,0 +1,314 @@
+// Host side of the drop-in boundary: SINA's stage surface for the hot path
+// (tray in, tray out) on top of the C ABI in include/sina_hip.h.
+//
+//   reference interface                       here
+//   ------------------------------------      -------------------------------------
+//   class tray           src/tray.h:41-57     sina::tray            (same fields)
+//   class search         src/search.h:51-106  sina::search          (same virtuals)
+//   class kmer_search    src/kmer_search.h    sina::kmer_search     (+ find_batch)
+//   class famfinder      src/famfinder.h:51   sina::famfinder       (+ batch call)
+//   class aligner        src/align.h:70-84    sina::aligner         (+ batch call)
+//   query_arb (ARB DB)   src/query_arb.h      sina::reference_store (aligned FASTA /
+//                                              packed arrays; ARB itself is out of scope)
+//
+// boost::program_options is not available here, so get_options_description /
+// validate_vm become set_option(name, value) / validate_options() with the SAME
+// option names and defaults (src/famfinder.cpp:144-211, src/align.cpp:231-274).
+#pragma once
+
+#include <condition_variable>
+#include <functional>
+#include <future>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "cseq.h"
+#include "sina_hip.h"
+
+namespace sina {
+
+// ---------------------------------------------------------------- search iface
+enum ENGINE_TYPE { ENGINE_ARB_PT = 0, ENGINE_SINA_KMER = 1 };
+
+class reference_store;
+
+class search {
+protected:
+    search() = default;
+
+public:
+    search(const search &) = delete;
+    search &operator=(const search &) = delete;
+    virtual ~search() = default;
+    struct result_item {
+        result_item(float sc, const cseq *seq) : score(sc), sequence(seq) {}
+        float score;
+        const cseq *sequence;
+        bool operator<(const result_item &o) const {
+            if (score < o.score) return true;
+            if (score > o.score) return false;
+            return *sequence < *o.sequence;
+        }
+        bool operator>(const result_item &o) const { return !operator<(o); }
+    };
+    using result_vector = std::vector<result_item>;
+
+    virtual double match(result_vector &family, const cseq &query, int min_match, int max_match, float min_score,
+                         float max_score, reference_store *arb, bool noid, int minlen, int num_full,
+                         int minlen_full, int range_cover, bool leave_query_out) = 0;
+    virtual void find(const cseq &query, result_vector &results, unsigned int max) = 0;
+    virtual unsigned int size() const = 0;
+};
+
+// ---------------------------------------------------------------- alignment_stats
+// Only what the aligner reads (src/alignment_stats.h): name, width, per-column
+// weights.  Default-constructed (width 0) selects scoring_scheme_simple
+// (src/align.cpp:405-408).  Computing weights from ARB SAI data is out of scope.
+class alignment_stats {
+public:
+    alignment_stats() = default;
+    alignment_stats(std::string name_, std::vector<float> weights_)
+        : name(std::move(name_)), weights(std::move(weights_)) {}
+    const std::string &getName() const { return name; }
+    unsigned int getWidth() const { return (unsigned int)weights.size(); }
+    const std::vector<float> &getWeights() const { return weights; }
+
+private:
+    std::string name;
+    std::vector<float> weights;
+};
+
+// ---------------------------------------------------------------- tray
+class tray {
+public:
+    unsigned int seqno{0};
+    cseq *input_sequence{nullptr};
+    cseq *aligned_sequence{nullptr};
+    search::result_vector *alignment_reference{nullptr};
+    search::result_vector *search_result{nullptr};
+    std::stringstream log;
+    alignment_stats *astats{nullptr};
+
+    tray() = default;
+    tray(const tray &o);
+    tray &operator=(const tray &o);
+    ~tray() = default;
+    void destroy();
+};
+
+// ---------------------------------------------------------------- reference store
+// Holds the aligned reference sequences on the host (cseq objects the result
+// items point into, like query_arb's sequence cache) and owns the device context
+// with the packed copy + k-mer index in HBM.
+class reference_store {
+public:
+    // register / look up by "database path" (famfinder --db)
+    static std::shared_ptr<reference_store> open(const std::string &path);  // aligned FASTA file
+    static std::shared_ptr<reference_store> from_packed(const std::string &path_key, const uint32_t *ab,
+                                                         const uint64_t *off, uint32_t n, uint32_t width,
+                                                         const char *const *names = nullptr);
+    static std::shared_ptr<reference_store> get(const std::string &path);
+    static void close(const std::string &path);
+
+    ~reference_store();
+    const std::string &getFileName() const { return path; }
+    unsigned int size() const { return (unsigned int)seqs.size(); }
+    unsigned int getAlignmentWidth() const { return width; }
+    const cseq &getCseq(unsigned int id) const { return seqs[id]; }
+    const cseq &getCseq(const std::string &name) const;
+    unsigned int id_of(const cseq *c) const { return (unsigned int)(c - seqs.data()); }
+    std::vector<std::string> getSequenceNames() const;
+    void loadKey(const cseq &c, const std::string &key) const;  // acc := name, start := "0" if absent
+    std::vector<alignment_stats> &getAlignmentStats() { return vastats; }
+
+    // device side
+    void set_device(int device) { device_id = device; }
+    sina_hip_ctx *device();                    // lazily creates the context and uploads the references
+    void ensure_index(unsigned k, bool nofast);  // builds the k-mer index on the GPU once per (k, nofast)
+    std::mutex &gpu_mutex() { return gpu_mu; }
+
+private:
+    reference_store() = default;
+    std::string path;
+    std::vector<cseq> seqs;
+    unsigned int width{0};
+    std::vector<alignment_stats> vastats;
+    int device_id{0};
+    sina_hip_ctx *ctx{nullptr};
+    int idx_k{-1};
+    bool idx_nofast{false};
+    std::mutex gpu_mu;
+};
+
+// ---------------------------------------------------------------- kmer_search
+class kmer_search : public search {
+public:
+    static kmer_search *get_kmer_search(const std::string &filename, int k = 10, bool nofast = false);
+    static void release_kmer_search(const std::string &filename, int k = 10, bool nofast = false);
+
+    double match(result_vector &, const cseq &, int, int, float, float, reference_store *, bool, int, int, int, int,
+                 bool) override;
+    void find(const cseq &query, result_vector &results, unsigned int max) override;
+    // one launch for many queries; results[i] gets min(max, size()) items
+    void find_batch(const std::vector<const cseq *> &queries, std::vector<result_vector> &results,
+                    unsigned int max);
+    unsigned int size() const override;
+    ~kmer_search() override;
+
+    class impl;
+
+private:
+    explicit kmer_search(std::shared_ptr<impl> pimpl_);
+    std::shared_ptr<impl> pimpl;
+};
+
+// ---------------------------------------------------------------- famfinder
+enum TURN_TYPE { TURN_NONE = 0, TURN_REVCOMP = 1, TURN_ALL = 2 };
+
+class famfinder {
+    class impl;
+    std::shared_ptr<impl> pimpl;
+
+public:
+    famfinder();
+    famfinder(const famfinder &o);
+    famfinder &operator=(const famfinder &o);
+    ~famfinder();
+    tray operator()(const tray &t);
+    void operator()(std::vector<tray> &batch);  // batched form of the same stage
+    int turn_check(const cseq &query, bool all);
+
+    // option names as on the SINA command line: "db", "turn", "fs-kmer-len", "fs-req", "fs-min",
+    // "fs-max", "fs-msc", "fs-req-full", "fs-full-len", "fs-req-gaps", "fs-min-len",
+    // "fs-kmer-no-fast", "fs-msc-max", "fs-leave-query-out", "fs-cover-gene", "filter"
+    static void set_option(const std::string &name, const std::string &value);
+    static void reset_options();
+    static void validate_options();
+    static ENGINE_TYPE get_engine();
+};
+
+// ---------------------------------------------------------------- aligner
+enum OVERHANG_TYPE { OVERHANG_ATTACH, OVERHANG_REMOVE, OVERHANG_EDGE };
+enum LOWERCASE_TYPE { LOWERCASE_NONE, LOWERCASE_ORIGINAL, LOWERCASE_UNALIGNED };
+enum INSERTION_TYPE { INSERTION_SHIFT, INSERTION_FORBID, INSERTION_REMOVE };
+
+class aligner {
+public:
+    struct options {
+        bool realign;
+        OVERHANG_TYPE overhang;
+        LOWERCASE_TYPE lowercase;
+        INSERTION_TYPE insertion;
+        bool calc_idty;
+        bool fs_no_graph;
+        float fs_weight;
+        float match_score, mismatch_score, gap_penalty, gap_ext_penalty;
+        bool debug_graph, write_used_rels, use_subst_matrix;
+        bool device_graph;  // build the family DAG on the GPU (default) or on the host
+        std::string database;  // reference store the DAGs are built from (same as famfinder "db")
+    };
+    static options *opts;
+    aligner();
+    aligner(const aligner &rhs);
+    ~aligner();
+    aligner &operator=(const aligner &rhs);
+    tray operator()(tray t);
+    void operator()(std::vector<tray> &batch);
+
+    // "realign", "overhang", "lowercase", "insertion", "fs-weight", "match-score",
+    // "mismatch-score", "pen-gap", "pen-gapext", "write-used-rels", "calc-idty", "db"
+    static void set_option(const std::string &name, const std::string &value);
+    static void reset_options();
+    static void validate_options();
+};
+
+// ---------------------------------------------------------------- batching shim
+// SINA calls a stage once per tray from many TBB workers (function_node with
+// unlimited concurrency, src/sina.cpp:497-519); the GPU wants thousands of
+// queries per launch.  batched<Stage> has the single-tray call signature of the
+// reference stage, is re-entrant, and groups concurrent callers into one batch.
+template <class Stage> class batched {
+public:
+    explicit batched(Stage s, size_t max_batch = 1024, unsigned linger_us = 300)
+        : st(std::make_shared<state>(std::move(s), max_batch, linger_us)) {}
+    tray operator()(tray t) {
+        std::future<tray> f;
+        {
+            std::unique_lock<std::mutex> lk(st->mu);
+            st->pending.emplace_back(std::move(t), std::promise<tray>());
+            f = st->pending.back().second.get_future();
+            st->cv.notify_all();
+        }
+        return f.get();
+    }
+
+private:
+    struct state {
+        Stage stage;
+        size_t max_batch;
+        unsigned linger_us;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<std::pair<tray, std::promise<tray>>> pending;
+        bool stop = false;
+        std::thread worker;
+        state(Stage s, size_t mb, unsigned lu) : stage(std::move(s)), max_batch(mb), linger_us(lu) {
+            worker = std::thread([this] { run(); });
+        }
+        ~state() {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                stop = true;
+            }
+            cv.notify_all();
+            worker.join();
+        }
+        void run() {
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [this] { return stop || !pending.empty(); });
+                if (stop && pending.empty()) return;
+                // linger briefly so that concurrent callers end up in the same launch
+                cv.wait_for(lk, std::chrono::microseconds(linger_us),
+                            [this] { return stop || pending.size() >= max_batch; });
+                std::vector<std::pair<tray, std::promise<tray>>> work;
+                work.swap(pending);
+                lk.unlock();
+                std::vector<tray> batch;
+                batch.reserve(work.size());
+                for (auto &w : work) batch.push_back(w.first);
+                try {
+                    stage(batch);
+                    for (size_t i = 0; i < work.size(); i++) work[i].second.set_value(batch[i]);
+                } catch (...) {
+                    for (auto &w : work) w.second.set_exception(std::current_exception());
+                }
+                lk.lock();
+            }
+        }
+    };
+    std::shared_ptr<state> st;
+};
+
+// ---------------------------------------------------------------- helpers
+// parallel for over [0, n) on a process-wide pool (stands in for TBB's workers)
+void parallel_for(size_t n, const std::function<void(size_t)> &fn);
+void set_host_threads(unsigned n);
+unsigned host_threads();
+
+// Family DAG on the host (flat CSR) -- used when aligner option device_graph is off
+// and by tests; see src/mseq.cpp:47-118 for the behaviour it reproduces.
+struct host_graph {
+    std::vector<uint32_t> pos;
+    std::vector<uint8_t> mask;
+    std::vector<float> weight;
+    std::vector<uint32_t> pred_off, pred, succ_minpos;
+    uint32_t width = 0;
+};
+void build_family_graph(const std::vector<const cseq *> &family, float fs_weight, host_graph *g);
+
+}  // namespace sina

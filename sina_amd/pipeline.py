@@ -1,0 +1,161 @@
+"""Python driver over the C++ stage mirror (sina_amd/libsina_host.so).
+
+famfinder -> aligner exactly as SINA wires them (tray in, tray out), with the
+k-mer search and the mesh DP on the GPU through the C ABI.  Used by the tests and
+bench.py; fails loudly when the native libraries are missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "libsina_host.so")
+_host = None
+
+
+def load_host():
+    global _host
+    if _host is not None:
+        return _host
+    capi.load()  # libsina_hip.so first (RPATH $ORIGIN resolves it as well)
+    if not os.path.exists(HOST_LIB_PATH):
+        raise RuntimeError("sina_amd/libsina_host.so is missing: build it with __graft_entry__.build()")
+    H = C.CDLL(HOST_LIB_PATH)
+    vp = C.c_void_p
+    H.sina_host_last_error.restype = C.c_char_p
+    H.sina_host_store_from_packed.argtypes = [C.c_char_p, capi.u32p, capi.u64p, C.c_uint32, C.c_uint32, C.c_int]
+    H.sina_host_store_close.argtypes = [C.c_char_p]
+    H.sina_host_add_filter.argtypes = [C.c_char_p, C.c_char_p, capi.f32p, C.c_uint32]
+    H.sina_host_set_option.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    H.sina_host_pipeline_create.restype = vp
+    H.sina_host_pipeline_destroy.argtypes = [vp]
+    H.sina_host_pipeline_destroy.restype = None
+    H.sina_host_pipeline_run.argtypes = [vp, capi.u8p, capi.u64p, C.c_uint32, C.c_uint32, C.c_uint32]
+    H.sina_host_result.argtypes = [vp, C.c_uint32] + [C.POINTER(C.c_int)] * 4 + [capi.u32p, capi.u32p]
+    H.sina_host_result_bases.restype = capi.u32p
+    H.sina_host_result_bases.argtypes = [vp, C.c_uint32]
+    H.sina_host_result_log.restype = C.c_char_p
+    H.sina_host_result_log.argtypes = [vp, C.c_uint32]
+    H.sina_host_result_family.restype = C.c_char_p
+    H.sina_host_result_family.argtypes = [vp, C.c_uint32]
+    H.sina_host_timings.argtypes = [vp] + [C.POINTER(C.c_double)] * 3
+    H.sina_host_timings.restype = None
+    H.sina_host_build_graph.argtypes = [C.c_char_p, capi.u32p, C.c_uint32, C.c_float, capi.u32p, capi.u32p,
+                                        capi.u32p, capi.u8p, capi.f32p, capi.u32p, capi.u32p, capi.u32p,
+                                        C.c_uint32, C.c_uint32]
+    H.sina_host_cseq_op.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32, capi.u32p,
+                                    capi.u32p]
+    H.sina_host_fix_duplicates.argtypes = [capi.u32p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_char_p,
+                                           C.c_uint32]
+    _host = H
+    return H
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise HostError(load_host().sina_host_last_error().decode())
+
+
+class Store:
+    """A reference store registered under `key` (what SINA calls --db)."""
+
+    def __init__(self, key, refs, device=0):
+        self.H = load_host()
+        self.key = key
+        ab = np.ascontiguousarray(refs.ab, np.uint32)
+        off = np.ascontiguousarray(refs.off, np.uint64)
+        _chk(self.H.sina_host_store_from_packed(key.encode(), ab.ctypes.data_as(capi.u32p),
+                                                off.ctypes.data_as(capi.u64p), refs.n, refs.width, device))
+
+    def add_filter(self, name, weights):
+        w = np.ascontiguousarray(weights, np.float32)
+        _chk(self.H.sina_host_add_filter(self.key.encode(), name.encode(), w.ctypes.data_as(capi.f32p), len(w)))
+
+    def build_graph(self, ids, fs_weight=1.0):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        cap_n, cap_e = 200000, 400000
+        nn, ne = C.c_uint32(), C.c_uint32()
+        pos = np.zeros(cap_n, np.uint32)
+        mask = np.zeros(cap_n, np.uint8)
+        w = np.zeros(cap_n, np.float32)
+        poff = np.zeros(cap_n + 1, np.uint32)
+        pred = np.zeros(cap_e, np.uint32)
+        smin = np.zeros(cap_n, np.uint32)
+        _chk(self.H.sina_host_build_graph(self.key.encode(), ids.ctypes.data_as(capi.u32p), len(ids), fs_weight,
+                                          C.byref(nn), C.byref(ne), pos.ctypes.data_as(capi.u32p),
+                                          mask.ctypes.data_as(capi.u8p), w.ctypes.data_as(capi.f32p),
+                                          poff.ctypes.data_as(capi.u32p), pred.ctypes.data_as(capi.u32p),
+                                          smin.ctypes.data_as(capi.u32p), cap_n, cap_e))
+        n, e = nn.value, ne.value
+        return dict(n=n, pos=pos[:n].copy(), mask=mask[:n].copy(), weight=w[:n].copy(),
+                    pred_off=poff[:n + 1].copy(), pred=pred[:e].copy(), succ_minpos=smin[:n].copy())
+
+    def close(self):
+        self.H.sina_host_store_close(self.key.encode())
+
+
+class Pipeline:
+    """famfinder + aligner over one Store.  Options use SINA's command-line names."""
+
+    def __init__(self, store, famfinder=None, aligner=None, host_threads=None):
+        self.H = load_host()
+        self.store = store
+        self.H.sina_host_reset_options()
+        self._set("famfinder", "db", store.key)
+        self._set("aligner", "db", store.key)
+        for k, v in (famfinder or {}).items():
+            self._set("famfinder", k, v)
+        for k, v in (aligner or {}).items():
+            self._set("aligner", k, v)
+        if host_threads:
+            self._set("host", "threads", host_threads)
+        self.h = self.H.sina_host_pipeline_create()
+        if not self.h:
+            raise HostError(self.H.sina_host_last_error().decode())
+
+    def _set(self, stage, name, value):
+        if isinstance(value, bool):
+            value = "1" if value else "0"
+        _chk(self.H.sina_host_set_option(stage.encode(), name.encode(), str(value).encode()))
+
+    def run(self, qmask, qoff, batch=1024, inflight=2):
+        qmask = np.ascontiguousarray(qmask, np.uint8)
+        qoff = np.ascontiguousarray(qoff, np.uint64)
+        self.nq = len(qoff) - 1
+        _chk(self.H.sina_host_pipeline_run(self.h, qmask.ctypes.data_as(capi.u8p), qoff.ctypes.data_as(capi.u64p),
+                                           self.nq, batch, inflight))
+        return self.timings()
+
+    def timings(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self.H.sina_host_timings(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(wall_s=a.value, famfinder_s=b.value, aligner_s=c.value)
+
+    def result(self, q):
+        st, hd, tl, ql = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        w, n = C.c_uint32(), C.c_uint32()
+        _chk(self.H.sina_host_result(self.h, q, C.byref(st), C.byref(hd), C.byref(tl), C.byref(ql), C.byref(w),
+                                     C.byref(n)))
+        ab = np.ctypeslib.as_array(self.H.sina_host_result_bases(self.h, q), shape=(n.value,)).copy() \
+            if n.value else np.zeros(0, np.uint32)
+        return dict(status=st.value, head=hd.value, tail=tl.value, qual=ql.value, width=w.value, packed=ab,
+                    log=self.H.sina_host_result_log(self.h, q).decode(),
+                    family=self.H.sina_host_result_family(self.h, q).decode())
+
+    def close(self):
+        if self.h:
+            self.H.sina_host_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

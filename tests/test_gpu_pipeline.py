@@ -1,0 +1,143 @@
+"""GPU end-to-end: tray -> famfinder -> aligner through the C++ stage mirror (k-mer
+search and mesh DP on the GPU) vs the CPU oracle run query by query."""
+import numpy as np
+import pytest
+
+from sina_amd import pipeline, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_run(oracle, cs, idx, qs, qi, ff=None, al=None):
+    q = util.query_cseq(qs, qi, upper=False)
+    ids, sc, fflog = idx.famfinder(q, oracle.ff_opts(**(ff or {})))
+    if len(ids) == 0:
+        return dict(status=2, log=fflog, ids=ids, sc=sc)
+    r = oracle.align([cs[i] for i in ids], q, oracle.align_opts(**(al or {})))
+    r["log"] = fflog + r["log"]
+    r["ids"], r["sc"] = ids, sc
+    return r
+
+
+def _check(oracle, refs, qs, pl, cs, idx, ff=None, al=None):
+    n_dp = n_copy = 0
+    for qi in range(qs.n):
+        want = _oracle_run(oracle, cs, idx, qs, qi, ff, al)
+        got = pl.result(qi)
+        fam = "".join("ref%d.0:%.2f " % (i, s) for i, s in zip(want["ids"], want["sc"]))
+        if want["status"] == 2:
+            assert got["status"] == 2 and got["log"] == want["log"]
+            continue
+        assert got["family"] == fam
+        assert got["status"] == want["status"], (qi, got["log"], want["log"])
+        assert synth.aligned_string(got["packed"], got["width"]) == want["aligned"].replace(".", "-")
+        assert (got["packed"] == want["packed"]).all()          # columns AND case bits
+        assert (got["head"], got["tail"], got["qual"]) == (want["head"], want["tail"], want["qual"])
+        if want["status"] == 0:
+            assert got["log"] == want["log"]                      # NAST + scoring text
+            n_dp += 1
+        else:
+            n_copy += 1
+    return n_dp, n_copy
+
+
+@pytest.fixture(scope="module")
+def world(oracle):
+    refs = synth.make_refs(500, length=320, width=3200, seed=51, amb_rate=0.01, lower_rate=0.02)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    st = pipeline.Store(":mem:gpu-e2e", refs)
+    yield refs, cs, idx, st
+    st.close()
+
+
+def test_pipeline_defaults(oracle, world):
+    refs, cs, idx, st = world
+    qs = synth.make_queries(refs, 40, seed=52, amb_rate=0.01, lower_rate=0.05)
+    pl = pipeline.Pipeline(st, famfinder={"fs-min-len": 100, "fs-full-len": 250})
+    pl.run(qs.mask, qs.off, batch=16, inflight=2)
+    n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250))
+    assert n_dp >= 35
+    pl.close()
+
+
+@pytest.mark.parametrize("al,oal", [
+    ({"overhang": "remove"}, dict(overhang=1)),
+    ({"overhang": "edge", "lowercase": "unaligned"}, dict(overhang=2, lowercase=2)),
+    ({"insertion": "forbid"}, dict(insertion=1)),
+    ({"lowercase": "original", "fs-weight": 0.5, "pen-gap": 4, "pen-gapext": 1.5, "match-score": 3,
+      "mismatch-score": -2}, dict(lowercase=1, fs_weight=0.5, gap_penalty=4, gap_ext_penalty=1.5, match_score=3,
+                                  mismatch_score=-2)),
+])
+def test_pipeline_aligner_options(oracle, world, al, oal):
+    refs, cs, idx, st = world
+    # V4-like windows give head/tail overhang; extra indels give insertions to place
+    qs = synth.make_queries(refs, 24, seed=53, window=(0.3, 120), ins=0.02, dele=0.02, lower_rate=0.05)
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    pl = pipeline.Pipeline(st, famfinder=ff, aligner=al)
+    pl.run(qs.mask, qs.off, batch=24, inflight=1)
+    n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250), al=oal)
+    assert n_dp >= 20
+    pl.close()
+
+
+def test_pipeline_copy_shortcut_and_realign(oracle, world):
+    """Queries that ARE (substrings of) references: alignment is copied (align.cpp:349-388) unless --realign."""
+    refs, cs, idx, st = world
+    qs = synth.make_queries(refs, 16, seed=54, sub=0.0, dele=0.0, ins=0.0)
+    half = synth.make_queries(refs, 16, seed=54, sub=0.0, dele=0.0, ins=0.0, window=(0.25, 150))
+    for queries in (qs, half):
+        ff = {"fs-min-len": 100, "fs-full-len": 250}
+        pl = pipeline.Pipeline(st, famfinder=ff)
+        pl.run(queries.mask, queries.off)
+        _, n_copy = _check(oracle, refs, queries, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250))
+        assert n_copy >= 12
+        pl.close()
+        pl = pipeline.Pipeline(st, famfinder=ff, aligner={"realign": True})
+        pl.run(queries.mask, queries.off)
+        n_dp, n_copy = _check(oracle, refs, queries, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250),
+                              al=dict(realign=1))
+        assert n_copy == 0 and n_dp >= 12
+        pl.close()
+
+
+def test_pipeline_family_escalation_and_rejects(oracle, world):
+    """Default fs-min-len/full-len reject most of these short references: the candidate list
+    escalates 41 -> 410 -> all (famfinder.cpp:591-608) and some queries end with no relatives."""
+    refs, cs, idx, st = world
+    qs = synth.make_queries(refs, 12, seed=55)
+    pl = pipeline.Pipeline(st, famfinder={"fs-full-len": 318, "fs-min-len": 150})
+    pl.run(qs.mask, qs.off)
+    _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_full_len=318, fs_min_len=150))
+    pl.close()
+    pl = pipeline.Pipeline(st)   # SINA defaults: nothing is "full length" (>=1400) here
+    pl.run(qs.mask, qs.off)
+    _check(oracle, refs, qs, pl, cs, idx)
+    pl.close()
+
+
+def test_pipeline_weighted_scheme(oracle, world):
+    refs, cs, idx, st = world
+    rng = np.random.default_rng(8)
+    w = rng.uniform(0.3, 1.4, size=refs.width).astype(np.float32)
+    st.add_filter("posvar", w)
+    qs = synth.make_queries(refs, 12, seed=56)
+    ff = {"fs-min-len": 100, "fs-full-len": 250, "filter": "posvar"}
+    pl = pipeline.Pipeline(st, famfinder=ff)
+    pl.run(qs.mask, qs.off)
+    n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250),
+                     al=dict(weights=w))
+    assert n_dp >= 10
+    pl.close()
+
+
+def test_single_tray_batching_shim(oracle, world):
+    """batch=1: every tray goes through the stages alone, as SINA's TBB nodes would call them."""
+    refs, cs, idx, st = world
+    qs = synth.make_queries(refs, 6, seed=57)
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    pl = pipeline.Pipeline(st, famfinder=ff)
+    pl.run(qs.mask, qs.off, batch=1, inflight=3)
+    _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250))
+    pl.close()

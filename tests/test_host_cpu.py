@@ -1,0 +1,131 @@
+"""CPU tests of the host side: the C ABI library loads and exports every symbol the
+header declares, and the C++ stage mirror's host logic (cseq container, NAST fix-up,
+family DAG) agrees with the oracle.  No GPU compute is invoked here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from sina_amd import capi, pipeline, synth
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_abi_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "sina_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(sina_hip_[a-z_]+)\s*\(", hdr)))
+    assert declared == sorted(capi.ABI_SYMBOLS)
+    L = capi.load()
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.sina_hip_abi_version() == 1
+
+
+def test_abi_rejects_bad_arguments_without_gpu():
+    L = capi.load()
+    assert L.sina_hip_init(0, None) != 0
+    assert b"null" in L.sina_hip_last_error()
+    assert L.sina_hip_sync(None) != 0
+    p = capi.AlignParams()
+    L.sina_hip_align_params_default(C.byref(p))
+    assert (p.match_score, p.mismatch_score, p.gap_penalty, p.gap_ext_penalty, p.fs_weight) == (2, -1, 5, 2, 1)
+
+
+def _op(aligned, op=0, arg=0, what=0):
+    H = pipeline.load_host()
+    buf = C.create_string_buffer(4096)
+    n, w = C.c_uint32(), C.c_uint32()
+    rc = H.sina_host_cseq_op(aligned.encode(), op, arg, what, buf, len(buf), C.byref(n), C.byref(w))
+    return rc, buf.value.decode(), n.value, w.value
+
+
+def test_host_cseq_matches_reference_kats():
+    k = json.load(open(os.path.join(GOLD, "cseq_kat.json")))
+    rc, s, n, w = _op(k["rna_aligned"])
+    assert (rc, s, n, w) == (0, k["rna_aligned"], len(k["rna"]), len(k["rna_aligned"]))
+    assert _op(k["rna_aligned"], what=1)[1] == k["rna_aligned_dots"]
+    assert _op(k["rna_aligned"], what=3)[1] == k["rna"]
+    for wdt, s in k["setwidth_chain"]:
+        assert _op(k["rna_aligned"], 1, wdt)[:2] == (0, s)
+    assert _op(k["rna_aligned"], 1, k["setwidth_throws"])[0] == 2      # runtime_error
+    assert _op(k["rna_aligned"], 2)[1] == k["rna_aligned"][::-1]
+    assert _op(k["rna"], 3, what=3)[1] == k["complement_bases"]
+    low = k["rna_aligned"].lower()
+    assert _op(low, what=2)[1] == low.replace("u", "t")
+    assert _op(low, 4)[1] == k["rna_aligned"]
+    assert _op("ACGX")[0] == 3                                          # bad_character_exception
+
+
+def test_host_nast_fixup_equals_oracle(oracle):
+    """50 random position vectors per setting: positions, case flags, log text and
+    the throw/no-throw outcome must match the oracle."""
+    H = pipeline.load_host()
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    n_shift = n_throw = 0
+    for it in range(400):
+        n = int(rng.integers(1, 60))
+        width = int(rng.integers(n, n + 40)) if it % 5 else n   # tight widths force shifting
+        if it % 7 == 0:
+            width = max(1, n - int(rng.integers(1, 4)))        # more bases than columns: must throw
+        pos = np.sort(rng.integers(0, width, size=n)).astype(np.uint32)
+        if it % 3 == 0:
+            pos[rng.integers(0, n):] = pos[-1]                  # pile-up at the end
+        mask = rng.choice([1, 2, 4, 8], size=n).astype(np.uint32)
+        ab = (pos | (mask << 24)).astype(np.uint32)
+        for lowercase in (0, 1):
+            mine = ab.copy()
+            log = C.create_string_buffer(4096)
+            rc = H.sina_host_fix_duplicates(mine.ctypes.data_as(capi.u32p), n, width, lowercase, 0, log, len(log))
+            c = oracle.Cseq.from_packed("x", ab, width)
+            lg = oracle.new_log()
+            orc = L.so_cseq_fix_duplicate_positions(c.h, C.byref(lg), lowercase, 0)
+            otxt = oracle.log_text(lg)
+            L.so_log_free(C.byref(lg))
+            assert (rc == 2) == (orc == -1)
+            if rc == 0:
+                assert (mine == c.packed()).all()
+                assert log.value.decode() == otxt
+                n_shift += "shifting" in otxt
+            else:
+                n_throw += 1
+    assert n_shift > 20 and n_throw > 5     # the hard branches were exercised
+
+
+def test_host_family_graph_equals_oracle(oracle):
+    refs = synth.make_refs(80, length=300, width=3000, seed=41, amb_rate=0.02, lower_rate=0.03,
+                           long_del_prob=0.3)
+    cs = util.cseqs_from_refs(refs)
+    st = pipeline.Store(":mem:hostgraph", refs)
+    rng = np.random.default_rng(1)
+    try:
+        for fsw in (1.0, 0.0, 3.0):
+            for _ in range(6):
+                ids = rng.choice(refs.n, size=int(rng.integers(1, 41)), replace=False).astype(np.uint32)
+                g = st.build_graph(ids, fsw)
+                o = util.graph_dict([cs[i] for i in ids], fsw)
+                assert g["n"] == o["n"]
+                assert (g["pos"] == o["pos"]).all() and (g["mask"] == o["mask"]).all()
+                assert (util.f32_bits(g["weight"]) == util.f32_bits(o["weight"])).all()
+                assert (g["pred_off"] == o["pred_off"]).all() and (g["pred"] == o["pred"]).all()
+                assert (g["succ_minpos"] == o["succ_minpos"]).all()
+    finally:
+        st.close()
+
+
+def test_option_names_and_validation():
+    H = pipeline.load_host()
+    H.sina_host_reset_options()
+    assert H.sina_host_set_option(b"famfinder", b"fs-min", b"20") == 0
+    assert H.sina_host_set_option(b"aligner", b"overhang", b"edge") == 0
+    assert H.sina_host_set_option(b"aligner", b"overhang", b"sideways") != 0
+    assert H.sina_host_set_option(b"famfinder", b"no-such-option", b"1") != 0
+    H.sina_host_reset_options()
+    assert not H.sina_host_pipeline_create()          # no --db: "Must have reference database"
+    assert b"reference database" in H.sina_host_last_error()

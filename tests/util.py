@@ -9,7 +9,7 @@ from sina_amd import synth
 
 def cseqs_from_refs(refs, idxs=None):
     idxs = range(refs.n) if idxs is None else idxs
-    return [po.Cseq.from_packed("r%d" % i, refs.seq(i), refs.width) for i in idxs]
+    return [po.Cseq.from_packed("ref%d" % i, refs.seq(i), refs.width) for i in idxs]
 
 
 def query_cseq(qs, i, upper=True):
