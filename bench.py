@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned sequences/sec of the SINA hot path on MI355X.
+
+Metric (BASELINE.json): aligned sequences / second, whole job, index build
+excluded -- the definition SINA prints (reference src/sina.cpp:584-589).
+
+Workload at N=1 (config.workload): BASELINE.json configs[1] -- full-length 16S
+queries (~1500 bp) against a 100k-sequence SILVA-NR-like aligned reference
+(synthetic clade model of SURVEY.md section 8d, alignment width 50 000, seed 2),
+SINA default options.  One "step" = one batch of --batch queries through
+famfinder (k-mer search + family selection) and aligner (family DAG, mesh DP,
+backtrack, NAST fix-up).  Queries, references and index are resident before the
+timed region; every rank runs its own K steps on its own queries (weak scaling,
+no per-step collective; one RCCL broadcast of the index at start-up).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--refs R]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+DP_BYTES_PER_CELL = 8          # two u32 trace-back indices per mesh cell (algorithmic)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="queries per step and rank")
+    ap.add_argument("--refs", type=int, default=100000)
+    ap.add_argument("--length", type=int, default=1500)
+    ap.add_argument("--width", type=int, default=50000)
+    ap.add_argument("--window", type=int, default=0, help="cut queries to this many bases (V4: 250)")
+    ap.add_argument("--inflight", type=int, default=3, help="batches worked on concurrently per rank")
+    ap.add_argument("--sub-batch", type=int, default=1024, help="queries per GPU launch inside a step")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="queries for the CPU baseline (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-graph", action="store_true", help="build family DAGs on the host")
+    return ap.parse_args()
+
+
+def cpu_baseline(refs, qs, n_sample, threads):
+    """Times the oracle (CPU restatement, test infrastructure) on a bounded sample of the same
+    workload, all host threads.  Reported beside the GPU number; never part of it."""
+    from oracle import pyoracle as po
+    t0 = time.time()
+    cs = [po.Cseq.from_packed("ref%d" % i, refs.seq(i), refs.width) for i in range(refs.n)]
+    idx = po.Index(cs, k=10)
+    build_s = time.time() - t0
+    queries = []
+    for i in range(n_sample):
+        m = qs.seq(i)
+        ab = np.arange(len(m), dtype=np.uint32) | (m.astype(np.uint32) << 24)
+        queries.append(po.Cseq.from_packed("q%d" % i, ab, len(m)))
+    r = po.bench_run(idx, queries, threads)
+    return dict(value=r["aligned"] / r["seconds"], unit="sequences/s", cores=threads, kind="port",
+                sample="%d of the same synthetic queries vs the same %d references, oracle (plain C restatement), "
+                       "%d threads, %.1f s wall, %.1f Mcell/s; index build %.0f s not timed"
+                       % (n_sample, refs.n, threads, r["seconds"], r["cells"] / r["seconds"] / 1e6, build_s))
+
+
+def main():
+    a = parse()
+    import torch
+    from sina_amd import dist as sdist
+    from sina_amd import pipeline, synth
+
+    rank, local_rank, world, dist = sdist.init()
+    if world != a.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    # ---- synthetic inputs (identical on every rank; queries differ per rank)
+    refs = synth.make_refs(a.refs, length=a.length, width=a.width, seed=2)
+    n_q = a.batch * (a.steps + a.warmup)
+    window = (1.0 / 3.0, a.window) if a.window else None
+    qs = synth.make_queries(refs, n_q, seed=3 + 1000 * rank, window=window)
+
+    # ---- resident state: references + index in HBM, stages constructed
+    store = pipeline.Store(":mem:bench", refs, device=local_rank)
+    t_idx = time.time()
+    if world > 1:
+        n_post = sdist.broadcast_device_index(store, 10, False, rank, dist, device)
+    else:
+        store.build_index(10, False)
+        n_post = None
+    idx_s = time.time() - t_idx
+    al_opts = {"device-graph": not a.host_graph}
+    pl = pipeline.Pipeline(store, aligner=al_opts)
+
+    def run_steps(first, count):
+        lo, hi = qs.off[first * a.batch], qs.off[(first + count) * a.batch]
+        off = (qs.off[first * a.batch:(first + count) * a.batch + 1] - lo).astype(np.uint64)
+        return pl.run(qs.mask[lo:hi], off, batch=a.sub_batch, inflight=a.inflight)
+
+    if a.warmup:
+        run_steps(0, a.warmup)
+    s0 = store.stats()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.time()
+    timing = run_steps(a.warmup, a.steps)
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.time() - t0
+    s1 = store.stats()
+
+    n_done = a.batch * a.steps
+    n_aligned = sum(1 for q in range(n_done) if pl.result(q)["status"] in (0, 1))
+    if dist is not None:
+        elapsed = sdist.reduce_max(elapsed, dist, device)
+        n_aligned = int(sdist.reduce_sum(n_aligned, dist, device))
+    dp_ms = s1["dp_ms"] - s0["dp_ms"]
+    dp_cells = s1["dp_cells"] - s0["dp_cells"]
+    dp_launches = s1["dp_launches"] - s0["dp_launches"]
+    achieved = DP_BYTES_PER_CELL * dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "aligned sequences/sec (whole node), 100k full-length 16S vs SILVA-NR-scale ref",
+            "value": n_aligned / elapsed,
+            "unit": "sequences/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: full-length 16S (~%d bp%s) vs %d-seq SILVA-NR-like aligned reference, "
+                            "width %d, SINA defaults (k=10 fast, family 40, match 2/mismatch -1/gap 5/ext 2)"
+                            % (a.length, (", cut to %d" % a.window) if a.window else "", a.refs, a.width),
+                "queries_per_step_per_gpu": a.batch,
+                "queries_per_launch": a.sub_batch,
+                "inflight_batches": a.inflight,
+                "family_dag": "host" if a.host_graph else "device",
+                "sharding": "queries block-sharded over %d rank(s); index %s" %
+                            (world, "RCCL-broadcast from rank 0" if world > 1 else "built on device"),
+                "index_build_s": idx_s,
+            },
+            "roofline": {
+                "kernel": "mesh_dp_kernel",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "cells_per_launch": dp_cells / dp_launches if dp_launches else 0,
+                "ms_per_launch": dp_ms / dp_launches if dp_launches else 0,
+                "gcells_per_s": dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0,
+            },
+            "stages_ms_per_step": {
+                "famfinder_host_wall": 1e3 * timing["famfinder_s"] / a.steps,
+                "aligner_host_wall": 1e3 * timing["aligner_s"] / a.steps,
+                "kmer_count_kernel": (s1["kmer_count_ms"] - s0["kmer_count_ms"]) / a.steps,
+                "kmer_select_kernel": (s1["kmer_select_ms"] - s0["kmer_select_ms"]) / a.steps,
+                "graph_kernel": (s1["graph_ms"] - s0["graph_ms"]) / a.steps,
+                "mesh_dp_kernel": dp_ms / a.steps,
+                "backtrack_kernel": (s1["backtrack_ms"] - s0["backtrack_ms"]) / a.steps,
+            },
+        }
+        if not a.no_cpu_baseline and world == 1:
+            threads = os.cpu_count() or 1
+            n_sample = a.cpu_sample or min(n_q, max(64, 8 * threads))
+            out["cpu_baseline"] = cpu_baseline(refs, qs, n_sample, threads)
+        print(json.dumps(out))
+    pl.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

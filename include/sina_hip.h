@@ -186,8 +186,8 @@ int sina_hip_debug_mesh(sina_hip_ctx *ctx, const sina_hip_graph_batch *g, const 
                         uint32_t qlen, const sina_hip_align_params *p, uint32_t *tb_vm,
                         uint32_t *tb_vs, float *value);
 
-/* Statistics of the most recent sina_hip_align_* / kmer_topk call on this
- * context (kernel time from HIP events on the context's stream). */
+/* Cumulative statistics of this context since sina_hip_init (callers take
+ * differences); kernel times come from HIP events on the context stream. */
 typedef struct sina_hip_stats {
     double dp_ms;          /* mesh DP fill kernel(s)                  */
     double backtrack_ms;   /* backtrack walk kernel                   */

@@ -130,6 +130,9 @@ def lib():
         L.so_score_op.restype = C.c_float
         L.so_score_op.argtypes = [C.c_int, C.c_float, C.c_uint32, C.c_int, C.c_float, C.c_int, C.c_int,
                                   C.c_float, C.c_float, C.c_float, C.c_float, f32p, C.c_uint32]
+        L.so_bench_run.restype = C.c_double
+        L.so_bench_run.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(FFOpts),
+                                   C.POINTER(AlignOpts), C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.so_log_init.argtypes = [C.POINTER(Log)]
         L.so_log_free.argtypes = [C.POINTER(Log)]
         _lib = L
@@ -376,3 +379,15 @@ def align(fam, query, opts=None):
              cells=res.cells, log=txt, packed=out.packed(), width=out.width)
     d["aligned"] = out.aligned() if res.status in (0, 1) else None
     return d
+
+
+def bench_run(index, queries, threads, ff=None, al=None):
+    """Times the oracle's whole path over `queries` (list of Cseq) on `threads` host threads.
+    Returns dict(seconds, cells, aligned)."""
+    ff = ff or ff_opts()
+    al = al or align_opts()
+    qh = handles(queries)
+    cells, aligned = C.c_uint64(), C.c_uint32()
+    sec = lib().so_bench_run(index.h, index._h, qh, len(queries), C.byref(ff), C.byref(al), threads,
+                             C.byref(cells), C.byref(aligned))
+    return dict(seconds=sec, cells=cells.value, aligned=aligned.value)

@@ -1275,13 +1275,22 @@ part_done:;
             goto done;
         }
         uint32_t L = c->n;
-        so_cell *cells = (so_cell *)malloc(sizeof(so_cell) * (size_t)g->n * L);
+        /* per-thread scratch, grown on demand and kept: the reference's mesh comes from
+         * tbb's caching allocator (align.cpp:484-488), so a fresh 100+ MB mmap per query
+         * would understate the CPU baseline */
+        static __thread so_cell *tl_cells = NULL;
+        static __thread size_t tl_cap = 0;
+        if ((size_t)g->n * L > tl_cap) {
+            free(tl_cells);
+            tl_cap = (size_t)g->n * L + ((size_t)g->n * L >> 3);
+            tl_cells = (so_cell *)malloc(sizeof(so_cell) * tl_cap);
+        }
+        so_cell *cells = tl_cells;
         so_mesh_compute(g, c->ab, L, o, cells); /* do_align :495 */
         so_cseq_clear(out);                     /* c.clearSequence() :498 */
         memcpy(out->name, c->name, sizeof(out->name));
         float score = so_backtrack(g, c->ab, L, cells, o, out, &res->head, &res->tail, log);
         res->cells = (uint64_t)g->n * L;
-        free(cells);
         so_graph_free(g);
         if (score == -1e30f) {
             res->status = -1;

@@ -110,9 +110,6 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
                                 hipMemcpyHostToDevice, c->stream));
     }
 
-    c->stats.dp_ms = c->stats.backtrack_ms = 0;
-    c->stats.dp_cells = 0;
-    c->stats.dp_launches = 0;
     const uint64_t tb_budget_cells = c->tb_budget_bytes / 4;
     HostPrep hp;
     uint32_t q0 = 0;

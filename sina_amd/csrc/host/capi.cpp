@@ -69,6 +69,36 @@ int sina_host_add_filter(const char *key, const char *name, const float *weights
     }
 }
 
+// Device context of a store (creates it and uploads the references on first use): lets a
+// launcher reach sina_hip_store_view_get / sina_hip_store_alloc_like for the start-up
+// broadcast of the index over RCCL.
+void *sina_host_store_ctx(const char *key) {
+    try {
+        return reference_store::get(key)->device();
+    } catch (const std::exception &e) {
+        fail(e);
+        return nullptr;
+    }
+}
+int sina_host_store_build_index(const char *key, unsigned k, int nofast) {
+    try {
+        reference_store::get(key)->ensure_index(k, nofast != 0);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+// After the index arrived by broadcast (sina_hip_store_alloc_like + RCCL): tell the store
+// not to rebuild it.
+int sina_host_store_index_ready(const char *key, unsigned k, int nofast) {
+    try {
+        reference_store::get(key)->adopt_index(k, nofast != 0);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
 int sina_host_reset_options(void) {
     famfinder::reset_options();
     aligner::reset_options();

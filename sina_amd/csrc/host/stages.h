@@ -129,6 +129,11 @@ public:
     void set_device(int device) { device_id = device; }
     sina_hip_ctx *device();                    // lazily creates the context and uploads the references
     void ensure_index(unsigned k, bool nofast);  // builds the k-mer index on the GPU once per (k, nofast)
+    void adopt_index(unsigned k, bool nofast) {  // index already in HBM (broadcast from another rank)
+        std::lock_guard<std::mutex> lk(gpu_mu);
+        idx_k = (int)k;
+        idx_nofast = nofast;
+    }
     std::mutex &gpu_mutex() { return gpu_mu; }
 
 private:

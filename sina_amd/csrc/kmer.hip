@@ -461,9 +461,6 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
     const uint64_t nqm = qoff[nq] - qoff[0];
     // sub-batches bound the [nq][n_refs] int16 score matrix to ~2 GiB
     const uint32_t per = (uint32_t)std::max<uint64_t>(1, ((uint64_t)2 << 30) / (2ull * std::max<uint32_t>(c->n_refs, 1)));
-    c->stats.kmer_count_ms = c->stats.kmer_select_ms = 0;
-    c->stats.postings = 0;
-    c->stats.kmer_launches = 0;
     if (c->qmask.reserve(std::max<uint64_t>(nqm, 1)) || c->k_qoff.reserve(8 * ((uint64_t)nq + 1))) return 1;
     std::vector<uint64_t> rel(nq + 1);
     for (uint32_t q = 0; q <= nq; q++) rel[q] = qoff[q] - qoff[0];

@@ -50,6 +50,10 @@ def load_host():
                                     capi.u32p]
     H.sina_host_fix_duplicates.argtypes = [capi.u32p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_char_p,
                                            C.c_uint32]
+    H.sina_host_store_ctx.restype = vp
+    H.sina_host_store_ctx.argtypes = [C.c_char_p]
+    H.sina_host_store_build_index.argtypes = [C.c_char_p, C.c_uint, C.c_int]
+    H.sina_host_store_index_ready.argtypes = [C.c_char_p, C.c_uint, C.c_int]
     _host = H
     return H
 
@@ -96,6 +100,25 @@ class Store:
         n, e = nn.value, ne.value
         return dict(n=n, pos=pos[:n].copy(), mask=mask[:n].copy(), weight=w[:n].copy(),
                     pred_off=poff[:n + 1].copy(), pred=pred[:e].copy(), succ_minpos=smin[:n].copy())
+
+    def ctx_handle(self):
+        """Raw sina_hip_ctx* of this store (device context with the references uploaded)."""
+        h = self.H.sina_host_store_ctx(self.key.encode())
+        if not h:
+            raise HostError(self.H.sina_host_last_error().decode())
+        return C.c_void_p(h)
+
+    def build_index(self, k=10, nofast=False):
+        _chk(self.H.sina_host_store_build_index(self.key.encode(), k, int(nofast)))
+
+    def index_ready(self, k=10, nofast=False):
+        _chk(self.H.sina_host_store_index_ready(self.key.encode(), k, int(nofast)))
+
+    def stats(self):
+        s = capi.Stats()
+        if capi.load().sina_hip_get_stats(self.ctx_handle(), C.byref(s)) != 0:
+            raise HostError("get_stats failed")
+        return {f[0]: getattr(s, f[0]) for f in capi.Stats._fields_}
 
     def close(self):
         self.H.sina_host_store_close(self.key.encode())
