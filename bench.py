@@ -111,6 +111,7 @@ def main():
 
     if a.warmup:
         run_steps(0, a.warmup)
+        pl.profile(reset=True)
     s0 = store.stats()
     if dist is not None:
         dist.barrier()
@@ -133,6 +134,8 @@ def main():
     dp_launches = s1["dp_launches"] - s0["dp_launches"]
     achieved = DP_BYTES_PER_CELL * dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
 
+    if rank == 0 and os.environ.get("SINA_HOST_PROFILE"):
+        print(pl.profile(), file=sys.stderr)
     if rank == 0:
         out = {
             "metric": "aligned sequences/sec (whole node), 100k full-length 16S vs SILVA-NR-scale ref",

@@ -18,25 +18,34 @@ static size_t env_size(const char *name, size_t dflt) {
     return (size_t)strtoull(v, nullptr, 10);
 }
 
-// Host-side preparation shared by the host-graph and device-graph paths: given
-// per-query N, L and the pred CSR on the HOST, fills descriptors, sink flags and
-// spill assignment for ring depth W.
+int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl) {
+    if (!pick_geom(maxL, &pl->geom)) SH_FAIL("align: query longer than the largest DP geometry (6144)");
+    const size_t slot = dp_slot_bytes(pl->geom), fixed = dp_fixed_lds_bytes(pl->geom);
+    size_t budget = c->lds_budget;
+    if (budget < fixed + slot) budget = fixed + slot;
+    if (budget > 160 * 1024) budget = 160 * 1024;
+    int W = (int)((budget - fixed) / slot);
+    if (W < 1) SH_FAIL("align: LDS cannot hold one DP row");
+    W = std::min(W, dp_max_ring(pl->geom));
+    pl->W = W;
+    pl->lds = fixed + (size_t)W * slot;
+    return 0;
+}
+
+// Host-side preparation of a range of host-built graphs: descriptors, row records
+// (sink flag, spill slot for rows with a successor further than W rows away).
 struct HostPrep {
     std::vector<QDesc> qd;
-    std::vector<uint32_t> pred_off;   // concatenated, N+1 per query
-    std::vector<uint32_t> spill_idx;  // per node
-    std::vector<uint8_t> flags;       // per node
+    std::vector<uint4> rec;
     uint64_t tb_cells = 0, spill_rows = 0, cells = 0;
 };
 
-static void prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint32_t q0, uint32_t q1,
-                       int Lp, int W, HostPrep *hp) {
+static void prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint32_t q0, uint32_t q1, int Lp, int W,
+                       HostPrep *hp) {
     const uint64_t nbase = g->node_off[q0], ebase = g->edge_off[q0];
     const uint64_t nn = g->node_off[q1] - nbase;
     hp->qd.resize(q1 - q0);
-    hp->pred_off.resize(nn + (q1 - q0));
-    hp->spill_idx.assign(nn, 0xFFFFFFFFu);
-    hp->flags.assign(nn, 1);  // sink until a successor shows up
+    hp->rec.resize(nn);
     hp->tb_cells = hp->spill_rows = hp->cells = 0;
     for (uint32_t q = q0; q < q1; q++) {
         QDesc &d = hp->qd[q - q0];
@@ -44,7 +53,6 @@ static void prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint
         const uint32_t N = (uint32_t)(g->node_off[q + 1] - no);
         d.node_off = no - nbase;
         d.edge_off = eo - ebase;
-        d.poff_off = (no - nbase) + (q - q0);
         d.q_off = qoff[q] - qoff[q0];
         d.tb_off = hp->tb_cells;
         d.spill_off = hp->spill_rows;
@@ -52,20 +60,25 @@ static void prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint
         d.L = (uint32_t)(qoff[q + 1] - qoff[q]);
         d.pad = 0;
         const uint32_t *po = g->pred_off + no + q;  // N+1 entries, relative to eo
-        uint32_t *dst = hp->pred_off.data() + d.poff_off;
-        memcpy(dst, po, sizeof(uint32_t) * (N + 1));
-        uint32_t nsp = 0;
-        uint32_t *sp = hp->spill_idx.data() + d.node_off;
-        uint8_t *fl = hp->flags.data() + d.node_off;
+        uint4 *rec = hp->rec.data() + d.node_off;
+        for (uint32_t m = 0; m < N; m++) {
+            uint32_t wbits;
+            memcpy(&wbits, &g->node_weight[no + m], 4);
+            rec[m].x = po[m];
+            rec[m].y = wbits;
+            rec[m].z = ((po[m + 1] - po[m]) & 0xffu) | ((uint32_t)(g->node_mask[no + m] & 0xffu) << 8) | kRecSink;
+            rec[m].w = 0xFFFFFFFFu;
+        }
         for (uint32_t m = 0; m < N; m++) {
             for (uint32_t e = po[m]; e < po[m + 1]; e++) {
                 const uint32_t p = g->pred[eo + e];
-                fl[p] = 0;
-                if (m - p > (uint32_t)W && sp[p] == 0xFFFFFFFFu) sp[p] = 0;  // mark
+                rec[p].z &= ~kRecSink;
+                if (m - p > (uint32_t)W) rec[p].w = 0;  // mark: needs a spill row
             }
         }
+        uint32_t nsp = 0;
         for (uint32_t m = 0; m < N; m++)
-            if (sp[m] == 0) sp[m] = nsp++;
+            if (rec[m].w == 0) rec[m].w = nsp++;
         d.n_spill = nsp;
         hp->spill_rows += nsp;
         hp->tb_cells += (uint64_t)N * Lp;
@@ -73,15 +86,88 @@ static void prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint
     }
 }
 
+// Runs DP + backtrack for bq queries whose graphs (qd, rec, pred, node_pos, succ_minpos) and
+// query masks are already in the context's device buffers; copies results back.
+int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, uint32_t bq, uint64_t tb_cells, uint64_t spill_rows,
+                  uint64_t cells, uint64_t nqm, const sina_hip_align_params *p, uint32_t width,
+                  sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value) {
+    hipStream_t s = c->stream;
+    const int Lp = pl.geom.Lp();
+    const bool weighted = p->weights != nullptr && p->n_weights > 0;
+    const bool forbid = p->insertion == SINA_INSERTION_FORBID;
+    if (c->tb.reserve(4 * tb_cells) || c->spill.reserve(std::max<uint64_t>(spill_rows, 1) * 12 * (uint64_t)Lp) ||
+        c->res.reserve(sizeof(DpResult) * bq) || c->out.reserve(sizeof(sina_hip_align_out) * bq) ||
+        c->out_pos.reserve(4 * std::max<uint64_t>(nqm, 1)))
+        return 1;
+    if (want_dbg_value && c->dbg.reserve(4 * tb_cells)) return 1;
+    DpArgs a;
+    a.qd = c->qd.as<QDesc>();
+    a.rec = c->rec.as<uint4>();
+    a.pred = c->pred.as<uint32_t>();
+    a.node_pos = c->node_pos.as<uint32_t>();
+    a.succ_minpos = c->succ_minpos.as<uint32_t>();
+    a.qmask = c->qmask.as<uint8_t>();
+    a.tb = c->tb.as<uint32_t>();
+    a.dbg_value = want_dbg_value ? c->dbg.as<float>() : nullptr;
+    a.spill = c->spill.as<float>();
+    a.res = c->res.as<DpResult>();
+    a.weights = weighted ? c->weights.as<float>() : nullptr;
+    a.n_weights = weighted ? p->n_weights : 0;
+    a.ms = -p->match_score;  // scoring_scheme_*(-match, -mismatch, gap, gapext), align.cpp:406-414
+    a.mms = -p->mismatch_score;
+    a.gp = p->gap_penalty;
+    a.gpe = p->gap_ext_penalty;
+    a.W = pl.W;
+
+    SH_CHECK(hipEventRecord(c->ev[0], s));
+    if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, s)) return 1;
+    SH_CHECK(hipEventRecord(c->ev[1], s));
+    BtArgs b;
+    b.qd = a.qd;
+    b.rec = a.rec;
+    b.node_pos = a.node_pos;
+    b.tb = a.tb;
+    b.res = a.res;
+    b.weights = a.weights;
+    b.n_weights = a.n_weights;
+    b.out = c->out.as<sina_hip_align_out>();
+    b.out_pos = c->out_pos.as<uint32_t>();
+    b.nq = bq;
+    b.width = width;
+    b.Lp = (uint32_t)Lp;
+    b.ms = a.ms;
+    b.overhang = p->overhang;
+    if (launch_backtrack(b, s)) return 1;
+    SH_CHECK(hipEventRecord(c->ev[2], s));
+    SH_CHECK(hipMemcpyAsync(out, c->out.p, sizeof(sina_hip_align_out) * bq, hipMemcpyDeviceToHost, s));
+    SH_CHECK(hipMemcpyAsync(out_pos, c->out_pos.p, 4 * nqm, hipMemcpyDeviceToHost, s));
+    SH_CHECK(hipStreamSynchronize(s));
+    float ms = 0;
+    SH_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->stats.dp_ms += ms;
+    SH_CHECK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+    c->stats.backtrack_ms += ms;
+    c->stats.dp_cells += cells;
+    c->stats.dp_launches++;
+    return 0;
+}
+
+int upload_weights(sina_hip_ctx *c, const sina_hip_align_params *p) {
+    if (p->weights != nullptr && p->n_weights > 0) {
+        if (c->weights.reserve(sizeof(float) * p->n_weights)) return 1;
+        SH_CHECK(hipMemcpyAsync(c->weights.p, p->weights, sizeof(float) * p->n_weights, hipMemcpyHostToDevice,
+                                c->stream));
+    }
+    return 0;
+}
+
 static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, const uint8_t *qmask,
-                             const uint64_t *qoff, const sina_hip_align_params *p,
-                             sina_hip_align_out *out, uint32_t *out_pos, float *dbg_value_host,
-                             uint32_t *dbg_vm, uint32_t *dbg_vs) {
+                             const uint64_t *qoff, const sina_hip_align_params *p, sina_hip_align_out *out,
+                             uint32_t *out_pos, float *dbg_value_host, uint32_t *dbg_vm, uint32_t *dbg_vs) {
     if (!c || !g || !qmask || !qoff || !p || !out || !out_pos) SH_FAIL("align_graphs: null argument");
     const uint32_t nq = g->nq;
     if (nq == 0) return 0;
     SH_CHECK(hipSetDevice(c->device));
-    const bool weighted = p->weights != nullptr && p->n_weights > 0;
     const bool forbid = p->insertion == SINA_INSERTION_FORBID;
     if (forbid && !g->succ_minpos) SH_FAIL("align_graphs: insertion=forbid needs succ_minpos");
     uint32_t maxL = 0;
@@ -92,23 +178,10 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         if (L > 65535 || N > 65535) SH_FAIL("align_graphs: N or L exceeds 16-bit trace-back fields");
         maxL = std::max<uint32_t>(maxL, (uint32_t)L);
     }
-    DpGeom geom;
-    if (!pick_geom(maxL, &geom)) SH_FAIL("align_graphs: query longer than the largest DP geometry (6144)");
-    const int Lp = geom.Lp();
-    const size_t slot = dp_slot_bytes(geom), fixed = dp_fixed_lds_bytes(geom);
-    size_t budget = c->lds_budget;
-    if (budget < fixed + slot) budget = fixed + slot;
-    if (budget > 160 * 1024) budget = 160 * 1024;
-    int W = (int)((budget - fixed) / slot);
-    if (W < 1) SH_FAIL("align_graphs: LDS cannot hold one DP row");
-    if (W > 64) W = 64;
-    const size_t lds = fixed + (size_t)W * slot;
-
-    if (weighted) {
-        if (c->weights.reserve(sizeof(float) * p->n_weights)) return 1;
-        SH_CHECK(hipMemcpyAsync(c->weights.p, p->weights, sizeof(float) * p->n_weights,
-                                hipMemcpyHostToDevice, c->stream));
-    }
+    DpPlan pl;
+    if (plan_dp(c, maxL, &pl)) return 1;
+    const int Lp = pl.geom.Lp();
+    if (upload_weights(c, p)) return 1;
 
     const uint64_t tb_budget_cells = c->tb_budget_bytes / 4;
     HostPrep hp;
@@ -124,98 +197,35 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
             q1++;
         }
         if (dbg_vm) q1 = q0 + 1;
-        prep_range(g, qoff, q0, q1, Lp, W, &hp);
+        prep_range(g, qoff, q0, q1, Lp, pl.W, &hp);
         const uint32_t bq = q1 - q0;
         const uint64_t nbase = g->node_off[q0], nn = g->node_off[q1] - nbase;
         const uint64_t ebase = g->edge_off[q0], ne = g->edge_off[q1] - ebase;
         const uint64_t qbase = qoff[q0], nqm = qoff[q1] - qbase;
-
-        if (c->qd.reserve(sizeof(QDesc) * bq) || c->node_pos.reserve(4 * nn) || c->node_mask.reserve(nn) ||
-            c->node_weight.reserve(4 * nn) || c->pred_off.reserve(4 * (nn + bq)) ||
+        if (c->qd.reserve(sizeof(QDesc) * bq) || c->rec.reserve(sizeof(uint4) * nn) || c->node_pos.reserve(4 * nn) ||
             c->pred.reserve(4 * std::max<uint64_t>(ne, 1)) || c->succ_minpos.reserve(4 * nn) ||
-            c->spill_idx.reserve(4 * nn) || c->node_flags.reserve(nn) || c->qmask.reserve(nqm) ||
-            c->tb.reserve(4 * hp.tb_cells) ||
-            c->spill.reserve(std::max<uint64_t>(hp.spill_rows, 1) * 12 * (uint64_t)Lp) ||
-            c->res.reserve(sizeof(DpResult) * bq) || c->out.reserve(sizeof(sina_hip_align_out) * bq) ||
-            c->out_pos.reserve(4 * nqm))
+            c->qmask.reserve(nqm))
             return 1;
         hipStream_t s = c->stream;
         SH_CHECK(hipMemcpyAsync(c->qd.p, hp.qd.data(), sizeof(QDesc) * bq, hipMemcpyHostToDevice, s));
+        SH_CHECK(hipMemcpyAsync(c->rec.p, hp.rec.data(), sizeof(uint4) * nn, hipMemcpyHostToDevice, s));
         SH_CHECK(hipMemcpyAsync(c->node_pos.p, g->node_pos + nbase, 4 * nn, hipMemcpyHostToDevice, s));
-        SH_CHECK(hipMemcpyAsync(c->node_mask.p, g->node_mask + nbase, nn, hipMemcpyHostToDevice, s));
-        SH_CHECK(hipMemcpyAsync(c->node_weight.p, g->node_weight + nbase, 4 * nn, hipMemcpyHostToDevice, s));
-        SH_CHECK(hipMemcpyAsync(c->pred_off.p, hp.pred_off.data(), 4 * (nn + bq), hipMemcpyHostToDevice, s));
         if (ne) SH_CHECK(hipMemcpyAsync(c->pred.p, g->pred + ebase, 4 * ne, hipMemcpyHostToDevice, s));
         if (g->succ_minpos)
             SH_CHECK(hipMemcpyAsync(c->succ_minpos.p, g->succ_minpos + nbase, 4 * nn, hipMemcpyHostToDevice, s));
-        SH_CHECK(hipMemcpyAsync(c->spill_idx.p, hp.spill_idx.data(), 4 * nn, hipMemcpyHostToDevice, s));
-        SH_CHECK(hipMemcpyAsync(c->node_flags.p, hp.flags.data(), nn, hipMemcpyHostToDevice, s));
         SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qbase, nqm, hipMemcpyHostToDevice, s));
-        float *dbg_dev = nullptr;
-        if (dbg_value_host) {
-            if (c->dbg.reserve(4 * hp.tb_cells)) return 1;
-            dbg_dev = c->dbg.as<float>();
-        }
-
-        DpArgs a;
-        a.qd = c->qd.as<QDesc>();
-        a.node_pos = c->node_pos.as<uint32_t>();
-        a.node_mask = c->node_mask.as<uint8_t>();
-        a.node_weight = c->node_weight.as<float>();
-        a.pred_off = c->pred_off.as<uint32_t>();
-        a.pred = c->pred.as<uint32_t>();
-        a.succ_minpos = c->succ_minpos.as<uint32_t>();
-        a.spill_idx = c->spill_idx.as<uint32_t>();
-        a.node_flags = c->node_flags.as<uint8_t>();
-        a.qmask = c->qmask.as<uint8_t>();
-        a.tb = c->tb.as<uint32_t>();
-        a.dbg_value = dbg_dev;
-        a.spill = c->spill.as<float>();
-        a.res = c->res.as<DpResult>();
-        a.weights = weighted ? c->weights.as<float>() : nullptr;
-        a.n_weights = weighted ? p->n_weights : 0;
-        a.ms = -p->match_score;      // scoring_scheme_*(-match, -mismatch, gap, gapext), align.cpp:406-414
-        a.mms = -p->mismatch_score;
-        a.gp = p->gap_penalty;
-        a.gpe = p->gap_ext_penalty;
-        a.W = W;
-
-        SH_CHECK(hipEventRecord(c->ev[0], s));
-        if (launch_mesh_dp(geom, weighted, forbid, a, bq, lds, s)) return 1;
-        SH_CHECK(hipEventRecord(c->ev[1], s));
-
-        BtArgs b;
-        b.qd = a.qd;
-        b.node_pos = a.node_pos;
-        b.node_weight = a.node_weight;
-        b.pred_off = a.pred_off;
-        b.tb = a.tb;
-        b.res = a.res;
-        b.weights = a.weights;
-        b.n_weights = a.n_weights;
-        b.out = c->out.as<sina_hip_align_out>();
-        b.out_pos = c->out_pos.as<uint32_t>();
-        b.nq = bq;
-        b.width = g->width;
-        b.Lp_T = (uint32_t)geom.T;
-        b.Lp_B = (uint32_t)geom.B;
-        b.ms = a.ms;
-        b.overhang = p->overhang;
-        if (launch_backtrack(b, s)) return 1;
-        SH_CHECK(hipEventRecord(c->ev[2], s));
-
-        SH_CHECK(hipMemcpyAsync(out + q0, c->out.p, sizeof(sina_hip_align_out) * bq, hipMemcpyDeviceToHost, s));
-        SH_CHECK(hipMemcpyAsync(out_pos + qbase, c->out_pos.p, 4 * nqm, hipMemcpyDeviceToHost, s));
+        if (run_dp_device(c, pl, bq, hp.tb_cells, hp.spill_rows, hp.cells, nqm, p, g->width, out + q0,
+                          out_pos + qbase, dbg_value_host != nullptr))
+            return 1;
         if (dbg_vm) {  // single-query debug: unpack the planes
             const QDesc &d = hp.qd[0];
             std::vector<uint32_t> tbh((size_t)d.N * Lp);
-            SH_CHECK(hipMemcpyAsync(tbh.data(), c->tb.p, 4 * tbh.size(), hipMemcpyDeviceToHost, s));
+            SH_CHECK(hipMemcpy(tbh.data(), c->tb.p, 4 * tbh.size(), hipMemcpyDeviceToHost));
             std::vector<float> vh;
             if (dbg_value_host) {
                 vh.resize(tbh.size());
-                SH_CHECK(hipMemcpyAsync(vh.data(), c->dbg.p, 4 * vh.size(), hipMemcpyDeviceToHost, s));
+                SH_CHECK(hipMemcpy(vh.data(), c->dbg.p, 4 * vh.size(), hipMemcpyDeviceToHost));
             }
-            SH_CHECK(hipStreamSynchronize(s));
             for (uint32_t m = 0; m < d.N; m++)
                 for (uint32_t x = 0; x < d.L; x++) {
                     const uint32_t cell = tbh[(size_t)m * Lp + x];
@@ -224,14 +234,6 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
                     if (dbg_value_host) dbg_value_host[(size_t)m * d.L + x] = vh[(size_t)m * Lp + x];
                 }
         }
-        SH_CHECK(hipStreamSynchronize(s));
-        float ms = 0;
-        SH_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-        c->stats.dp_ms += ms;
-        SH_CHECK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
-        c->stats.backtrack_ms += ms;
-        c->stats.dp_cells += hp.cells;
-        c->stats.dp_launches++;
         q0 = q1;
     }
     return 0;
@@ -256,7 +258,7 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
     c->device = device;
     SH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
-    c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 80) * 1024;
+    c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 36) * 1024;
     c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 24) << 30;
     memset(&c->stats, 0, sizeof(c->stats));
     *ctx = c;

@@ -55,15 +55,21 @@ struct DevBuf {
 
 // Per-query descriptor of one DP problem inside a batch.
 struct QDesc {
-    uint64_t node_off;   // into node arrays
+    uint64_t node_off;   // into the node arrays (rec, node_pos, succ_minpos)
     uint64_t edge_off;   // into pred
-    uint64_t poff_off;   // into pred_off (N+1 entries)
     uint64_t q_off;      // into qmask / out_pos
     uint64_t tb_off;     // into traceback plane (u32 cells), row stride = Lp
     uint64_t spill_off;  // into spill rows (row units)
     uint32_t N, L;
     uint32_t n_spill, pad;
 };
+
+// Row record of one DAG node, read through the scalar cache once per row:
+//   x = first predecessor (offset into this query's pred list)
+//   y = node weight (float bits, mseq.cpp:113)
+//   z = #pred | iupac mask << 8 | flags << 16   (flags bit0: sink = no successors)
+//   w = spill row index, or 0xFFFFFFFF when every successor is within the LDS ring
+constexpr uint32_t kRecSink = 1u << 16;
 
 struct DpResult {
     uint32_t end_m, end_s;
@@ -73,14 +79,10 @@ struct DpResult {
 
 struct DpArgs {
     const QDesc *qd;
-    const uint32_t *node_pos;
-    const uint8_t *node_mask;
-    const float *node_weight;
-    const uint32_t *pred_off;
+    const uint4 *rec;
     const uint32_t *pred;
+    const uint32_t *node_pos;
     const uint32_t *succ_minpos;
-    const uint32_t *spill_idx;  // per node: spill row index or 0xFFFFFFFF
-    const uint8_t *node_flags;  // per node: bit0 = sink (no successors)
     const uint8_t *qmask;
     uint32_t *tb;               // (value_midx << 16) | value_sidx
     float *dbg_value;           // optional [N*Lp] plane of the first query
@@ -94,16 +96,15 @@ struct DpArgs {
 
 struct BtArgs {
     const QDesc *qd;
+    const uint4 *rec;
     const uint32_t *node_pos;
-    const float *node_weight;
-    const uint32_t *pred_off;
     const uint32_t *tb;
     const DpResult *res;
     const float *weights;
     uint32_t n_weights;
     sina_hip_align_out *out;
     uint32_t *out_pos;
-    uint32_t nq, width, Lp_T, Lp_B;  // Lp = Lp_T * Lp_B
+    uint32_t nq, width, Lp;
     float ms;
     int overhang;
 };
@@ -116,8 +117,27 @@ struct DpGeom {
 bool pick_geom(uint32_t maxL, DpGeom *g);
 size_t dp_slot_bytes(const DpGeom &g);
 size_t dp_fixed_lds_bytes(const DpGeom &g);
+int dp_max_ring(const DpGeom &g);  // deepest LDS ring the wave pipeline supports
 int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
                    size_t lds_bytes, hipStream_t s);
 int launch_backtrack(const BtArgs &a, hipStream_t s);
+
+// geometry + LDS ring depth chosen for a batch
+struct DpPlan {
+    DpGeom geom;
+    int W;
+    size_t lds;
+};
+
+}  // namespace sina_hip
+
+struct sina_hip_ctx;
+
+namespace sina_hip {
+int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl);
+int upload_weights(sina_hip_ctx *c, const sina_hip_align_params *p);
+int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, uint32_t bq, uint64_t tb_cells, uint64_t spill_rows,
+                  uint64_t cells, uint64_t nqm, const sina_hip_align_params *p, uint32_t width,
+                  sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value);
 
 }  // namespace sina_hip

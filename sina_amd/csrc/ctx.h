@@ -16,18 +16,16 @@ struct sina_hip_ctx {
     bool have_refs = false, have_index = false;
 
     // per-batch scratch, grown on demand and reused
-    sina_hip::DevBuf qd, node_pos, node_mask, node_weight, pred_off, pred, succ_minpos, spill_idx, node_flags,
-        qmask, tb, spill, res, weights, out, out_pos, dbg;
+    sina_hip::DevBuf qd, rec, node_pos, pred, succ_minpos, qmask, tb, spill, res, weights, out, out_pos, dbg;
     sina_hip::DevBuf k_qoff, k_scores, k_out_ids, k_out_scores, k_out_n, k_tmp0, k_tmp1, k_tmp2;
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes;
 
-    size_t lds_budget = 80 * 1024;
+    size_t lds_budget = 36 * 1024;
     uint64_t tb_budget_bytes = (uint64_t)24 << 30;
     sina_hip_stats stats;
 
     void free_all() {
-        sina_hip::DevBuf *all[] = {&ref_ab, &ref_off, &idx_off, &idx_ids, &qd, &node_pos, &node_mask,
-                                   &node_weight, &pred_off, &pred, &succ_minpos, &spill_idx, &node_flags,
+        sina_hip::DevBuf *all[] = {&ref_ab, &ref_off, &idx_off, &idx_ids, &qd, &rec, &node_pos, &pred, &succ_minpos,
                                    &qmask, &tb, &spill, &res, &weights, &out, &out_pos, &dbg, &k_qoff,
                                    &k_scores, &k_out_ids, &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2,
                                    &g_fam_ids, &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes};

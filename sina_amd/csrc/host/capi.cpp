@@ -150,6 +150,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                     const uint32_t b0 = next.fetch_add(batch);
                     if (b0 >= nq) break;
                     const uint32_t b1 = std::min(nq, b0 + batch);
+                    const auto t_in = std::chrono::steady_clock::now();
                     std::vector<tray> trays(b1 - b0);
                     for (uint32_t q = b0; q < b1; q++) {
                         tray &t = trays[q - b0];
@@ -225,6 +226,13 @@ void sina_host_timings(void *pp, double *wall_s, double *famfinder_s, double *al
     *wall_s = p->wall_s;
     *famfinder_s = p->ff_s;
     *aligner_s = p->al_s;
+}
+
+// per-phase host timings (SINA_HOST_PROFILE=1); returned string is valid until the next call
+const char *sina_host_profile(int reset) {
+    static thread_local std::string s;
+    s = host_profile_dump(reset != 0);
+    return s.c_str();
 }
 
 // host DAG build exposed for tests (compares with the oracle's mseq)

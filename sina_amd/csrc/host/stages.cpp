@@ -11,12 +11,55 @@
 #include <cstring>
 #include <ctime>
 #include <fstream>
+#include <chrono>
 #include <map>
 
 namespace sina {
 
 static void hip_check(int rc, const char *what) {
     if (rc != 0) throw std::runtime_error(std::string(what) + ": " + sina_hip_last_error());
+}
+
+// ================================================================ phase profiler (SINA_HOST_PROFILE=1)
+
+namespace {
+struct prof_state {
+    std::mutex mu;
+    std::map<std::string, std::pair<double, uint64_t>> acc;
+    bool on = getenv("SINA_HOST_PROFILE") != nullptr;
+};
+prof_state &prof() {
+    static prof_state p;
+    return p;
+}
+struct scoped_phase {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    explicit scoped_phase(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~scoped_phase() {
+        prof_state &p = prof();
+        if (!p.on) return;
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lk(p.mu);
+        auto &e = p.acc[name];
+        e.first += s;
+        e.second++;
+    }
+};
+}  // namespace
+
+std::string host_profile_dump(bool reset) {
+    prof_state &p = prof();
+    std::lock_guard<std::mutex> lk(p.mu);
+    std::string out;
+    char buf[160];
+    for (auto &kv : p.acc) {
+        snprintf(buf, sizeof(buf), "%-28s %9.3f s  %6llu calls\n", kv.first.c_str(), kv.second.first,
+                 (unsigned long long)kv.second.second);
+        out += buf;
+    }
+    if (reset) p.acc.clear();
+    return out;
 }
 
 // ================================================================ thread pool
@@ -346,9 +389,12 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
     if (max <= 4096) {
         std::vector<uint32_t> ids((size_t)queries.size() * max), cnt(queries.size());
         std::vector<float> sc((size_t)queries.size() * max);
-        hip_check(sina_hip_kmer_topk(ctx, qmask.data(), qoff.data(), (uint32_t)queries.size(), max, ids.data(),
-                                     sc.data(), cnt.data()),
-                  "kmer_topk");
+        {
+            scoped_phase ph("ff.kmer_topk(C-ABI)");
+            hip_check(sina_hip_kmer_topk(ctx, qmask.data(), qoff.data(), (uint32_t)queries.size(), max, ids.data(),
+                                         sc.data(), cnt.data()),
+                      "kmer_topk");
+        }
         for (size_t i = 0; i < queries.size(); i++) {
             results[i].reserve(cnt[i]);
             for (uint32_t x = 0; x < cnt[i]; x++)
@@ -613,8 +659,12 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
         std::vector<const cseq *> qs;
         for (tray *t : todo) qs.push_back(t->input_sequence);
         std::vector<search::result_vector> found;
-        index->find_batch(qs, found, (unsigned)std::min<size_t>(max_results, isize));
+        {
+            scoped_phase ph_find("ff.find_batch");
+            index->find_batch(qs, found, (unsigned)std::min<size_t>(max_results, isize));
+        }
         std::vector<char> done(todo.size(), 0);
+        scoped_phase ph_match("ff.match_pass");
         parallel_for(todo.size(), [&](size_t i) {
             search::result_vector &res = *todo[i]->alignment_reference;
             res = std::move(found[i]);
@@ -632,6 +682,7 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
         todo.swap(next);
         max_results *= 10;
     }
+    scoped_phase ph_post("ff.post");
     parallel_for(batch.size(), [&](size_t i) {
         tray &t = *batch[i];
         auto &vc = *t.alignment_reference;
@@ -845,6 +896,7 @@ void aligner::operator()(std::vector<tray> &batch) {
     std::vector<dp_job> jobs(batch.size());
     std::vector<char> need_dp(batch.size(), 0);
 
+    std::unique_ptr<scoped_phase> ph(new scoped_phase("al.prepare(partition)"));
     parallel_for(batch.size(), [&](size_t i) {
         tray &t = batch[i];
         if (t.input_sequence == nullptr || t.alignment_reference == nullptr || t.astats == nullptr) return;  // :310-318
@@ -906,6 +958,7 @@ void aligner::operator()(std::vector<tray> &batch) {
         need_dp[i] = 1;
     });
 
+    ph.reset();
     // group DP jobs by scoring scheme: default-constructed astats (width 0) => simple
     // scheme, otherwise weighted with that tray's weights (src/align.cpp:404-416)
     std::map<std::vector<float>, std::vector<size_t>> groups;
@@ -934,6 +987,7 @@ void aligner::operator()(std::vector<tray> &batch) {
         p.weights = weights.empty() ? nullptr : weights.data();
         p.n_weights = (uint32_t)weights.size();
 
+        ph.reset(new scoped_phase("al.pack_queries"));
         std::vector<uint64_t> qoff(nq + 1, 0);
         for (size_t x = 0; x < nq; x++) qoff[x + 1] = qoff[x] + jobs[idx[x]].c->size();
         std::vector<uint8_t> qmask(qoff.back() ? qoff.back() : 1);
@@ -954,12 +1008,15 @@ void aligner::operator()(std::vector<tray> &batch) {
                 for (size_t y = 0; y < jobs[idx[x]].family.size(); y++)
                     fids[foff[x] + y] = store->id_of(jobs[idx[x]].family[y]);
             width = store->getAlignmentWidth();
+            ph.reset(new scoped_phase("al.align_families(C-ABI)"));
             hip_check(sina_hip_align_families(ctx, fids.data(), foff.data(), (uint32_t)nq, qmask.data(), qoff.data(),
                                               &p, out.data(), out_pos.data()),
                       "align_families");
         } else {
             std::vector<host_graph> gs(nq);
+            ph.reset(new scoped_phase("al.host_graph_build"));
             parallel_for(nq, [&](size_t x) { build_family_graph(jobs[idx[x]].family, o.fs_weight, &gs[x]); });
+            ph.reset(new scoped_phase("al.host_graph_concat"));
             sina_hip_graph_batch gb;
             std::vector<uint64_t> node_off(nq + 1, 0), edge_off(nq + 1, 0);
             for (size_t x = 0; x < nq; x++) {
@@ -990,11 +1047,13 @@ void aligner::operator()(std::vector<tray> &batch) {
             gb.pred = pred.data();
             gb.succ_minpos = smin.data();
             gb.width = width;
+            ph.reset(new scoped_phase("al.align_graphs(C-ABI)"));
             hip_check(sina_hip_align_graphs(ctx, &gb, qmask.data(), qoff.data(), &p, out.data(), out_pos.data()),
                       "align_graphs");
         }
 
         // cseq container steps of backtrack() (src/mesh.h:603-736) + do_align attrs (:507-509)
+        ph.reset(new scoped_phase("al.finish(NAST,log)"));
         parallel_for(nq, [&](size_t x) {
             dp_job &jb = jobs[idx[x]];
             tray &t = *jb.t;

@@ -9,21 +9,30 @@
 // SSE build.
 //
 // How it maps to the hardware (no MFMA: this is a compare/select recurrence):
-//   * one workgroup per query; thread j owns B consecutive query columns, the
-//     whole workgroup sweeps the DAG rows in topological (id) order, so the
-//     predecessor list of a row is wave-uniform (scalar loads, no divergence);
-//   * the last W rows of {value, gapm_val, gapm_idx} live in an LDS ring (10 B
-//     per column); the rare predecessors further back than W rows are read
-//     from a per-query spill area in HBM that the producing row also wrote;
-//   * the only dependency inside a row is the insertion chain along the query
-//     (cell (m,s) needs the final (m,s-1)).  Each thread runs the chain over
-//     its own B cells serially (exact reference order) and assumes no chain
-//     enters from the left; after one barrier it re-runs the chain with the
-//     left neighbour's real exit state and a workgroup vote repeats that only
-//     while some exit state still changed (a chain crossing a whole thread
-//     block, i.e. >= B consecutive insertions);
+//   * one workgroup per query; lane l of wave w owns B consecutive query columns
+//     (wave w owns a contiguous block of 64*B columns);
+//   * every wave sweeps the DAG rows in topological (id) order ON ITS OWN: the row
+//     record {first pred, weight, #pred|mask|flags, spill slot} and the pred list
+//     are wave-uniform and come through the scalar cache (s_load), so there is no
+//     divergence on graph structure and no vector-memory latency on the row
+//     critical path;
+//   * the last W rows of {value, gapm_val, gapm_idx} of a wave's own columns live
+//     in an LDS ring (10 B per column) that only that wave touches; the rare
+//     predecessors further back than W rows are read from a per-query spill area
+//     in HBM that the producing row also wrote;
+//   * the only dependencies between column blocks are (a) the insertion chain
+//     along the query (cell (m,s) needs the final (m,s-1)) and (b) the match
+//     candidate from (p,s-1).  Inside a wave both travel by lane shuffle: each
+//     lane runs the chain over its B cells serially (exact reference order),
+//     first assuming that no gap enters from the left, then again with the left
+//     lane's real exit state, repeated only while some exit state still changed
+//     (wave vote, no barrier).  Between waves they travel through two small LDS
+//     histories (boundary value and exit state per row) guarded by a per-wave
+//     progress counter: wave w starts row m once wave w-1 has published it.  The
+//     waves of a workgroup thus form a software pipeline skewed by one row and
+//     the main loop contains no s_barrier at all;
 //   * the only per-cell HBM traffic is the write-once trace-back cell
-//     (value_midx:16 | value_sidx:16), coalesced row-major.
+//     (value_midx:16 | value_sidx:16), row-major.
 #include "common.h"
 
 namespace sina_hip {
@@ -31,6 +40,7 @@ namespace sina_hip {
 namespace {
 
 constexpr uint32_t kNoSpill = 0xFFFFFFFFu;
+constexpr int kHist = 32;  // rows of boundary/exit-state history kept per wave (power of two)
 
 struct ChainState {  // canonical exit state of cell (m, s): what cell (m, s+1) can observe
     float v;         // final value
@@ -43,92 +53,119 @@ __device__ __forceinline__ bool same_state(const ChainState &a, const ChainState
     return a.v == b.v && a.e == b.e && (!a.e || (a.gsi == b.gsi && a.gmax == b.gmax));
 }
 
+__device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int T, int B, bool WEIGHTED, bool FORBID>
-__global__ void __launch_bounds__(T) mesh_dp_kernel(DpArgs a) {
+__global__ void __launch_bounds__(T)
+mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, const uint32_t *__restrict__ predv,
+               const uint32_t *__restrict__ node_posv, const uint32_t *__restrict__ succ_minposv,
+               const uint8_t *__restrict__ qmaskv, const float *__restrict__ weights, uint32_t n_weights,
+               uint32_t *__restrict__ tbv, float *__restrict__ dbg_value, float *spillv,
+               DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe, int W) {
     constexpr int Lp = T * B;
-    constexpr int NW = (T + 63) / 64;
+    constexpr int NW = T / 64;
+    constexpr int WCOLS = 64 * B;  // columns per wave
+    static_assert(T % 64 == 0, "whole waves only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int j = threadIdx.x;
-    const QDesc d = a.qd[blockIdx.x];
+    const int lane = j & 63;
+    const int w = j >> 6;
+    const QDesc d = qdv[blockIdx.x];
     const uint32_t N = d.N, L = d.L;
     const uint32_t s0 = (uint32_t)j * B;
 
-    // ---- LDS carve (all dynamic; base 16-B aligned, every offset a multiple of 16)
-    float *xs_v = reinterpret_cast<float *>(smem);
-    uint32_t *xs_e = reinterpret_cast<uint32_t *>(smem + 4 * T);
-    uint32_t *xs_gmax = reinterpret_cast<uint32_t *>(smem + 8 * T);
-    float *red_v = reinterpret_cast<float *>(smem + 12 * T);
-    uint32_t *red_s = reinterpret_cast<uint32_t *>(smem + 12 * T + 64);
-    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + 12 * T + 128);
-    unsigned char *ring = smem + 12 * T + 256;
-    constexpr size_t kValBytes = (size_t)(Lp + 4) * 4;
+    // ---- LDS carve (all dynamic; every offset a multiple of 16)
+    uint32_t *progress = reinterpret_cast<uint32_t *>(smem);                    // [NW] rows done by wave
+    float *bnd_val = reinterpret_cast<float *>(smem + 64);                      // [NW][kHist]
+    float *xs_v = bnd_val + NW * kHist;                                          // [NW][kHist]
+    uint32_t *xs_e = reinterpret_cast<uint32_t *>(xs_v + NW * kHist);            // [NW][kHist]
+    uint32_t *xs_gmax = xs_e + NW * kHist;                                       // [NW][kHist]
+    uint32_t *fin = xs_gmax + NW * kHist;                                        // [NW][16] per-wave results
+    unsigned char *ring = smem + 64 + 16 * NW * kHist + 64 * NW;
+    constexpr size_t kValBytes = (size_t)Lp * 4;
     constexpr size_t kGmBytes = (size_t)Lp * 4;
     constexpr size_t kSlotBytes = kValBytes + kGmBytes + (size_t)Lp * 2;
-    const int W = a.W;
 
-    const uint32_t *pred_off = a.pred_off + d.poff_off;
-    const uint32_t *pred = a.pred + d.edge_off;
-    const uint32_t *node_pos = a.node_pos + d.node_off;
-    const uint8_t *node_mask = a.node_mask + d.node_off;
-    const float *node_weight = a.node_weight + d.node_off;
-    const uint32_t *spill_idx = a.spill_idx + d.node_off;
-    const uint8_t *node_flags = a.node_flags + d.node_off;
-    uint32_t *tb = a.tb + d.tb_off;
-    float *spill = a.spill + d.spill_off * (size_t)(3 * Lp);
+    const uint4 *__restrict__ rec = recv + d.node_off;
+    const uint32_t *__restrict__ pred = predv + d.edge_off;
+    const uint32_t *__restrict__ node_pos = node_posv + d.node_off;
+    const uint32_t *__restrict__ succ_minpos = succ_minposv + d.node_off;
+    uint32_t *__restrict__ tb = tbv + d.tb_off;
+    float *spill = spillv + d.spill_off * (size_t)(3 * Lp);
+
+    if (j < NW) progress[j] = 0;
+    __syncthreads();
 
     // query masks of my columns (0 beyond L: never matches, never stored)
     uint32_t qm[B];
 #pragma unroll
     for (int k = 0; k < B; k++) {
-        uint32_t s = s0 + k;
-        qm[k] = (s < L) ? (uint32_t)(a.qmask[d.q_off + s] & 0xf) : 0u;
+        const uint32_t s = s0 + k;
+        qm[k] = (s < L) ? (uint32_t)(qmaskv[d.q_off + s] & 0xf) : 0u;
     }
 
     // end-cell search state (mesh.h:567-592)
     const bool own_last = (L - 1) / B == (uint32_t)j;
     const int k_last = (int)((L - 1) % B);
-    float lc_min = 0.f, lc_snk0 = 0.f;  // step 1: min over all rows at column L-1
+    float lc_min = 0.f, lc_snk0 = 0.f;  // step 1: rows at column L-1 (lane own_last only)
     uint32_t lc_arg = 0;
     bool lc_any = false;
-    float sk_min = 0.f;  // step 2: min over sink rows x all columns (first in scan order)
-    uint32_t sk_m = 0, sk_s = 0, snk0 = 0;
+    float sk_min = __builtin_inff();  // step 2: sink rows x my wave's columns, first in scan order
+    uint32_t sk_m = 0, sk_s = 0xffffffffu, snk0 = 0;
     bool sk_any = false;
 
+    const uint32_t throttle = (uint32_t)(kHist - W - 2);
+    uint4 cur = rec[0];
     for (uint32_t m = 0; m < N; ++m) {
-        const uint32_t pb = pred_off[m], pe = pred_off[m + 1];
-        const float wgt = node_weight[m];
-        const uint32_t mmask = node_mask[m] & 0xfu;
-        const bool edge_row = (pb == pe);
+        const uint4 nxt = rec[m + 1 < N ? m + 1 : m];  // scalar prefetch of the next row record
+        const uint32_t pb = cur.x;
+        const float wgt = __uint_as_float(cur.y);
+        const uint32_t npred = cur.z & 0xffu;
+        const uint32_t mmask = (cur.z >> 8) & 0xfu;
+        const bool is_sink = ((cur.z >> 16) & 1u) != 0;
+        const uint32_t sp = cur.w;
+        const bool edge_row = (npred == 0);
         uint32_t mpos = 0;
         float cM, cX, gd_open, gd_ext, gi_open;
         if constexpr (WEIGHTED) {
             mpos = node_pos[m];
-            const uint32_t nw1 = a.n_weights - 1;
-            const float wp = a.weights[mpos < nw1 ? mpos : nw1];
-            const float wp1 = a.weights[mpos + 1 < nw1 ? mpos + 1 : nw1];
-            cM = a.ms * wp * wgt;  // (c * weights[pos]) * weight, scoring_schemes.h:232
-            cX = a.mms * wp * wgt;
-            gd_open = a.gp * wp;   // :211
-            gd_ext = a.gpe * wp;   // :222
-            gi_open = a.gp * wp1;  // :187
+            const uint32_t nw1 = n_weights - 1;
+            const float wp = weights[mpos < nw1 ? mpos : nw1];
+            const float wp1 = weights[mpos + 1 < nw1 ? mpos + 1 : nw1];
+            cM = ms * wp * wgt;  // (c * weights[pos]) * weight, scoring_schemes.h:232
+            cX = mms * wp * wgt;
+            gd_open = gp * wp;   // :211
+            gd_ext = gpe * wp;   // :222
+            gi_open = gp * wp1;  // :187
         } else {
-            cM = a.ms * wgt;       // scoring_schemes.h:154
-            cX = a.mms * wgt;
-            gd_open = a.gp;
-            gd_ext = a.gpe;
-            gi_open = a.gp;
+            cM = ms * wgt;       // scoring_schemes.h:154
+            cX = mms * wgt;
+            gd_open = gp;
+            gd_ext = gpe;
+            gi_open = gp;
         }
         uint32_t smax = 0;
         if constexpr (FORBID) {
             if (!WEIGHTED) mpos = node_pos[m];
             // int max_insert = min_mpos - pos - 1, passed as unsigned idx_type (mesh.h:480-489)
-            smax = (uint32_t)(int)(a.succ_minpos[d.node_off + m] - mpos - 1);
+            smax = (uint32_t)(int)(succ_minpos[m] - mpos - 1);
         }
         const float init_v = edge_row ? 1.0f : 1000000.0f;
 
+        // ---- wave pipeline hand-shake (LDS flags, no barrier)
+        if (w > 0) {  // the wave to my left must have published row m
+            while (lds_load_relaxed(&progress[w - 1]) <= m) __builtin_amdgcn_s_sleep(1);
+        }
+        if (w < NW - 1) {  // do not lap the history slots the wave to my right still needs
+            while (m >= lds_load_relaxed(&progress[w + 1]) + throttle) __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
         // ---- phase 1: deletion + match candidates from every predecessor row
-        float dv[B], gm[B], mt[B];
+        float dv[B], gm[B], mt[B], csel[B];
         uint32_t dvm[B], gmi[B], mtp[B];
         bool ddel[B];  // best-so-far is a deletion (value_sidx = s) rather than the init cell
 #pragma unroll
@@ -141,17 +178,18 @@ __global__ void __launch_bounds__(T) mesh_dp_kernel(DpArgs a) {
             gmi[k] = 0;
             mtp[k] = 0;
             ddel[k] = false;
+            csel[k] = (mmask & qm[k]) ? cM : cX;  // comp(): optimistic IUPAC match (aligned_base.h:153)
         }
-        for (uint32_t e = pb; e < pe; ++e) {
-            const uint32_t p = pred[e];
+        for (uint32_t e = 0; e < npred; ++e) {
+            const uint32_t p = pred[pb + e];
             float sv[B], sg[B], svl;
             uint32_t sgi[B];
-            if (m - p <= (uint32_t)W) {  // LDS ring
+            const bool near = (m - p <= (uint32_t)W);
+            if (near) {  // LDS ring, my own columns
                 const unsigned char *slot = ring + (size_t)(p % (uint32_t)W) * kSlotBytes;
-                const float *pv = reinterpret_cast<const float *>(slot) + 4;
+                const float *pv = reinterpret_cast<const float *>(slot);
                 const float *pg = reinterpret_cast<const float *>(slot + kValBytes);
                 const uint16_t *pi = reinterpret_cast<const uint16_t *>(slot + kValBytes + kGmBytes);
-                svl = pv[(int)s0 - 1];
 #pragma unroll
                 for (int k = 0; k < B; k++) {
                     sv[k] = pv[s0 + k];
@@ -159,14 +197,19 @@ __global__ void __launch_bounds__(T) mesh_dp_kernel(DpArgs a) {
                     sgi[k] = pi[s0 + k];
                 }
             } else {  // spilled row in HBM
-                const float *row = spill + (size_t)spill_idx[p] * (3 * Lp);
-                svl = (s0 > 0) ? row[s0 - 1] : 0.f;
+                const float *row = spill + (size_t)rec[p].w * (3 * Lp);
 #pragma unroll
                 for (int k = 0; k < B; k++) {
                     sv[k] = row[s0 + k];
                     sg[k] = row[Lp + s0 + k];
                     sgi[k] = reinterpret_cast<const uint32_t *>(row)[2 * Lp + s0 + k];
                 }
+            }
+            // value[p][s0-1]: from the lane to my left; lane 0 takes the left wave's boundary
+            svl = __shfl_up(sv[B - 1], 1);
+            if (lane == 0 && w > 0) {
+                if (near) svl = bnd_val[(w - 1) * kHist + (p & (kHist - 1))];
+                else svl = (spill + (size_t)rec[p].w * (3 * Lp))[s0 - 1];
             }
 #pragma unroll
             for (int k = 0; k < B; k++) {
@@ -178,18 +221,16 @@ __global__ void __launch_bounds__(T) mesh_dp_kernel(DpArgs a) {
                 const uint32_t cm = op ? p : sgi[k];
                 gm[k] = cand;
                 gmi[k] = cm;
-                if (cand < dv[k]) {
-                    dv[k] = cand;
-                    dvm[k] = cm;
-                    ddel[k] = true;
-                }
+                const bool better = cand < dv[k];
+                dv[k] = better ? cand : dv[k];
+                dvm[k] = better ? cm : dvm[k];
+                ddel[k] = better ? true : ddel[k];
                 // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
                 const float pvv = (k == 0) ? svl : sv[k - 1];
-                const float mv = pvv + ((mmask & qm[k]) ? cM : cX);
-                if ((s0 + k) > 0 && mv < mt[k]) {
-                    mt[k] = mv;
-                    mtp[k] = p;
-                }
+                const float mv = pvv + csel[k];
+                const bool mb = ((s0 + k) > 0) && (mv < mt[k]);
+                mt[k] = mb ? mv : mt[k];
+                mtp[k] = mb ? p : mtp[k];
             }
         }
 
@@ -205,49 +246,36 @@ __global__ void __launch_bounds__(T) mesh_dp_kernel(DpArgs a) {
                 float v = dv[k];
                 uint32_t vm = dvm[k];
                 uint32_t vs = ddel[k] ? s : 0u;
-                float gs;
+                float gs = 1.0f;  // init_edge at s == 0, no insertion step there
                 uint32_t gsi = 0, gmax = 0;
                 if (s > 0) {
                     bool ins = true;
-                    if (!c.e) {  // opening gap (mesh.h:340-343 / :415-419)
-                        if (FORBID && smax < 1) {
-                            ins = false;
-                        } else {
-                            gs = c.v + gi_open;
-                            gsi = s - 1;
-                            if (FORBID) gmax = smax - 1;
+                    float gi_cost = gi_open;  // opening gap (mesh.h:340-343 / :415-419)
+                    uint32_t gsi_n = s - 1, gmax_n = 0;
+                    if (FORBID) {
+                        ins = (smax >= 1) && (!c.e || c.gmax > 0);
+                        gmax_n = c.e ? c.gmax - 1 : smax - 1;
+                    }
+                    if (c.e) {  // extending gap (:344-349 / :420-425); gaps_val == value here
+                        gi_cost = gpe;
+                        if constexpr (WEIGHTED) {
+                            const uint32_t nw1 = n_weights - 1;
+                            const uint32_t wi = mpos + 1 + ((s - 1) - c.gsi);
+                            gi_cost = gpe * weights[wi < nw1 ? wi : nw1];
                         }
-                    } else {  // extending gap (:344-349 / :420-425); gaps_val == value here
-                        if (FORBID && (smax < 1 || c.gmax == 0)) {
-                            ins = false;
-                        } else {
-                            float gi_ext = a.gpe;
-                            if constexpr (WEIGHTED) {
-                                const uint32_t nw1 = a.n_weights - 1;
-                                const uint32_t wi = mpos + 1 + ((s - 1) - c.gsi);
-                                gi_ext = a.gpe * a.weights[wi < nw1 ? wi : nw1];
-                            }
-                            gs = c.v + gi_ext;
-                            gsi = c.gsi;
-                            if (FORBID) gmax = c.gmax - 1;
-                        }
+                        gsi_n = c.gsi;
                     }
-                    if (!ins) {  // cell keeps its initial gaps_val / gaps_idx / gaps_max
-                        gs = init_v;
-                        gsi = 0;
-                        gmax = 0;
-                    } else if (gs <= v) {  // mesh.h:351-357
-                        v = gs;
-                        vm = m;
-                        vs = gsi;
-                    }
-                    if (mt[k] < v) {
-                        v = mt[k];
-                        vm = mtp[k];
-                        vs = s - 1;
-                    }
-                } else {
-                    gs = 1.0f;  // init_edge at s == 0, no insertion step
+                    gs = ins ? (c.v + gi_cost) : init_v;  // untouched cell keeps its initial gaps_*
+                    gsi = ins ? gsi_n : 0u;
+                    gmax = ins ? gmax_n : 0u;
+                    const bool take = ins && (gs <= v);  // mesh.h:351-357
+                    v = take ? gs : v;
+                    vm = take ? m : vm;
+                    vs = take ? gsi : vs;
+                    const bool mtk = mt[k] < v;
+                    v = mtk ? mt[k] : v;
+                    vm = mtk ? mtp[k] : vm;
+                    vs = mtk ? s - 1 : vs;
                 }
                 fv[k] = v;
                 fvm[k] = vm;
@@ -260,63 +288,57 @@ __global__ void __launch_bounds__(T) mesh_dp_kernel(DpArgs a) {
             ex = c;
         };
 
-        // speculative pass: pretend the left neighbour's last cell did not end in a gap
-        // and is so expensive that opening from it can never win.
+        // speculative pass: pretend the cell to my left did not end in a gap and is so
+        // expensive that opening from it can never win.
         ChainState left;
         left.v = __builtin_inff();
         left.e = 0;
         left.gsi = 0;
         left.gmax = 0;
         run_chain(left);
-        ChainState published = ex;
-        xs_v[j] = ex.v;
-        xs_e[j] = (ex.e << 31) | ex.gsi;
-        if (FORBID) xs_gmax[j] = ex.gmax;
-        __syncthreads();  // B1: all ring reads of this row done, exit states visible
-
-        unsigned char *myslot = ring + (size_t)(m % (uint32_t)W) * kSlotBytes;
-        float *wv = reinterpret_cast<float *>(myslot) + 4;
-        float *wg = reinterpret_cast<float *>(myslot + kValBytes);
-        uint16_t *wi = reinterpret_cast<uint16_t *>(myslot + kValBytes + kGmBytes);
-#pragma unroll
-        for (int k = 0; k < B; k++) {
-            wg[s0 + k] = gm[k];
-            wi[s0 + k] = (uint16_t)gmi[k];
+        // lane 0 of wave > 0 knows its real left state already (published by the left wave)
+        ChainState wave_left;
+        wave_left.v = 0.f;
+        wave_left.e = wave_left.gsi = wave_left.gmax = 0;
+        if (w > 0) {
+            const int h = (w - 1) * kHist + (int)(m & (kHist - 1));
+            wave_left.v = xs_v[h];
+            const uint32_t pe_ = xs_e[h];
+            wave_left.e = pe_ >> 31;
+            wave_left.gsi = pe_ & 0x7fffffffu;
+            wave_left.gmax = FORBID ? xs_gmax[h] : 0u;
         }
         for (;;) {
-            if (j > 0) {
-                left.v = xs_v[j - 1];
-                const uint32_t pe_ = xs_e[j - 1];
-                left.e = pe_ >> 31;
-                left.gsi = pe_ & 0x7fffffffu;
-                left.gmax = FORBID ? xs_gmax[j - 1] : 0u;
-                run_chain(left);
-            }
-#pragma unroll
-            for (int k = 0; k < B; k++) wv[s0 + k] = fv[k];
-            const bool changed = !same_state(ex, published);
-            // the vote is also the barrier that publishes this row's ring slot
-            if (!__syncthreads_or(changed ? 1 : 0)) break;
-            if (changed) {
-                published = ex;
-                xs_v[j] = ex.v;
-                xs_e[j] = (ex.e << 31) | ex.gsi;
-                if (FORBID) xs_gmax[j] = ex.gmax;
-            }
-            __syncthreads();
+            const ChainState prev = ex;
+            left.v = __shfl_up(ex.v, 1);
+            left.e = __shfl_up(ex.e, 1);
+            left.gsi = __shfl_up(ex.gsi, 1);
+            left.gmax = FORBID ? __shfl_up(ex.gmax, 1) : 0u;
+            if (lane == 0) left = wave_left;
+            if (j > 0) run_chain(left);
+            if (!__any(!same_state(ex, prev))) break;
         }
 
-        // ---- outputs of the row
+        // ---- publish: ring (own columns), boundary + exit state for the wave to my right
         {
-            uint32_t *trow = tb + (size_t)m * Lp + s0;
+            unsigned char *myslot = ring + (size_t)(m % (uint32_t)W) * kSlotBytes;
+            float *wv = reinterpret_cast<float *>(myslot);
+            float *wg = reinterpret_cast<float *>(myslot + kValBytes);
+            uint16_t *wi = reinterpret_cast<uint16_t *>(myslot + kValBytes + kGmBytes);
 #pragma unroll
-            for (int k = 0; k < B; k++) trow[k] = (fvm[k] << 16) | (fvs[k] & 0xffffu);
+            for (int k = 0; k < B; k++) {
+                wv[s0 + k] = fv[k];
+                wg[s0 + k] = gm[k];
+                wi[s0 + k] = (uint16_t)gmi[k];
+            }
+            if (lane == 63) {
+                const int h = w * kHist + (int)(m & (kHist - 1));
+                bnd_val[h] = fv[B - 1];
+                xs_v[h] = ex.v;
+                xs_e[h] = (ex.e << 31) | ex.gsi;
+                if (FORBID) xs_gmax[h] = ex.gmax;
+            }
         }
-        if (a.dbg_value != nullptr && blockIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < B; k++) a.dbg_value[(size_t)m * Lp + s0 + k] = fv[k];
-        }
-        const uint32_t sp = spill_idx[m];
         if (sp != kNoSpill) {
             float *row = spill + (size_t)sp * (3 * Lp);
 #pragma unroll
@@ -326,106 +348,120 @@ __global__ void __launch_bounds__(T) mesh_dp_kernel(DpArgs a) {
                 reinterpret_cast<uint32_t *>(row)[2 * Lp + s0 + k] = gmi[k];
             }
         }
+        // release: LDS writes (and the spill row, if any) before the progress counter
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&progress[w], m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 
-        // step 1 of the end-cell search: rows at the last query column
-        const bool is_sink = (node_flags[m] & 1u) != 0;
+        // ---- trace-back cells: the only per-cell HBM traffic
+        {
+            uint32_t *trow = tb + (size_t)m * Lp + s0;
+#pragma unroll
+            for (int k = 0; k < B; k++) trow[k] = (fvm[k] << 16) | (fvs[k] & 0xffffu);
+        }
+        if (dbg_value != nullptr && blockIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < B; k++) dbg_value[(size_t)m * Lp + s0 + k] = fv[k];
+        }
+
+        // ---- end-cell search, step 1: rows at the last query column (one lane)
         if (own_last) {
             float v = fv[0];
 #pragma unroll
-            for (int k = 1; k < B; k++)
-                if (k == k_last) v = fv[k];
+            for (int k = 1; k < B; k++) v = (k == k_last) ? fv[k] : v;
             if (!lc_any || v < lc_min) {
                 lc_min = v;
                 lc_arg = m;
                 lc_any = true;
             }
+            if (is_sink && !sk_any) lc_snk0 = v;  // value of sinks[0] at column L-1
         }
-        // step 2: sink rows, every column (uniform branch: is_sink is a row property)
+        // step 2: sink rows x every column; each wave keeps the best of its own columns
         if (is_sink) {
             float bv = __builtin_inff();
             uint32_t bs = 0xffffffffu;
 #pragma unroll
             for (int k = 0; k < B; k++) {
                 const uint32_t s = s0 + k;
-                if (s < L && fv[k] < bv) {
-                    bv = fv[k];
-                    bs = s;
-                }
+                const bool b = (s < L) && (fv[k] < bv);
+                bv = b ? fv[k] : bv;
+                bs = b ? s : bs;
             }
-            // wave reduce: smaller value, then smaller column
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
+            for (int off = 32; off > 0; off >>= 1) {  // smaller value, then smaller column
                 const float ov = __shfl_xor(bv, off);
                 const uint32_t os = __shfl_xor(bs, off);
-                if (ov < bv || (ov == bv && os < bs)) {
-                    bv = ov;
-                    bs = os;
-                }
+                const bool b = (ov < bv) || (ov == bv && os < bs);
+                bv = b ? ov : bv;
+                bs = b ? os : bs;
             }
-            if ((j & 63) == 0) {
-                red_v[j >> 6] = bv;
-                red_s[j >> 6] = bs;
-            }
-            if (own_last) {  // value of this sink row at column L-1, for sinks[0]
-                float v = fv[0];
-#pragma unroll
-                for (int k = 1; k < B; k++)
-                    if (k == k_last) v = fv[k];
-                red_v[NW] = v;
-            }
-            __syncthreads();
-            float rv = red_v[0];
-            uint32_t rs = red_s[0];
-            for (int w = 1; w < NW; w++) {
-                if (red_v[w] < rv || (red_v[w] == rv && red_s[w] < rs)) {
-                    rv = red_v[w];
-                    rs = red_s[w];
-                }
-            }
-            if (!sk_any) {  // first sink == sinks[0] (ascending ids)
-                snk0 = m;
-                lc_snk0 = red_v[NW];
-                sk_min = rv;
+            if (!sk_any) snk0 = m;  // sinks ascend with the row id: the first one is sinks[0]
+            if (bv < sk_min) {       // strict <: the first sink row with the minimum wins
+                sk_min = bv;
                 sk_m = m;
-                sk_s = rs;
-                sk_any = true;
-            } else if (rv < sk_min) {
-                sk_min = rv;
-                sk_m = m;
-                sk_s = rs;
+                sk_s = bs;
             }
-            __syncthreads();
+            sk_any = true;
         }
+        cur = nxt;
     }
 
     // ---- combine (mesh.h:567-592)
+    if (lane == 0) {
+        uint32_t *f = fin + w * 16;
+        f[0] = __float_as_uint(sk_min);
+        f[1] = sk_m;
+        f[2] = sk_s;
+        f[3] = snk0;
+        f[4] = sk_any ? 1u : 0u;
+    }
     if (own_last) {
-        misc[0] = lc_arg;
-        misc[1] = __float_as_uint(lc_min);
+        uint32_t *f = fin + w * 16;
+        f[8] = 1u;
+        f[9] = lc_arg;
+        f[10] = __float_as_uint(lc_min);
+        f[11] = __float_as_uint(lc_snk0);
     }
     __syncthreads();
     if (j == 0) {
         DpResult r;
         r.status = 0;
-        const float v1min = __uint_as_float(misc[1]);
+        // step 2 across waves: min value, then smaller sink id, then smaller column
+        float bmin = __builtin_inff();
+        uint32_t bm = 0, bs = 0;
+        bool any = false;
+        for (int x = 0; x < NW; x++) {
+            const uint32_t *f = fin + x * 16;
+            if (!f[4]) continue;
+            const float v = __uint_as_float(f[0]);
+            if (!any || v < bmin || (v == bmin && (f[1] < bm || (f[1] == bm && f[2] < bs)))) {
+                bmin = v;
+                bm = f[1];
+                bs = f[2];
+            }
+            any = true;
+        }
+        const int wl = (int)(((L - 1) / B) >> 6);  // wave of the lane that owns column L-1
+        const uint32_t *fl = fin + wl * 16;
+        const float v1min = __uint_as_float(fl[10]);
+        const float v_snk0 = __uint_as_float(fl[11]);
         // m = sinks[0]; replaced only by a strictly smaller value, first such row wins
-        uint32_t em = snk0, es = L - 1;
-        float ev = lc_snk0;
-        if (v1min < lc_snk0) {
-            em = misc[0];
+        uint32_t em = fin[3], es = L - 1;
+        float ev = v_snk0;
+        if (v1min < v_snk0) {
+            em = fl[9];
             ev = v1min;
         }
         // sinks x columns, strict <, scan order (t asc, x asc)
-        if (sk_any && sk_min < ev) {
-            em = sk_m;
-            es = sk_s;
-            ev = sk_min;
+        if (any && bmin < ev) {
+            em = bm;
+            es = bs;
+            ev = bmin;
         }
-        if (!sk_any) r.status = -2;
+        if (!any) r.status = -2;
         r.end_m = em;
         r.end_s = es;
         r.raw = ev;
-        a.res[blockIdx.x] = r;
+        resv[blockIdx.x] = r;
     }
 }
 
@@ -436,11 +472,10 @@ __global__ void backtrack_kernel(BtArgs a) {
     if (q >= a.nq) return;
     const QDesc d = a.qd[q];
     const uint32_t L = d.L;
-    const uint32_t Lp = a.Lp_T * a.Lp_B;
+    const uint32_t Lp = a.Lp;
     const uint32_t *tb = a.tb + d.tb_off;
-    const uint32_t *pred_off = a.pred_off + d.poff_off;
+    const uint4 *rec = a.rec + d.node_off;
     const uint32_t *node_pos = a.node_pos + d.node_off;
-    const float *node_weight = a.node_weight + d.node_off;
     uint32_t *out = a.out_pos + d.q_off;
     const DpResult r = a.res[q];
     sina_hip_align_out o;
@@ -472,12 +507,13 @@ __global__ void backtrack_kernel(BtArgs a) {
         }
     }
     auto mscore = [&](uint32_t node) -> float {  // tr.s.match(sum, ab2, ab1) with comp()==true
+        const float wgt = __uint_as_float(rec[node].y);
         if (a.weights != nullptr) {
             const uint32_t nw1 = a.n_weights - 1;
             const uint32_t np = node_pos[node];
-            return a.ms * a.weights[np < nw1 ? np : nw1] * node_weight[node];
+            return a.ms * a.weights[np < nw1 ? np : nw1] * wgt;
         }
-        return a.ms * node_weight[node];
+        return a.ms * wgt;
     };
     unsigned int pos = width - 1 - node_pos[m];
     float sum_weight = 0.f;
@@ -486,8 +522,8 @@ __global__ void backtrack_kernel(BtArgs a) {
     aligned++;
     sum_weight = sum_weight + mscore(m);
 
-    // :642-685
-    while (s != 0 && pred_off[m + 1] != pred_off[m]) {
+    // :642-685 (a source node has no predecessors)
+    while (s != 0 && (rec[m].z & 0xffu) != 0) {
         const uint32_t c = tb[(size_t)m * Lp + s];
         const uint32_t snew = c & 0xffffu;
         m = c >> 16;
@@ -525,12 +561,14 @@ __global__ void backtrack_kernel(BtArgs a) {
 
 template <int T, int B>
 int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, size_t lds, hipStream_t s) {
-#define SH_LAUNCH(WG, FB)                                                                            \
-    do {                                                                                             \
-        auto kfn = mesh_dp_kernel<T, B, WG, FB>;                                                     \
-        SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                            \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
-        hipLaunchKernelGGL(kfn, dim3(nq), dim3(T), lds, s, a);                                       \
+#define SH_LAUNCH(WG, FB)                                                                               \
+    do {                                                                                                \
+        auto kfn = mesh_dp_kernel<T, B, WG, FB>;                                                        \
+        SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                               \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+        hipLaunchKernelGGL(kfn, dim3(nq), dim3(T), lds, s, a.qd, a.rec, a.pred, a.node_pos, a.succ_minpos, \
+                           a.qmask, a.weights, a.n_weights, a.tb, a.dbg_value, a.spill, a.res, a.ms, a.mms, \
+                           a.gp, a.gpe, a.W);                                                           \
     } while (0)
     if (!weighted && !forbid) SH_LAUNCH(false, false);
     else if (weighted && !forbid) SH_LAUNCH(true, false);
@@ -555,8 +593,12 @@ bool pick_geom(uint32_t maxL, DpGeom *g) {
     return false;
 }
 
-size_t dp_slot_bytes(const DpGeom &g) { return (size_t)(g.Lp() + 4) * 4 + (size_t)g.Lp() * 4 + (size_t)g.Lp() * 2; }
-size_t dp_fixed_lds_bytes(const DpGeom &g) { return (size_t)12 * g.T + 256; }
+size_t dp_slot_bytes(const DpGeom &g) { return (size_t)g.Lp() * 10; }
+size_t dp_fixed_lds_bytes(const DpGeom &g) {
+    const size_t nw = (size_t)g.T / 64;
+    return 64 + 16 * nw * kHist + 64 * nw;
+}
+int dp_max_ring(const DpGeom &) { return kHist - 4; }
 
 int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
                    size_t lds, hipStream_t s) {

@@ -43,6 +43,8 @@ def load_host():
     H.sina_host_result_family.argtypes = [vp, C.c_uint32]
     H.sina_host_timings.argtypes = [vp] + [C.POINTER(C.c_double)] * 3
     H.sina_host_timings.restype = None
+    H.sina_host_profile.restype = C.c_char_p
+    H.sina_host_profile.argtypes = [C.c_int]
     H.sina_host_build_graph.argtypes = [C.c_char_p, capi.u32p, C.c_uint32, C.c_float, capi.u32p, capi.u32p,
                                         capi.u32p, capi.u8p, capi.f32p, capi.u32p, capi.u32p, capi.u32p,
                                         C.c_uint32, C.c_uint32]
@@ -155,6 +157,10 @@ class Pipeline:
         _chk(self.H.sina_host_pipeline_run(self.h, qmask.ctypes.data_as(capi.u8p), qoff.ctypes.data_as(capi.u64p),
                                            self.nq, batch, inflight))
         return self.timings()
+
+    def profile(self, reset=True):
+        """Per-phase host wall times (needs SINA_HOST_PROFILE=1 in the environment)."""
+        return self.H.sina_host_profile(int(reset)).decode()
 
     def timings(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
