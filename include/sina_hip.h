@@ -186,6 +186,15 @@ int sina_hip_debug_mesh(sina_hip_ctx *ctx, const sina_hip_graph_batch *g, const 
                         uint32_t qlen, const sina_hip_align_params *p, uint32_t *tb_vm,
                         uint32_t *tb_vs, float *value);
 
+/* Test hook: the DAG the GPU builds for ONE family (ids into the uploaded store, in family
+ * order), in compact CSR form, for comparison with mseq (src/mseq.cpp:47-118).
+ * ring_depth is the LDS ring depth the spill assignment is made for. */
+int sina_hip_debug_family_graph(sina_hip_ctx *ctx, const uint32_t *fam_ids, uint32_t F, float fs_weight,
+                                uint32_t ring_depth, uint32_t *n_nodes, uint32_t *n_edges, uint32_t *pos,
+                                uint8_t *mask, float *weight, uint32_t *pred_off, uint32_t *pred,
+                                uint32_t *succ_minpos, uint8_t *sink, uint32_t *spill_idx, uint32_t cap_nodes,
+                                uint32_t cap_edges);
+
 /* Cumulative statistics of this context since sina_hip_init (callers take
  * differences); kernel times come from HIP events on the context stream. */
 typedef struct sina_hip_stats {

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "sina_hip_upload_refs", "sina_hip_build_index", "sina_hip_upload_index", "sina_hip_store_view_get",
     "sina_hip_store_alloc_like", "sina_hip_kmer_topk", "sina_hip_kmer_scores",
     "sina_hip_align_params_default", "sina_hip_align_graphs", "sina_hip_align_families",
-    "sina_hip_debug_mesh", "sina_hip_get_stats",
+    "sina_hip_debug_mesh", "sina_hip_debug_family_graph", "sina_hip_get_stats",
 ]
 
 
@@ -101,6 +101,8 @@ def load():
                                           C.POINTER(AlignOut), u32p]
     L.sina_hip_debug_mesh.argtypes = [vp, C.POINTER(GraphBatch), u8p, C.c_uint32, C.POINTER(AlignParams),
                                       u32p, u32p, f32p]
+    L.sina_hip_debug_family_graph.argtypes = [vp, u32p, C.c_uint32, C.c_float, C.c_uint32, u32p, u32p, u32p, u8p,
+                                              f32p, u32p, u32p, u32p, u8p, u32p, C.c_uint32, C.c_uint32]
     L.sina_hip_get_stats.argtypes = [vp, C.POINTER(Stats)]
     _lib = L
     return L
@@ -269,6 +271,27 @@ class Context:
                                                _ptr(vm, u32p), _ptr(vs, u32p),
                                                _ptr(val, f32p) if want_value else None))
         return vm, vs, val
+
+    def debug_family_graph(self, fam_ids, fs_weight=1.0, ring_depth=4):
+        fam_ids = _c(fam_ids, np.uint32)
+        cap_n, cap_e = 65536, 400000
+        nn, ne = C.c_uint32(), C.c_uint32()
+        pos = np.zeros(cap_n, np.uint32)
+        mask = np.zeros(cap_n, np.uint8)
+        w = np.zeros(cap_n, np.float32)
+        poff = np.zeros(cap_n + 1, np.uint32)
+        pred = np.zeros(cap_e, np.uint32)
+        smin = np.zeros(cap_n, np.uint32)
+        sink = np.zeros(cap_n, np.uint8)
+        spill = np.zeros(cap_n, np.uint32)
+        self._check(self.L.sina_hip_debug_family_graph(self.h, _ptr(fam_ids, u32p), len(fam_ids), fs_weight,
+                                                       ring_depth, C.byref(nn), C.byref(ne), _ptr(pos, u32p),
+                                                       _ptr(mask, u8p), _ptr(w, f32p), _ptr(poff, u32p),
+                                                       _ptr(pred, u32p), _ptr(smin, u32p), _ptr(sink, u8p),
+                                                       _ptr(spill, u32p), cap_n, cap_e))
+        n, e = nn.value, ne.value
+        return dict(n=n, pos=pos[:n].copy(), mask=mask[:n].copy(), weight=w[:n].copy(), pred_off=poff[:n + 1].copy(),
+                    pred=pred[:e].copy(), succ_minpos=smin[:n].copy(), sink=sink[:n].copy(), spill=spill[:n].copy())
 
     def stats(self):
         s = Stats()

@@ -305,6 +305,7 @@ int sina_hip_upload_refs(sina_hip_ctx *c, const uint32_t *ab, const uint64_t *of
     SH_CHECK(hipMemcpyAsync(c->ref_ab.p, ab, 4 * total, hipMemcpyHostToDevice, c->stream));
     SH_CHECK(hipMemcpyAsync(c->ref_off.p, off, 8 * ((uint64_t)n_refs + 1), hipMemcpyHostToDevice, c->stream));
     SH_CHECK(hipStreamSynchronize(c->stream));
+    c->ref_off_host.assign(off, off + n_refs + 1);
     c->n_refs = n_refs;
     c->width = width;
     c->total_bases = total;

@@ -1,9 +1,547 @@
-// Device-side family DAG build (mseq ctor + reduce_edges) -- see below.
+// Family DAG build on the GPU + sina_hip_align_families.
+//
+// What it computes: mseq::mseq + sort + reduce_edges for every query's family
+// (reference src/mseq.cpp:47-118, src/graph.h:332-357,451-488; spec SURVEY.md A.3):
+//   * one node per (alignment column, IUPAC character incl. case) that occurs in the
+//     family; node ids ascend with the column and, inside a column, with the family
+//     index of the first reference showing that character;
+//   * node weight from the number of references sharing the node (mseq.cpp:113);
+//   * edge a->b whenever some reference has consecutive bases in nodes a, b; per node
+//     the predecessor ids ascending and unique; sources / sinks implicit.
+//
+// How it maps to the hardware: one workgroup per query, everything column-parallel.
+//   1. occupied-column bitmap in LDS (atomicOr per base), prefix-popcount -> dense
+//      column index ("rank") of every alignment column;
+//   2. a [column][family member] table in HBM scratch (one u32 per entry: base mask,
+//      local node index, dense column of that reference's previous base), filled with
+//      one store per base;
+//   3. one thread per column scans its F entries in family order: first appearance of
+//      a mask opens a node (exact reference order), later ones count; block scans
+//      turn per-column node / raw-edge counts into node ids and CSR segments;
+//   4. one thread per column emits node records and, per node, inserts the
+//      predecessor ids (node base of the previous column + local index there) into a
+//      sorted unique list in its CSR segment; atomicMin collects the successor
+//      minimum column (for --insertion=forbid) and marks rows whose successors lie
+//      beyond the DP kernel's LDS ring (spill rows).
+// All arithmetic is integer except the node weight, which is looked up in a table the
+// HOST computed with the reference's own mixed double/float expression.
+#include <algorithm>
+#include <cstring>
+
 #include "common.h"
 #include "ctx.h"
-using namespace sina_hip;
-extern "C" int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *, const uint64_t *, uint32_t,
-                                       const uint8_t *, const uint64_t *, const sina_hip_align_params *,
-                                       sina_hip_align_out *, uint32_t *) {
-    SH_FAIL("align_families: not built yet");
+
+namespace sina_hip {
+namespace {
+
+constexpr int kGT = 256;          // threads per workgroup
+constexpr uint32_t kNoPrev = 0xFFFFu;
+constexpr int kMaxFam = 128;
+
+struct GraphArgs {
+    const uint32_t *ref_ab;
+    const uint64_t *ref_off;
+    const uint32_t *fam_ids;   // concatenated
+    const uint64_t *fam_off;   // [nq+1]
+    const uint64_t *tab_off;   // [nq] offset of this query's column table (u32 units)
+    const uint64_t *pred_off;  // [nq] offset of this query's pred area
+    const float *wtab;         // [(kMaxFam+1) * (kMaxFam+1)]: weight for (F, count)
+    uint32_t *tab;             // scratch: [NC][F] per query
+    uint4 *rec;                // [nq][ncap]
+    uint32_t *node_pos;        // [nq][ncap]
+    uint32_t *succ_min;        // [nq][ncap]
+    uint8_t *far_mark;         // [nq][ncap]
+    uint32_t *pred;            // per query area of total-family-bases entries
+    uint32_t *sizes;           // [nq][4]: N, raw edge entries, n_spill, status (0 ok, 1 NC cap, 2 N cap)
+    uint32_t width, nccap, ncap;
+    int W;                     // DP ring depth: edges longer than this need a spill row
+};
+
+// exclusive scan of in[0..n) into out[0..n) (may alias if same type); returns the total.
+template <typename In, typename Out>
+__device__ uint32_t block_exscan(const In *in, Out *out, uint32_t n, uint32_t *tmp) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = (n + kGT - 1) / kGT;
+    const uint32_t b = min(n, tid * chunk), e = min(n, b + chunk);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; i++) s += (uint32_t)in[i];
+    // exclusive scan of the kGT partial sums (wave shuffle + 4 wave totals)
+    uint32_t x = s;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) tmp[wave] = x;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < kGT / 64; w++) {
+        if (w < wave) base += tmp[w];
+        total += tmp[w];
+    }
+    uint32_t run = base + x - s;
+    __syncthreads();
+    for (uint32_t i = b; i < e; i++) {
+        const uint32_t v = (uint32_t)in[i];
+        out[i] = (Out)run;
+        run += v;
+    }
+    __syncthreads();
+    return total;
 }
+
+__global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_ids[kMaxFam];
+    __shared__ uint32_t s_len[kMaxFam];
+    __shared__ uint64_t s_beg[kMaxFam];
+    __shared__ uint32_t s_tmp[8];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t nwords = (a.width + 31) / 32;
+    // LDS carve
+    uint32_t *bitmap = reinterpret_cast<uint32_t *>(smem);                 // [nwords]
+    uint16_t *wrank = reinterpret_cast<uint16_t *>(bitmap + nwords);        // [nwords]
+    uint32_t *cpos = reinterpret_cast<uint32_t *>(smem + ((6 * (size_t)nwords + 15) & ~(size_t)15));  // [nccap]
+    uint32_t *ebase = cpos + a.nccap;                                       // [nccap]
+    uint16_t *nbase = reinterpret_cast<uint16_t *>(ebase + a.nccap);        // [nccap]
+    uint8_t *nn = reinterpret_cast<uint8_t *>(nbase + a.nccap);             // [nccap] nodes per column
+    uint8_t *rc = nn + a.nccap;                                             // [nccap] raw edges per column
+
+    const uint64_t f0 = a.fam_off[q];
+    const uint32_t F = (uint32_t)(a.fam_off[q + 1] - f0);
+    uint32_t *sz = a.sizes + 4 * (size_t)q;
+    for (uint32_t j = tid; j < F; j += kGT) {
+        const uint32_t id = a.fam_ids[f0 + j];
+        s_ids[j] = id;
+        s_beg[j] = a.ref_off[id];
+        s_len[j] = (uint32_t)(a.ref_off[id + 1] - a.ref_off[id]);
+    }
+    for (uint32_t i = tid; i < nwords; i += kGT) bitmap[i] = 0;
+    __syncthreads();
+
+    // 1. occupied columns
+    for (uint32_t j = 0; j < F; j++) {
+        const uint32_t *b = a.ref_ab + s_beg[j];
+        for (uint32_t i = tid; i < s_len[j]; i += kGT) {
+            const uint32_t pos = b[i] & 0xFFFFFFu;
+            atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+        }
+    }
+    __syncthreads();
+    // 2. dense column index: rank(pos) = wrank[pos >> 5] + popc(bits below)
+    {
+        const uint32_t chunk = (nwords + kGT - 1) / kGT;
+        const uint32_t b = min(nwords, tid * chunk), e = min(nwords, b + chunk);
+        uint32_t s = 0;
+        for (uint32_t i = b; i < e; i++) s += __popc(bitmap[i]);
+        uint32_t x = s;
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) s_tmp[wave] = x;
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+        for (int w = 0; w < kGT / 64; w++) {
+            if (w < wave) base += s_tmp[w];
+            total += s_tmp[w];
+        }
+        if (total > a.nccap) {  // column table too small: the host retries with a larger cap
+            if (tid == 0) {
+                sz[0] = total;
+                sz[1] = sz[2] = 0;
+                sz[3] = 1;
+            }
+            return;
+        }
+        uint32_t run = base + x - s;
+        for (uint32_t i = b; i < e; i++) {
+            wrank[i] = (uint16_t)run;
+            run += __popc(bitmap[i]);
+        }
+        if (tid == 0) s_tmp[4] = total;
+    }
+    __syncthreads();
+    const uint32_t NC = s_tmp[4];
+    auto rank = [&](uint32_t pos) -> uint32_t {
+        return (uint32_t)wrank[pos >> 5] + __popc(bitmap[pos >> 5] & ((1u << (pos & 31)) - 1u));
+    };
+    // 3. column table: T[c][j] = mask | 0xFF << 8 | dense column of j's previous base << 16
+    uint32_t *T = a.tab + a.tab_off[q];
+    for (uint32_t i = tid; i < NC * F; i += kGT) T[i] = 0;
+    __syncthreads();
+    for (uint32_t j = 0; j < F; j++) {
+        const uint32_t *b = a.ref_ab + s_beg[j];
+        for (uint32_t i = tid; i < s_len[j]; i += kGT) {
+            const uint32_t ab = b[i];
+            const uint32_t pos = ab & 0xFFFFFFu;
+            const uint32_t c = rank(pos);
+            const uint32_t pc = (i > 0) ? rank(b[i - 1] & 0xFFFFFFu) : kNoPrev;
+            T[(size_t)c * F + j] = ((ab >> 24) & 0xFFu) | (0xFFu << 8) | (pc << 16);
+            cpos[c] = pos;
+        }
+    }
+    __syncthreads();
+    // 4. per column: nodes in order of first appearance (family order), raw edge count
+    for (uint32_t c = tid; c < NC; c += kGT) {
+        uint32_t seen = 0;          // bit m: mask value m already has a node in this column
+        uint64_t idx0 = 0, idx1 = 0, idx2 = 0;  // local node index of mask m, 5 bits each (12/12/8 masks)
+        uint32_t k = 0, raw = 0;
+        uint32_t *row = T + (size_t)c * F;
+        for (uint32_t j = 0; j < F; j++) {
+            const uint32_t t = row[j];
+            const uint32_t m = t & 0x1Fu;
+            if ((t & 0xFFu) == 0) continue;
+            uint32_t li;
+            if (!((seen >> m) & 1u)) {
+                seen |= 1u << m;
+                li = k++;
+                if (m < 12) idx0 |= (uint64_t)li << (5 * m);
+                else if (m < 24) idx1 |= (uint64_t)li << (5 * (m - 12));
+                else idx2 |= (uint64_t)li << (5 * (m - 24));
+            } else {
+                li = (m < 12) ? (uint32_t)(idx0 >> (5 * m)) & 31u
+                     : (m < 24) ? (uint32_t)(idx1 >> (5 * (m - 12))) & 31u
+                                : (uint32_t)(idx2 >> (5 * (m - 24))) & 31u;
+            }
+            row[j] = (t & 0xFFFF00FFu) | (li << 8);
+            if ((t >> 16) != kNoPrev) raw++;
+        }
+        nn[c] = (uint8_t)k;
+        rc[c] = (uint8_t)raw;
+    }
+    __syncthreads();
+    const uint32_t N = block_exscan(nn, nbase, NC, s_tmp);
+    const uint32_t E = block_exscan(rc, ebase, NC, s_tmp);
+    if (N > a.ncap || N > 65535u) {
+        if (tid == 0) {
+            sz[0] = N;
+            sz[1] = sz[2] = 0;
+            sz[3] = 2;
+        }
+        return;
+    }
+    uint4 *rec = a.rec + (size_t)q * a.ncap;
+    uint32_t *node_pos = a.node_pos + (size_t)q * a.ncap;
+    uint32_t *smin = a.succ_min + (size_t)q * a.ncap;
+    uint8_t *far = a.far_mark + (size_t)q * a.ncap;
+    uint32_t *pred = a.pred + a.pred_off[q];
+    for (uint32_t i = tid; i < N; i += kGT) {
+        smin[i] = 0xFFFFFFFFu;
+        far[i] = 0;
+    }
+    __syncthreads();
+    // 5. node records + sorted unique predecessor lists
+    const float *wt = a.wtab + (size_t)F * (kMaxFam + 1);
+    for (uint32_t c = tid; c < NC; c += kGT) {
+        const uint32_t *row = T + (size_t)c * F;
+        const uint32_t knodes = nn[c];
+        const uint32_t pos = cpos[c];
+        uint32_t seg = ebase[c];
+        for (uint32_t k = 0; k < knodes; k++) {
+            const uint32_t node = (uint32_t)nbase[c] + k;
+            uint32_t cnt = 0, np = 0, rawk = 0, mask = 0;
+            for (uint32_t j = 0; j < F; j++) {
+                const uint32_t t = row[j];
+                if ((t & 0xFFu) == 0 || ((t >> 8) & 0xFFu) != k) continue;
+                mask = t & 0xFFu;
+                cnt++;
+                const uint32_t pc = t >> 16;
+                if (pc == kNoPrev) continue;
+                rawk++;
+                const uint32_t pt = T[(size_t)pc * F + j];
+                const uint32_t pa = (uint32_t)nbase[pc] + ((pt >> 8) & 0xFFu);
+                // sorted unique insert into pred[seg .. seg+np)
+                uint32_t x = 0;
+                while (x < np && pred[seg + x] < pa) x++;
+                if (x < np && pred[seg + x] == pa) continue;
+                for (uint32_t y = np; y > x; y--) pred[seg + y] = pred[seg + y - 1];
+                pred[seg + x] = pa;
+                np++;
+                atomicMin(&smin[pa], pos);
+                if (node - pa > (uint32_t)a.W) far[pa] = 1;
+            }
+            uint4 r;
+            r.x = seg;
+            r.y = __float_as_uint(wt[cnt]);
+            r.z = (np & 0xFFu) | (mask << 8);
+            r.w = 0xFFFFFFFFu;
+            rec[node] = r;
+            node_pos[node] = pos;
+            seg += rawk;
+        }
+    }
+    __syncthreads();
+    // 6. sinks, successor minimum, spill rows
+    // exclusive scan over the far marks, chunked per thread (global memory, N entries)
+    {
+        const uint32_t chunk = (N + kGT - 1) / kGT;
+        const uint32_t b = min(N, tid * chunk), e = min(N, b + chunk);
+        uint32_t s = 0;
+        for (uint32_t i = b; i < e; i++) s += far[i];
+        uint32_t x = s;
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) s_tmp[wave] = x;
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+        for (int w = 0; w < kGT / 64; w++) {
+            if (w < wave) base += s_tmp[w];
+            total += s_tmp[w];
+        }
+        uint32_t run = base + x - s;
+        for (uint32_t i = b; i < e; i++) {
+            uint4 r = rec[i];
+            if (far[i]) r.w = run++;
+            const uint32_t sm = smin[i];
+            if (sm == 0xFFFFFFFFu) {
+                r.z |= kRecSink;
+                smin[i] = 1000000u;  // "no successor" sentinel of mesh.h:480
+            }
+            rec[i] = r;
+        }
+        if (tid == 0) {
+            sz[0] = N;
+            sz[1] = E;
+            sz[2] = total;
+            sz[3] = 0;
+        }
+    }
+}
+
+size_t graph_lds_bytes(uint32_t width, uint32_t nccap) {
+    const size_t nwords = (width + 31) / 32;
+    return ((6 * nwords + 15) & ~(size_t)15) + (size_t)nccap * (4 + 4 + 2 + 1 + 1) + 64;
+}
+
+}  // namespace
+}  // namespace sina_hip
+
+using namespace sina_hip;
+
+namespace {
+
+struct BuiltGraphs {
+    uint32_t nccap = 0, ncap = 0;
+    std::vector<uint64_t> pred_off;  // per query, into c->pred
+    std::vector<uint32_t> sizes;     // per query: N, raw edge entries, n_spill, status
+};
+
+// Builds the DAGs of bq families (fam_off is absolute, first family = q0) into the context's
+// rec / node_pos / succ_minpos / pred buffers; grows the per-query caps and retries on overflow.
+int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t *fam_off, uint32_t q0,
+                        uint32_t bq, float fs_weight, int W, BuiltGraphs *bg) {
+    hipStream_t s = c->stream;
+    if (c->ref_off_host.size() != (size_t)c->n_refs + 1) {  // store arrived by broadcast (store_alloc_like)
+        c->ref_off_host.resize((size_t)c->n_refs + 1);
+        SH_CHECK(hipMemcpy(c->ref_off_host.data(), c->ref_off.p, 8 * ((size_t)c->n_refs + 1), hipMemcpyDeviceToHost));
+    }
+    // weight table: the reference's expression (mseq.cpp:113) evaluated on the host
+    if (!(c->wtab_fs_weight == fs_weight) || !c->g_wtab.p) {
+        std::vector<float> wt((size_t)(kMaxFam + 1) * (kMaxFam + 1), 0.f);
+        const float weight = fs_weight;
+        for (unsigned F = 1; F <= (unsigned)kMaxFam; F++)
+            for (unsigned cnt = 0; cnt <= F; cnt++)
+                wt[(size_t)F * (kMaxFam + 1) + cnt] =
+                    (float)(1.0 / (double)(weight + 1) + (double)(weight * ((float)cnt / (float)F)));
+        if (c->g_wtab.reserve(wt.size() * 4)) return 1;
+        SH_CHECK(hipMemcpyAsync(c->g_wtab.p, wt.data(), wt.size() * 4, hipMemcpyHostToDevice, s));
+        SH_CHECK(hipStreamSynchronize(s));
+        c->wtab_fs_weight = fs_weight;
+    }
+    std::vector<uint64_t> foff(bq + 1), tab_off(bq), elems(bq, 0);
+    bg->pred_off.assign(bq, 0);
+    for (uint32_t q = 0; q <= bq; q++) foff[q] = fam_off[q0 + q] - fam_off[q0];
+    for (uint32_t q = 0; q < bq; q++) {
+        for (uint64_t x = fam_off[q0 + q]; x < fam_off[q0 + q + 1]; x++) {
+            const uint32_t id = fam_ids[x];
+            if (id >= c->n_refs) SH_FAIL("align_families: reference id out of range");
+            elems[q] += c->ref_off_host[id + 1] - c->ref_off_host[id];
+        }
+    }
+    uint32_t nccap = std::min<uint32_t>(c->width, 4096);
+    uint32_t ncap = std::min<uint32_t>(65535, 3 * nccap);
+    for (int attempt = 0;; attempt++) {
+        uint64_t tab_total = 0, pred_total = 0;
+        for (uint32_t q = 0; q < bq; q++) {
+            tab_off[q] = tab_total;
+            tab_total += (uint64_t)nccap * (foff[q + 1] - foff[q]);
+            bg->pred_off[q] = pred_total;
+            pred_total += elems[q] + 8;  // +8: slack behind every list
+        }
+        const size_t glds = graph_lds_bytes(c->width, nccap);
+        if (glds > 160 * 1024) SH_FAIL("align_families: family too wide for the device DAG build");
+        if (c->g_fam_ids.reserve(4 * std::max<uint64_t>(foff[bq], 1)) || c->g_fam_off.reserve(8 * ((uint64_t)bq + 1)) ||
+            c->g_tmp0.reserve(8 * (uint64_t)bq) || c->g_tmp1.reserve(8 * (uint64_t)bq) ||
+            c->g_tmp2.reserve(4 * std::max<uint64_t>(tab_total, 1)) ||
+            c->rec.reserve(sizeof(uint4) * (uint64_t)bq * ncap) || c->node_pos.reserve(4 * (uint64_t)bq * ncap) ||
+            c->succ_minpos.reserve(4 * (uint64_t)bq * ncap) || c->g_tmp3.reserve((uint64_t)bq * ncap) ||
+            c->pred.reserve(4 * pred_total) || c->g_sizes.reserve(16 * (uint64_t)bq))
+            return 1;
+        SH_CHECK(hipMemcpyAsync(c->g_fam_ids.p, fam_ids + fam_off[q0], 4 * foff[bq], hipMemcpyHostToDevice, s));
+        SH_CHECK(hipMemcpyAsync(c->g_fam_off.p, foff.data(), 8 * ((uint64_t)bq + 1), hipMemcpyHostToDevice, s));
+        SH_CHECK(hipMemcpyAsync(c->g_tmp0.p, tab_off.data(), 8 * (uint64_t)bq, hipMemcpyHostToDevice, s));
+        SH_CHECK(hipMemcpyAsync(c->g_tmp1.p, bg->pred_off.data(), 8 * (uint64_t)bq, hipMemcpyHostToDevice, s));
+        GraphArgs ga;
+        ga.ref_ab = c->ref_ab.as<uint32_t>();
+        ga.ref_off = c->ref_off.as<uint64_t>();
+        ga.fam_ids = c->g_fam_ids.as<uint32_t>();
+        ga.fam_off = c->g_fam_off.as<uint64_t>();
+        ga.tab_off = c->g_tmp0.as<uint64_t>();
+        ga.pred_off = c->g_tmp1.as<uint64_t>();
+        ga.wtab = c->g_wtab.as<float>();
+        ga.tab = c->g_tmp2.as<uint32_t>();
+        ga.rec = c->rec.as<uint4>();
+        ga.node_pos = c->node_pos.as<uint32_t>();
+        ga.succ_min = c->succ_minpos.as<uint32_t>();
+        ga.far_mark = c->g_tmp3.as<uint8_t>();
+        ga.pred = c->pred.as<uint32_t>();
+        ga.sizes = c->g_sizes.as<uint32_t>();
+        ga.width = c->width;
+        ga.nccap = nccap;
+        ga.ncap = ncap;
+        ga.W = W;
+        SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(family_graph_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+        SH_CHECK(hipEventRecord(c->ev[6], s));
+        hipLaunchKernelGGL(family_graph_kernel, dim3(bq), dim3(kGT), glds, s, ga);
+        SH_CHECK(hipGetLastError());
+        SH_CHECK(hipEventRecord(c->ev[7], s));
+        bg->sizes.resize(4 * (size_t)bq);
+        SH_CHECK(hipMemcpyAsync(bg->sizes.data(), c->g_sizes.p, 16 * (uint64_t)bq, hipMemcpyDeviceToHost, s));
+        SH_CHECK(hipStreamSynchronize(s));
+        float gms = 0;
+        SH_CHECK(hipEventElapsedTime(&gms, c->ev[6], c->ev[7]));
+        c->stats.graph_ms += gms;
+        uint32_t need_nc = 0, need_n = 0;
+        for (uint32_t q = 0; q < bq; q++) {
+            if (bg->sizes[4 * q + 3] == 1) need_nc = std::max(need_nc, bg->sizes[4 * q]);
+            if (bg->sizes[4 * q + 3] == 2) need_n = std::max(need_n, bg->sizes[4 * q]);
+        }
+        if (!need_nc && !need_n) break;
+        if (attempt >= 3 || need_n > 65535u) SH_FAIL("align_families: family DAG exceeds device limits");
+        if (need_nc) nccap = std::min<uint32_t>(c->width, need_nc + need_nc / 8 + 16);
+        ncap = std::min<uint32_t>(65535, std::max<uint32_t>(3 * nccap, need_n + need_n / 8 + 16));
+    }
+    bg->nccap = nccap;
+    bg->ncap = ncap;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t *fam_off, uint32_t nq,
+                            const uint8_t *qmask, const uint64_t *qoff, const sina_hip_align_params *p,
+                            sina_hip_align_out *out, uint32_t *out_pos) {
+    if (!c || !fam_ids || !fam_off || !qmask || !qoff || !p || !out || !out_pos)
+        SH_FAIL("align_families: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_refs) SH_FAIL("align_families: upload references first");
+    if (nq == 0) return 0;
+    SH_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (c->width > 524288u) SH_FAIL("align_families: alignment wider than 524288 columns (use align_graphs)");
+    uint32_t maxL = 0;
+    for (uint32_t q = 0; q < nq; q++) {
+        const uint64_t L = qoff[q + 1] - qoff[q], F = fam_off[q + 1] - fam_off[q];
+        if (L == 0 || L > 65535) SH_FAIL("align_families: query length must be in 1..65535");
+        if (F == 0 || F > (uint64_t)kMaxFam) SH_FAIL("align_families: family size must be in 1..128");
+        maxL = std::max<uint32_t>(maxL, (uint32_t)L);
+    }
+    DpPlan pl;
+    if (plan_dp(c, maxL, &pl)) return 1;
+    const int Lp = pl.geom.Lp();
+    if (upload_weights(c, p)) return 1;
+
+    const uint64_t tb_budget_cells = c->tb_budget_bytes / 4;
+    const uint32_t chunk_q = 2048;
+    BuiltGraphs bg;
+    for (uint32_t q0 = 0; q0 < nq; q0 += chunk_q) {
+        const uint32_t bq = std::min(chunk_q, nq - q0);
+        if (build_family_graphs(c, fam_ids, fam_off, q0, bq, p->fs_weight, pl.W, &bg)) return 1;
+        // DP in sub-ranges that fit the trace-back budget
+        uint32_t r0 = 0;
+        while (r0 < bq) {
+            uint32_t r1 = r0;
+            uint64_t tbc = 0, sprows = 0, cells = 0;
+            std::vector<QDesc> qd;
+            while (r1 < bq) {
+                const uint32_t N = bg.sizes[4 * r1];
+                if (r1 > r0 && tbc + (uint64_t)N * Lp > tb_budget_cells) break;
+                QDesc d;
+                d.node_off = (uint64_t)r1 * bg.ncap;
+                d.edge_off = bg.pred_off[r1];
+                d.q_off = qoff[q0 + r1] - qoff[q0 + r0];
+                d.tb_off = tbc;
+                d.spill_off = sprows;
+                d.N = N;
+                d.L = (uint32_t)(qoff[q0 + r1 + 1] - qoff[q0 + r1]);
+                d.n_spill = bg.sizes[4 * r1 + 2];
+                d.pad = 0;
+                qd.push_back(d);
+                tbc += (uint64_t)N * Lp;
+                sprows += d.n_spill;
+                cells += (uint64_t)N * d.L;
+                r1++;
+            }
+            const uint32_t rq = r1 - r0;
+            const uint64_t qbase = qoff[q0 + r0], nqm = qoff[q0 + r1] - qbase;
+            if (c->qd.reserve(sizeof(QDesc) * rq) || c->qmask.reserve(std::max<uint64_t>(nqm, 1))) return 1;
+            SH_CHECK(hipMemcpyAsync(c->qd.p, qd.data(), sizeof(QDesc) * rq, hipMemcpyHostToDevice, s));
+            SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qbase, nqm, hipMemcpyHostToDevice, s));
+            if (run_dp_device(c, pl, rq, tbc, sprows, cells, nqm, p, c->width, out + q0 + r0, out_pos + qbase, false))
+                return 1;
+            r0 = r1;
+        }
+    }
+    return 0;
+}
+
+int sina_hip_debug_family_graph(sina_hip_ctx *c, const uint32_t *fam_ids, uint32_t F, float fs_weight,
+                                uint32_t ring_depth, uint32_t *n_nodes, uint32_t *n_edges, uint32_t *pos,
+                                uint8_t *mask, float *weight, uint32_t *pred_off, uint32_t *pred,
+                                uint32_t *succ_minpos, uint8_t *sink, uint32_t *spill_idx, uint32_t cap_nodes,
+                                uint32_t cap_edges) {
+    if (!c || !fam_ids || !n_nodes || !n_edges) SH_FAIL("debug_family_graph: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_refs) SH_FAIL("debug_family_graph: upload references first");
+    if (F == 0 || F > (uint32_t)kMaxFam) SH_FAIL("debug_family_graph: family size must be in 1..128");
+    SH_CHECK(hipSetDevice(c->device));
+    const uint64_t foff[2] = {0, F};
+    BuiltGraphs bg;
+    if (build_family_graphs(c, fam_ids, foff, 0, 1, fs_weight, (int)ring_depth, &bg)) return 1;
+    const uint32_t N = bg.sizes[0];
+    std::vector<uint4> rec(N);
+    std::vector<uint32_t> pr(bg.sizes[1] + 8);
+    SH_CHECK(hipMemcpy(rec.data(), c->rec.p, sizeof(uint4) * N, hipMemcpyDeviceToHost));
+    SH_CHECK(hipMemcpy(pr.data(), c->pred.p, 4 * pr.size(), hipMemcpyDeviceToHost));
+    uint32_t E = 0;
+    for (uint32_t m = 0; m < N; m++) E += rec[m].z & 0xffu;
+    *n_nodes = N;
+    *n_edges = E;
+    if (N > cap_nodes || E > cap_edges) SH_FAIL("debug_family_graph: output buffers too small");
+    SH_CHECK(hipMemcpy(pos, c->node_pos.p, 4 * N, hipMemcpyDeviceToHost));
+    SH_CHECK(hipMemcpy(succ_minpos, c->succ_minpos.p, 4 * N, hipMemcpyDeviceToHost));
+    uint32_t e = 0;
+    for (uint32_t m = 0; m < N; m++) {
+        mask[m] = (uint8_t)((rec[m].z >> 8) & 0xffu);
+        memcpy(&weight[m], &rec[m].y, 4);
+        sink[m] = (rec[m].z & kRecSink) ? 1 : 0;
+        spill_idx[m] = rec[m].w;
+        pred_off[m] = e;
+        for (uint32_t x = 0; x < (rec[m].z & 0xffu); x++) pred[e++] = pr[rec[m].x + x];
+    }
+    pred_off[N] = e;
+    return 0;
+}
+
+}  // extern "C"

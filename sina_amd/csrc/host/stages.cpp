@@ -811,7 +811,7 @@ static aligner::options al_defaults() {  // src/align.cpp:231-274
     o.gap_penalty = 5.0f;
     o.gap_ext_penalty = 2.0f;
     o.debug_graph = o.write_used_rels = o.use_subst_matrix = false;
-    o.device_graph = false;  // flipped to true once sina_hip_align_families is the faster path
+    o.device_graph = true;  // family DAGs are built on the GPU (sina_hip_align_families)
     return o;
 }
 static aligner::options &al_opts() {

@@ -544,6 +544,7 @@ int sina_hip_store_alloc_like(sina_hip_ctx *c, sina_hip_store_view *v) {
     c->nofast = v->nofast;
     c->n_postings = v->n_postings;
     c->have_refs = c->have_index = true;
+    c->ref_off_host.clear();  // re-read from the device after the broadcast filled it
     v->ref_ab = c->ref_ab.p;
     v->ref_ab_bytes = 4 * v->total_bases;
     v->ref_off = c->ref_off.p;

@@ -115,3 +115,53 @@ def test_device_index_build_equals_oracle_csr(oracle, gpu_ctx, small):
         for qi in range(qs.n):
             q = util.query_cseq(qs, qi)
             assert (gpu_ctx.kmer_scores(qs.seq(qi)) == oidx.scores(q)).all()
+
+
+def test_device_family_graph_equals_oracle(oracle, gpu_ctx):
+    """The DAG built on the GPU (sina_hip_align_families' first stage) vs mseq in the oracle: node order,
+    columns, masks, weight bits, predecessor lists, successor minimum, sinks, spill rows."""
+    refs = synth.make_refs(300, length=400, width=4000, seed=71, amb_rate=0.03, lower_rate=0.05, long_del_prob=0.4)
+    cs = util.cseqs_from_refs(refs)
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    rng = np.random.default_rng(4)
+    for fsw in (1.0, 0.0, 2.5):
+        for F in (1, 2, 7, 40, 41, 100):
+            ids = rng.choice(refs.n, size=F, replace=False).astype(np.uint32)
+            for ring in (1, 3, 8):
+                g = gpu_ctx.debug_family_graph(ids, fsw, ring)
+                o = util.graph_dict([cs[i] for i in ids], fsw)
+                assert g["n"] == o["n"]
+                assert (g["pos"] == o["pos"]).all() and (g["mask"] == o["mask"]).all()
+                assert (util.f32_bits(g["weight"]) == util.f32_bits(o["weight"])).all()
+                assert (g["pred_off"] == o["pred_off"]).all() and (g["pred"] == o["pred"]).all()
+                assert (g["succ_minpos"] == o["succ_minpos"]).all()
+                sink = np.zeros(o["n"], np.uint8)
+                sink[o["snk"]] = 1
+                assert (g["sink"] == sink).all()
+                m = np.repeat(np.arange(o["n"]), np.diff(o["pred_off"]))
+                far = np.unique(o["pred"][(m - o["pred"]) > ring])
+                want = np.full(o["n"], 0xFFFFFFFF, np.uint32)
+                want[far] = np.arange(len(far))
+                assert (g["spill"] == want).all()
+
+
+def test_align_families_equals_align_graphs(oracle, gpu_ctx, small):
+    refs, qs, cs, idx = small
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    fams, graphs, qms = [], [], []
+    for qi in range(qs.n):
+        q, fam, ids = _family(oracle, refs, cs, idx, qs, qi)
+        if len(ids) == 0:
+            continue
+        fams.append(ids.astype(np.uint32))
+        graphs.append(util.graph_dict(fam))
+        qms.append((q.packed() >> 24).astype(np.uint8))
+    qoff = np.zeros(len(qms) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(m) for m in qms])
+    foff = np.zeros(len(fams) + 1, np.uint64)
+    foff[1:] = np.cumsum([len(f) for f in fams])
+    for ins in (0, 1):
+        p = gpu_ctx.params(insertion=ins)
+        o1, p1 = gpu_ctx.align_graphs(gpu_ctx.graph_batch(graphs, refs.width), np.concatenate(qms), qoff, p)
+        o2, p2 = gpu_ctx.align_families(np.concatenate(fams), foff, np.concatenate(qms), qoff, p)
+        assert (o1 == o2).all() and (p1 == p2).all()
