@@ -53,6 +53,12 @@ __device__ __forceinline__ bool same_state(const ChainState &a, const ChainState
     return a.v == b.v && a.e == b.e && (!a.e || (a.gsi == b.gsi && a.gmax == b.gmax));
 }
 
+// value of `x` in lane-1 (lane 0 gets an unspecified value): one DPP move, no LDS round trip
+__device__ __forceinline__ uint32_t lane_shr1(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float lane_shr1(float x) { return __uint_as_float(lane_shr1(__float_as_uint(x))); }
+
 __device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -162,7 +168,9 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         if (w < NW - 1) {  // do not lap the history slots the wave to my right still needs
             while (m >= lds_load_relaxed(&progress[w + 1]) + throttle) __builtin_amdgcn_s_sleep(1);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // LDS is in-order per CU: everything the publishing wave wrote before its progress
+        // store is visible once the counter is; only the compiler must not hoist loads.
+        asm volatile("" ::: "memory");
 
         // ---- phase 1: deletion + match candidates from every predecessor row
         float dv[B], gm[B], mt[B], csel[B];
@@ -206,7 +214,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 }
             }
             // value[p][s0-1]: from the lane to my left; lane 0 takes the left wave's boundary
-            svl = __shfl_up(sv[B - 1], 1);
+            svl = lane_shr1(sv[B - 1]);
             if (lane == 0 && w > 0) {
                 if (near) svl = bnd_val[(w - 1) * kHist + (p & (kHist - 1))];
                 else svl = (spill + (size_t)rec[p].w * (3 * Lp))[s0 - 1];
@@ -310,10 +318,10 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         }
         for (;;) {
             const ChainState prev = ex;
-            left.v = __shfl_up(ex.v, 1);
-            left.e = __shfl_up(ex.e, 1);
-            left.gsi = __shfl_up(ex.gsi, 1);
-            left.gmax = FORBID ? __shfl_up(ex.gmax, 1) : 0u;
+            left.v = lane_shr1(ex.v);
+            left.e = lane_shr1(ex.e);
+            left.gsi = lane_shr1(ex.gsi);
+            left.gmax = FORBID ? lane_shr1(ex.gmax) : 0u;
             if (lane == 0) left = wave_left;
             if (j > 0) run_chain(left);
             if (!__any(!same_state(ex, prev))) break;
@@ -348,8 +356,14 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 reinterpret_cast<uint32_t *>(row)[2 * Lp + s0 + k] = gmi[k];
             }
         }
-        // release: LDS writes (and the spill row, if any) before the progress counter
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // release: LDS writes (and the spill row, if any) before the progress counter.  Rows
+        // without a spill row only need the LDS queue drained -- a full workgroup-scope release
+        // would also wait (vmcnt) for the previous row's trace-back stores.
+        if (sp != kNoSpill) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         if (lane == 0) __hip_atomic_store(&progress[w], m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 
         // ---- trace-back cells: the only per-cell HBM traffic

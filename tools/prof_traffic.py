@@ -1,0 +1,39 @@
+"""Summarises a tools/prof_bench.sh output directory: per-kernel time (kernel trace) and HBM
+traffic per launch from the FETCH_SIZE / WRITE_SIZE passes (KiB units; FETCH_SIZE of wide
+coalesced streams is reported at 1/2 on gfx950 -- MI355X_MICROARCH.md, HBM section -- both the
+raw and the x2-corrected read figure are printed)."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+d = sys.argv[1]
+lines = []
+for f in glob.glob(os.path.join(d, "kt", "*kernel_stats.csv")):
+    for r in csv.DictReader(open(f)):
+        lines.append("%-72s calls %5s  avg %10.3f ms  total %10.1f ms  %6s%%" % (
+            r["Name"][:72], r["Calls"], float(r["AverageNs"]) / 1e6, float(r["TotalDurationNs"]) / 1e6,
+            r["Percentage"]))
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(set)
+for kind in ("fetch", "write"):
+    for f in glob.glob(os.path.join(d, "pmc_" + kind, "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"][:72]
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
+lines.append("")
+lines.append("HBM traffic per launch (KiB counters * 1024):")
+for k in sorted(agg):
+    parts = []
+    for c in sorted(agg[k]):
+        n = max(1, len(cnt[(k, c)]))
+        b = agg[k][c] * 1024 / n
+        parts.append("%s %.1f MB/launch (%d launches)" % (c, b / 1e6, n))
+        if c == "FETCH_SIZE":
+            parts.append("FETCH x2 (gfx950 wide-stream correction) %.1f MB" % (2 * b / 1e6))
+    lines.append("%-72s %s" % (k, "; ".join(parts)))
+out = "\n".join(lines)
+print(out)
+open(os.path.join(d, "summary.txt"), "w").write(out + "\n")
