@@ -30,7 +30,7 @@
 namespace sina_hip {
 namespace {
 
-constexpr int kCountThreads = 256;
+constexpr int kCountThreads = 1024;
 constexpr int kTileRefs = 32768;            // refs per LDS histogram tile (64 KiB)
 constexpr int kMaxQueryLen = 8192;          // k-mer list capacity in LDS (32 KiB)
 constexpr int kSelThreads = 256;
@@ -107,77 +107,109 @@ struct CountArgs {
     const uint64_t *qoff;
     const uint32_t *idx_off;
     const uint32_t *idx_ids;
-    int16_t *scores;  // [nq][n_refs]
+    int16_t *scores;  // [nq][stride]
+    uint32_t *nkq;    // [nq] number of query k-mers (upper bound of any score)
     unsigned long long *postings;
-    uint32_t n_refs;
+    uint32_t n_refs, stride, kmax;
     unsigned k;
     int fast;
 };
 
+// One workgroup (16 waves) per query.  Every query k-mer keeps a cursor into its (ascending)
+// posting list; the reference range is processed in tiles of kTileRefs whose int16 counters
+// live in LDS (two per 32-bit word).  For a tile, a wave takes a k-mer, streams postings from
+// its cursor with four independent coalesced 256-byte loads in flight, bumps the LDS counters of
+// those below the tile end (a prefix, the lists being sorted) and advances the cursor: every
+// posting is read exactly once, there is no search, and the tile is written out once.
 __global__ void __launch_bounds__(kCountThreads) kmer_count_kernel(CountArgs a) {
-    __shared__ uint32_t hist[kTileRefs / 2];
-    __shared__ uint32_t kmers[kMaxQueryLen];
-    __shared__ uint32_t n_kmers;
-    const uint32_t q = blockIdx.y;
-    const uint32_t tile_lo = blockIdx.x * kTileRefs;
-    const uint32_t tile_hi = min(tile_lo + (uint32_t)kTileRefs, a.n_refs);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t n_kmers, next_kmer;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);                 // [kTileRefs/2]
+    uint32_t *cur = hist + kTileRefs / 2;                                // [kmax]
+    uint32_t *end = cur + a.kmax;                                        // [kmax]
+    uint8_t *qb = reinterpret_cast<uint8_t *>(end + a.kmax);             // [kmax] query masks
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63;
     const uint8_t *qm = a.qmask + a.qoff[q];
     const uint32_t len = (uint32_t)(a.qoff[q + 1] - a.qoff[q]);
-    if (threadIdx.x == 0) n_kmers = 0;
-    for (uint32_t i = threadIdx.x; i < kTileRefs / 2; i += kCountThreads) hist[i] = 0;
+    if (tid == 0) n_kmers = 0;
+    for (uint32_t i = tid; i < len; i += kCountThreads) qb[i] = qm[i];
     __syncthreads();
-    for (uint32_t e = threadIdx.x; e < len; e += kCountThreads) {
+    unsigned long long mine = 0;
+    for (uint32_t e = tid; e < len; e += kCountThreads) {
         uint32_t v;
-        if (kmer_at(qm, len, e, a.k, a.fast != 0, &v)) kmers[atomicAdd(&n_kmers, 1u)] = v;
+        if (kmer_at(qb, len, e, a.k, a.fast != 0, &v)) {
+            const uint32_t lo = a.idx_off[v], hi = a.idx_off[v + 1];
+            if (lo != hi) {
+                const uint32_t slot = atomicAdd(&n_kmers, 1u);
+                cur[slot] = lo;
+                end[slot] = hi;
+                mine += hi - lo;
+            }
+        }
     }
     __syncthreads();
     const uint32_t nk = n_kmers;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long visited = 0;
-    for (uint32_t i = wave; i < nk; i += kCountThreads / 64) {
-        const uint32_t v = kmers[i];
-        uint32_t lo = a.idx_off[v], hi = a.idx_off[v + 1];
-        if (lo == hi) continue;
-        // first posting >= tile_lo, first posting >= tile_hi (ids ascending)
-        uint32_t b = lo, e = hi;
-        if (tile_lo > 0) {
-            uint32_t l = lo, h = hi;
-            while (l < h) {
-                const uint32_t mid = (l + h) >> 1;
-                if (a.idx_ids[mid] < tile_lo) l = mid + 1; else h = mid;
+    const uint32_t ntiles = (a.n_refs + kTileRefs - 1) / kTileRefs;
+    int16_t *row = a.scores + (size_t)q * a.stride;
+    for (uint32_t t = 0; t < ntiles; t++) {
+        const uint32_t tile_lo = t * kTileRefs;
+        const uint32_t tile_hi = min(tile_lo + (uint32_t)kTileRefs, a.n_refs);
+        for (uint32_t i = tid; i < kTileRefs / 2; i += kCountThreads) hist[i] = 0;
+        if (tid == 0) next_kmer = 0;
+        __syncthreads();
+        for (uint32_t guard = 0; guard < (1u << 22); guard++) {
+            uint32_t i = 0;
+            if (lane == 0) i = atomicAdd(&next_kmer, 1u);
+            i = __builtin_amdgcn_readfirstlane(i);
+            if (i >= nk) break;
+            uint32_t c = cur[i];
+            const uint32_t e = end[i];
+            for (uint32_t g2 = 0; c < e && g2 < (1u << 22); g2++) {
+                uint32_t id[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t x = c + (uint32_t)lane + 64u * u;
+                    id[u] = (x < e) ? a.idx_ids[x] : 0xFFFFFFFFu;
+                }
+                uint32_t n_in = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool in = id[u] < tile_hi;
+                    if (in) {
+                        const uint32_t r = id[u] - tile_lo;
+                        atomicAdd(&hist[r >> 1], 1u << (16 * (r & 1)));
+                    }
+                    n_in += (uint32_t)__popcll(__ballot(in));
+                }
+                c += n_in;
+                if (n_in < 256u) break;
             }
-            b = l;
+            if (lane == 0) cur[i] = c;
         }
-        if (tile_hi < a.n_refs) {
-            uint32_t l = b, h = hi;
-            while (l < h) {
-                const uint32_t mid = (l + h) >> 1;
-                if (a.idx_ids[mid] < tile_hi) l = mid + 1; else h = mid;
-            }
-            e = l;
-        }
-        for (uint32_t x = b + lane; x < e; x += 64) {
-            const uint32_t id = a.idx_ids[x] - tile_lo;
-            atomicAdd(&hist[id >> 1], 1u << (16 * (id & 1)));
-        }
-        if (lane == 0) visited += e - b;
+        __syncthreads();
+        // tile scores out: two int16 per 32-bit store (row stride is even)
+        uint32_t *dst = reinterpret_cast<uint32_t *>(row + tile_lo);
+        const uint32_t words = (tile_hi - tile_lo + 1) / 2;
+        for (uint32_t i = tid; i < words; i += kCountThreads) dst[i] = hist[i];
+        __syncthreads();
     }
-    __syncthreads();
-    int16_t *dst = a.scores + (size_t)q * a.n_refs + tile_lo;
-    const uint32_t cnt = tile_hi - tile_lo;
-    for (uint32_t i = threadIdx.x; i < cnt; i += kCountThreads)
-        dst[i] = (int16_t)((hist[i >> 1] >> (16 * (i & 1))) & 0xffffu);
-    if (lane == 0 && visited) atomicAdd(a.postings, visited);
+    // postings visited = sum of the list lengths of the query's k-mers (each read once)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0 && mine) atomicAdd(a.postings, mine);
+    if (tid == 0) a.nkq[q] = (uint32_t)((len > a.k) ? len - a.k : 0);
 }
 
 // ---------------------------------------------------------------- select
 
 struct SelectArgs {
-    const int16_t *scores;  // [nq][n_refs]
+    const int16_t *scores;  // [nq][stride]
+    const uint32_t *nkq;    // [nq] upper bound of the scores of query q
     uint32_t *out_ids;      // [nq][max]
     float *out_scores;
     uint32_t *out_n;
-    uint32_t n_refs, max;
+    uint32_t n_refs, stride, max;
 };
 
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, uint32_t *total) {
@@ -207,19 +239,20 @@ __global__ void __launch_bounds__(kSelThreads) kmer_select_kernel(SelectArgs a) 
     __shared__ uint32_t wsum[kSelThreads / 64];
     __shared__ uint32_t sh_cut, sh_need_eq, sh_skip_eq, sh_ncand;
     const uint32_t q = blockIdx.x;
-    const int16_t *sc = a.scores + (size_t)q * a.n_refs;
+    const int16_t *sc = a.scores + (size_t)q * a.stride;
     const uint32_t M = min(a.max, a.n_refs);
-    for (uint32_t i = threadIdx.x; i <= kMaxQueryLen; i += kSelThreads) hist[i] = 0;
+    const int top = (int)min(a.nkq[q], (uint32_t)kMaxQueryLen);  // no score can exceed the k-mer count
+    for (uint32_t i = threadIdx.x; i <= (uint32_t)top; i += kSelThreads) hist[i] = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < a.n_refs; i += kSelThreads) {
         int v = sc[i];
-        v = v < 0 ? 0 : (v > kMaxQueryLen ? kMaxQueryLen : v);
+        v = v < 0 ? 0 : (v > top ? top : v);
         atomicAdd(&hist[v], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t acc = 0;
-        int t = kMaxQueryLen;
+        int t = top;
         for (; t >= 0; t--) {
             if (acc + hist[t] >= M) break;
             acc += hist[t];
@@ -294,9 +327,11 @@ static int index_ready(sina_hip_ctx *c) {
 
 // counts + selects for nq queries whose masks are already on the device
 static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint64_t *d_qoff, uint32_t nq,
-                            uint32_t max, bool want_scores_only) {
+                            uint32_t max, uint32_t max_qlen, bool want_scores_only) {
     hipStream_t s = c->stream;
-    if (c->k_scores.reserve((size_t)nq * c->n_refs * 2) || c->k_tmp2.reserve(8)) return 1;
+    const uint32_t stride = (c->n_refs + 1u) & ~1u;  // even: tiles are stored two scores per word
+    if (c->k_scores.reserve((size_t)nq * stride * 2 + 64) || c->k_tmp2.reserve(8) || c->k_tmp0.reserve(4 * (size_t)nq))
+        return 1;
     SH_CHECK(hipMemsetAsync(c->k_tmp2.p, 0, 8, s));
     CountArgs ca;
     ca.qmask = d_qmask;
@@ -304,13 +339,18 @@ static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint6
     ca.idx_off = c->idx_off.as<uint32_t>();
     ca.idx_ids = c->idx_ids.as<uint32_t>();
     ca.scores = c->k_scores.as<int16_t>();
+    ca.nkq = c->k_tmp0.as<uint32_t>();
     ca.postings = c->k_tmp2.as<unsigned long long>();
     ca.n_refs = c->n_refs;
+    ca.stride = stride;
+    ca.kmax = (max_qlen + 63u) & ~63u;
     ca.k = c->k;
     ca.fast = c->nofast ? 0 : 1;
-    const uint32_t tiles = (c->n_refs + kTileRefs - 1) / kTileRefs;
+    const size_t clds = (size_t)kTileRefs * 2 + (size_t)ca.kmax * 9 + 64;
+    SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kmer_count_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
     SH_CHECK(hipEventRecord(c->ev[3], s));
-    hipLaunchKernelGGL(kmer_count_kernel, dim3(tiles, nq), dim3(kCountThreads), 0, s, ca);
+    hipLaunchKernelGGL(kmer_count_kernel, dim3(nq), dim3(kCountThreads), clds, s, ca);
     SH_CHECK(hipGetLastError());
     SH_CHECK(hipEventRecord(c->ev[4], s));
     if (!want_scores_only) {
@@ -319,6 +359,8 @@ static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint6
             return 1;
         SelectArgs sa;
         sa.scores = ca.scores;
+        sa.nkq = ca.nkq;
+        sa.stride = stride;
         sa.out_ids = c->k_out_ids.as<uint32_t>();
         sa.out_scores = c->k_out_scores.as<float>();
         sa.out_n = c->k_out_n.as<uint32_t>();
@@ -455,8 +497,11 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
         return 0;
     }
     if (max > (uint32_t)kSelMax) SH_FAIL("kmer_topk: max > 4096 not supported by the LDS select kernel");
-    for (uint32_t q = 0; q < nq; q++)
+    uint32_t max_qlen = 1;
+    for (uint32_t q = 0; q < nq; q++) {
         if (qoff[q + 1] - qoff[q] > (uint64_t)kMaxQueryLen) SH_FAIL("kmer_topk: query longer than 8192 bases");
+        max_qlen = std::max<uint32_t>(max_qlen, (uint32_t)(qoff[q + 1] - qoff[q]));
+    }
     hipStream_t s = c->stream;
     const uint64_t nqm = qoff[nq] - qoff[0];
     // sub-batches bound the [nq][n_refs] int16 score matrix to ~2 GiB
@@ -468,7 +513,7 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
     SH_CHECK(hipMemcpyAsync(c->k_qoff.p, rel.data(), 8 * ((uint64_t)nq + 1), hipMemcpyHostToDevice, s));
     for (uint32_t q0 = 0; q0 < nq; q0 += per) {
         const uint32_t bq = std::min(per, nq - q0);
-        if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>() + q0, bq, max, false)) return 1;
+        if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>() + q0, bq, max, max_qlen, false)) return 1;
         SH_CHECK(hipMemcpyAsync(out_ids + (size_t)q0 * max, c->k_out_ids.p, (size_t)bq * max * 4, hipMemcpyDeviceToHost, s));
         SH_CHECK(hipMemcpyAsync(out_scores + (size_t)q0 * max, c->k_out_scores.p, (size_t)bq * max * 4, hipMemcpyDeviceToHost, s));
         SH_CHECK(hipMemcpyAsync(out_n + q0, c->k_out_n.p, (size_t)bq * 4, hipMemcpyDeviceToHost, s));
@@ -497,7 +542,7 @@ int sina_hip_kmer_scores(sina_hip_ctx *c, const uint8_t *qmask, uint32_t qlen, i
     if (c->qmask.reserve(std::max<uint32_t>(qlen, 1)) || c->k_qoff.reserve(16)) return 1;
     SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask, qlen, hipMemcpyHostToDevice, s));
     SH_CHECK(hipMemcpyAsync(c->k_qoff.p, rel, 16, hipMemcpyHostToDevice, s));
-    if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>(), 1, 1, true)) return 1;
+    if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>(), 1, 1, std::max<uint32_t>(qlen, 1), true)) return 1;
     SH_CHECK(hipMemcpyAsync(scores, c->k_scores.p, (size_t)c->n_refs * 2, hipMemcpyDeviceToHost, s));
     SH_CHECK(hipStreamSynchronize(s));
     return 0;
