@@ -37,6 +37,7 @@ int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl) {
 struct HostPrep {
     std::vector<QDesc> qd;
     std::vector<uint4> rec;
+    std::vector<uint32_t> pred;  // id | ring slot << 16 | far << 31 (what mesh_dp_kernel reads)
     uint64_t tb_cells = 0, spill_rows = 0, cells = 0;
 };
 
@@ -46,6 +47,7 @@ static void prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint
     const uint64_t nn = g->node_off[q1] - nbase;
     hp->qd.resize(q1 - q0);
     hp->rec.resize(nn);
+    hp->pred.resize(g->edge_off[q1] - ebase + 8);
     hp->tb_cells = hp->spill_rows = hp->cells = 0;
     for (uint32_t q = q0; q < q1; q++) {
         QDesc &d = hp->qd[q - q0];
@@ -73,7 +75,9 @@ static void prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint
             for (uint32_t e = po[m]; e < po[m + 1]; e++) {
                 const uint32_t p = g->pred[eo + e];
                 rec[p].z &= ~kRecSink;
-                if (m - p > (uint32_t)W) rec[p].w = 0;  // mark: needs a spill row
+                const bool far = m - p > (uint32_t)W;
+                if (far) rec[p].w = 0;  // mark: needs a spill row
+                hp->pred[d.edge_off + e] = p | ((p % (uint32_t)W) << 16) | (far ? 0x80000000u : 0u);
             }
         }
         uint32_t nsp = 0;
@@ -210,7 +214,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         SH_CHECK(hipMemcpyAsync(c->qd.p, hp.qd.data(), sizeof(QDesc) * bq, hipMemcpyHostToDevice, s));
         SH_CHECK(hipMemcpyAsync(c->rec.p, hp.rec.data(), sizeof(uint4) * nn, hipMemcpyHostToDevice, s));
         SH_CHECK(hipMemcpyAsync(c->node_pos.p, g->node_pos + nbase, 4 * nn, hipMemcpyHostToDevice, s));
-        if (ne) SH_CHECK(hipMemcpyAsync(c->pred.p, g->pred + ebase, 4 * ne, hipMemcpyHostToDevice, s));
+        if (ne) SH_CHECK(hipMemcpyAsync(c->pred.p, hp.pred.data(), 4 * ne, hipMemcpyHostToDevice, s));
         if (g->succ_minpos)
             SH_CHECK(hipMemcpyAsync(c->succ_minpos.p, g->succ_minpos + nbase, 4 * nn, hipMemcpyHostToDevice, s));
         SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qbase, nqm, hipMemcpyHostToDevice, s));
@@ -258,7 +262,7 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
     c->device = device;
     SH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
-    c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 36) * 1024;
+    c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 40) * 1024;
     c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 24) << 30;
     memset(&c->stats, 0, sizeof(c->stats));
     *ctx = c;

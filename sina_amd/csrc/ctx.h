@@ -24,7 +24,7 @@ struct sina_hip_ctx {
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes, g_wtab;
     float wtab_fs_weight = NAN;  // fs_weight the device weight table was computed for
 
-    size_t lds_budget = 36 * 1024;
+    size_t lds_budget = 40 * 1024;
     uint64_t tb_budget_bytes = (uint64_t)24 << 30;
     sina_hip_stats stats;
 

@@ -264,6 +264,11 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
                 atomicMin(&smin[pa], pos);
                 if (node - pa > (uint32_t)a.W) far[pa] = 1;
             }
+            // encode for the DP kernel: id | ring slot << 16 | far << 31
+            for (uint32_t x = 0; x < np; x++) {
+                const uint32_t pa = pred[seg + x];
+                pred[seg + x] = pa | ((pa % (uint32_t)a.W) << 16) | ((node - pa > (uint32_t)a.W) ? 0x80000000u : 0u);
+            }
             uint4 r;
             r.x = seg;
             r.y = __float_as_uint(wt[cnt]);
@@ -538,7 +543,7 @@ int sina_hip_debug_family_graph(sina_hip_ctx *c, const uint32_t *fam_ids, uint32
         sink[m] = (rec[m].z & kRecSink) ? 1 : 0;
         spill_idx[m] = rec[m].w;
         pred_off[m] = e;
-        for (uint32_t x = 0; x < (rec[m].z & 0xffu); x++) pred[e++] = pr[rec[m].x + x];
+        for (uint32_t x = 0; x < (rec[m].z & 0xffu); x++) pred[e++] = pr[rec[m].x + x] & 0xffffu;
     }
     pred_off[N] = e;
     return 0;

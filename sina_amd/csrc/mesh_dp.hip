@@ -17,7 +17,7 @@
 //     divergence on graph structure and no vector-memory latency on the row
 //     critical path;
 //   * the last W rows of {value, gapm_val, gapm_idx} of a wave's own columns live
-//     in an LDS ring (10 B per column) that only that wave touches; the rare
+//     in an LDS ring (12 B per column) that only that wave touches; the rare
 //     predecessors further back than W rows are read from a per-query spill area
 //     in HBM that the producing row also wrote;
 //   * the only dependencies between column blocks are (a) the insertion chain
@@ -33,6 +33,9 @@
 //     the main loop contains no s_barrier at all;
 //   * the only per-cell HBM traffic is the write-once trace-back cell
 //     (value_midx:16 | value_sidx:16), row-major.
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace sina_hip {
@@ -64,7 +67,7 @@ __device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p) {
 }
 
 template <int T, int B, bool WEIGHTED, bool FORBID>
-__global__ void __launch_bounds__(T)
+__global__ void __launch_bounds__(T, (B <= 6 ? 4 : (B <= 8 ? 3 : 2)))
 mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, const uint32_t *__restrict__ predv,
                const uint32_t *__restrict__ node_posv, const uint32_t *__restrict__ succ_minposv,
                const uint8_t *__restrict__ qmaskv, const float *__restrict__ weights, uint32_t n_weights,
@@ -93,7 +96,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
     unsigned char *ring = smem + 64 + 16 * NW * kHist + 64 * NW;
     constexpr size_t kValBytes = (size_t)Lp * 4;
     constexpr size_t kGmBytes = (size_t)Lp * 4;
-    constexpr size_t kSlotBytes = kValBytes + kGmBytes + (size_t)Lp * 2;
+    constexpr size_t kSlotBytes = kValBytes + kGmBytes + (size_t)Lp * 4;  // value f32 | gapm_val f32 | gapm_idx u32
 
     const uint4 *__restrict__ rec = recv + d.node_off;
     const uint32_t *__restrict__ pred = predv + d.edge_off;
@@ -125,6 +128,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
 
     const uint32_t throttle = (uint32_t)(kHist - W - 2);
     uint4 cur = rec[0];
+    uint32_t my_slot = 0;  // ring slot of the current row (m % W), advanced incrementally
     for (uint32_t m = 0; m < N; ++m) {
         const uint4 nxt = rec[m + 1 < N ? m + 1 : m];  // scalar prefetch of the next row record
         const uint32_t pb = cur.x;
@@ -174,8 +178,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
 
         // ---- phase 1: deletion + match candidates from every predecessor row
         float dv[B], gm[B], mt[B], csel[B];
-        uint32_t dvm[B], gmi[B], mtp[B];
-        bool ddel[B];  // best-so-far is a deletion (value_sidx = s) rather than the init cell
+        uint32_t dvm[B], dvs[B], gmi[B], mtp[B];
 #pragma unroll
         for (int k = 0; k < B; k++) {
             const float iv = (s0 + k == 0) ? 1.0f : init_v;
@@ -183,42 +186,12 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
             gm[k] = iv;
             mt[k] = __builtin_inff();
             dvm[k] = 0;
+            dvs[k] = 0;
             gmi[k] = 0;
             mtp[k] = 0;
-            ddel[k] = false;
             csel[k] = (mmask & qm[k]) ? cM : cX;  // comp(): optimistic IUPAC match (aligned_base.h:153)
         }
-        for (uint32_t e = 0; e < npred; ++e) {
-            const uint32_t p = pred[pb + e];
-            float sv[B], sg[B], svl;
-            uint32_t sgi[B];
-            const bool near = (m - p <= (uint32_t)W);
-            if (near) {  // LDS ring, my own columns
-                const unsigned char *slot = ring + (size_t)(p % (uint32_t)W) * kSlotBytes;
-                const float *pv = reinterpret_cast<const float *>(slot);
-                const float *pg = reinterpret_cast<const float *>(slot + kValBytes);
-                const uint16_t *pi = reinterpret_cast<const uint16_t *>(slot + kValBytes + kGmBytes);
-#pragma unroll
-                for (int k = 0; k < B; k++) {
-                    sv[k] = pv[s0 + k];
-                    sg[k] = pg[s0 + k];
-                    sgi[k] = pi[s0 + k];
-                }
-            } else {  // spilled row in HBM
-                const float *row = spill + (size_t)rec[p].w * (3 * Lp);
-#pragma unroll
-                for (int k = 0; k < B; k++) {
-                    sv[k] = row[s0 + k];
-                    sg[k] = row[Lp + s0 + k];
-                    sgi[k] = reinterpret_cast<const uint32_t *>(row)[2 * Lp + s0 + k];
-                }
-            }
-            // value[p][s0-1]: from the lane to my left; lane 0 takes the left wave's boundary
-            svl = lane_shr1(sv[B - 1]);
-            if (lane == 0 && w > 0) {
-                if (near) svl = bnd_val[(w - 1) * kHist + (p & (kHist - 1))];
-                else svl = (spill + (size_t)rec[p].w * (3 * Lp))[s0 - 1];
-            }
+        auto relax = [&](uint32_t p, const float(&sv)[B], const float(&sg)[B], const uint32_t(&sgi)[B], float svl) {
 #pragma unroll
             for (int k = 0; k < B; k++) {
                 // deletion (mesh.h:307-330): gapm_* is overwritten by every predecessor
@@ -232,7 +205,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 const bool better = cand < dv[k];
                 dv[k] = better ? cand : dv[k];
                 dvm[k] = better ? cm : dvm[k];
-                ddel[k] = better ? true : ddel[k];
+                dvs[k] = better ? s0 + k : dvs[k];  // value_sidx of a deletion is the column itself
                 // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
                 const float pvv = (k == 0) ? svl : sv[k - 1];
                 const float mv = pvv + csel[k];
@@ -240,12 +213,60 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 mt[k] = mb ? mv : mt[k];
                 mtp[k] = mb ? p : mtp[k];
             }
+        };
+        // pred entry: id | ring slot << 16 | far << 31.  Ids ascend, so the predecessors beyond
+        // the LDS ring (spill rows in HBM) come first.
+        uint32_t e = 0;
+        for (; e < npred; ++e) {
+            const uint32_t pe = pred[pb + e];
+            if (!(pe >> 31)) break;
+            const uint32_t p = pe & 0xffffu;
+            const float *row = spill + (size_t)rec[p].w * (3 * Lp);
+            float sv[B], sg[B];
+            uint32_t sgi[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                sv[k] = row[s0 + k];
+                sg[k] = row[Lp + s0 + k];
+                sgi[k] = reinterpret_cast<const uint32_t *>(row)[2 * Lp + s0 + k];
+            }
+            float svl = lane_shr1(sv[B - 1]);  // value[p][s0-1] lives in the lane to my left
+            if (lane == 0 && w > 0) svl = row[s0 - 1];
+            relax(p, sv, sg, sgi, svl);
+        }
+        for (; e < npred; ++e) {
+            const uint32_t pe = pred[pb + e];
+            const uint32_t p = pe & 0xffffu;
+            const unsigned char *slot = ring + (size_t)((pe >> 16) & 0xffu) * kSlotBytes;
+            const float *pv = reinterpret_cast<const float *>(slot);
+            const float *pg = reinterpret_cast<const float *>(slot + kValBytes);
+            const uint32_t *pi = reinterpret_cast<const uint32_t *>(slot + kValBytes + kGmBytes);
+            float sv[B], sg[B];
+            uint32_t sgi[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                sv[k] = pv[s0 + k];
+                sg[k] = pg[s0 + k];
+                sgi[k] = pi[s0 + k];
+            }
+            float svl = lane_shr1(sv[B - 1]);
+            if (lane == 0 && w > 0) svl = bnd_val[(w - 1) * kHist + (p & (kHist - 1))];  // left wave's boundary
+            relax(p, sv, sg, sgi, svl);
         }
 
         // ---- phase 2: insertion chain along my B cells
         float fv[B];
         uint32_t fvm[B], fvs[B];
         ChainState ex;
+        auto ext_cost = [&](uint32_t s, uint32_t gsi_prev) -> float {
+            if constexpr (WEIGHTED) {
+                const uint32_t nw1 = n_weights - 1;
+                const uint32_t wi = mpos + 1 + ((s - 1) - gsi_prev);
+                return gpe * weights[wi < nw1 ? wi : nw1];
+            } else {
+                return gpe;
+            }
+        };
         auto run_chain = [&](const ChainState &left) {
             ChainState c = left;
 #pragma unroll
@@ -253,7 +274,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 const uint32_t s = s0 + k;
                 float v = dv[k];
                 uint32_t vm = dvm[k];
-                uint32_t vs = ddel[k] ? s : 0u;
+                uint32_t vs = dvs[k];
                 float gs = 1.0f;  // init_edge at s == 0, no insertion step there
                 uint32_t gsi = 0, gmax = 0;
                 if (s > 0) {
@@ -265,12 +286,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                         gmax_n = c.e ? c.gmax - 1 : smax - 1;
                     }
                     if (c.e) {  // extending gap (:344-349 / :420-425); gaps_val == value here
-                        gi_cost = gpe;
-                        if constexpr (WEIGHTED) {
-                            const uint32_t nw1 = n_weights - 1;
-                            const uint32_t wi = mpos + 1 + ((s - 1) - c.gsi);
-                            gi_cost = gpe * weights[wi < nw1 ? wi : nw1];
-                        }
+                        gi_cost = ext_cost(s, c.gsi);
                         gsi_n = c.gsi;
                     }
                     gs = ins ? (c.v + gi_cost) : init_v;  // untouched cell keeps its initial gaps_*
@@ -316,28 +332,49 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
             wave_left.gsi = pe_ & 0x7fffffffu;
             wave_left.gmax = FORBID ? xs_gmax[h] : 0u;
         }
-        for (;;) {
-            const ChainState prev = ex;
+        // The speculation is exact unless the gap arriving from the left wins my first cell
+        // (gs <= value after deletions, and no match beats it): one add and two compares per
+        // lane verify that.  Only if some lane's first cell does take the gap are the chains
+        // re-run with the real left states, until no exit state changes any more.  (With
+        // --insertion=forbid a cell that may NOT take a gap keeps its initial gaps_val, which
+        // the shortcut cannot see: always re-run there.)
+        bool rerun = true;
+        if constexpr (!FORBID) {
             left.v = lane_shr1(ex.v);
             left.e = lane_shr1(ex.e);
             left.gsi = lane_shr1(ex.gsi);
-            left.gmax = FORBID ? lane_shr1(ex.gmax) : 0u;
             if (lane == 0) left = wave_left;
-            if (j > 0) run_chain(left);
-            if (!__any(!same_state(ex, prev))) break;
+            bool take0 = false;
+            if (j > 0) {
+                const float g0 = left.v + (left.e ? ext_cost(s0, left.gsi) : gi_open);
+                take0 = (g0 <= dv[0]) && !(mt[0] < g0);
+            }
+            rerun = __any(take0);
+        }
+        if (rerun) {
+            for (;;) {
+                const ChainState prev = ex;
+                left.v = lane_shr1(ex.v);
+                left.e = lane_shr1(ex.e);
+                left.gsi = lane_shr1(ex.gsi);
+                left.gmax = FORBID ? lane_shr1(ex.gmax) : 0u;
+                if (lane == 0) left = wave_left;
+                if (j > 0) run_chain(left);
+                if (!__any(!same_state(ex, prev))) break;
+            }
         }
 
         // ---- publish: ring (own columns), boundary + exit state for the wave to my right
         {
-            unsigned char *myslot = ring + (size_t)(m % (uint32_t)W) * kSlotBytes;
+            unsigned char *myslot = ring + (size_t)my_slot * kSlotBytes;
             float *wv = reinterpret_cast<float *>(myslot);
             float *wg = reinterpret_cast<float *>(myslot + kValBytes);
-            uint16_t *wi = reinterpret_cast<uint16_t *>(myslot + kValBytes + kGmBytes);
+            uint32_t *wi = reinterpret_cast<uint32_t *>(myslot + kValBytes + kGmBytes);
 #pragma unroll
             for (int k = 0; k < B; k++) {
                 wv[s0 + k] = fv[k];
                 wg[s0 + k] = gm[k];
-                wi[s0 + k] = (uint16_t)gmi[k];
+                wi[s0 + k] = gmi[k];
             }
             if (lane == 63) {
                 const int h = w * kHist + (int)(m & (kHist - 1));
@@ -346,6 +383,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 xs_e[h] = (ex.e << 31) | ex.gsi;
                 if (FORBID) xs_gmax[h] = ex.gmax;
             }
+            my_slot = (my_slot + 1 == (uint32_t)W) ? 0u : my_slot + 1;
         }
         if (sp != kNoSpill) {
             float *row = spill + (size_t)sp * (3 * Lp);
@@ -595,9 +633,22 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, size_t l
 
 }  // namespace
 
-static const DpGeom kGeoms[] = {{64, 4}, {128, 4}, {256, 4}, {256, 6}, {256, 8}, {512, 6}, {512, 8}, {512, 12}};
+// Few, fat lanes win: the per-row fixed work of a wave (row record, hand-shake, chain exchange,
+// publish) is amortised over more cells, and 12 cells per lane keep the LDS accesses 16-byte
+// aligned.  Measured on MI355X (16S, 1024 queries): 128x12 146 Gcell/s, 256x6 130, 512x3 97.
+static const DpGeom kGeoms[] = {{64, 4}, {64, 8}, {64, 12}, {128, 8}, {128, 12}, {256, 8}, {256, 12}, {512, 8}, {512, 12}};
 
 bool pick_geom(uint32_t maxL, DpGeom *g) {
+    // tuning override: SINA_HIP_DP_GEOM="T,B" (used if it covers the batch's longest query)
+    if (const char *ov = getenv("SINA_HIP_DP_GEOM")) {
+        int t = 0, b = 0;
+        if (sscanf(ov, "%d,%d", &t, &b) == 2 && (uint32_t)(t * b) >= maxL &&
+            ((t == 256 && b == 6) || (t == 512 && b == 6) || (t == 192 && b == 8) || (t == 128 && b == 12))) {
+            g->T = t;
+            g->B = b;
+            return true;
+        }
+    }
     for (const DpGeom &c : kGeoms) {
         if ((uint32_t)c.Lp() >= maxL) {
             *g = c;
@@ -607,7 +658,7 @@ bool pick_geom(uint32_t maxL, DpGeom *g) {
     return false;
 }
 
-size_t dp_slot_bytes(const DpGeom &g) { return (size_t)g.Lp() * 10; }
+size_t dp_slot_bytes(const DpGeom &g) { return (size_t)g.Lp() * 12; }
 size_t dp_fixed_lds_bytes(const DpGeom &g) {
     const size_t nw = (size_t)g.T / 64;
     return 64 + 16 * nw * kHist + 64 * nw;
@@ -616,14 +667,21 @@ int dp_max_ring(const DpGeom &) { return kHist - 4; }
 
 int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
                    size_t lds, hipStream_t s) {
-    if (g.T == 64 && g.B == 4) return launch_tb<64, 4>(weighted, forbid, a, nq, lds, s);
-    if (g.T == 128 && g.B == 4) return launch_tb<128, 4>(weighted, forbid, a, nq, lds, s);
-    if (g.T == 256 && g.B == 4) return launch_tb<256, 4>(weighted, forbid, a, nq, lds, s);
-    if (g.T == 256 && g.B == 6) return launch_tb<256, 6>(weighted, forbid, a, nq, lds, s);
-    if (g.T == 256 && g.B == 8) return launch_tb<256, 8>(weighted, forbid, a, nq, lds, s);
-    if (g.T == 512 && g.B == 6) return launch_tb<512, 6>(weighted, forbid, a, nq, lds, s);
-    if (g.T == 512 && g.B == 8) return launch_tb<512, 8>(weighted, forbid, a, nq, lds, s);
-    if (g.T == 512 && g.B == 12) return launch_tb<512, 12>(weighted, forbid, a, nq, lds, s);
+#define SH_GEOM(TT, BB) \
+    if (g.T == TT && g.B == BB) return launch_tb<TT, BB>(weighted, forbid, a, nq, lds, s)
+    SH_GEOM(64, 4);
+    SH_GEOM(64, 8);
+    SH_GEOM(64, 12);
+    SH_GEOM(128, 8);
+    SH_GEOM(128, 12);
+    SH_GEOM(256, 8);
+    SH_GEOM(256, 12);
+    SH_GEOM(512, 8);
+    SH_GEOM(512, 12);
+    SH_GEOM(256, 6);   // tuning alternatives (SINA_HIP_DP_GEOM)
+    SH_GEOM(512, 6);
+    SH_GEOM(192, 8);
+#undef SH_GEOM
     SH_FAIL("mesh_dp: unsupported geometry");
 }
 
