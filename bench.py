@@ -53,7 +53,10 @@ def parse():
 
 def cpu_baseline(refs, qs, n_sample, threads):
     """Times the oracle (CPU restatement, test infrastructure) on a bounded sample of the same
-    workload, all host threads.  Reported beside the GPU number; never part of it."""
+    workload.  Two thread counts are tried (all hardware threads, and half of them = one per
+    core on an SMT-2 host) and the faster one is reported; every thread first runs one untimed
+    query so that its mesh scratch is mapped (steady state, like a 100k-query run).  Reported
+    beside the GPU number; never part of it."""
     from oracle import pyoracle as po
     t0 = time.time()
     cs = [po.Cseq.from_packed("ref%d" % i, refs.seq(i), refs.width) for i in range(refs.n)]
@@ -64,11 +67,19 @@ def cpu_baseline(refs, qs, n_sample, threads):
         m = qs.seq(i)
         ab = np.arange(len(m), dtype=np.uint32) | (m.astype(np.uint32) << 24)
         queries.append(po.Cseq.from_packed("q%d" % i, ab, len(m)))
-    r = po.bench_run(idx, queries, threads)
-    return dict(value=r["aligned"] / r["seconds"], unit="sequences/s", cores=threads, kind="port",
-                sample="%d of the same synthetic queries vs the same %d references, oracle (plain C restatement), "
-                       "%d threads, %.1f s wall, %.1f Mcell/s; index build %.0f s not timed"
-                       % (n_sample, refs.n, threads, r["seconds"], r["cells"] / r["seconds"] / 1e6, build_s))
+    best = None
+    for th in sorted({threads, max(1, threads // 2)}, reverse=True):
+        r = po.bench_run(idx, queries, th)
+        r["threads"] = th
+        if best is None or r["aligned"] / r["seconds"] > best["aligned"] / best["seconds"]:
+            best = r
+    return dict(value=best["aligned"] / best["seconds"], unit="sequences/s", cores=best["threads"], kind="port",
+                sample="%d of the same synthetic queries vs the same %d references, oracle (plain C restatement of "
+                       "the reference algorithm, full 28-byte-cell mesh), best of %d and %d threads, %.1f s wall, "
+                       "%.1f Mcell/s, %.1f Mcell/s/thread; index build %.0f s not timed"
+                       % (n_sample, refs.n, threads, max(1, threads // 2), best["seconds"],
+                          best["cells"] / best["seconds"] / 1e6,
+                          best["cells"] / best["seconds"] / 1e6 / best["threads"], build_s))
 
 
 def main():
@@ -186,7 +197,7 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             threads = os.cpu_count() or 1
-            n_sample = a.cpu_sample or min(n_q, max(64, 8 * threads))
+            n_sample = a.cpu_sample or min(n_q, max(64, 12 * threads))
             out["cpu_baseline"] = cpu_baseline(refs, qs, n_sample, threads)
         print(json.dumps(out))
     pl.close()
