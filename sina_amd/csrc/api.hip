@@ -21,6 +21,11 @@ static size_t env_size(const char *name, size_t dflt) {
 int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl) {
     if (!pick_geom(maxL, &pl->geom)) SH_FAIL("align: query longer than the largest DP geometry (6144)");
     const size_t slot = dp_slot_bytes(pl->geom), fixed = dp_fixed_lds_bytes(pl->geom);
+    if (pl->geom.RW > 0) {  // ring in registers: depth is a compile-time property of the geometry
+        pl->W = pl->geom.RW;
+        pl->lds = fixed;
+        return 0;
+    }
     size_t budget = c->lds_budget;
     if (budget < fixed + slot) budget = fixed + slot;
     if (budget > 160 * 1024) budget = 160 * 1024;

@@ -112,6 +112,7 @@ struct BtArgs {
 // Picks the (threads, cells per thread) geometry for the longest query of a batch.
 struct DpGeom {
     int T, B;
+    int RW;  // depth of the register-resident ring of recent rows (0: ring in LDS, run-time depth)
     int Lp() const { return T * B; }
 };
 bool pick_geom(uint32_t maxL, DpGeom *g);

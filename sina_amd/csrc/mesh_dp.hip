@@ -35,6 +35,7 @@
 //     (value_midx:16 | value_sidx:16), row-major.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -62,12 +63,26 @@ __device__ __forceinline__ uint32_t lane_shr1(uint32_t x) {
 }
 __device__ __forceinline__ float lane_shr1(float x) { return __uint_as_float(lane_shr1(__float_as_uint(x))); }
 
+// calls f(integral_constant<S>) for the (wave-uniform) run-time slot number: a scalar branch
+// chain, so that register-resident ring rows are only ever indexed with compile-time constants
+template <int S, int RW, typename F>
+__device__ __forceinline__ void slot_dispatch(uint32_t slot, F &&f) {
+    if constexpr (S < RW) {
+        if (slot == (uint32_t)S) f(std::integral_constant<int, S>{});
+        else slot_dispatch<S + 1, RW>(slot, f);
+    }
+}
+
 __device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int T, int B, bool WEIGHTED, bool FORBID>
-__global__ void __launch_bounds__(T, (B <= 6 ? 4 : (B <= 8 ? 3 : 2)))
+// RW == 0: the ring of recent rows lives in LDS (run-time depth W).
+// RW  > 0: the ring lives in REGISTERS (RW rows x B cells x {value, gapm_val, gapm_idx} per lane):
+//          the register file of a CU is 3x its LDS, near predecessors cost no LDS traffic at all,
+//          and the ring can be deeper at the same occupancy, so far fewer rows spill to HBM.
+template <int T, int B, int RW, bool WEIGHTED, bool FORBID>
+__global__ void __launch_bounds__(T, (RW > 0 ? 2 : (B <= 6 ? 4 : (B <= 8 ? 3 : 2))))
 mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, const uint32_t *__restrict__ predv,
                const uint32_t *__restrict__ node_posv, const uint32_t *__restrict__ succ_minposv,
                const uint8_t *__restrict__ qmaskv, const float *__restrict__ weights, uint32_t n_weights,
@@ -129,6 +144,11 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
     const uint32_t throttle = (uint32_t)(kHist - W - 2);
     uint4 cur = rec[0];
     uint32_t my_slot = 0;  // ring slot of the current row (m % W), advanced incrementally
+    struct RingRow {  // one ring row of this lane's cells, register resident when RW > 0
+        float v[B], g[B];
+        uint32_t i[B];
+    };
+    RingRow r0, r1, r2, r3, r4, r5;  // distinct objects (not an array) so that they scalarise
     for (uint32_t m = 0; m < N; ++m) {
         const uint4 nxt = rec[m + 1 < N ? m + 1 : m];  // scalar prefetch of the next row record
         const uint32_t pb = cur.x;
@@ -237,21 +257,40 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         for (; e < npred; ++e) {
             const uint32_t pe = pred[pb + e];
             const uint32_t p = pe & 0xffffu;
-            const unsigned char *slot = ring + (size_t)((pe >> 16) & 0xffu) * kSlotBytes;
-            const float *pv = reinterpret_cast<const float *>(slot);
-            const float *pg = reinterpret_cast<const float *>(slot + kValBytes);
-            const uint32_t *pi = reinterpret_cast<const uint32_t *>(slot + kValBytes + kGmBytes);
-            float sv[B], sg[B];
-            uint32_t sgi[B];
+            if constexpr (RW > 0) {
+                const uint32_t sl = (pe >> 16) & 0xffu;
+                float bnd = 0.f;
+                if (lane == 0 && w > 0) bnd = bnd_val[(w - 1) * kHist + (p & (kHist - 1))];
+#define SH_RELAX_FROM(R)                                          \
+    {                                                             \
+        float svl = lane_shr1(R.v[B - 1]);                        \
+        if (lane == 0 && w > 0) svl = bnd;                        \
+        relax(p, R.v, R.g, R.i, svl);                             \
+    }
+                if (sl == 0) SH_RELAX_FROM(r0)
+                else if (RW > 1 && sl == 1) SH_RELAX_FROM(r1)
+                else if (RW > 2 && sl == 2) SH_RELAX_FROM(r2)
+                else if (RW > 3 && sl == 3) SH_RELAX_FROM(r3)
+                else if (RW > 4 && sl == 4) SH_RELAX_FROM(r4)
+                else if (RW > 5 && sl == 5) SH_RELAX_FROM(r5)
+#undef SH_RELAX_FROM
+            } else {
+                const unsigned char *slot = ring + (size_t)((pe >> 16) & 0xffu) * kSlotBytes;
+                const float *pv = reinterpret_cast<const float *>(slot);
+                const float *pg = reinterpret_cast<const float *>(slot + kValBytes);
+                const uint32_t *pi = reinterpret_cast<const uint32_t *>(slot + kValBytes + kGmBytes);
+                float sv[B], sg[B];
+                uint32_t sgi[B];
 #pragma unroll
-            for (int k = 0; k < B; k++) {
-                sv[k] = pv[s0 + k];
-                sg[k] = pg[s0 + k];
-                sgi[k] = pi[s0 + k];
+                for (int k = 0; k < B; k++) {
+                    sv[k] = pv[s0 + k];
+                    sg[k] = pg[s0 + k];
+                    sgi[k] = pi[s0 + k];
+                }
+                float svl = lane_shr1(sv[B - 1]);
+                if (lane == 0 && w > 0) svl = bnd_val[(w - 1) * kHist + (p & (kHist - 1))];  // left wave's boundary
+                relax(p, sv, sg, sgi, svl);
             }
-            float svl = lane_shr1(sv[B - 1]);
-            if (lane == 0 && w > 0) svl = bnd_val[(w - 1) * kHist + (p & (kHist - 1))];  // left wave's boundary
-            relax(p, sv, sg, sgi, svl);
         }
 
         // ---- phase 2: insertion chain along my B cells
@@ -366,15 +405,33 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
 
         // ---- publish: ring (own columns), boundary + exit state for the wave to my right
         {
-            unsigned char *myslot = ring + (size_t)my_slot * kSlotBytes;
-            float *wv = reinterpret_cast<float *>(myslot);
-            float *wg = reinterpret_cast<float *>(myslot + kValBytes);
-            uint32_t *wi = reinterpret_cast<uint32_t *>(myslot + kValBytes + kGmBytes);
+            if constexpr (RW > 0) {
+#define SH_STORE_TO(R)                  \
+    {                                   \
+        _Pragma("unroll") for (int k = 0; k < B; k++) { \
+            R.v[k] = fv[k];             \
+            R.g[k] = gm[k];             \
+            R.i[k] = gmi[k];            \
+        }                               \
+    }
+                if (my_slot == 0) SH_STORE_TO(r0)
+                else if (RW > 1 && my_slot == 1) SH_STORE_TO(r1)
+                else if (RW > 2 && my_slot == 2) SH_STORE_TO(r2)
+                else if (RW > 3 && my_slot == 3) SH_STORE_TO(r3)
+                else if (RW > 4 && my_slot == 4) SH_STORE_TO(r4)
+                else if (RW > 5 && my_slot == 5) SH_STORE_TO(r5)
+#undef SH_STORE_TO
+            } else {
+                unsigned char *myslot = ring + (size_t)my_slot * kSlotBytes;
+                float *wv = reinterpret_cast<float *>(myslot);
+                float *wg = reinterpret_cast<float *>(myslot + kValBytes);
+                uint32_t *wi = reinterpret_cast<uint32_t *>(myslot + kValBytes + kGmBytes);
 #pragma unroll
-            for (int k = 0; k < B; k++) {
-                wv[s0 + k] = fv[k];
-                wg[s0 + k] = gm[k];
-                wi[s0 + k] = gmi[k];
+                for (int k = 0; k < B; k++) {
+                    wv[s0 + k] = fv[k];
+                    wg[s0 + k] = gm[k];
+                    wi[s0 + k] = gmi[k];
+                }
             }
             if (lane == 63) {
                 const int h = w * kHist + (int)(m & (kHist - 1));
@@ -611,11 +668,11 @@ __global__ void backtrack_kernel(BtArgs a) {
     a.out[q] = o;
 }
 
-template <int T, int B>
+template <int T, int B, int RW>
 int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, size_t lds, hipStream_t s) {
 #define SH_LAUNCH(WG, FB)                                                                               \
     do {                                                                                                \
-        auto kfn = mesh_dp_kernel<T, B, WG, FB>;                                                        \
+        auto kfn = mesh_dp_kernel<T, B, RW, WG, FB>;                                                        \
         SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                               \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(T), lds, s, a.qd, a.rec, a.pred, a.node_pos, a.succ_minpos, \
@@ -634,18 +691,20 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, size_t l
 }  // namespace
 
 // Few, fat lanes win: the per-row fixed work of a wave (row record, hand-shake, chain exchange,
-// publish) is amortised over more cells, and 12 cells per lane keep the LDS accesses 16-byte
-// aligned.  Measured on MI355X (16S, 1024 queries): 128x12 146 Gcell/s, 256x6 130, 512x3 97.
-static const DpGeom kGeoms[] = {{64, 4}, {64, 8}, {64, 12}, {128, 8}, {128, 12}, {256, 8}, {256, 12}, {512, 8}, {512, 12}};
+// publish) is amortised over more cells.  Third field: register-ring depth (0 = LDS ring).
+// Measured on MI355X (16S, 1024 queries, Gcell/s): LDS ring 128x12 152, 256x6 133, 512x3 97;
+// register ring 256x6 depth 4: 90, 192x8 depth 4: 82 (2 waves/SIMD: occupancy beats ring depth).
+static const DpGeom kGeoms[] = {{64, 4, 0},  {64, 8, 0},   {64, 12, 0},  {128, 8, 0}, {128, 12, 0},
+                                {256, 8, 0}, {256, 12, 0}, {512, 8, 0}, {512, 12, 0}};
 
 bool pick_geom(uint32_t maxL, DpGeom *g) {
-    // tuning override: SINA_HIP_DP_GEOM="T,B" (used if it covers the batch's longest query)
+    // tuning override: SINA_HIP_DP_GEOM="T,B,RW" (used if it covers the batch's longest query)
     if (const char *ov = getenv("SINA_HIP_DP_GEOM")) {
-        int t = 0, b = 0;
-        if (sscanf(ov, "%d,%d", &t, &b) == 2 && (uint32_t)(t * b) >= maxL &&
-            ((t == 256 && b == 6) || (t == 512 && b == 6) || (t == 192 && b == 8) || (t == 128 && b == 12))) {
+        int t = 0, b = 0, r = 0;
+        if (sscanf(ov, "%d,%d,%d", &t, &b, &r) >= 2 && (uint32_t)(t * b) >= maxL) {
             g->T = t;
             g->B = b;
+            g->RW = r;
             return true;
         }
     }
@@ -658,7 +717,7 @@ bool pick_geom(uint32_t maxL, DpGeom *g) {
     return false;
 }
 
-size_t dp_slot_bytes(const DpGeom &g) { return (size_t)g.Lp() * 12; }
+size_t dp_slot_bytes(const DpGeom &g) { return g.RW > 0 ? 0 : (size_t)g.Lp() * 12; }
 size_t dp_fixed_lds_bytes(const DpGeom &g) {
     const size_t nw = (size_t)g.T / 64;
     return 64 + 16 * nw * kHist + 64 * nw;
@@ -667,20 +726,20 @@ int dp_max_ring(const DpGeom &) { return kHist - 4; }
 
 int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
                    size_t lds, hipStream_t s) {
-#define SH_GEOM(TT, BB) \
-    if (g.T == TT && g.B == BB) return launch_tb<TT, BB>(weighted, forbid, a, nq, lds, s)
-    SH_GEOM(64, 4);
-    SH_GEOM(64, 8);
-    SH_GEOM(64, 12);
-    SH_GEOM(128, 8);
-    SH_GEOM(128, 12);
-    SH_GEOM(256, 8);
-    SH_GEOM(256, 12);
-    SH_GEOM(512, 8);
-    SH_GEOM(512, 12);
-    SH_GEOM(256, 6);   // tuning alternatives (SINA_HIP_DP_GEOM)
-    SH_GEOM(512, 6);
-    SH_GEOM(192, 8);
+#define SH_GEOM(TT, BB, RR) \
+    if (g.T == TT && g.B == BB && g.RW == RR) return launch_tb<TT, BB, RR>(weighted, forbid, a, nq, lds, s)
+    SH_GEOM(64, 4, 0);
+    SH_GEOM(64, 8, 0);
+    SH_GEOM(64, 12, 0);
+    SH_GEOM(128, 8, 0);
+    SH_GEOM(128, 12, 0);
+    SH_GEOM(256, 8, 0);
+    SH_GEOM(256, 12, 0);
+    SH_GEOM(512, 8, 0);
+    SH_GEOM(512, 12, 0);
+    // tuning alternatives (SINA_HIP_DP_GEOM)
+    SH_GEOM(256, 6, 0);
+    SH_GEOM(256, 6, 4);
 #undef SH_GEOM
     SH_FAIL("mesh_dp: unsupported geometry");
 }
