@@ -89,6 +89,14 @@ def main():
     from sina_amd import pipeline, synth
 
     rank, local_rank, world, dist = sdist.init()
+    if dist is None and os.environ.get("SINA_BENCH_FORCE_DIST"):
+        # exercise the RCCL start-up path on a single GPU (world size 1): process group, device
+        # tensor views over the C ABI's buffers, in-place broadcast
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        tdist.init_process_group(backend="nccl", rank=0, world_size=1)
+        dist = tdist
     if world != a.gpus:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
@@ -106,7 +114,7 @@ def main():
     # ---- resident state: references + index in HBM, stages constructed
     store = pipeline.Store(":mem:bench", refs, device=local_rank)
     t_idx = time.time()
-    if world > 1:
+    if dist is not None:
         n_post = sdist.broadcast_device_index(store, 10, False, rank, dist, device)
     else:
         store.build_index(10, False)
@@ -199,11 +207,13 @@ def main():
             threads = os.cpu_count() or 1
             n_sample = a.cpu_sample or min(n_q, max(64, 12 * threads))
             out["cpu_baseline"] = cpu_baseline(refs, qs, n_sample, threads)
-        print(json.dumps(out))
     pl.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)  # the ONE JSON line, after RCCL has said whatever it says
 
 
 if __name__ == "__main__":

@@ -141,3 +141,26 @@ def test_single_tray_batching_shim(oracle, world):
     pl.run(qs.mask, qs.off, batch=1, inflight=3)
     _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250))
     pl.close()
+
+
+@pytest.mark.parametrize("shape", ["v4_amplicon", "lsu_23s"])
+def test_baseline_config_shapes(oracle, shape):
+    """BASELINE.json configs[2] (250 bp V4 amplicons vs full-length 16S references) and configs[4]
+    (23S-like ~3000 bp, width 150k): the short-query and the long-query / wide-graph DP shapes."""
+    if shape == "v4_amplicon":
+        refs = synth.make_refs(300, length=1500, width=50000, seed=81)
+        qs = synth.make_queries(refs, 10, seed=82, window=(1.0 / 3.0, 250))
+    else:
+        refs = synth.make_refs(120, length=3000, width=150000, seed=83)
+        qs = synth.make_queries(refs, 2, seed=84)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    st = pipeline.Store(":mem:gpu-shape-" + shape, refs)
+    try:
+        pl = pipeline.Pipeline(st)
+        pl.run(qs.mask, qs.off)
+        n_dp, _ = _check(oracle, refs, qs, pl, cs, idx)
+        assert n_dp == qs.n
+        pl.close()
+    finally:
+        st.close()
