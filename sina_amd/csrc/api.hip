@@ -21,11 +21,6 @@ static size_t env_size(const char *name, size_t dflt) {
 int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl) {
     if (!pick_geom(maxL, &pl->geom)) SH_FAIL("align: query longer than the largest DP geometry (6144)");
     const size_t slot = dp_slot_bytes(pl->geom), fixed = dp_fixed_lds_bytes(pl->geom);
-    if (pl->geom.RW > 0) {  // ring in registers: depth is a compile-time property of the geometry
-        pl->W = pl->geom.RW;
-        pl->lds = fixed;
-        return 0;
-    }
     size_t budget = c->lds_budget;
     if (budget < fixed + slot) budget = fixed + slot;
     if (budget > 160 * 1024) budget = 160 * 1024;
@@ -42,7 +37,7 @@ int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl) {
 struct HostPrep {
     std::vector<QDesc> qd;
     std::vector<uint4> rec;
-    std::vector<uint32_t> pred;  // id | ring slot << 16 | far << 31 (what mesh_dp_kernel reads)
+    std::vector<uint32_t> pred;  // id | (ring slot or spill row) << 16 (what mesh_dp_kernel reads)
     uint64_t tb_cells = 0, spill_rows = 0, cells = 0;
 };
 
@@ -80,14 +75,23 @@ static void prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint
             for (uint32_t e = po[m]; e < po[m + 1]; e++) {
                 const uint32_t p = g->pred[eo + e];
                 rec[p].z &= ~kRecSink;
-                const bool far = m - p > (uint32_t)W;
-                if (far) rec[p].w = 0;  // mark: needs a spill row
-                hp->pred[d.edge_off + e] = p | ((p % (uint32_t)W) << 16) | (far ? 0x80000000u : 0u);
+                if (m - p > (uint32_t)W) rec[p].w = 0;  // mark: needs a spill row
+                if (m - p > (uint32_t)kFarLds) rec[p].z |= kRecFence;
             }
         }
         uint32_t nsp = 0;
         for (uint32_t m = 0; m < N; m++)
             if (rec[m].w == 0) rec[m].w = nsp++;
+        for (uint32_t m = 0; m < N; m++) {
+            uint32_t nfar = 0;
+            for (uint32_t e = po[m]; e < po[m + 1]; e++) {
+                const uint32_t p = g->pred[eo + e];
+                const bool far = m - p > (uint32_t)W;
+                nfar += far ? 1u : 0u;
+                hp->pred[d.edge_off + e] = p | ((far ? rec[p].w : p % (uint32_t)W) << 16);
+            }
+            rec[m].z |= nfar << 24;
+        }
         d.n_spill = nsp;
         hp->spill_rows += nsp;
         hp->tb_cells += (uint64_t)N * Lp;

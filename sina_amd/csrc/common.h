@@ -67,9 +67,17 @@ struct QDesc {
 // Row record of one DAG node, read through the scalar cache once per row:
 //   x = first predecessor (offset into this query's pred list)
 //   y = node weight (float bits, mseq.cpp:113)
-//   z = #pred | iupac mask << 8 | flags << 16   (flags bit0: sink = no successors)
+//   z = #pred | iupac mask << 8 | flags << 16 | #far pred << 24
+//       flags bit0: sink = no successors; bit1: some successor is further than kFarLds rows away
+//       (its spill row must be visible to the whole workgroup before the row is published)
 //   w = spill row index, or 0xFFFFFFFF when every successor is within the LDS ring
+// Predecessor entries (ids ascend, so the far ones come first):
+//   far  (more than W rows back): id | spill row index << 16
+//   near (within the LDS ring)  : id | ring slot << 16
 constexpr uint32_t kRecSink = 1u << 16;
+constexpr uint32_t kRecFence = 1u << 17;
+constexpr int kBndHist = 256;  // rows of left-boundary value history kept in LDS per wave (power of two)
+constexpr int kFarLds = 192;   // far predecessors up to this distance find their boundary value there
 
 struct DpResult {
     uint32_t end_m, end_s;
@@ -112,7 +120,6 @@ struct BtArgs {
 // Picks the (threads, cells per thread) geometry for the longest query of a batch.
 struct DpGeom {
     int T, B;
-    int RW;  // depth of the register-resident ring of recent rows (0: ring in LDS, run-time depth)
     int Lp() const { return T * B; }
 };
 bool pick_geom(uint32_t maxL, DpGeom *g);

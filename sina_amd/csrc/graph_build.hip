@@ -50,7 +50,7 @@ struct GraphArgs {
     uint4 *rec;                // [nq][ncap]
     uint32_t *node_pos;        // [nq][ncap]
     uint32_t *succ_min;        // [nq][ncap]
-    uint8_t *far_mark;         // [nq][ncap]
+    uint32_t *far_mark;        // [nq][ncap] bit0: has a successor beyond the ring, bit1: beyond kFarLds
     uint32_t *pred;            // per query area of total-family-bases entries
     uint32_t *sizes;           // [nq][4]: N, raw edge entries, n_spill, status (0 ok, 1 NC cap, 2 N cap)
     uint32_t width, nccap, ncap;
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
     uint4 *rec = a.rec + (size_t)q * a.ncap;
     uint32_t *node_pos = a.node_pos + (size_t)q * a.ncap;
     uint32_t *smin = a.succ_min + (size_t)q * a.ncap;
-    uint8_t *far = a.far_mark + (size_t)q * a.ncap;
+    uint32_t *far = a.far_mark + (size_t)q * a.ncap;
     uint32_t *pred = a.pred + a.pred_off[q];
     for (uint32_t i = tid; i < N; i += kGT) {
         smin[i] = 0xFFFFFFFFu;
@@ -262,17 +262,21 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
                 pred[seg + x] = pa;
                 np++;
                 atomicMin(&smin[pa], pos);
-                if (node - pa > (uint32_t)a.W) far[pa] = 1;
+                if (node - pa > (uint32_t)a.W) atomicOr(&far[pa], node - pa > (uint32_t)kFarLds ? 3u : 1u);
             }
-            // encode for the DP kernel: id | ring slot << 16 | far << 31
+            // encode for the DP kernel: id | ring slot << 16; far entries (they come first, ids
+            // ascend) get their spill row index once those are known (step 7)
+            uint32_t nfar = 0;
             for (uint32_t x = 0; x < np; x++) {
                 const uint32_t pa = pred[seg + x];
-                pred[seg + x] = pa | ((pa % (uint32_t)a.W) << 16) | ((node - pa > (uint32_t)a.W) ? 0x80000000u : 0u);
+                const bool isfar = node - pa > (uint32_t)a.W;
+                nfar += isfar ? 1u : 0u;
+                pred[seg + x] = pa | ((isfar ? 0xFFFFu : pa % (uint32_t)a.W) << 16);
             }
             uint4 r;
             r.x = seg;
             r.y = __float_as_uint(wt[cnt]);
-            r.z = (np & 0xFFu) | (mask << 8);
+            r.z = (np & 0xFFu) | (mask << 8) | (nfar << 24);
             r.w = 0xFFFFFFFFu;
             rec[node] = r;
             node_pos[node] = pos;
@@ -286,7 +290,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         const uint32_t chunk = (N + kGT - 1) / kGT;
         const uint32_t b = min(N, tid * chunk), e = min(N, b + chunk);
         uint32_t s = 0;
-        for (uint32_t i = b; i < e; i++) s += far[i];
+        for (uint32_t i = b; i < e; i++) s += far[i] & 1u;
         uint32_t x = s;
         const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -304,7 +308,8 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         uint32_t run = base + x - s;
         for (uint32_t i = b; i < e; i++) {
             uint4 r = rec[i];
-            if (far[i]) r.w = run++;
+            if (far[i] & 1u) r.w = run++;
+            if (far[i] & 2u) r.z |= kRecFence;
             const uint32_t sm = smin[i];
             if (sm == 0xFFFFFFFFu) {
                 r.z |= kRecSink;
@@ -317,6 +322,16 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
             sz[1] = E;
             sz[2] = total;
             sz[3] = 0;
+        }
+    }
+    __syncthreads();
+    // 7. far predecessor entries: id | spill row index << 16
+    for (uint32_t i = tid; i < N; i += kGT) {
+        const uint4 r = rec[i];
+        const uint32_t nfar = r.z >> 24;
+        for (uint32_t x = 0; x < nfar; x++) {
+            const uint32_t pa = pred[r.x + x] & 0xFFFFu;
+            pred[r.x + x] = pa | (rec[pa].w << 16);
         }
     }
 }
@@ -387,7 +402,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
             c->g_tmp0.reserve(8 * (uint64_t)bq) || c->g_tmp1.reserve(8 * (uint64_t)bq) ||
             c->g_tmp2.reserve(4 * std::max<uint64_t>(tab_total, 1)) ||
             c->rec.reserve(sizeof(uint4) * (uint64_t)bq * ncap) || c->node_pos.reserve(4 * (uint64_t)bq * ncap) ||
-            c->succ_minpos.reserve(4 * (uint64_t)bq * ncap) || c->g_tmp3.reserve((uint64_t)bq * ncap) ||
+            c->succ_minpos.reserve(4 * (uint64_t)bq * ncap) || c->g_tmp3.reserve(4 * (uint64_t)bq * ncap) ||
             c->pred.reserve(4 * pred_total) || c->g_sizes.reserve(16 * (uint64_t)bq))
             return 1;
         SH_CHECK(hipMemcpyAsync(c->g_fam_ids.p, fam_ids + fam_off[q0], 4 * foff[bq], hipMemcpyHostToDevice, s));
@@ -406,7 +421,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         ga.rec = c->rec.as<uint4>();
         ga.node_pos = c->node_pos.as<uint32_t>();
         ga.succ_min = c->succ_minpos.as<uint32_t>();
-        ga.far_mark = c->g_tmp3.as<uint8_t>();
+        ga.far_mark = c->g_tmp3.as<uint32_t>();
         ga.pred = c->pred.as<uint32_t>();
         ga.sizes = c->g_sizes.as<uint32_t>();
         ga.width = c->width;

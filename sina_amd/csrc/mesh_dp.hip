@@ -35,7 +35,6 @@
 //     (value_midx:16 | value_sidx:16), row-major.
 #include <cstdio>
 #include <cstdlib>
-#include <type_traits>
 
 #include "common.h"
 
@@ -63,26 +62,80 @@ __device__ __forceinline__ uint32_t lane_shr1(uint32_t x) {
 }
 __device__ __forceinline__ float lane_shr1(float x) { return __uint_as_float(lane_shr1(__float_as_uint(x))); }
 
-// calls f(integral_constant<S>) for the (wave-uniform) run-time slot number: a scalar branch
-// chain, so that register-resident ring rows are only ever indexed with compile-time constants
-template <int S, int RW, typename F>
-__device__ __forceinline__ void slot_dispatch(uint32_t slot, F &&f) {
-    if constexpr (S < RW) {
-        if (slot == (uint32_t)S) f(std::integral_constant<int, S>{});
-        else slot_dispatch<S + 1, RW>(slot, f);
+// B consecutive 4-byte cells starting at a 16-byte aligned address (B % 4 == 0) or 8-byte aligned
+// one (B % 2 == 0): wide loads/stores, both for LDS and for global memory
+template <int B, typename T>
+__device__ __forceinline__ void load_cells(const T *__restrict__ src, T (&dst)[B]) {
+    static_assert(sizeof(T) == 4 && B % 2 == 0, "4-byte cells, even count");
+    if constexpr (B % 4 == 0) {
+        using V = __attribute__((ext_vector_type(4))) T;
+#pragma unroll
+        for (int k = 0; k < B; k += 4) {
+            const V v = *reinterpret_cast<const V *>(src + k);
+            dst[k] = v.x;
+            dst[k + 1] = v.y;
+            dst[k + 2] = v.z;
+            dst[k + 3] = v.w;
+        }
+    } else {
+        using V = __attribute__((ext_vector_type(2))) T;
+#pragma unroll
+        for (int k = 0; k < B; k += 2) {
+            const V v = *reinterpret_cast<const V *>(src + k);
+            dst[k] = v.x;
+            dst[k + 1] = v.y;
+        }
     }
 }
+template <int B, typename T>
+__device__ __forceinline__ void store_cells(T *__restrict__ dst, const T (&src)[B]) {
+    static_assert(sizeof(T) == 4 && B % 2 == 0, "4-byte cells, even count");
+    if constexpr (B % 4 == 0) {
+        using V = __attribute__((ext_vector_type(4))) T;
+#pragma unroll
+        for (int k = 0; k < B; k += 4) {
+            V v;
+            v.x = src[k];
+            v.y = src[k + 1];
+            v.z = src[k + 2];
+            v.w = src[k + 3];
+            *reinterpret_cast<V *>(dst + k) = v;
+        }
+    } else {
+        using V = __attribute__((ext_vector_type(2))) T;
+#pragma unroll
+        for (int k = 0; k < B; k += 2) {
+            V v;
+            v.x = src[k];
+            v.y = src[k + 1];
+            *reinterpret_cast<V *>(dst + k) = v;
+        }
+    }
+}
+
+#ifdef SINA_DP_PROFILE
+// Profiling build only (make PROFILE=1): per-phase s_memtime totals summed over all waves.
+__device__ unsigned long long g_dp_prof[32];
+__device__ int g_dp_abl;  // ablation mask (timing experiments only, results are WRONG when set)
+#define SH_ABL(bit) (abl_ & (bit))
+#define SH_PROF_DECL unsigned long long pa_[32] = {}; unsigned long long pt_ = __builtin_amdgcn_s_memtime();
+#define SH_PROF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pa_[i] += t_ - pt_; pt_ = t_; }
+#define SH_PROF_CNT(i, n) pa_[i] += (n);
+#define SH_PROF_FLUSH if (lane == 0) { for (int i_ = 0; i_ < 32; i_++) atomicAdd(&g_dp_prof[i_], pa_[i_]); }
+#else
+#define SH_ABL(bit) false
+#define SH_PROF_DECL
+#define SH_PROF(i)
+#define SH_PROF_CNT(i, n)
+#define SH_PROF_FLUSH
+#endif
 
 __device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// RW == 0: the ring of recent rows lives in LDS (run-time depth W).
-// RW  > 0: the ring lives in REGISTERS (RW rows x B cells x {value, gapm_val, gapm_idx} per lane):
-//          the register file of a CU is 3x its LDS, near predecessors cost no LDS traffic at all,
-//          and the ring can be deeper at the same occupancy, so far fewer rows spill to HBM.
-template <int T, int B, int RW, bool WEIGHTED, bool FORBID>
-__global__ void __launch_bounds__(T, (RW > 0 ? 2 : (B <= 6 ? 4 : (B <= 8 ? 3 : 2))))
+template <int T, int B, bool WEIGHTED, bool FORBID>
+__global__ void __launch_bounds__(T, (B <= 4 ? 4 : (B <= 8 ? 3 : 2)))
 mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, const uint32_t *__restrict__ predv,
                const uint32_t *__restrict__ node_posv, const uint32_t *__restrict__ succ_minposv,
                const uint8_t *__restrict__ qmaskv, const float *__restrict__ weights, uint32_t n_weights,
@@ -90,8 +143,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe, int W) {
     constexpr int Lp = T * B;
     constexpr int NW = T / 64;
-    constexpr int WCOLS = 64 * B;  // columns per wave
     static_assert(T % 64 == 0, "whole waves only");
+    static_assert(B % 4 == 0, "16-byte accesses per array");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int j = threadIdx.x;
@@ -103,12 +156,12 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
 
     // ---- LDS carve (all dynamic; every offset a multiple of 16)
     uint32_t *progress = reinterpret_cast<uint32_t *>(smem);                    // [NW] rows done by wave
-    float *bnd_val = reinterpret_cast<float *>(smem + 64);                      // [NW][kHist]
-    float *xs_v = bnd_val + NW * kHist;                                          // [NW][kHist]
+    float *bnd_val = reinterpret_cast<float *>(smem + 64);                      // [NW][kBndHist]
+    float *xs_v = bnd_val + NW * kBndHist;                                       // [NW][kHist]
     uint32_t *xs_e = reinterpret_cast<uint32_t *>(xs_v + NW * kHist);            // [NW][kHist]
     uint32_t *xs_gmax = xs_e + NW * kHist;                                       // [NW][kHist]
     uint32_t *fin = xs_gmax + NW * kHist;                                        // [NW][16] per-wave results
-    unsigned char *ring = smem + 64 + 16 * NW * kHist + 64 * NW;
+    unsigned char *ring = smem + 64 + 4 * NW * kBndHist + 12 * NW * kHist + 64 * NW;
     constexpr size_t kValBytes = (size_t)Lp * 4;
     constexpr size_t kGmBytes = (size_t)Lp * 4;
     constexpr size_t kSlotBytes = kValBytes + kGmBytes + (size_t)Lp * 4;  // value f32 | gapm_val f32 | gapm_idx u32
@@ -141,67 +194,77 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
     uint32_t sk_m = 0, sk_s = 0xffffffffu, snk0 = 0;
     bool sk_any = false;
 
-    const uint32_t throttle = (uint32_t)(kHist - W - 2);
-    uint4 cur = rec[0];
+    // the wave to my right reads my exit state of its current row only (kHist slots) and my
+    // boundary values up to kFarLds rows back (kBndHist slots): I may run this far ahead of it
+    const uint32_t throttle = (uint32_t)(kHist - 2);
+    static_assert(kFarLds + kHist <= kBndHist, "boundary history too short");
     uint32_t my_slot = 0;  // ring slot of the current row (m % W), advanced incrementally
-    struct RingRow {  // one ring row of this lane's cells, register resident when RW > 0
-        float v[B], g[B];
-        uint32_t i[B];
-    };
-    RingRow r0, r1, r2, r3, r4, r5;  // distinct objects (not an array) so that they scalarise
-    for (uint32_t m = 0; m < N; ++m) {
-        const uint4 nxt = rec[m + 1 < N ? m + 1 : m];  // scalar prefetch of the next row record
-        const uint32_t pb = cur.x;
-        const float wgt = __uint_as_float(cur.y);
-        const uint32_t npred = cur.z & 0xffu;
-        const uint32_t mmask = (cur.z >> 8) & 0xfu;
-        const bool is_sink = ((cur.z >> 16) & 1u) != 0;
-        const uint32_t sp = cur.w;
-        const bool edge_row = (npred == 0);
-        uint32_t mpos = 0;
-        float cM, cX, gd_open, gd_ext, gi_open;
-        if constexpr (WEIGHTED) {
-            mpos = node_pos[m];
-            const uint32_t nw1 = n_weights - 1;
-            const float wp = weights[mpos < nw1 ? mpos : nw1];
-            const float wp1 = weights[mpos + 1 < nw1 ? mpos + 1 : nw1];
-            cM = ms * wp * wgt;  // (c * weights[pos]) * weight, scoring_schemes.h:232
-            cX = mms * wp * wgt;
-            gd_open = gp * wp;   // :211
-            gd_ext = gpe * wp;   // :222
-            gi_open = gp * wp1;  // :187
-        } else {
-            cM = ms * wgt;       // scoring_schemes.h:154
-            cX = mms * wgt;
-            gd_open = gp;
-            gd_ext = gpe;
-            gi_open = gp;
-        }
-        uint32_t smax = 0;
-        if constexpr (FORBID) {
-            if (!WEIGHTED) mpos = node_pos[m];
-            // int max_insert = min_mpos - pos - 1, passed as unsigned idx_type (mesh.h:480-489)
-            smax = (uint32_t)(int)(succ_minpos[m] - mpos - 1);
-        }
-        const float init_v = edge_row ? 1.0f : 1000000.0f;
+    SH_PROF_DECL
+#ifdef SINA_DP_PROFILE
+    const int abl_ = g_dp_abl;
+#endif
 
-        // ---- wave pipeline hand-shake (LDS flags, no barrier)
-        if (w > 0) {  // the wave to my left must have published row m
+    // Per-row scalars (wave-uniform, from the row record through the scalar cache).
+    struct Row {
+        uint32_t pb, npred, nfar, mmask, sp, z, mpos, smax;
+        float cM, cX, gd_open, gd_ext, gi_open, init_v;
+    };
+    auto setup_row = [&](const uint4 r, uint32_t m) {
+        Row o;
+        o.pb = r.x;
+        const float wgt = __uint_as_float(r.y);
+        o.z = r.z;
+        o.npred = r.z & 0xffu;
+        o.mmask = (r.z >> 8) & 0xfu;
+        o.nfar = r.z >> 24;
+        o.sp = r.w;
+        o.mpos = 0;
+        if constexpr (WEIGHTED) {
+            o.mpos = node_pos[m];
+            const uint32_t nw1 = n_weights - 1;
+            const float wp = weights[o.mpos < nw1 ? o.mpos : nw1];
+            const float wp1 = weights[o.mpos + 1 < nw1 ? o.mpos + 1 : nw1];
+            o.cM = ms * wp * wgt;  // (c * weights[pos]) * weight, scoring_schemes.h:232
+            o.cX = mms * wp * wgt;
+            o.gd_open = gp * wp;   // :211
+            o.gd_ext = gpe * wp;   // :222
+            o.gi_open = gp * wp1;  // :187
+        } else {
+            o.cM = ms * wgt;       // scoring_schemes.h:154
+            o.cX = mms * wgt;
+            o.gd_open = gp;
+            o.gd_ext = gpe;
+            o.gi_open = gp;
+        }
+        o.smax = 0;
+        if constexpr (FORBID) {
+            if (!WEIGHTED) o.mpos = node_pos[m];
+            // int max_insert = min_mpos - pos - 1, passed as unsigned idx_type (mesh.h:480-489)
+            o.smax = (uint32_t)(int)(succ_minpos[m] - o.mpos - 1);
+        }
+        o.init_v = (o.npred == 0) ? 1.0f : 1000000.0f;  // edge rows start at 1 (mesh.h init_edge)
+        return o;
+    };
+    // wave pipeline hand-shake for row m (LDS flags, no barrier)
+    auto handshake = [&](uint32_t m) {
+        if (w > 0 && !SH_ABL(8)) {  // the wave to my left must have published row m
             while (lds_load_relaxed(&progress[w - 1]) <= m) __builtin_amdgcn_s_sleep(1);
         }
-        if (w < NW - 1) {  // do not lap the history slots the wave to my right still needs
+        if (w < NW - 1 && !SH_ABL(8)) {  // do not lap the history slots the wave to my right still needs
             while (m >= lds_load_relaxed(&progress[w + 1]) + throttle) __builtin_amdgcn_s_sleep(1);
         }
         // LDS is in-order per CU: everything the publishing wave wrote before its progress
         // store is visible once the counter is; only the compiler must not hoist loads.
         asm volatile("" ::: "memory");
+    };
 
-        // ---- phase 1: deletion + match candidates from every predecessor row
-        float dv[B], gm[B], mt[B], csel[B];
-        uint32_t dvm[B], dvs[B], gmi[B], mtp[B];
+    // phase-1 results of the current row: deletion / match candidates of my B cells
+    float dv[B], gm[B], mt[B];
+    uint32_t dvm[B], dvs[B], gmi[B], mtp[B];
+    auto init_cells = [&](const Row &r) {
 #pragma unroll
         for (int k = 0; k < B; k++) {
-            const float iv = (s0 + k == 0) ? 1.0f : init_v;
+            const float iv = (s0 + k == 0) ? 1.0f : r.init_v;
             dv[k] = iv;
             gm[k] = iv;
             mt[k] = __builtin_inff();
@@ -209,89 +272,31 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
             dvs[k] = 0;
             gmi[k] = 0;
             mtp[k] = 0;
-            csel[k] = (mmask & qm[k]) ? cM : cX;  // comp(): optimistic IUPAC match (aligned_base.h:153)
         }
-        auto relax = [&](uint32_t p, const float(&sv)[B], const float(&sg)[B], const uint32_t(&sgi)[B], float svl) {
+    };
+
+    // Rows are software-pipelined across loop iterations: iteration m finishes row m (insertion
+    // chain, publish, trace-back) and then starts row m+1 (hand-shake, candidates from its
+    // predecessors).  That way the spill row of row m+1's first far predecessor can be requested
+    // in the middle of the iteration and is consumed at its end, with the chain-independent tail
+    // of row m in between -- and the compiler sees load and use in one straight line, so it waits
+    // for exactly that load instead of draining all outstanding trace-back stores.
+    // Row 0 has no predecessors (they have smaller ids), its candidates are the initial values.
+    float pf_v[B], pf_g[B];  // spill row of the next row's first far predecessor, in flight
+    uint32_t pf_i[B];
 #pragma unroll
-            for (int k = 0; k < B; k++) {
-                // deletion (mesh.h:307-330): gapm_* is overwritten by every predecessor
-                const float v = sv[k] + gd_open;
-                const float g = sg[k] + gd_ext;
-                const bool op = v < g;
-                const float cand = op ? v : g;
-                const uint32_t cm = op ? p : sgi[k];
-                gm[k] = cand;
-                gmi[k] = cm;
-                const bool better = cand < dv[k];
-                dv[k] = better ? cand : dv[k];
-                dvm[k] = better ? cm : dvm[k];
-                dvs[k] = better ? s0 + k : dvs[k];  // value_sidx of a deletion is the column itself
-                // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
-                const float pvv = (k == 0) ? svl : sv[k - 1];
-                const float mv = pvv + csel[k];
-                const bool mb = ((s0 + k) > 0) && (mv < mt[k]);
-                mt[k] = mb ? mv : mt[k];
-                mtp[k] = mb ? p : mtp[k];
-            }
-        };
-        // pred entry: id | ring slot << 16 | far << 31.  Ids ascend, so the predecessors beyond
-        // the LDS ring (spill rows in HBM) come first.
-        uint32_t e = 0;
-        for (; e < npred; ++e) {
-            const uint32_t pe = pred[pb + e];
-            if (!(pe >> 31)) break;
-            const uint32_t p = pe & 0xffffu;
-            const float *row = spill + (size_t)rec[p].w * (3 * Lp);
-            float sv[B], sg[B];
-            uint32_t sgi[B];
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-                sv[k] = row[s0 + k];
-                sg[k] = row[Lp + s0 + k];
-                sgi[k] = reinterpret_cast<const uint32_t *>(row)[2 * Lp + s0 + k];
-            }
-            float svl = lane_shr1(sv[B - 1]);  // value[p][s0-1] lives in the lane to my left
-            if (lane == 0 && w > 0) svl = row[s0 - 1];
-            relax(p, sv, sg, sgi, svl);
-        }
-        for (; e < npred; ++e) {
-            const uint32_t pe = pred[pb + e];
-            const uint32_t p = pe & 0xffffu;
-            if constexpr (RW > 0) {
-                const uint32_t sl = (pe >> 16) & 0xffu;
-                float bnd = 0.f;
-                if (lane == 0 && w > 0) bnd = bnd_val[(w - 1) * kHist + (p & (kHist - 1))];
-#define SH_RELAX_FROM(R)                                          \
-    {                                                             \
-        float svl = lane_shr1(R.v[B - 1]);                        \
-        if (lane == 0 && w > 0) svl = bnd;                        \
-        relax(p, R.v, R.g, R.i, svl);                             \
+    for (int k = 0; k < B; k++) {
+        pf_v[k] = pf_g[k] = 0.f;
+        pf_i[k] = 0;
     }
-                if (sl == 0) SH_RELAX_FROM(r0)
-                else if (RW > 1 && sl == 1) SH_RELAX_FROM(r1)
-                else if (RW > 2 && sl == 2) SH_RELAX_FROM(r2)
-                else if (RW > 3 && sl == 3) SH_RELAX_FROM(r3)
-                else if (RW > 4 && sl == 4) SH_RELAX_FROM(r4)
-                else if (RW > 5 && sl == 5) SH_RELAX_FROM(r5)
-#undef SH_RELAX_FROM
-            } else {
-                const unsigned char *slot = ring + (size_t)((pe >> 16) & 0xffu) * kSlotBytes;
-                const float *pv = reinterpret_cast<const float *>(slot);
-                const float *pg = reinterpret_cast<const float *>(slot + kValBytes);
-                const uint32_t *pi = reinterpret_cast<const uint32_t *>(slot + kValBytes + kGmBytes);
-                float sv[B], sg[B];
-                uint32_t sgi[B];
-#pragma unroll
-                for (int k = 0; k < B; k++) {
-                    sv[k] = pv[s0 + k];
-                    sg[k] = pg[s0 + k];
-                    sgi[k] = pi[s0 + k];
-                }
-                float svl = lane_shr1(sv[B - 1]);
-                if (lane == 0 && w > 0) svl = bnd_val[(w - 1) * kHist + (p & (kHist - 1))];  // left wave's boundary
-                relax(p, sv, sg, sgi, svl);
-            }
-        }
+    Row r = setup_row(rec[0], 0);
+    handshake(0);
+    init_cells(r);
+    for (uint32_t m = 0; m < N; ++m) {
+        const bool has_next = m + 1 < N;
+        const uint4 nrec = rec[has_next ? m + 1 : m];  // scalar load, used after the chain
+        const bool is_sink = (r.z & kRecSink) != 0;
+        SH_PROF(0)
 
         // ---- phase 2: insertion chain along my B cells
         float fv[B];
@@ -300,7 +305,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         auto ext_cost = [&](uint32_t s, uint32_t gsi_prev) -> float {
             if constexpr (WEIGHTED) {
                 const uint32_t nw1 = n_weights - 1;
-                const uint32_t wi = mpos + 1 + ((s - 1) - gsi_prev);
+                const uint32_t wi = r.mpos + 1 + ((s - 1) - gsi_prev);
                 return gpe * weights[wi < nw1 ? wi : nw1];
             } else {
                 return gpe;
@@ -318,17 +323,17 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 uint32_t gsi = 0, gmax = 0;
                 if (s > 0) {
                     bool ins = true;
-                    float gi_cost = gi_open;  // opening gap (mesh.h:340-343 / :415-419)
+                    float gi_cost = r.gi_open;  // opening gap (mesh.h:340-343 / :415-419)
                     uint32_t gsi_n = s - 1, gmax_n = 0;
                     if (FORBID) {
-                        ins = (smax >= 1) && (!c.e || c.gmax > 0);
-                        gmax_n = c.e ? c.gmax - 1 : smax - 1;
+                        ins = (r.smax >= 1) && (!c.e || c.gmax > 0);
+                        gmax_n = c.e ? c.gmax - 1 : r.smax - 1;
                     }
                     if (c.e) {  // extending gap (:344-349 / :420-425); gaps_val == value here
                         gi_cost = ext_cost(s, c.gsi);
                         gsi_n = c.gsi;
                     }
-                    gs = ins ? (c.v + gi_cost) : init_v;  // untouched cell keeps its initial gaps_*
+                    gs = ins ? (c.v + gi_cost) : r.init_v;  // untouched cell keeps its initial gaps_*
                     gsi = ins ? gsi_n : 0u;
                     gmax = ins ? gmax_n : 0u;
                     const bool take = ins && (gs <= v);  // mesh.h:351-357
@@ -373,10 +378,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         }
         // The speculation is exact unless the gap arriving from the left wins my first cell
         // (gs <= value after deletions, and no match beats it): one add and two compares per
-        // lane verify that.  Only if some lane's first cell does take the gap are the chains
-        // re-run with the real left states, until no exit state changes any more.  (With
-        // --insertion=forbid a cell that may NOT take a gap keeps its initial gaps_val, which
-        // the shortcut cannot see: always re-run there.)
+        // lane verify that.  (With --insertion=forbid a cell that may NOT take a gap keeps its
+        // initial gaps_val, which the shortcut cannot see: always re-run there.)
         bool rerun = true;
         if constexpr (!FORBID) {
             left.v = lane_shr1(ex.v);
@@ -385,13 +388,62 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
             if (lane == 0) left = wave_left;
             bool take0 = false;
             if (j > 0) {
-                const float g0 = left.v + (left.e ? ext_cost(s0, left.gsi) : gi_open);
+                const float g0 = left.v + (left.e ? ext_cost(s0, left.gsi) : r.gi_open);
                 take0 = (g0 <= dv[0]) && !(mt[0] < g0);
             }
             rerun = __any(take0);
+            if (SH_ABL(1)) rerun = false;
         }
+        SH_PROF(4)
+#ifdef SINA_DP_PROFILE
+        int it_ = 0;
+#endif
+        // Simple scheme: a gap that enters my cells from the left either runs through ALL of them
+        // (every cell: gap <= min(deletion, match) candidates) and leaves as the same gap, B adds
+        // later -- or it dies at some cell, and from that cell on everything is what the
+        // speculative pass computed (with gap_open >= gap_extend the speculative gap candidate of
+        // that cell is no smaller than the real one, so it lost there as well).  Exit states can
+        // therefore be propagated lane to lane with B adds and B compares per step instead of a
+        // full chain evaluation; one full evaluation with the converged left states finishes.
+        if constexpr (!WEIGHTED && !FORBID) {
+            if (rerun && gp >= gpe) {
+                float loc[B];
+#pragma unroll
+                for (int k = 0; k < B; k++) loc[k] = (mt[k] < dv[k]) ? mt[k] : dv[k];
+                const ChainState sx = ex;
+                for (int guard = 0; guard < (1 << 20); ++guard) {
+                    SH_PROF_CNT(10, 1)
+#ifdef SINA_DP_PROFILE
+                    it_++;
+#endif
+                    const ChainState prev = ex;
+                    float g = left.v + (left.e ? gpe : gp);
+                    bool pass = (j > 0) && (g <= loc[0]);
+#pragma unroll
+                    for (int k = 1; k < B; k++) {
+                        g = g + gpe;
+                        pass = pass && (g <= loc[k]);
+                    }
+                    ex.v = pass ? g : sx.v;
+                    ex.e = pass ? 1u : sx.e;
+                    ex.gsi = pass ? (left.e ? left.gsi : s0 - 1) : sx.gsi;
+                    if (!__any(!same_state(ex, prev))) break;
+                    left.v = lane_shr1(ex.v);
+                    left.e = lane_shr1(ex.e);
+                    left.gsi = lane_shr1(ex.gsi);
+                    if (lane == 0) left = wave_left;
+                }
+                if (j > 0) run_chain(left);
+                rerun = false;
+            }
+        }
+        // General case: re-run the chains with the real left states until no exit state changes.
         if (rerun) {
-            for (;;) {
+            for (int guard = 0; guard < (1 << 20); ++guard) {
+                SH_PROF_CNT(10, 1)
+#ifdef SINA_DP_PROFILE
+                it_++;
+#endif
                 const ChainState prev = ex;
                 left.v = lane_shr1(ex.v);
                 left.e = lane_shr1(ex.e);
@@ -402,75 +454,66 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 if (!__any(!same_state(ex, prev))) break;
             }
         }
+#ifdef SINA_DP_PROFILE
+        {   // histogram of rerun iterations per row: 0,1,2,3,4,5-8,9-16,17-32,33+
+            const int b_ = it_ <= 4 ? it_ : (it_ <= 8 ? 5 : (it_ <= 16 ? 6 : (it_ <= 32 ? 7 : 8)));
+            pa_[16 + b_] += 1;
+        }
+#endif
+        SH_PROF(5)
 
         // ---- publish: ring (own columns), boundary + exit state for the wave to my right
         {
-            if constexpr (RW > 0) {
-#define SH_STORE_TO(R)                  \
-    {                                   \
-        _Pragma("unroll") for (int k = 0; k < B; k++) { \
-            R.v[k] = fv[k];             \
-            R.g[k] = gm[k];             \
-            R.i[k] = gmi[k];            \
-        }                               \
-    }
-                if (my_slot == 0) SH_STORE_TO(r0)
-                else if (RW > 1 && my_slot == 1) SH_STORE_TO(r1)
-                else if (RW > 2 && my_slot == 2) SH_STORE_TO(r2)
-                else if (RW > 3 && my_slot == 3) SH_STORE_TO(r3)
-                else if (RW > 4 && my_slot == 4) SH_STORE_TO(r4)
-                else if (RW > 5 && my_slot == 5) SH_STORE_TO(r5)
-#undef SH_STORE_TO
-            } else {
-                unsigned char *myslot = ring + (size_t)my_slot * kSlotBytes;
-                float *wv = reinterpret_cast<float *>(myslot);
-                float *wg = reinterpret_cast<float *>(myslot + kValBytes);
-                uint32_t *wi = reinterpret_cast<uint32_t *>(myslot + kValBytes + kGmBytes);
-#pragma unroll
-                for (int k = 0; k < B; k++) {
-                    wv[s0 + k] = fv[k];
-                    wg[s0 + k] = gm[k];
-                    wi[s0 + k] = gmi[k];
-                }
-            }
+            unsigned char *myslot = ring + (size_t)my_slot * kSlotBytes;
+            store_cells<B>(reinterpret_cast<float *>(myslot) + s0, fv);
+            store_cells<B>(reinterpret_cast<float *>(myslot + kValBytes) + s0, gm);
+            store_cells<B>(reinterpret_cast<uint32_t *>(myslot + kValBytes + kGmBytes) + s0, gmi);
             if (lane == 63) {
                 const int h = w * kHist + (int)(m & (kHist - 1));
-                bnd_val[h] = fv[B - 1];
+                bnd_val[w * kBndHist + (int)(m & (kBndHist - 1))] = fv[B - 1];
                 xs_v[h] = ex.v;
                 xs_e[h] = (ex.e << 31) | ex.gsi;
                 if (FORBID) xs_gmax[h] = ex.gmax;
             }
             my_slot = (my_slot + 1 == (uint32_t)W) ? 0u : my_slot + 1;
         }
-        if (sp != kNoSpill) {
-            float *row = spill + (size_t)sp * (3 * Lp);
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-                row[s0 + k] = fv[k];
-                row[Lp + s0 + k] = gm[k];
-                reinterpret_cast<uint32_t *>(row)[2 * Lp + s0 + k] = gmi[k];
-            }
+        if (r.sp != kNoSpill && !SH_ABL(2)) {
+            float *row = spill + (size_t)r.sp * (3 * Lp);
+            store_cells<B>(row + s0, fv);
+            store_cells<B>(row + Lp + s0, gm);
+            store_cells<B>(reinterpret_cast<uint32_t *>(row) + 2 * Lp + s0, gmi);
         }
-        // release: LDS writes (and the spill row, if any) before the progress counter.  Rows
-        // without a spill row only need the LDS queue drained -- a full workgroup-scope release
-        // would also wait (vmcnt) for the previous row's trace-back stores.
-        if (sp != kNoSpill) {
+        // release: LDS writes before the progress counter.  A spill row is read back by the lane
+        // that wrote it (program order suffices) -- except by successors further than kFarLds
+        // rows away, whose left-boundary value has left the LDS history: only rows with such a
+        // successor pay for a workgroup-scope release (which also waits for older trace-back stores).
+        if ((r.z & kRecFence) && !SH_ABL(2)) {
+            SH_PROF_CNT(11, 1)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if (lane == 0) __hip_atomic_store(&progress[w], m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        SH_PROF(6)
+
+        // ---- request the spill row of the first far predecessor of row m+1 (after my own spill
+        // stores, so that waiting for it later does not wait for them; before the trace-back stores)
+        const uint32_t n_nfar = has_next ? (nrec.z >> 24) : 0u;
+        if (n_nfar != 0 && !SH_ABL(2)) {  // (no else: the registers keep their stale contents, never read)
+            const float *row = spill + (size_t)(pred[nrec.x] >> 16) * (3 * Lp);
+            load_cells<B>(row + s0, pf_v);
+            load_cells<B>(row + Lp + s0, pf_g);
+            load_cells<B>(reinterpret_cast<const uint32_t *>(row) + 2 * Lp + s0, pf_i);
+        }
 
         // ---- trace-back cells: the only per-cell HBM traffic
-        {
-            uint32_t *trow = tb + (size_t)m * Lp + s0;
+        if (!SH_ABL(4)) {
+            uint32_t tc[B];
 #pragma unroll
-            for (int k = 0; k < B; k++) trow[k] = (fvm[k] << 16) | (fvs[k] & 0xffffu);
+            for (int k = 0; k < B; k++) tc[k] = (fvm[k] << 16) | (fvs[k] & 0xffffu);
+            store_cells<B>(tb + (size_t)m * Lp + s0, tc);
         }
-        if (dbg_value != nullptr && blockIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < B; k++) dbg_value[(size_t)m * Lp + s0 + k] = fv[k];
-        }
+        if (dbg_value != nullptr && blockIdx.x == 0) store_cells<B>(dbg_value + (size_t)m * Lp + s0, fv);
 
         // ---- end-cell search, step 1: rows at the last query column (one lane)
         if (own_last) {
@@ -511,8 +554,93 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
             }
             sk_any = true;
         }
-        cur = nxt;
+        SH_PROF(7)
+        SH_PROF_CNT(8, 1)
+        if (!has_next) break;
+
+        // ================= row m+1: candidates from its predecessor rows =================
+        const uint32_t mn = m + 1;
+        r = setup_row(nrec, mn);
+        handshake(mn);
+        SH_PROF(1)
+        init_cells(r);
+        float csel[B];
+#pragma unroll
+        for (int k = 0; k < B; k++) csel[k] = (r.mmask & qm[k]) ? r.cM : r.cX;  // comp(): optimistic IUPAC match (aligned_base.h:153)
+        auto relax = [&](uint32_t p, const float(&sv)[B], const float(&sg)[B], const uint32_t(&sgi)[B], float svl) {
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                // deletion (mesh.h:307-330): gapm_* is overwritten by every predecessor
+                const float v = sv[k] + r.gd_open;
+                const float g = sg[k] + r.gd_ext;
+                const bool op = v < g;
+                const float cand = op ? v : g;
+                const uint32_t cm = op ? p : sgi[k];
+                gm[k] = cand;
+                gmi[k] = cm;
+                const bool better = cand < dv[k];
+                dv[k] = better ? cand : dv[k];
+                dvm[k] = better ? cm : dvm[k];
+                dvs[k] = better ? s0 + k : dvs[k];  // value_sidx of a deletion is the column itself
+                // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
+                const float pvv = (k == 0) ? svl : sv[k - 1];
+                const float mv = pvv + csel[k];
+                const bool mb = ((s0 + k) > 0) && (mv < mt[k]);
+                mt[k] = mb ? mv : mt[k];
+                mtp[k] = mb ? p : mtp[k];
+            }
+        };
+        // Far predecessors (beyond the LDS ring; they come first, ids ascend): pred entry =
+        // id | spill row << 16.  My own columns of a spill row were written by me; the single
+        // value I need from the wave to my left (column s0-1, lane 0 only) comes from its boundary
+        // history in LDS, or -- further back than kFarLds rows -- from the spill row itself, which
+        // such rows publish with a workgroup-scope release.
+        uint32_t e = 0;
+        for (; e < r.nfar; ++e) {
+            if (SH_ABL(2)) continue;
+            const uint32_t pe = pred[r.pb + e];
+            const uint32_t p = pe & 0xffffu;
+            const float *row = spill + (size_t)(pe >> 16) * (3 * Lp);
+            float sv[B], sg[B];
+            uint32_t sgi[B];
+            if (e == 0) {
+#pragma unroll
+                for (int k = 0; k < B; k++) {
+                    sv[k] = pf_v[k];
+                    sg[k] = pf_g[k];
+                    sgi[k] = pf_i[k];
+                }
+            } else {
+                load_cells<B>(row + s0, sv);
+                load_cells<B>(row + Lp + s0, sg);
+                load_cells<B>(reinterpret_cast<const uint32_t *>(row) + 2 * Lp + s0, sgi);
+            }
+            float svl = lane_shr1(sv[B - 1]);  // value[p][s0-1] lives in the lane to my left
+            if (lane == 0 && w > 0) {
+                if (mn - p <= (uint32_t)kFarLds) svl = bnd_val[(w - 1) * kBndHist + (p & (kBndHist - 1))];
+                else svl = row[s0 - 1];
+            }
+            relax(p, sv, sg, sgi, svl);
+            SH_PROF_CNT(9, 1)
+        }
+        SH_PROF(2)
+        // Near predecessors: the LDS ring; pred entry = id | ring slot << 16.
+        for (; e < r.npred; ++e) {
+            const uint32_t pe = pred[r.pb + e];
+            const uint32_t p = pe & 0xffffu;
+            const unsigned char *slot = ring + (size_t)(pe >> 16) * kSlotBytes;
+            float sv[B], sg[B];
+            uint32_t sgi[B];
+            load_cells<B>(reinterpret_cast<const float *>(slot) + s0, sv);
+            load_cells<B>(reinterpret_cast<const float *>(slot + kValBytes) + s0, sg);
+            load_cells<B>(reinterpret_cast<const uint32_t *>(slot + kValBytes + kGmBytes) + s0, sgi);
+            float svl = lane_shr1(sv[B - 1]);
+            if (lane == 0 && w > 0) svl = bnd_val[(w - 1) * kBndHist + (p & (kBndHist - 1))];  // left wave's boundary
+            relax(p, sv, sg, sgi, svl);
+        }
+        SH_PROF(3)
     }
+    SH_PROF_FLUSH
 
     // ---- combine (mesh.h:567-592)
     if (lane == 0) {
@@ -668,11 +796,11 @@ __global__ void backtrack_kernel(BtArgs a) {
     a.out[q] = o;
 }
 
-template <int T, int B, int RW>
+template <int T, int B>
 int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, size_t lds, hipStream_t s) {
 #define SH_LAUNCH(WG, FB)                                                                               \
     do {                                                                                                \
-        auto kfn = mesh_dp_kernel<T, B, RW, WG, FB>;                                                        \
+        auto kfn = mesh_dp_kernel<T, B, WG, FB>;                                                            \
         SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                               \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(T), lds, s, a.qd, a.rec, a.pred, a.node_pos, a.succ_minpos, \
@@ -691,21 +819,24 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, size_t l
 }  // namespace
 
 // Few, fat lanes win: the per-row fixed work of a wave (row record, hand-shake, chain exchange,
-// publish) is amortised over more cells.  Third field: register-ring depth (0 = LDS ring).
-// Measured on MI355X (16S, 1024 queries, Gcell/s): LDS ring 128x12 152, 256x6 133, 512x3 97;
-// register ring 256x6 depth 4: 90, 192x8 depth 4: 82 (2 waves/SIMD: occupancy beats ring depth).
-static const DpGeom kGeoms[] = {{64, 4, 0},  {64, 8, 0},   {64, 12, 0},  {128, 8, 0}, {128, 12, 0},
-                                {256, 8, 0}, {256, 12, 0}, {512, 8, 0}, {512, 12, 0}};
+// publish) is amortised over more cells.  Measured on MI355X (16S, 1024 queries, Gcell/s, before
+// the far-row prefetch): 128x12 152, 256x6 133, 512x3 97.  A variant that kept the ring of
+// recent rows in registers instead of LDS (deeper ring, but 2 waves/SIMD and scratch spills)
+// reached 82-90 and was dropped.
+static const DpGeom kGeoms[] = {{64, 4},  {64, 8},  {64, 12},  {128, 8}, {128, 12},
+                                {256, 8}, {256, 12}, {512, 8}, {512, 12}};
 
 bool pick_geom(uint32_t maxL, DpGeom *g) {
-    // tuning override: SINA_HIP_DP_GEOM="T,B,RW" (used if it covers the batch's longest query)
+    // tuning override: SINA_HIP_DP_GEOM="T,B" (used if it covers the batch's longest query)
     if (const char *ov = getenv("SINA_HIP_DP_GEOM")) {
-        int t = 0, b = 0, r = 0;
-        if (sscanf(ov, "%d,%d,%d", &t, &b, &r) >= 2 && (uint32_t)(t * b) >= maxL) {
-            g->T = t;
-            g->B = b;
-            g->RW = r;
-            return true;
+        int t = 0, b = 0;
+        if (sscanf(ov, "%d,%d", &t, &b) == 2 && (uint32_t)(t * b) >= maxL) {
+            for (const DpGeom &c : kGeoms) {
+                if (c.T == t && c.B == b) {
+                    *g = c;
+                    return true;
+                }
+            }
         }
     }
     for (const DpGeom &c : kGeoms) {
@@ -717,32 +848,44 @@ bool pick_geom(uint32_t maxL, DpGeom *g) {
     return false;
 }
 
-size_t dp_slot_bytes(const DpGeom &g) { return g.RW > 0 ? 0 : (size_t)g.Lp() * 12; }
+size_t dp_slot_bytes(const DpGeom &g) { return (size_t)g.Lp() * 12; }
 size_t dp_fixed_lds_bytes(const DpGeom &g) {
     const size_t nw = (size_t)g.T / 64;
-    return 64 + 16 * nw * kHist + 64 * nw;
+    return 64 + 4 * nw * kBndHist + 12 * nw * kHist + 64 * nw;
 }
-int dp_max_ring(const DpGeom &) { return kHist - 4; }
+int dp_max_ring(const DpGeom &) { return 64; }  // near predecessors must stay within the boundary history (kFarLds)
 
 int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
                    size_t lds, hipStream_t s) {
-#define SH_GEOM(TT, BB, RR) \
-    if (g.T == TT && g.B == BB && g.RW == RR) return launch_tb<TT, BB, RR>(weighted, forbid, a, nq, lds, s)
-    SH_GEOM(64, 4, 0);
-    SH_GEOM(64, 8, 0);
-    SH_GEOM(64, 12, 0);
-    SH_GEOM(128, 8, 0);
-    SH_GEOM(128, 12, 0);
-    SH_GEOM(256, 8, 0);
-    SH_GEOM(256, 12, 0);
-    SH_GEOM(512, 8, 0);
-    SH_GEOM(512, 12, 0);
-    // tuning alternatives (SINA_HIP_DP_GEOM)
-    SH_GEOM(256, 6, 0);
-    SH_GEOM(256, 6, 4);
+#define SH_GEOM(TT, BB) \
+    if (g.T == TT && g.B == BB) return launch_tb<TT, BB>(weighted, forbid, a, nq, lds, s)
+    SH_GEOM(64, 4);
+    SH_GEOM(64, 8);
+    SH_GEOM(64, 12);
+    SH_GEOM(128, 8);
+    SH_GEOM(128, 12);
+    SH_GEOM(256, 8);
+    SH_GEOM(256, 12);
+    SH_GEOM(512, 8);
+    SH_GEOM(512, 12);
 #undef SH_GEOM
     SH_FAIL("mesh_dp: unsupported geometry");
 }
+
+#ifdef SINA_DP_PROFILE
+extern "C" int sina_hip_debug_dp_ablate(int mask) {
+    SH_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dp_abl), &mask, sizeof mask));
+    return 0;
+}
+extern "C" int sina_hip_debug_dp_profile(unsigned long long *out32, int reset) {
+    SH_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_dp_prof), sizeof(unsigned long long) * 32));
+    if (reset) {
+        unsigned long long z[32] = {};
+        SH_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dp_prof), z, sizeof z));
+    }
+    return 0;
+}
+#endif
 
 int launch_backtrack(const BtArgs &a, hipStream_t s) {
     const int threads = 64;

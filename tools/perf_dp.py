@@ -21,8 +21,30 @@ qoff=np.zeros(nq+1,np.uint64); qoff[1:]=np.cumsum([len(m) for m in qms])
 ctx=capi.Context(0)
 gb=ctx.graph_batch(graphs, refs.width)
 qm=np.concatenate(qms)
-for lds in (os.environ.get('SINA_HIP_DP_LDS_KB','128'),):
+import ctypes
+lib = capi.load()
+prof = hasattr(lib, "sina_hip_debug_dp_profile")
+masks = [int(x) for x in os.environ.get("SINA_DP_ABL", "0").split(",")] if prof else [0]
+for mask in masks:
+    if prof:
+        lib.sina_hip_debug_dp_ablate(mask)
     for rep in range(3):
-        t=time.time(); out,pos=ctx.align_graphs(gb,qm,qoff); dt=time.time()-t
-        st=ctx.stats()
-        print("lds",lds,"wall %.3fs dp %.2f ms bt %.2f ms cells %.3g  -> %.1f Gcell/s  %.1f GB/s(8B/cell)  q/s(dp) %.0f"%(dt,st['dp_ms'],st['backtrack_ms'],st['dp_cells'],st['dp_cells']/st['dp_ms']/1e6, 8*st['dp_cells']/st['dp_ms']/1e6, nq/st['dp_ms']*1e3))
+        s0 = ctx.stats()
+        t = time.time(); out, pos = ctx.align_graphs(gb, qm, qoff); dt = time.time() - t
+        st = ctx.stats()
+        dp = st['dp_ms'] - s0['dp_ms']; cells = st['dp_cells'] - s0['dp_cells']
+        print("abl %d wall %.3fs dp %.2f ms bt %.2f ms cells %.3g  -> %.1f Gcell/s  q/s(dp) %.0f" % (
+            mask, dt, dp, st['backtrack_ms'] - s0['backtrack_ms'], cells, cells / dp / 1e6, nq / dp * 1e3))
+# profiling build (make -C sina_amd/csrc PROFILE=1): per-phase share of wave time
+if prof:
+    a = (ctypes.c_ulonglong * 32)()
+    lib.sina_hip_debug_dp_profile(a, 1)
+    names = ["setup", "handshake", "far preds", "near preds", "chain+verify", "rerun", "publish", "tb+end"]
+    tot = float(sum(a[:8]))
+    rows = a[8]
+    for i, n in enumerate(names):
+        print("%-14s %5.1f%%  %8.0f ticks/row" % (n, 100 * a[i] / tot, a[i] / rows))
+    print("wave-rows %d  far preds/row %.3f  rerun iters/row %.3f  spill rows/row %.3f" % (
+        rows, a[9] / rows, a[10] / rows, a[11] / rows))
+    print("rerun iterations/row histogram [0,1,2,3,4,5-8,9-16,17-32,33+]:",
+          " ".join("%.3f" % (a[16 + i] / rows) for i in range(9)))
