@@ -37,11 +37,12 @@ int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl) {
 struct HostPrep {
     std::vector<QDesc> qd;
     std::vector<uint4> rec;
-    std::vector<uint32_t> pred;  // id | (ring slot or spill row) << 16 (what mesh_dp_kernel reads)
+    std::vector<uint32_t> pred;  // id | (LDS slot or spill row) << 16 | spilled << 31 (what mesh_dp_kernel reads)
+    std::vector<uint32_t> last;  // scratch: last successor per row
     uint64_t tb_cells = 0, spill_rows = 0, cells = 0;
 };
 
-static void prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint32_t q0, uint32_t q1, int Lp, int W,
+static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint32_t q0, uint32_t q1, int Lp, int W,
                        HostPrep *hp) {
     const uint64_t nbase = g->node_off[q0], ebase = g->edge_off[q0];
     const uint64_t nn = g->node_off[q1] - nbase;
@@ -69,34 +70,56 @@ static void prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint
             rec[m].x = po[m];
             rec[m].y = wbits;
             rec[m].z = ((po[m + 1] - po[m]) & 0xffu) | ((uint32_t)(g->node_mask[no + m] & 0xffu) << 8) | kRecSink;
-            rec[m].w = 0xFFFFFFFFu;
+            rec[m].w = kRowNone;
         }
+        // last successor of every row (0 = none), sink and fence flags
+        std::vector<uint32_t> &last = hp->last;
+        last.assign(N, 0);
         for (uint32_t m = 0; m < N; m++) {
             for (uint32_t e = po[m]; e < po[m + 1]; e++) {
                 const uint32_t p = g->pred[eo + e];
                 rec[p].z &= ~kRecSink;
-                if (m - p > (uint32_t)W) rec[p].w = 0;  // mark: needs a spill row
+                last[p] = m;  // rows ascend
                 if (m - p > (uint32_t)kFarLds) rec[p].z |= kRecFence;
             }
         }
+        // LDS slots by liveness, first free slot wins; a row that finds none is spilled
         uint32_t nsp = 0;
-        for (uint32_t m = 0; m < N; m++)
-            if (rec[m].w == 0) rec[m].w = nsp++;
+        uint32_t free_at[64];
+        for (int x = 0; x < W; x++) free_at[x] = 0;
         for (uint32_t m = 0; m < N; m++) {
-            uint32_t nfar = 0;
+            if (rec[m].z & kRecSink) continue;  // w stays kRowNone
+            int slot = -1;
+            if (!(rec[m].z & kRecFence))  // (a row with a successor beyond kFarLds must be a spill row)
+                for (int x = 0; x < W; x++)
+                    if (free_at[x] <= m) {
+                        slot = x;
+                        break;
+                    }
+            if (slot >= 0) {
+                free_at[slot] = last[m];
+                rec[m].w = (uint32_t)slot;
+            } else {
+                rec[m].w = kRowSpilled | nsp++;
+            }
+        }
+        for (uint32_t m = 0; m < N; m++) {
+            uint32_t first_far = 0;
             for (uint32_t e = po[m]; e < po[m + 1]; e++) {
                 const uint32_t p = g->pred[eo + e];
-                const bool far = m - p > (uint32_t)W;
-                nfar += far ? 1u : 0u;
-                hp->pred[d.edge_off + e] = p | ((far ? rec[p].w : p % (uint32_t)W) << 16);
+                const bool sp = (rec[p].w & kRowSpilled) != 0;
+                if (sp && first_far == 0) first_far = e - po[m] + 1;
+                hp->pred[d.edge_off + e] = p | ((rec[p].w & 0x7FFFu) << 16) | (sp ? kPredSpilled : 0u);
             }
-            rec[m].z |= nfar << 24;
+            rec[m].z |= first_far << 24;
         }
+        if (nsp > kMaxSpillRows) SH_FAIL("align_graphs: too many spill rows for one query");
         d.n_spill = nsp;
         hp->spill_rows += nsp;
         hp->tb_cells += (uint64_t)N * Lp;
         hp->cells += (uint64_t)N * d.L;
     }
+    return 0;
 }
 
 // Runs DP + backtrack for bq queries whose graphs (qd, rec, pred, node_pos, succ_minpos) and
@@ -108,7 +131,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, uint32_t bq, uint64_t tb_ce
     const int Lp = pl.geom.Lp();
     const bool weighted = p->weights != nullptr && p->n_weights > 0;
     const bool forbid = p->insertion == SINA_INSERTION_FORBID;
-    if (c->tb.reserve(4 * tb_cells) || c->spill.reserve(std::max<uint64_t>(spill_rows, 1) * 12 * (uint64_t)Lp) ||
+    if (c->tb.reserve(4 * tb_cells) || c->spill.reserve(std::max<uint64_t>(spill_rows, 1) * 8 * (uint64_t)Lp) ||
         c->res.reserve(sizeof(DpResult) * bq) || c->out.reserve(sizeof(sina_hip_align_out) * bq) ||
         c->out_pos.reserve(4 * std::max<uint64_t>(nqm, 1)))
         return 1;
@@ -130,7 +153,6 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, uint32_t bq, uint64_t tb_ce
     a.mms = -p->mismatch_score;
     a.gp = p->gap_penalty;
     a.gpe = p->gap_ext_penalty;
-    a.W = pl.W;
 
     SH_CHECK(hipEventRecord(c->ev[0], s));
     if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, s)) return 1;
@@ -138,6 +160,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, uint32_t bq, uint64_t tb_ce
     BtArgs b;
     b.qd = a.qd;
     b.rec = a.rec;
+    b.pred = a.pred;
     b.node_pos = a.node_pos;
     b.tb = a.tb;
     b.res = a.res;
@@ -188,7 +211,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         const uint64_t L = qoff[q + 1] - qoff[q];
         const uint64_t N = g->node_off[q + 1] - g->node_off[q];
         if (L == 0 || N == 0) SH_FAIL("align_graphs: empty query or graph");
-        if (L > 65535 || N > 65535) SH_FAIL("align_graphs: N or L exceeds 16-bit trace-back fields");
+        if (L > kTbSMask || N > 65535) SH_FAIL("align_graphs: N or L exceeds the trace-back cell fields");
         maxL = std::max<uint32_t>(maxL, (uint32_t)L);
     }
     DpPlan pl;
@@ -210,7 +233,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
             q1++;
         }
         if (dbg_vm) q1 = q0 + 1;
-        prep_range(g, qoff, q0, q1, Lp, pl.W, &hp);
+        if (prep_range(g, qoff, q0, q1, Lp, pl.W, &hp)) return 1;
         const uint32_t bq = q1 - q0;
         const uint64_t nbase = g->node_off[q0], nn = g->node_off[q1] - nbase;
         const uint64_t ebase = g->edge_off[q0], ne = g->edge_off[q1] - ebase;
@@ -239,11 +262,25 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
                 vh.resize(tbh.size());
                 SH_CHECK(hipMemcpy(vh.data(), c->dbg.p, 4 * vh.size(), hipMemcpyDeviceToHost));
             }
+            // value_midx of a gap-extending deletion is the predecessor's gapm_idx (common.h, kTbExt)
+            const uint4 *rec = hp.rec.data() + d.node_off;
+            const uint32_t *pr = hp.pred.data() + d.edge_off;
+            auto gapm_idx = [&](uint32_t x, uint32_t col) -> uint32_t {
+                for (;;) {
+                    const uint32_t np = rec[x].z & 0xffu;
+                    if (np == 0) return 0;
+                    const uint32_t lastp = pr[rec[x].x + np - 1] & 0xffffu;
+                    if (tbh[(size_t)x * Lp + col] & kTbOpLast) return lastp;
+                    x = lastp;
+                }
+            };
             for (uint32_t m = 0; m < d.N; m++)
                 for (uint32_t x = 0; x < d.L; x++) {
                     const uint32_t cell = tbh[(size_t)m * Lp + x];
-                    dbg_vm[(size_t)m * d.L + x] = cell >> 16;
-                    dbg_vs[(size_t)m * d.L + x] = cell & 0xffffu;
+                    uint32_t vm = cell >> 16;
+                    if (cell & kTbExt) vm = gapm_idx(vm, x);
+                    dbg_vm[(size_t)m * d.L + x] = vm;
+                    dbg_vs[(size_t)m * d.L + x] = cell & kTbSMask;
                     if (dbg_value_host) dbg_value_host[(size_t)m * d.L + x] = vh[(size_t)m * Lp + x];
                 }
         }

@@ -67,17 +67,36 @@ struct QDesc {
 // Row record of one DAG node, read through the scalar cache once per row:
 //   x = first predecessor (offset into this query's pred list)
 //   y = node weight (float bits, mseq.cpp:113)
-//   z = #pred | iupac mask << 8 | flags << 16 | #far pred << 24
+//   z = #pred | iupac mask << 8 | flags << 16 | (index of the first spilled predecessor + 1) << 24
 //       flags bit0: sink = no successors; bit1: some successor is further than kFarLds rows away
 //       (its spill row must be visible to the whole workgroup before the row is published)
-//   w = spill row index, or 0xFFFFFFFF when every successor is within the LDS ring
-// Predecessor entries (ids ascend, so the far ones come first):
-//   far  (more than W rows back): id | spill row index << 16
-//   near (within the LDS ring)  : id | ring slot << 16
+//   w = where the finished row {value, gapm_val} is kept for its successors:
+//       0xFFFFFFFF nowhere (no successors), kRowSpilled | spill row index, or the LDS slot number.
+// LDS slots are handed out by liveness (a slot is reused once the last successor of its row has
+// been computed); a row that finds every slot busy, or that has a successor more than kFarLds
+// rows away (kRecFence), goes to a spill row in HBM instead.
+// Predecessor entries, ascending ids (= the reference's evaluation order, which decides ties):
+//   id | (LDS slot or spill row index) << 16 | spilled << 31
 constexpr uint32_t kRecSink = 1u << 16;
 constexpr uint32_t kRecFence = 1u << 17;
+constexpr uint32_t kRowNone = 0xFFFFFFFFu;
+constexpr uint32_t kRowSpilled = 0x80000000u;
+constexpr uint32_t kPredSpilled = 0x80000000u;
+constexpr uint32_t kMaxSpillRows = 32768;  // 15 bits in a predecessor entry
 constexpr int kBndHist = 256;  // rows of left-boundary value history kept in LDS per wave (power of two)
-constexpr int kFarLds = 192;   // far predecessors up to this distance find their boundary value there
+constexpr int kFarLds = 192;   // predecessors up to this distance find their left-boundary value there
+
+// Trace-back cell (one u32 per DP cell, the only per-cell HBM traffic):
+//   bits 31..16 value_midx, bits 12..0 value_sidx, and two bits that replace carrying gapm_idx
+//   through the recurrence (it is only ever needed for cells ON the final path):
+//   kTbExt:    the cell took a deletion that EXTENDS the gap of its predecessor `value_midx`; the
+//              reference's value_midx is that row's gapm_idx at this column (mesh.h:318-330)
+//   kTbOpLast: this row's own gapm at this column was OPENED from its last predecessor, i.e.
+//              gapm_idx = last predecessor; otherwise gapm_idx = the last predecessor's gapm_idx.
+// backtrack resolves kTbExt by walking last predecessors until a kTbOpLast cell (resolve_gapm_idx).
+constexpr uint32_t kTbSMask = 0x1FFFu;
+constexpr uint32_t kTbExt = 1u << 13;
+constexpr uint32_t kTbOpLast = 1u << 14;
 
 struct DpResult {
     uint32_t end_m, end_s;
@@ -92,19 +111,19 @@ struct DpArgs {
     const uint32_t *node_pos;
     const uint32_t *succ_minpos;
     const uint8_t *qmask;
-    uint32_t *tb;               // (value_midx << 16) | value_sidx
+    uint32_t *tb;               // trace-back cells (kTb* above)
     float *dbg_value;           // optional [N*Lp] plane of the first query
-    float *spill;               // spill rows: value[Lp] | gm[Lp] | gmi(u32)[Lp]
+    float *spill;               // spill rows: value[Lp] | gapm_val[Lp]
     DpResult *res;
     const float *weights;       // posvar weights (device) or nullptr
     uint32_t n_weights;
     float ms, mms, gp, gpe;     // scheme ctor args: -match, -mismatch, gap, gapext
-    int W;                      // ring slots in LDS
 };
 
 struct BtArgs {
     const QDesc *qd;
     const uint4 *rec;
+    const uint32_t *pred;
     const uint32_t *node_pos;
     const uint32_t *tb;
     const DpResult *res;

@@ -50,9 +50,9 @@ struct GraphArgs {
     uint4 *rec;                // [nq][ncap]
     uint32_t *node_pos;        // [nq][ncap]
     uint32_t *succ_min;        // [nq][ncap]
-    uint32_t *far_mark;        // [nq][ncap] bit0: has a successor beyond the ring, bit1: beyond kFarLds
+    uint32_t *far_mark;        // [nq][ncap] last successor row of every node (0: none)
     uint32_t *pred;            // per query area of total-family-bases entries
-    uint32_t *sizes;           // [nq][4]: N, raw edge entries, n_spill, status (0 ok, 1 NC cap, 2 N cap)
+    uint32_t *sizes;           // [nq][4]: N, raw edge entries, n_spill, status (0 ok, 1 NC cap, 2 N cap, 4 spill rows)
     uint32_t width, nccap, ncap;
     int W;                     // DP ring depth: edges longer than this need a spill row
 };
@@ -227,11 +227,11 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
     uint4 *rec = a.rec + (size_t)q * a.ncap;
     uint32_t *node_pos = a.node_pos + (size_t)q * a.ncap;
     uint32_t *smin = a.succ_min + (size_t)q * a.ncap;
-    uint32_t *far = a.far_mark + (size_t)q * a.ncap;
+    uint32_t *last = a.far_mark + (size_t)q * a.ncap;
     uint32_t *pred = a.pred + a.pred_off[q];
     for (uint32_t i = tid; i < N; i += kGT) {
         smin[i] = 0xFFFFFFFFu;
-        far[i] = 0;
+        last[i] = 0;
     }
     __syncthreads();
     // 5. node records + sorted unique predecessor lists
@@ -262,77 +262,88 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
                 pred[seg + x] = pa;
                 np++;
                 atomicMin(&smin[pa], pos);
-                if (node - pa > (uint32_t)a.W) atomicOr(&far[pa], node - pa > (uint32_t)kFarLds ? 3u : 1u);
-            }
-            // encode for the DP kernel: id | ring slot << 16; far entries (they come first, ids
-            // ascend) get their spill row index once those are known (step 7)
-            uint32_t nfar = 0;
-            for (uint32_t x = 0; x < np; x++) {
-                const uint32_t pa = pred[seg + x];
-                const bool isfar = node - pa > (uint32_t)a.W;
-                nfar += isfar ? 1u : 0u;
-                pred[seg + x] = pa | ((isfar ? 0xFFFFu : pa % (uint32_t)a.W) << 16);
+                atomicMax(&last[pa], node);
             }
             uint4 r;
             r.x = seg;
             r.y = __float_as_uint(wt[cnt]);
-            r.z = (np & 0xFFu) | (mask << 8) | (nfar << 24);
-            r.w = 0xFFFFFFFFu;
+            r.z = (np & 0xFFu) | (mask << 8);
+            r.w = kRowNone;
             rec[node] = r;
             node_pos[node] = pos;
             seg += rawk;
         }
     }
     __syncthreads();
-    // 6. sinks, successor minimum, spill rows
-    // exclusive scan over the far marks, chunked per thread (global memory, N entries)
-    {
-        const uint32_t chunk = (N + kGT - 1) / kGT;
-        const uint32_t b = min(N, tid * chunk), e = min(N, b + chunk);
-        uint32_t s = 0;
-        for (uint32_t i = b; i < e; i++) s += far[i] & 1u;
-        uint32_t x = s;
-        const int lane = tid & 63, wave = tid >> 6;
+    // 6. sinks, successor minimum, fence flag
+    for (uint32_t i = tid; i < N; i += kGT) {
+        uint32_t z = rec[i].z;
+        if (smin[i] == 0xFFFFFFFFu) {
+            z |= kRecSink;
+            smin[i] = 1000000u;  // "no successor" sentinel of mesh.h:480
+        }
+        if (last[i] > i && last[i] - i > (uint32_t)kFarLds) z |= kRecFence;
+        rec[i].z = z;
+    }
+    __syncthreads();
+    // 7. where every finished DP row is kept for its successors: LDS slots by liveness (first slot
+    // whose row has seen its last successor), otherwise a spill row.  Inherently sequential over
+    // the rows; one wave walks them 64 at a time (coalesced loads, wave-uniform bookkeeping).
+    if (tid < 64) {
+        uint32_t free_at[8];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t y = __shfl_up(x, off);
-            if (lane >= off) x += y;
-        }
-        if (lane == 63) s_tmp[wave] = x;
-        __syncthreads();
-        uint32_t base = 0, total = 0;
-        for (int w = 0; w < kGT / 64; w++) {
-            if (w < wave) base += s_tmp[w];
-            total += s_tmp[w];
-        }
-        uint32_t run = base + x - s;
-        for (uint32_t i = b; i < e; i++) {
-            uint4 r = rec[i];
-            if (far[i] & 1u) r.w = run++;
-            if (far[i] & 2u) r.z |= kRecFence;
-            const uint32_t sm = smin[i];
-            if (sm == 0xFFFFFFFFu) {
-                r.z |= kRecSink;
-                smin[i] = 1000000u;  // "no successor" sentinel of mesh.h:480
+        for (int x = 0; x < 8; x++) free_at[x] = (x < a.W) ? 0u : 0xFFFFFFFFu;
+        uint32_t nsp = 0;
+        for (uint32_t m0 = 0; m0 < N; m0 += 64) {
+            const uint32_t mi = m0 + tid;
+            const uint32_t l_c = (mi < N) ? last[mi] : 0u;
+            const uint32_t z_c = (mi < N) ? rec[mi].z : kRecSink;
+            const uint32_t s_c = (z_c & kRecSink) ? 1u : ((z_c & kRecFence) ? 2u : 0u);
+            uint32_t myw = kRowNone;
+            const uint32_t cnt = min(64u, N - m0);
+            for (uint32_t i = 0; i < cnt; i++) {
+                const uint32_t li = __shfl(l_c, (int)i), sk = __shfl(s_c, (int)i);
+                if (sk == 1) continue;
+                const uint32_t m = m0 + i;
+                int slot = -1;
+                if (sk == 0) {  // (a row with a successor beyond kFarLds must be a spill row)
+#pragma unroll
+                    for (int x = 7; x >= 0; x--)
+                        if (free_at[x] <= m) slot = x;
+                }
+                uint32_t wv;
+                if (slot >= 0) {
+#pragma unroll
+                    for (int x = 0; x < 8; x++) free_at[x] = (x == slot) ? li : free_at[x];
+                    wv = (uint32_t)slot;
+                } else {
+                    wv = kRowSpilled | nsp++;
+                }
+                if (tid == i) myw = wv;
             }
-            rec[i] = r;
+            if (mi < N) rec[mi].w = myw;
         }
         if (tid == 0) {
             sz[0] = N;
             sz[1] = E;
-            sz[2] = total;
-            sz[3] = 0;
+            sz[2] = nsp;
+            sz[3] = (nsp > kMaxSpillRows) ? 4u : 0u;
         }
     }
     __syncthreads();
-    // 7. far predecessor entries: id | spill row index << 16
+    // 8. predecessor entries for the DP kernel: id | (LDS slot or spill row) << 16 | spilled << 31
     for (uint32_t i = tid; i < N; i += kGT) {
         const uint4 r = rec[i];
-        const uint32_t nfar = r.z >> 24;
-        for (uint32_t x = 0; x < nfar; x++) {
-            const uint32_t pa = pred[r.x + x] & 0xFFFFu;
-            pred[r.x + x] = pa | (rec[pa].w << 16);
+        const uint32_t np = r.z & 0xFFu;
+        uint32_t first_far = 0;
+        for (uint32_t x = 0; x < np; x++) {
+            const uint32_t pa = pred[r.x + x];
+            const uint32_t pw = rec[pa].w;
+            const bool sp = (pw & kRowSpilled) != 0;
+            if (sp && first_far == 0) first_far = x + 1;
+            pred[r.x + x] = pa | ((pw & 0x7FFFu) << 16) | (sp ? kPredSpilled : 0u);
         }
+        rec[i].z = r.z | (first_far << 24);
     }
 }
 
@@ -444,6 +455,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         for (uint32_t q = 0; q < bq; q++) {
             if (bg->sizes[4 * q + 3] == 1) need_nc = std::max(need_nc, bg->sizes[4 * q]);
             if (bg->sizes[4 * q + 3] == 2) need_n = std::max(need_n, bg->sizes[4 * q]);
+            if (bg->sizes[4 * q + 3] == 4) SH_FAIL("align_families: too many spill rows for one query");
         }
         if (!need_nc && !need_n) break;
         if (attempt >= 3 || need_n > 65535u) SH_FAIL("align_families: family DAG exceeds device limits");

@@ -16,10 +16,15 @@
 //     are wave-uniform and come through the scalar cache (s_load), so there is no
 //     divergence on graph structure and no vector-memory latency on the row
 //     critical path;
-//   * the last W rows of {value, gapm_val, gapm_idx} of a wave's own columns live
-//     in an LDS ring (12 B per column) that only that wave touches; the rare
-//     predecessors further back than W rows are read from a per-query spill area
-//     in HBM that the producing row also wrote;
+//   * finished rows {value, gapm_val} of a wave's own columns are kept for their
+//     successors in W LDS slots (8 B per column) that only that wave touches; slots
+//     are handed out by liveness when the graph is built, and a row that finds every
+//     slot busy goes to a per-query spill area in HBM instead (read back by the lane
+//     that wrote it, the first such row of the next DP row prefetched);
+//   * gapm_idx is not carried at all: the trace-back cell records whether a deletion
+//     extends its predecessor's gap and whether the row's own gap was opened from its
+//     last predecessor, and backtrack() resolves the index for the few cells on the
+//     final path (common.h, kTbExt / kTbOpLast);
 //   * the only dependencies between column blocks are (a) the insertion chain
 //     along the query (cell (m,s) needs the final (m,s-1)) and (b) the match
 //     candidate from (p,s-1).  Inside a wave both travel by lane shuffle: each
@@ -31,8 +36,7 @@
 //     progress counter: wave w starts row m once wave w-1 has published it.  The
 //     waves of a workgroup thus form a software pipeline skewed by one row and
 //     the main loop contains no s_barrier at all;
-//   * the only per-cell HBM traffic is the write-once trace-back cell
-//     (value_midx:16 | value_sidx:16), row-major.
+//   * the only per-cell HBM traffic is the write-once trace-back cell (4 bytes), row-major.
 #include <cstdio>
 #include <cstdlib>
 
@@ -42,7 +46,6 @@ namespace sina_hip {
 
 namespace {
 
-constexpr uint32_t kNoSpill = 0xFFFFFFFFu;
 constexpr int kHist = 32;  // rows of boundary/exit-state history kept per wave (power of two)
 
 struct ChainState {  // canonical exit state of cell (m, s): what cell (m, s+1) can observe
@@ -140,7 +143,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                const uint32_t *__restrict__ node_posv, const uint32_t *__restrict__ succ_minposv,
                const uint8_t *__restrict__ qmaskv, const float *__restrict__ weights, uint32_t n_weights,
                uint32_t *__restrict__ tbv, float *__restrict__ dbg_value, float *spillv,
-               DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe, int W) {
+               DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe) {
     constexpr int Lp = T * B;
     constexpr int NW = T / 64;
     static_assert(T % 64 == 0, "whole waves only");
@@ -163,15 +166,14 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
     uint32_t *fin = xs_gmax + NW * kHist;                                        // [NW][16] per-wave results
     unsigned char *ring = smem + 64 + 4 * NW * kBndHist + 12 * NW * kHist + 64 * NW;
     constexpr size_t kValBytes = (size_t)Lp * 4;
-    constexpr size_t kGmBytes = (size_t)Lp * 4;
-    constexpr size_t kSlotBytes = kValBytes + kGmBytes + (size_t)Lp * 4;  // value f32 | gapm_val f32 | gapm_idx u32
+    constexpr size_t kSlotBytes = 2 * kValBytes;  // value f32 | gapm_val f32
 
     const uint4 *__restrict__ rec = recv + d.node_off;
     const uint32_t *__restrict__ pred = predv + d.edge_off;
     const uint32_t *__restrict__ node_pos = node_posv + d.node_off;
     const uint32_t *__restrict__ succ_minpos = succ_minposv + d.node_off;
     uint32_t *__restrict__ tb = tbv + d.tb_off;
-    float *spill = spillv + d.spill_off * (size_t)(3 * Lp);
+    float *spill = spillv + d.spill_off * (size_t)(2 * Lp);
 
     if (j < NW) progress[j] = 0;
     __syncthreads();
@@ -198,7 +200,6 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
     // boundary values up to kFarLds rows back (kBndHist slots): I may run this far ahead of it
     const uint32_t throttle = (uint32_t)(kHist - 2);
     static_assert(kFarLds + kHist <= kBndHist, "boundary history too short");
-    uint32_t my_slot = 0;  // ring slot of the current row (m % W), advanced incrementally
     SH_PROF_DECL
 #ifdef SINA_DP_PROFILE
     const int abl_ = g_dp_abl;
@@ -206,7 +207,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
 
     // Per-row scalars (wave-uniform, from the row record through the scalar cache).
     struct Row {
-        uint32_t pb, npred, nfar, mmask, sp, z, mpos, smax;
+        uint32_t pb, npred, first_far, mmask, keep, z, mpos, smax;
         float cM, cX, gd_open, gd_ext, gi_open, init_v;
     };
     auto setup_row = [&](const uint4 r, uint32_t m) {
@@ -216,8 +217,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         o.z = r.z;
         o.npred = r.z & 0xffu;
         o.mmask = (r.z >> 8) & 0xfu;
-        o.nfar = r.z >> 24;
-        o.sp = r.w;
+        o.first_far = r.z >> 24;  // index + 1 of the first spilled predecessor, 0 = none
+        o.keep = r.w;
         o.mpos = 0;
         if constexpr (WEIGHTED) {
             o.mpos = node_pos[m];
@@ -259,8 +260,10 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
     };
 
     // phase-1 results of the current row: deletion / match candidates of my B cells
+    // (dvm / mtp hold value_midx already shifted into its trace-back position, dvm with kTbExt)
     float dv[B], gm[B], mt[B];
-    uint32_t dvm[B], dvs[B], gmi[B], mtp[B];
+    uint32_t dvm[B], dvs[B], mtp[B];
+    uint32_t oplast = 0;  // bit k: gapm of cell k was opened from the row's last predecessor
     auto init_cells = [&](const Row &r) {
 #pragma unroll
         for (int k = 0; k < B; k++) {
@@ -270,9 +273,9 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
             mt[k] = __builtin_inff();
             dvm[k] = 0;
             dvs[k] = 0;
-            gmi[k] = 0;
             mtp[k] = 0;
         }
+        oplast = 0;
     };
 
     // Rows are software-pipelined across loop iterations: iteration m finishes row m (insertion
@@ -282,13 +285,9 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
     // of row m in between -- and the compiler sees load and use in one straight line, so it waits
     // for exactly that load instead of draining all outstanding trace-back stores.
     // Row 0 has no predecessors (they have smaller ids), its candidates are the initial values.
-    float pf_v[B], pf_g[B];  // spill row of the next row's first far predecessor, in flight
-    uint32_t pf_i[B];
+    float pf_v[B], pf_g[B];  // spill row of the next row's first spilled predecessor, in flight
 #pragma unroll
-    for (int k = 0; k < B; k++) {
-        pf_v[k] = pf_g[k] = 0.f;
-        pf_i[k] = 0;
-    }
+    for (int k = 0; k < B; k++) pf_v[k] = pf_g[k] = 0.f;
     Row r = setup_row(rec[0], 0);
     handshake(0);
     init_cells(r);
@@ -338,7 +337,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                     gmax = ins ? gmax_n : 0u;
                     const bool take = ins && (gs <= v);  // mesh.h:351-357
                     v = take ? gs : v;
-                    vm = take ? m : vm;
+                    vm = take ? (m << 16) : vm;
                     vs = take ? gsi : vs;
                     const bool mtk = mt[k] < v;
                     v = mtk ? mt[k] : v;
@@ -462,26 +461,25 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
 #endif
         SH_PROF(5)
 
-        // ---- publish: ring (own columns), boundary + exit state for the wave to my right
-        {
-            unsigned char *myslot = ring + (size_t)my_slot * kSlotBytes;
-            store_cells<B>(reinterpret_cast<float *>(myslot) + s0, fv);
-            store_cells<B>(reinterpret_cast<float *>(myslot + kValBytes) + s0, gm);
-            store_cells<B>(reinterpret_cast<uint32_t *>(myslot + kValBytes + kGmBytes) + s0, gmi);
-            if (lane == 63) {
-                const int h = w * kHist + (int)(m & (kHist - 1));
-                bnd_val[w * kBndHist + (int)(m & (kBndHist - 1))] = fv[B - 1];
-                xs_v[h] = ex.v;
-                xs_e[h] = (ex.e << 31) | ex.gsi;
-                if (FORBID) xs_gmax[h] = ex.gmax;
-            }
-            my_slot = (my_slot + 1 == (uint32_t)W) ? 0u : my_slot + 1;
+        // ---- publish: boundary + exit state for the wave to my right; the row itself into its
+        // LDS slot or spill row (own columns only), unless nothing will ever read it
+        if (lane == 63) {
+            const int h = w * kHist + (int)(m & (kHist - 1));
+            bnd_val[w * kBndHist + (int)(m & (kBndHist - 1))] = fv[B - 1];
+            xs_v[h] = ex.v;
+            xs_e[h] = (ex.e << 31) | ex.gsi;
+            if (FORBID) xs_gmax[h] = ex.gmax;
         }
-        if (r.sp != kNoSpill && !SH_ABL(2)) {
-            float *row = spill + (size_t)r.sp * (3 * Lp);
-            store_cells<B>(row + s0, fv);
-            store_cells<B>(row + Lp + s0, gm);
-            store_cells<B>(reinterpret_cast<uint32_t *>(row) + 2 * Lp + s0, gmi);
+        if (r.keep != kRowNone) {
+            if (!(r.keep & kRowSpilled)) {
+                unsigned char *myslot = ring + (size_t)r.keep * kSlotBytes;
+                store_cells<B>(reinterpret_cast<float *>(myslot) + s0, fv);
+                store_cells<B>(reinterpret_cast<float *>(myslot + kValBytes) + s0, gm);
+            } else if (!SH_ABL(2)) {
+                float *row = spill + (size_t)(r.keep & ~kRowSpilled) * (2 * Lp);
+                store_cells<B>(row + s0, fv);
+                store_cells<B>(row + Lp + s0, gm);
+            }
         }
         // release: LDS writes before the progress counter.  A spill row is read back by the lane
         // that wrote it (program order suffices) -- except by successors further than kFarLds
@@ -496,21 +494,20 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         if (lane == 0) __hip_atomic_store(&progress[w], m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         SH_PROF(6)
 
-        // ---- request the spill row of the first far predecessor of row m+1 (after my own spill
+        // ---- request the spill row of the first spilled predecessor of row m+1 (after my own spill
         // stores, so that waiting for it later does not wait for them; before the trace-back stores)
-        const uint32_t n_nfar = has_next ? (nrec.z >> 24) : 0u;
-        if (n_nfar != 0 && !SH_ABL(2)) {  // (no else: the registers keep their stale contents, never read)
-            const float *row = spill + (size_t)(pred[nrec.x] >> 16) * (3 * Lp);
+        const uint32_t n_ff = has_next ? (nrec.z >> 24) : 0u;
+        if (n_ff != 0 && !SH_ABL(2)) {  // (no else: the registers keep their stale contents, never read)
+            const float *row = spill + (size_t)((pred[nrec.x + n_ff - 1] >> 16) & 0x7FFFu) * (2 * Lp);
             load_cells<B>(row + s0, pf_v);
             load_cells<B>(row + Lp + s0, pf_g);
-            load_cells<B>(reinterpret_cast<const uint32_t *>(row) + 2 * Lp + s0, pf_i);
         }
 
         // ---- trace-back cells: the only per-cell HBM traffic
         if (!SH_ABL(4)) {
             uint32_t tc[B];
 #pragma unroll
-            for (int k = 0; k < B; k++) tc[k] = (fvm[k] << 16) | (fvs[k] & 0xffffu);
+            for (int k = 0; k < B; k++) tc[k] = fvm[k] | fvs[k] | (((oplast >> k) & 1u) << 14);
             store_cells<B>(tb + (size_t)m * Lp + s0, tc);
         }
         if (dbg_value != nullptr && blockIdx.x == 0) store_cells<B>(dbg_value + (size_t)m * Lp + s0, fv);
@@ -567,7 +564,9 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         float csel[B];
 #pragma unroll
         for (int k = 0; k < B; k++) csel[k] = (r.mmask & qm[k]) ? r.cM : r.cX;  // comp(): optimistic IUPAC match (aligned_base.h:153)
-        auto relax = [&](uint32_t p, const float(&sv)[B], const float(&sg)[B], const uint32_t(&sgi)[B], float svl) {
+        auto relax = [&](uint32_t p, bool is_last, const float(&sv)[B], const float(&sg)[B], float svl) {
+            const uint32_t p_open = p << 16, p_ext = (p << 16) | kTbExt;
+            uint32_t ob = 0;
 #pragma unroll
             for (int k = 0; k < B; k++) {
                 // deletion (mesh.h:307-330): gapm_* is overwritten by every predecessor
@@ -575,68 +574,59 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 const float g = sg[k] + r.gd_ext;
                 const bool op = v < g;
                 const float cand = op ? v : g;
-                const uint32_t cm = op ? p : sgi[k];
                 gm[k] = cand;
-                gmi[k] = cm;
+                if (is_last) ob |= op ? (1u << k) : 0u;
                 const bool better = cand < dv[k];
                 dv[k] = better ? cand : dv[k];
-                dvm[k] = better ? cm : dvm[k];
+                dvm[k] = better ? (op ? p_open : p_ext) : dvm[k];
                 dvs[k] = better ? s0 + k : dvs[k];  // value_sidx of a deletion is the column itself
                 // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
                 const float pvv = (k == 0) ? svl : sv[k - 1];
                 const float mv = pvv + csel[k];
                 const bool mb = ((s0 + k) > 0) && (mv < mt[k]);
                 mt[k] = mb ? mv : mt[k];
-                mtp[k] = mb ? p : mtp[k];
+                mtp[k] = mb ? p_open : mtp[k];
             }
+            if (is_last) oplast = ob;
         };
-        // Far predecessors (beyond the LDS ring; they come first, ids ascend): pred entry =
-        // id | spill row << 16.  My own columns of a spill row were written by me; the single
-        // value I need from the wave to my left (column s0-1, lane 0 only) comes from its boundary
-        // history in LDS, or -- further back than kFarLds rows -- from the spill row itself, which
-        // such rows publish with a workgroup-scope release.
-        uint32_t e = 0;
-        for (; e < r.nfar; ++e) {
-            if (SH_ABL(2)) continue;
+        // Predecessors in ascending id order (the reference's order: the first minimum wins, the
+        // last one defines gapm).  Entry = id | (LDS slot or spill row) << 16 | spilled << 31.
+        // My own columns of a spill row were written by me; the single value I need from the wave
+        // to my left (column s0-1, lane 0 only) comes from its boundary history in LDS, or -- for
+        // predecessors further back than kFarLds rows -- from the spill row itself, which such rows
+        // publish with a workgroup-scope release (kRecFence; such rows are made to spill: see below).
+        for (uint32_t e = 0; e < r.npred; ++e) {
             const uint32_t pe = pred[r.pb + e];
             const uint32_t p = pe & 0xffffu;
-            const float *row = spill + (size_t)(pe >> 16) * (3 * Lp);
+            const bool is_last = (e + 1 == r.npred);
             float sv[B], sg[B];
-            uint32_t sgi[B];
-            if (e == 0) {
+            float far_bnd = 0.f;
+            if (pe & kPredSpilled) {
+                if (SH_ABL(2)) continue;
+                const float *row = spill + (size_t)((pe >> 16) & 0x7FFFu) * (2 * Lp);
+                if (e + 1 == r.first_far) {
 #pragma unroll
-                for (int k = 0; k < B; k++) {
-                    sv[k] = pf_v[k];
-                    sg[k] = pf_g[k];
-                    sgi[k] = pf_i[k];
+                    for (int k = 0; k < B; k++) {
+                        sv[k] = pf_v[k];
+                        sg[k] = pf_g[k];
+                    }
+                } else {
+                    load_cells<B>(row + s0, sv);
+                    load_cells<B>(row + Lp + s0, sg);
                 }
+                if (lane == 0 && w > 0 && mn - p > (uint32_t)kFarLds) far_bnd = row[s0 - 1];
+                SH_PROF_CNT(9, 1)
             } else {
-                load_cells<B>(row + s0, sv);
-                load_cells<B>(row + Lp + s0, sg);
-                load_cells<B>(reinterpret_cast<const uint32_t *>(row) + 2 * Lp + s0, sgi);
+                const unsigned char *slot = ring + (size_t)(pe >> 16) * kSlotBytes;
+                load_cells<B>(reinterpret_cast<const float *>(slot) + s0, sv);
+                load_cells<B>(reinterpret_cast<const float *>(slot + kValBytes) + s0, sg);
             }
             float svl = lane_shr1(sv[B - 1]);  // value[p][s0-1] lives in the lane to my left
             if (lane == 0 && w > 0) {
                 if (mn - p <= (uint32_t)kFarLds) svl = bnd_val[(w - 1) * kBndHist + (p & (kBndHist - 1))];
-                else svl = row[s0 - 1];
+                else svl = far_bnd;
             }
-            relax(p, sv, sg, sgi, svl);
-            SH_PROF_CNT(9, 1)
-        }
-        SH_PROF(2)
-        // Near predecessors: the LDS ring; pred entry = id | ring slot << 16.
-        for (; e < r.npred; ++e) {
-            const uint32_t pe = pred[r.pb + e];
-            const uint32_t p = pe & 0xffffu;
-            const unsigned char *slot = ring + (size_t)(pe >> 16) * kSlotBytes;
-            float sv[B], sg[B];
-            uint32_t sgi[B];
-            load_cells<B>(reinterpret_cast<const float *>(slot) + s0, sv);
-            load_cells<B>(reinterpret_cast<const float *>(slot + kValBytes) + s0, sg);
-            load_cells<B>(reinterpret_cast<const uint32_t *>(slot + kValBytes + kGmBytes) + s0, sgi);
-            float svl = lane_shr1(sv[B - 1]);
-            if (lane == 0 && w > 0) svl = bnd_val[(w - 1) * kBndHist + (p & (kBndHist - 1))];  // left wave's boundary
-            relax(p, sv, sg, sgi, svl);
+            relax(p, is_last, sv, sg, svl);
         }
         SH_PROF(3)
     }
@@ -759,14 +749,28 @@ __global__ void backtrack_kernel(BtArgs a) {
     aligned++;
     sum_weight = sum_weight + mscore(m);
 
+    // value_midx of a cell whose deletion extends the gap of predecessor x: gapm_idx[x][col]
+    // (common.h, kTbExt / kTbOpLast) -- follow last predecessors to the row that opened the gap
+    const uint32_t *pred = a.pred + d.edge_off;
+    auto gapm_idx = [&](uint32_t x, uint32_t col) -> uint32_t {
+        for (uint32_t guard = 0; guard < 65536u; ++guard) {
+            const uint4 rx = rec[x];
+            const uint32_t np = rx.z & 0xffu;
+            if (np == 0) return 0u;  // an edge row keeps its initial gapm_idx
+            const uint32_t lastp = pred[rx.x + np - 1] & 0xffffu;
+            if (tb[(size_t)x * Lp + col] & kTbOpLast) return lastp;
+            x = lastp;
+        }
+        return 0u;
+    };
     // :642-685 (a source node has no predecessors)
     while (s != 0 && (rec[m].z & 0xffu) != 0) {
         const uint32_t c = tb[(size_t)m * Lp + s];
-        const uint32_t snew = c & 0xffffu;
-        m = c >> 16;
+        const uint32_t snew = c & kTbSMask;
+        m = (c & kTbExt) ? gapm_idx(c >> 16, s) : (c >> 16);
         if (snew != 0) {
             const uint32_t c2 = tb[(size_t)m * Lp + snew];
-            if (snew == (c2 & 0xffffu)) m = c2 >> 16;
+            if (snew == (c2 & kTbSMask)) m = (c2 & kTbExt) ? gapm_idx(c2 >> 16, snew) : (c2 >> 16);
         }
         pos = width - 1 - node_pos[m];
         const float ms_w = mscore(m);
@@ -805,7 +809,7 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, size_t l
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(T), lds, s, a.qd, a.rec, a.pred, a.node_pos, a.succ_minpos, \
                            a.qmask, a.weights, a.n_weights, a.tb, a.dbg_value, a.spill, a.res, a.ms, a.mms, \
-                           a.gp, a.gpe, a.W);                                                           \
+                           a.gp, a.gpe);                                                           \
     } while (0)
     if (!weighted && !forbid) SH_LAUNCH(false, false);
     else if (weighted && !forbid) SH_LAUNCH(true, false);
@@ -848,12 +852,12 @@ bool pick_geom(uint32_t maxL, DpGeom *g) {
     return false;
 }
 
-size_t dp_slot_bytes(const DpGeom &g) { return (size_t)g.Lp() * 12; }
+size_t dp_slot_bytes(const DpGeom &g) { return (size_t)g.Lp() * 8; }
 size_t dp_fixed_lds_bytes(const DpGeom &g) {
     const size_t nw = (size_t)g.T / 64;
     return 64 + 4 * nw * kBndHist + 12 * nw * kHist + 64 * nw;
 }
-int dp_max_ring(const DpGeom &) { return 64; }  // near predecessors must stay within the boundary history (kFarLds)
+int dp_max_ring(const DpGeom &) { return 8; }  // the slot allocators keep 8 slot states; deeper rings gain nothing
 
 int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
                    size_t lds, hipStream_t s) {

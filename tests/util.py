@@ -74,3 +74,33 @@ def finish_alignment(q_masks, out, pos, width, lowercase_unaligned=False, insert
 
 def f32_bits(a):
     return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+def row_store_model(pred_off, pred, n_slots, far_lds=192):
+    """Where mesh_dp_kernel keeps each finished DP row for its successors (sina_amd/csrc/common.h):
+    0xFFFFFFFF nowhere (no successors), an LDS slot number (first slot whose occupant has seen its
+    last successor), or 0x80000000 | spill row index when no slot is free or some successor is more
+    than far_lds rows away."""
+    n = len(pred_off) - 1
+    last = np.zeros(n, np.int64)
+    node = np.repeat(np.arange(n), np.diff(pred_off))
+    np.maximum.at(last, np.asarray(pred, np.int64), node)
+    out = np.full(n, 0xFFFFFFFF, np.uint32)
+    free_at = [0] * n_slots
+    nsp = 0
+    for m in range(n):
+        if last[m] == 0:
+            continue
+        slot = -1
+        if last[m] - m <= far_lds:
+            for x in range(n_slots):
+                if free_at[x] <= m:
+                    slot = x
+                    break
+        if slot >= 0:
+            free_at[slot] = last[m]
+            out[m] = slot
+        else:
+            out[m] = 0x80000000 | nsp
+            nsp += 1
+    return out
