@@ -38,6 +38,13 @@ const char *sina_hip_last_error(void);
 
 /* Creates a context on HIP device `device` (own stream). */
 int sina_hip_init(int device, sina_hip_ctx **ctx);
+/* A second context on the same device that shares `parent`'s reference store, k-mer index and
+ * statistics but has its own stream and scratch buffers: calls on different contexts run
+ * concurrently on the GPU (the reference gets the same effect from its TBB pipeline running
+ * several famfinder/aligner filters at once, src/sina.cpp:430-470).  A fork cannot change the
+ * store (upload_refs / build_index / upload_index fail on it); destroy forks before the parent,
+ * and do not change the parent's store while forks are in use. */
+int sina_hip_fork(sina_hip_ctx *parent, sina_hip_ctx **ctx);
 void sina_hip_destroy(sina_hip_ctx *ctx);
 /* Blocks until all work queued on the context's stream has finished. */
 int sina_hip_sync(sina_hip_ctx *ctx);
@@ -188,14 +195,15 @@ int sina_hip_debug_mesh(sina_hip_ctx *ctx, const sina_hip_graph_batch *g, const 
 
 /* Test hook: the DAG the GPU builds for ONE family (ids into the uploaded store, in family
  * order), in compact CSR form, for comparison with mseq (src/mseq.cpp:47-118).
- * ring_depth is the LDS ring depth the spill assignment is made for. */
+ * ring_depth is the number of LDS row slots the DP kernel will have; spill_idx reports where each
+ * finished DP row is kept: 0xFFFFFFFF nowhere, slot number, or 0x80000000 | spill row. */
 int sina_hip_debug_family_graph(sina_hip_ctx *ctx, const uint32_t *fam_ids, uint32_t F, float fs_weight,
                                 uint32_t ring_depth, uint32_t *n_nodes, uint32_t *n_edges, uint32_t *pos,
                                 uint8_t *mask, float *weight, uint32_t *pred_off, uint32_t *pred,
                                 uint32_t *succ_minpos, uint8_t *sink, uint32_t *spill_idx, uint32_t cap_nodes,
                                 uint32_t cap_edges);
 
-/* Cumulative statistics of this context since sina_hip_init (callers take
+/* Cumulative statistics of this context and its forks since sina_hip_init (callers take
  * differences); kernel times come from HIP events on the context stream. */
 typedef struct sina_hip_stats {
     double dp_ms;          /* mesh DP fill kernel(s)                  */

@@ -21,7 +21,8 @@ i16p = C.POINTER(C.c_int16)
 
 # every extern "C" symbol include/sina_hip.h declares
 ABI_SYMBOLS = [
-    "sina_hip_abi_version", "sina_hip_last_error", "sina_hip_init", "sina_hip_destroy", "sina_hip_sync",
+    "sina_hip_abi_version", "sina_hip_last_error", "sina_hip_init", "sina_hip_fork", "sina_hip_destroy",
+    "sina_hip_sync",
     "sina_hip_upload_refs", "sina_hip_build_index", "sina_hip_upload_index", "sina_hip_store_view_get",
     "sina_hip_store_alloc_like", "sina_hip_kmer_topk", "sina_hip_kmer_scores",
     "sina_hip_align_params_default", "sina_hip_align_graphs", "sina_hip_align_families",
@@ -83,6 +84,7 @@ def load():
     L.sina_hip_abi_version.restype = C.c_int
     L.sina_hip_last_error.restype = C.c_char_p
     L.sina_hip_init.argtypes = [C.c_int, C.POINTER(vp)]
+    L.sina_hip_fork.argtypes = [vp, C.POINTER(vp)]
     L.sina_hip_destroy.argtypes = [vp]
     L.sina_hip_destroy.restype = None
     L.sina_hip_sync.argtypes = [vp]
@@ -123,12 +125,20 @@ def _c(a, dt):
 class Context:
     """Owns one sina_hip_ctx (one GPU, one stream)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _parent=None):
         self.L = load()
         self.h = C.c_void_p()
-        self._check(self.L.sina_hip_init(device, C.byref(self.h)))
+        if _parent is None:
+            self._check(self.L.sina_hip_init(device, C.byref(self.h)))
+        else:
+            self._check(self.L.sina_hip_fork(_parent.h, C.byref(self.h)))
+        self._parent = _parent  # keeps the owner of the store alive
         self.device = device
-        self.n_refs = 0
+        self.n_refs = 0 if _parent is None else _parent.n_refs
+
+    def fork(self):
+        """A context with its own stream and scratch that shares this one's store and index."""
+        return Context(self.device, _parent=self)
 
     def _check(self, rc):
         if rc != 0:

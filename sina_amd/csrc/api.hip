@@ -180,11 +180,12 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, uint32_t bq, uint64_t tb_ce
     SH_CHECK(hipStreamSynchronize(s));
     float ms = 0;
     SH_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-    c->stats.dp_ms += ms;
+    std::lock_guard<std::mutex> slk(c->st->stats_mu);
+    c->st->stats.dp_ms += ms;
     SH_CHECK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
-    c->stats.backtrack_ms += ms;
-    c->stats.dp_cells += cells;
-    c->stats.dp_launches++;
+    c->st->stats.backtrack_ms += ms;
+    c->st->stats.dp_cells += cells;
+    c->st->stats.dp_launches++;
     return 0;
 }
 
@@ -306,11 +307,28 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
     SH_CHECK(hipSetDevice(device));
     sina_hip_ctx *c = new sina_hip_ctx();
     c->device = device;
+    c->st = new sina_hip_store();
+    c->owns_store = true;
     SH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
     c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 40) * 1024;
     c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 24) << 30;
-    memset(&c->stats, 0, sizeof(c->stats));
+    memset(&c->st->stats, 0, sizeof(c->st->stats));
+    *ctx = c;
+    return 0;
+}
+
+int sina_hip_fork(sina_hip_ctx *parent, sina_hip_ctx **ctx) {
+    if (!parent || !ctx) SH_FAIL("fork: null argument");
+    SH_CHECK(hipSetDevice(parent->device));
+    sina_hip_ctx *c = new sina_hip_ctx();
+    c->device = parent->device;
+    c->st = parent->st;  // same reference store, index and counters; never freed by the fork
+    c->owns_store = false;
+    SH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
+    c->lds_budget = parent->lds_budget;
+    c->tb_budget_bytes = parent->tb_budget_bytes;
     *ctx = c;
     return 0;
 }
@@ -347,19 +365,20 @@ void sina_hip_align_params_default(sina_hip_align_params *p) {
 int sina_hip_upload_refs(sina_hip_ctx *c, const uint32_t *ab, const uint64_t *off, uint32_t n_refs,
                          uint32_t width) {
     if (!c || !ab || !off) SH_FAIL("upload_refs: null argument");
+    if (!c->owns_store) SH_FAIL("upload_refs: a forked context cannot change the reference store");
     std::lock_guard<std::mutex> lk(c->mu);
     SH_CHECK(hipSetDevice(c->device));
     const uint64_t total = off[n_refs];
-    if (c->ref_ab.reserve(4 * std::max<uint64_t>(total, 1)) || c->ref_off.reserve(8 * ((uint64_t)n_refs + 1)))
+    if (c->st->ref_ab.reserve(4 * std::max<uint64_t>(total, 1)) || c->st->ref_off.reserve(8 * ((uint64_t)n_refs + 1)))
         return 1;
-    SH_CHECK(hipMemcpyAsync(c->ref_ab.p, ab, 4 * total, hipMemcpyHostToDevice, c->stream));
-    SH_CHECK(hipMemcpyAsync(c->ref_off.p, off, 8 * ((uint64_t)n_refs + 1), hipMemcpyHostToDevice, c->stream));
+    SH_CHECK(hipMemcpyAsync(c->st->ref_ab.p, ab, 4 * total, hipMemcpyHostToDevice, c->stream));
+    SH_CHECK(hipMemcpyAsync(c->st->ref_off.p, off, 8 * ((uint64_t)n_refs + 1), hipMemcpyHostToDevice, c->stream));
     SH_CHECK(hipStreamSynchronize(c->stream));
-    c->ref_off_host.assign(off, off + n_refs + 1);
-    c->n_refs = n_refs;
-    c->width = width;
-    c->total_bases = total;
-    c->have_refs = true;
+    c->st->ref_off_host.assign(off, off + n_refs + 1);
+    c->st->n_refs = n_refs;
+    c->st->width = width;
+    c->st->total_bases = total;
+    c->st->have_refs = true;
     return 0;
 }
 
@@ -383,7 +402,8 @@ int sina_hip_debug_mesh(sina_hip_ctx *c, const sina_hip_graph_batch *g, const ui
 
 int sina_hip_get_stats(sina_hip_ctx *c, sina_hip_stats *s) {
     if (!c || !s) SH_FAIL("get_stats: null argument");
-    *s = c->stats;
+    std::lock_guard<std::mutex> slk(c->st->stats_mu);
+    *s = c->st->stats;
     return 0;
 }
 

@@ -302,7 +302,9 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
             uint32_t myw = kRowNone;
             const uint32_t cnt = min(64u, N - m0);
             for (uint32_t i = 0; i < cnt; i++) {
-                const uint32_t li = __shfl(l_c, (int)i), sk = __shfl(s_c, (int)i);
+                // wave-uniform copies (v_readlane): the bookkeeping below runs on the scalar unit
+                const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)l_c, (int)i);
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)s_c, (int)i);
                 if (sk == 1) continue;
                 const uint32_t m = m0 + i;
                 int slot = -1;
@@ -370,9 +372,9 @@ struct BuiltGraphs {
 int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t *fam_off, uint32_t q0,
                         uint32_t bq, float fs_weight, int W, BuiltGraphs *bg) {
     hipStream_t s = c->stream;
-    if (c->ref_off_host.size() != (size_t)c->n_refs + 1) {  // store arrived by broadcast (store_alloc_like)
-        c->ref_off_host.resize((size_t)c->n_refs + 1);
-        SH_CHECK(hipMemcpy(c->ref_off_host.data(), c->ref_off.p, 8 * ((size_t)c->n_refs + 1), hipMemcpyDeviceToHost));
+    if (c->st->ref_off_host.size() != (size_t)c->st->n_refs + 1) {  // store arrived by broadcast (store_alloc_like)
+        c->st->ref_off_host.resize((size_t)c->st->n_refs + 1);
+        SH_CHECK(hipMemcpy(c->st->ref_off_host.data(), c->st->ref_off.p, 8 * ((size_t)c->st->n_refs + 1), hipMemcpyDeviceToHost));
     }
     // weight table: the reference's expression (mseq.cpp:113) evaluated on the host
     if (!(c->wtab_fs_weight == fs_weight) || !c->g_wtab.p) {
@@ -393,11 +395,11 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
     for (uint32_t q = 0; q < bq; q++) {
         for (uint64_t x = fam_off[q0 + q]; x < fam_off[q0 + q + 1]; x++) {
             const uint32_t id = fam_ids[x];
-            if (id >= c->n_refs) SH_FAIL("align_families: reference id out of range");
-            elems[q] += c->ref_off_host[id + 1] - c->ref_off_host[id];
+            if (id >= c->st->n_refs) SH_FAIL("align_families: reference id out of range");
+            elems[q] += c->st->ref_off_host[id + 1] - c->st->ref_off_host[id];
         }
     }
-    uint32_t nccap = std::min<uint32_t>(c->width, 4096);
+    uint32_t nccap = std::min<uint32_t>(c->st->width, 4096);
     uint32_t ncap = std::min<uint32_t>(65535, 3 * nccap);
     for (int attempt = 0;; attempt++) {
         uint64_t tab_total = 0, pred_total = 0;
@@ -407,7 +409,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
             bg->pred_off[q] = pred_total;
             pred_total += elems[q] + 8;  // +8: slack behind every list
         }
-        const size_t glds = graph_lds_bytes(c->width, nccap);
+        const size_t glds = graph_lds_bytes(c->st->width, nccap);
         if (glds > 160 * 1024) SH_FAIL("align_families: family too wide for the device DAG build");
         if (c->g_fam_ids.reserve(4 * std::max<uint64_t>(foff[bq], 1)) || c->g_fam_off.reserve(8 * ((uint64_t)bq + 1)) ||
             c->g_tmp0.reserve(8 * (uint64_t)bq) || c->g_tmp1.reserve(8 * (uint64_t)bq) ||
@@ -421,8 +423,8 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         SH_CHECK(hipMemcpyAsync(c->g_tmp0.p, tab_off.data(), 8 * (uint64_t)bq, hipMemcpyHostToDevice, s));
         SH_CHECK(hipMemcpyAsync(c->g_tmp1.p, bg->pred_off.data(), 8 * (uint64_t)bq, hipMemcpyHostToDevice, s));
         GraphArgs ga;
-        ga.ref_ab = c->ref_ab.as<uint32_t>();
-        ga.ref_off = c->ref_off.as<uint64_t>();
+        ga.ref_ab = c->st->ref_ab.as<uint32_t>();
+        ga.ref_off = c->st->ref_off.as<uint64_t>();
         ga.fam_ids = c->g_fam_ids.as<uint32_t>();
         ga.fam_off = c->g_fam_off.as<uint64_t>();
         ga.tab_off = c->g_tmp0.as<uint64_t>();
@@ -435,7 +437,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         ga.far_mark = c->g_tmp3.as<uint32_t>();
         ga.pred = c->pred.as<uint32_t>();
         ga.sizes = c->g_sizes.as<uint32_t>();
-        ga.width = c->width;
+        ga.width = c->st->width;
         ga.nccap = nccap;
         ga.ncap = ncap;
         ga.W = W;
@@ -450,7 +452,10 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         SH_CHECK(hipStreamSynchronize(s));
         float gms = 0;
         SH_CHECK(hipEventElapsedTime(&gms, c->ev[6], c->ev[7]));
-        c->stats.graph_ms += gms;
+        {
+            std::lock_guard<std::mutex> slk(c->st->stats_mu);
+            c->st->stats.graph_ms += gms;
+        }
         uint32_t need_nc = 0, need_n = 0;
         for (uint32_t q = 0; q < bq; q++) {
             if (bg->sizes[4 * q + 3] == 1) need_nc = std::max(need_nc, bg->sizes[4 * q]);
@@ -459,7 +464,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         }
         if (!need_nc && !need_n) break;
         if (attempt >= 3 || need_n > 65535u) SH_FAIL("align_families: family DAG exceeds device limits");
-        if (need_nc) nccap = std::min<uint32_t>(c->width, need_nc + need_nc / 8 + 16);
+        if (need_nc) nccap = std::min<uint32_t>(c->st->width, need_nc + need_nc / 8 + 16);
         ncap = std::min<uint32_t>(65535, std::max<uint32_t>(3 * nccap, need_n + need_n / 8 + 16));
     }
     bg->nccap = nccap;
@@ -477,11 +482,11 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
     if (!c || !fam_ids || !fam_off || !qmask || !qoff || !p || !out || !out_pos)
         SH_FAIL("align_families: null argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    if (!c->have_refs) SH_FAIL("align_families: upload references first");
+    if (!c->st->have_refs) SH_FAIL("align_families: upload references first");
     if (nq == 0) return 0;
     SH_CHECK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    if (c->width > 524288u) SH_FAIL("align_families: alignment wider than 524288 columns (use align_graphs)");
+    if (c->st->width > 524288u) SH_FAIL("align_families: alignment wider than 524288 columns (use align_graphs)");
     uint32_t maxL = 0;
     for (uint32_t q = 0; q < nq; q++) {
         const uint64_t L = qoff[q + 1] - qoff[q], F = fam_off[q + 1] - fam_off[q];
@@ -530,7 +535,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
             if (c->qd.reserve(sizeof(QDesc) * rq) || c->qmask.reserve(std::max<uint64_t>(nqm, 1))) return 1;
             SH_CHECK(hipMemcpyAsync(c->qd.p, qd.data(), sizeof(QDesc) * rq, hipMemcpyHostToDevice, s));
             SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qbase, nqm, hipMemcpyHostToDevice, s));
-            if (run_dp_device(c, pl, rq, tbc, sprows, cells, nqm, p, c->width, out + q0 + r0, out_pos + qbase, false))
+            if (run_dp_device(c, pl, rq, tbc, sprows, cells, nqm, p, c->st->width, out + q0 + r0, out_pos + qbase, false))
                 return 1;
             r0 = r1;
         }
@@ -545,7 +550,7 @@ int sina_hip_debug_family_graph(sina_hip_ctx *c, const uint32_t *fam_ids, uint32
                                 uint32_t cap_edges) {
     if (!c || !fam_ids || !n_nodes || !n_edges) SH_FAIL("debug_family_graph: null argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    if (!c->have_refs) SH_FAIL("debug_family_graph: upload references first");
+    if (!c->st->have_refs) SH_FAIL("debug_family_graph: upload references first");
     if (F == 0 || F > (uint32_t)kMaxFam) SH_FAIL("debug_family_graph: family size must be in 1..128");
     SH_CHECK(hipSetDevice(c->device));
     const uint64_t foff[2] = {0, F};

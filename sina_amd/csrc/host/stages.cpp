@@ -272,7 +272,26 @@ std::shared_ptr<reference_store> reference_store::open(const std::string &path) 
 }
 
 reference_store::~reference_store() {
+    for (auto *f : idle_forks) sina_hip_destroy(f);
     if (ctx) sina_hip_destroy(ctx);
+}
+
+reference_store::lease reference_store::worker_device() {
+    sina_hip_ctx *root = device();
+    std::lock_guard<std::mutex> lk(gpu_mu);
+    sina_hip_ctx *c = nullptr;
+    if (!idle_forks.empty()) {
+        c = idle_forks.back();
+        idle_forks.pop_back();
+    } else {
+        hip_check(sina_hip_fork(root, &c), "sina_hip_fork");
+    }
+    return lease(this, c);
+}
+reference_store::lease::~lease() {
+    if (!c) return;
+    std::lock_guard<std::mutex> lk(st->gpu_mu);
+    st->idle_forks.push_back(c);
 }
 
 const cseq &reference_store::getCseq(const std::string &name) const {
@@ -385,7 +404,8 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
         const auto &b = queries[i]->getAlignedBases();
         for (size_t x = 0; x < b.size(); x++) qmask[qoff[i] + x] = b[x].getBase().mask();
     }
-    sina_hip_ctx *ctx = st.device();
+    auto dev = st.worker_device();
+    sina_hip_ctx *ctx = dev.get();
     if (max <= 4096) {
         std::vector<uint32_t> ids((size_t)queries.size() * max), cnt(queries.size());
         std::vector<float> sc((size_t)queries.size() * max);
@@ -997,7 +1017,8 @@ void aligner::operator()(std::vector<tray> &batch) {
         }
         std::vector<sina_hip_align_out> out(nq);
         std::vector<uint32_t> out_pos(qoff.back() ? qoff.back() : 1);
-        sina_hip_ctx *ctx = store->device();
+        auto dev = store->worker_device();
+        sina_hip_ctx *ctx = dev.get();
         uint32_t width = 0;
 
         if (o.device_graph) {

@@ -136,6 +136,22 @@ public:
     }
     std::mutex &gpu_mutex() { return gpu_mu; }
 
+    // A forked context (own stream + scratch, shared store/index: sina_hip_fork) for the duration
+    // of one GPU call, so that batches in flight on different host threads overlap on the GPU.
+    class lease {
+    public:
+        lease(reference_store *s, sina_hip_ctx *c) : st(s), c(c) {}
+        lease(lease &&o) : st(o.st), c(o.c) { o.c = nullptr; }
+        lease(const lease &) = delete;
+        ~lease();
+        sina_hip_ctx *get() const { return c; }
+
+    private:
+        reference_store *st;
+        sina_hip_ctx *c;
+    };
+    lease worker_device();
+
 private:
     reference_store() = default;
     std::string path;
@@ -144,6 +160,7 @@ private:
     std::vector<alignment_stats> vastats;
     int device_id{0};
     sina_hip_ctx *ctx{nullptr};
+    std::vector<sina_hip_ctx *> idle_forks;  // guarded by gpu_mu
     int idx_k{-1};
     bool idx_nofast{false};
     std::mutex gpu_mu;

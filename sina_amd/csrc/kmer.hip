@@ -320,8 +320,8 @@ __global__ void __launch_bounds__(kSelThreads) kmer_select_kernel(SelectArgs a) 
 }  // namespace
 
 static int index_ready(sina_hip_ctx *c) {
-    if (!c->have_refs) SH_FAIL("k-mer search: no references uploaded");
-    if (!c->have_index) SH_FAIL("k-mer search: no index (call sina_hip_build_index / upload_index)");
+    if (!c->st->have_refs) SH_FAIL("k-mer search: no references uploaded");
+    if (!c->st->have_index) SH_FAIL("k-mer search: no index (call sina_hip_build_index / upload_index)");
     return 0;
 }
 
@@ -329,23 +329,23 @@ static int index_ready(sina_hip_ctx *c) {
 static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint64_t *d_qoff, uint32_t nq,
                             uint32_t max, uint32_t max_qlen, bool want_scores_only) {
     hipStream_t s = c->stream;
-    const uint32_t stride = (c->n_refs + 1u) & ~1u;  // even: tiles are stored two scores per word
+    const uint32_t stride = (c->st->n_refs + 1u) & ~1u;  // even: tiles are stored two scores per word
     if (c->k_scores.reserve((size_t)nq * stride * 2 + 64) || c->k_tmp2.reserve(8) || c->k_tmp0.reserve(4 * (size_t)nq))
         return 1;
     SH_CHECK(hipMemsetAsync(c->k_tmp2.p, 0, 8, s));
     CountArgs ca;
     ca.qmask = d_qmask;
     ca.qoff = d_qoff;
-    ca.idx_off = c->idx_off.as<uint32_t>();
-    ca.idx_ids = c->idx_ids.as<uint32_t>();
+    ca.idx_off = c->st->idx_off.as<uint32_t>();
+    ca.idx_ids = c->st->idx_ids.as<uint32_t>();
     ca.scores = c->k_scores.as<int16_t>();
     ca.nkq = c->k_tmp0.as<uint32_t>();
     ca.postings = c->k_tmp2.as<unsigned long long>();
-    ca.n_refs = c->n_refs;
+    ca.n_refs = c->st->n_refs;
     ca.stride = stride;
     ca.kmax = (max_qlen + 63u) & ~63u;
-    ca.k = c->k;
-    ca.fast = c->nofast ? 0 : 1;
+    ca.k = c->st->k;
+    ca.fast = c->st->nofast ? 0 : 1;
     const size_t clds = (size_t)kTileRefs * 2 + (size_t)ca.kmax * 9 + 64;
     SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kmer_count_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
@@ -364,7 +364,7 @@ static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint6
         sa.out_ids = c->k_out_ids.as<uint32_t>();
         sa.out_scores = c->k_out_scores.as<float>();
         sa.out_n = c->k_out_n.as<uint32_t>();
-        sa.n_refs = c->n_refs;
+        sa.n_refs = c->st->n_refs;
         sa.max = max;
         hipLaunchKernelGGL(kmer_select_kernel, dim3(nq), dim3(kSelThreads), 0, s, sa);
         SH_CHECK(hipGetLastError());
@@ -383,29 +383,31 @@ int sina_hip_upload_index(sina_hip_ctx *c, unsigned k, int nofast, const uint32_
                           uint64_t n_postings) {
     if (!c || !offsets || (!ids && n_postings)) SH_FAIL("upload_index: null argument");
     if (k < 1 || k > 12) SH_FAIL("upload_index: k must be in 1..12");
+    if (!c->owns_store) SH_FAIL("upload_index: a forked context cannot change the reference store");
     std::lock_guard<std::mutex> lk(c->mu);
     SH_CHECK(hipSetDevice(c->device));
     const uint64_t nk = 1ull << (2 * k);
-    if (c->idx_off.reserve(4 * (nk + 1)) || c->idx_ids.reserve(4 * std::max<uint64_t>(n_postings, 1))) return 1;
-    SH_CHECK(hipMemcpyAsync(c->idx_off.p, offsets, 4 * (nk + 1), hipMemcpyHostToDevice, c->stream));
+    if (c->st->idx_off.reserve(4 * (nk + 1)) || c->st->idx_ids.reserve(4 * std::max<uint64_t>(n_postings, 1))) return 1;
+    SH_CHECK(hipMemcpyAsync(c->st->idx_off.p, offsets, 4 * (nk + 1), hipMemcpyHostToDevice, c->stream));
     if (n_postings)
-        SH_CHECK(hipMemcpyAsync(c->idx_ids.p, ids, 4 * n_postings, hipMemcpyHostToDevice, c->stream));
+        SH_CHECK(hipMemcpyAsync(c->st->idx_ids.p, ids, 4 * n_postings, hipMemcpyHostToDevice, c->stream));
     SH_CHECK(hipStreamSynchronize(c->stream));
-    c->k = k;
-    c->nofast = nofast ? 1 : 0;
-    c->n_postings = n_postings;
-    c->have_index = true;
+    c->st->k = k;
+    c->st->nofast = nofast ? 1 : 0;
+    c->st->n_postings = n_postings;
+    c->st->have_index = true;
     return 0;
 }
 
 int sina_hip_build_index(sina_hip_ctx *c, unsigned k, int nofast) {
     if (!c) SH_FAIL("build_index: null ctx");
     if (k < 1 || k > 12) SH_FAIL("build_index: k must be in 1..12");
+    if (!c->owns_store) SH_FAIL("build_index: a forked context cannot change the reference store");
     std::lock_guard<std::mutex> lk(c->mu);
-    if (!c->have_refs) SH_FAIL("build_index: upload references first");
+    if (!c->st->have_refs) SH_FAIL("build_index: upload references first");
     SH_CHECK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const uint64_t n = c->total_bases;
+    const uint64_t n = c->st->total_bases;
     const uint64_t nk = 1ull << (2 * k);
     if (n >= (1ull << 32)) SH_FAIL("build_index: more than 2^32 reference bases");
     DevBuf keys_in, keys_out, flag, pos, tmp;
@@ -414,9 +416,9 @@ int sina_hip_build_index(sina_hip_ctx *c, unsigned k, int nofast) {
         if (keys_in.reserve(8 * std::max<uint64_t>(n, 1)) || keys_out.reserve(8 * std::max<uint64_t>(n, 1)) ||
             flag.reserve(4 * std::max<uint64_t>(n, 1)) || pos.reserve(4 * std::max<uint64_t>(n, 1)))
             break;
-        if (c->n_refs)
-            hipLaunchKernelGGL(ref_kmer_keys, dim3(c->n_refs), dim3(256), 0, s, c->ref_ab.as<uint32_t>(),
-                               c->ref_off.as<uint64_t>(), c->n_refs, k, nofast == 0, keys_in.as<uint64_t>());
+        if (c->st->n_refs)
+            hipLaunchKernelGGL(ref_kmer_keys, dim3(c->st->n_refs), dim3(256), 0, s, c->st->ref_ab.as<uint32_t>(),
+                               c->st->ref_off.as<uint64_t>(), c->st->n_refs, k, nofast == 0, keys_in.as<uint64_t>());
         size_t tb = 0;
         const int end_bit = 32 + 2 * (int)k;
         if (hipcub::DeviceRadixSort::SortKeys(nullptr, tb, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(),
@@ -447,29 +449,29 @@ int sina_hip_build_index(sina_hip_ctx *c, unsigned k, int nofast) {
         }
         const uint64_t np = (uint64_t)last_flag + last_pos;
         DevBuf counts;
-        if (counts.reserve(4 * (nk + 1)) || c->idx_off.reserve(4 * (nk + 1)) ||
-            c->idx_ids.reserve(4 * std::max<uint64_t>(np, 1))) {
+        if (counts.reserve(4 * (nk + 1)) || c->st->idx_off.reserve(4 * (nk + 1)) ||
+            c->st->idx_ids.reserve(4 * std::max<uint64_t>(np, 1))) {
             counts.release();
             break;
         }
         bool ok = hipMemsetAsync(counts.p, 0, 4 * (nk + 1), s) == hipSuccess;
         if (ok && n)
             hipLaunchKernelGGL(scatter_unique, dim3(blocks), dim3(256), 0, s, keys_out.as<uint64_t>(),
-                               flag.as<uint32_t>(), pos.as<uint32_t>(), n, c->idx_ids.as<uint32_t>(),
+                               flag.as<uint32_t>(), pos.as<uint32_t>(), n, c->st->idx_ids.as<uint32_t>(),
                                counts.as<uint32_t>());
         size_t tb3 = 0;
-        ok = ok && hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, counts.as<uint32_t>(), c->idx_off.as<uint32_t>(),
+        ok = ok && hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, counts.as<uint32_t>(), c->st->idx_off.as<uint32_t>(),
                                                     (int)(nk + 1), s) == hipSuccess;
         ok = ok && tmp.reserve(tb3 + 16) == 0;
-        ok = ok && hipcub::DeviceScan::ExclusiveSum(tmp.p, tb3, counts.as<uint32_t>(), c->idx_off.as<uint32_t>(),
+        ok = ok && hipcub::DeviceScan::ExclusiveSum(tmp.p, tb3, counts.as<uint32_t>(), c->st->idx_off.as<uint32_t>(),
                                                     (int)(nk + 1), s) == hipSuccess;
         ok = ok && hipStreamSynchronize(s) == hipSuccess;
         counts.release();
         if (!ok) break;
-        c->k = k;
-        c->nofast = nofast ? 1 : 0;
-        c->n_postings = np;
-        c->have_index = true;
+        c->st->k = k;
+        c->st->nofast = nofast ? 1 : 0;
+        c->st->n_postings = np;
+        c->st->have_index = true;
         rc = 0;
     } while (0);
     keys_in.release();
@@ -491,7 +493,7 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
     if (index_ready(c)) return 1;
     if (nq == 0) return 0;
     SH_CHECK(hipSetDevice(c->device));
-    if (max > c->n_refs) max = c->n_refs;
+    if (max > c->st->n_refs) max = c->st->n_refs;
     if (max == 0) {
         memset(out_n, 0, sizeof(uint32_t) * nq);
         return 0;
@@ -505,7 +507,7 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
     hipStream_t s = c->stream;
     const uint64_t nqm = qoff[nq] - qoff[0];
     // sub-batches bound the [nq][n_refs] int16 score matrix to ~2 GiB
-    const uint32_t per = (uint32_t)std::max<uint64_t>(1, ((uint64_t)2 << 30) / (2ull * std::max<uint32_t>(c->n_refs, 1)));
+    const uint32_t per = (uint32_t)std::max<uint64_t>(1, ((uint64_t)2 << 30) / (2ull * std::max<uint32_t>(c->st->n_refs, 1)));
     if (c->qmask.reserve(std::max<uint64_t>(nqm, 1)) || c->k_qoff.reserve(8 * ((uint64_t)nq + 1))) return 1;
     std::vector<uint64_t> rel(nq + 1);
     for (uint32_t q = 0; q <= nq; q++) rel[q] = qoff[q] - qoff[0];
@@ -522,11 +524,12 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
         SH_CHECK(hipStreamSynchronize(s));
         float ms = 0;
         SH_CHECK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
-        c->stats.kmer_count_ms += ms;
+        std::lock_guard<std::mutex> slk(c->st->stats_mu);
+        c->st->stats.kmer_count_ms += ms;
         SH_CHECK(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
-        c->stats.kmer_select_ms += ms;
-        c->stats.postings += visited;
-        c->stats.kmer_launches++;
+        c->st->stats.kmer_select_ms += ms;
+        c->st->stats.postings += visited;
+        c->st->stats.kmer_launches++;
     }
     return 0;
 }
@@ -543,7 +546,7 @@ int sina_hip_kmer_scores(sina_hip_ctx *c, const uint8_t *qmask, uint32_t qlen, i
     SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask, qlen, hipMemcpyHostToDevice, s));
     SH_CHECK(hipMemcpyAsync(c->k_qoff.p, rel, 16, hipMemcpyHostToDevice, s));
     if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>(), 1, 1, std::max<uint32_t>(qlen, 1), true)) return 1;
-    SH_CHECK(hipMemcpyAsync(scores, c->k_scores.p, (size_t)c->n_refs * 2, hipMemcpyDeviceToHost, s));
+    SH_CHECK(hipMemcpyAsync(scores, c->k_scores.p, (size_t)c->st->n_refs * 2, hipMemcpyDeviceToHost, s));
     SH_CHECK(hipStreamSynchronize(s));
     return 0;
 }
@@ -551,23 +554,23 @@ int sina_hip_kmer_scores(sina_hip_ctx *c, const uint8_t *qmask, uint32_t qlen, i
 int sina_hip_store_view_get(sina_hip_ctx *c, sina_hip_store_view *v) {
     if (!c || !v) SH_FAIL("store_view_get: null argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    if (!c->have_refs) SH_FAIL("store_view_get: no references uploaded");
+    if (!c->st->have_refs) SH_FAIL("store_view_get: no references uploaded");
     memset(v, 0, sizeof(*v));
-    v->ref_ab = c->ref_ab.p;
-    v->ref_ab_bytes = 4 * c->total_bases;
-    v->ref_off = c->ref_off.p;
-    v->ref_off_bytes = 8 * ((uint64_t)c->n_refs + 1);
-    v->n_refs = c->n_refs;
-    v->width = c->width;
-    v->total_bases = c->total_bases;
-    if (c->have_index) {
-        v->idx_offsets = c->idx_off.p;
-        v->idx_offsets_bytes = 4 * ((1ull << (2 * c->k)) + 1);
-        v->idx_ids = c->idx_ids.p;
-        v->idx_ids_bytes = 4 * c->n_postings;
-        v->k = c->k;
-        v->nofast = c->nofast;
-        v->n_postings = c->n_postings;
+    v->ref_ab = c->st->ref_ab.p;
+    v->ref_ab_bytes = 4 * c->st->total_bases;
+    v->ref_off = c->st->ref_off.p;
+    v->ref_off_bytes = 8 * ((uint64_t)c->st->n_refs + 1);
+    v->n_refs = c->st->n_refs;
+    v->width = c->st->width;
+    v->total_bases = c->st->total_bases;
+    if (c->st->have_index) {
+        v->idx_offsets = c->st->idx_off.p;
+        v->idx_offsets_bytes = 4 * ((1ull << (2 * c->st->k)) + 1);
+        v->idx_ids = c->st->idx_ids.p;
+        v->idx_ids_bytes = 4 * c->st->n_postings;
+        v->k = c->st->k;
+        v->nofast = c->st->nofast;
+        v->n_postings = c->st->n_postings;
     }
     return 0;
 }
@@ -575,28 +578,29 @@ int sina_hip_store_view_get(sina_hip_ctx *c, sina_hip_store_view *v) {
 int sina_hip_store_alloc_like(sina_hip_ctx *c, sina_hip_store_view *v) {
     if (!c || !v) SH_FAIL("store_alloc_like: null argument");
     if (v->k < 1 || v->k > 12) SH_FAIL("store_alloc_like: k must be in 1..12");
+    if (!c->owns_store) SH_FAIL("store_alloc_like: a forked context cannot change the reference store");
     std::lock_guard<std::mutex> lk(c->mu);
     SH_CHECK(hipSetDevice(c->device));
     const uint64_t nk = 1ull << (2 * v->k);
-    if (c->ref_ab.reserve(4 * std::max<uint64_t>(v->total_bases, 1)) ||
-        c->ref_off.reserve(8 * ((uint64_t)v->n_refs + 1)) || c->idx_off.reserve(4 * (nk + 1)) ||
-        c->idx_ids.reserve(4 * std::max<uint64_t>(v->n_postings, 1)))
+    if (c->st->ref_ab.reserve(4 * std::max<uint64_t>(v->total_bases, 1)) ||
+        c->st->ref_off.reserve(8 * ((uint64_t)v->n_refs + 1)) || c->st->idx_off.reserve(4 * (nk + 1)) ||
+        c->st->idx_ids.reserve(4 * std::max<uint64_t>(v->n_postings, 1)))
         return 1;
-    c->n_refs = v->n_refs;
-    c->width = v->width;
-    c->total_bases = v->total_bases;
-    c->k = v->k;
-    c->nofast = v->nofast;
-    c->n_postings = v->n_postings;
-    c->have_refs = c->have_index = true;
-    c->ref_off_host.clear();  // re-read from the device after the broadcast filled it
-    v->ref_ab = c->ref_ab.p;
+    c->st->n_refs = v->n_refs;
+    c->st->width = v->width;
+    c->st->total_bases = v->total_bases;
+    c->st->k = v->k;
+    c->st->nofast = v->nofast;
+    c->st->n_postings = v->n_postings;
+    c->st->have_refs = c->st->have_index = true;
+    c->st->ref_off_host.clear();  // re-read from the device after the broadcast filled it
+    v->ref_ab = c->st->ref_ab.p;
     v->ref_ab_bytes = 4 * v->total_bases;
-    v->ref_off = c->ref_off.p;
+    v->ref_off = c->st->ref_off.p;
     v->ref_off_bytes = 8 * ((uint64_t)v->n_refs + 1);
-    v->idx_offsets = c->idx_off.p;
+    v->idx_offsets = c->st->idx_off.p;
     v->idx_offsets_bytes = 4 * (nk + 1);
-    v->idx_ids = c->idx_ids.p;
+    v->idx_ids = c->st->idx_ids.p;
     v->idx_ids_bytes = 4 * v->n_postings;
     return 0;
 }

@@ -119,6 +119,44 @@ def test_long_deletions_on_the_path(oracle, gpu_ctx, small):
     assert n_ext > 0
 
 
+def test_forked_contexts_run_concurrently(oracle, gpu_ctx, small):
+    """sina_hip_fork: contexts that share the store and index but own their stream and scratch give
+    the parent's results when driven from several threads at once; a fork cannot change the store."""
+    import threading
+    refs, qs, cs, idx = small
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    gpu_ctx.build_index(10, False)
+    want = gpu_ctx.kmer_topk(qs.mask, qs.off, 41)
+    fam_ids = [np.asarray(want[0][qi, :want[2][qi]], np.uint32) for qi in range(qs.n)]
+    foff = np.zeros(qs.n + 1, np.uint64)
+    foff[1:] = np.cumsum([len(f) for f in fam_ids])
+    masks = (qs.mask & 0x0f).astype(np.uint8)
+    want_al = gpu_ctx.align_families(np.concatenate(fam_ids), foff, masks, qs.off, gpu_ctx.params())
+    forks = [gpu_ctx.fork() for _ in range(3)]
+    got, errs = [None] * 3, []
+
+    def work(i):
+        try:
+            for _ in range(4):
+                k = forks[i].kmer_topk(qs.mask, qs.off, 41)
+                a = forks[i].align_families(np.concatenate(fam_ids), foff, masks, qs.off, forks[i].params())
+            got[i] = (k, a)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    for k, a in got:
+        assert all((x == y).all() for x, y in zip(k, want))
+        assert (a[0] == want_al[0]).all() and (a[1] == want_al[1]).all()
+    with pytest.raises(capi.SinaHipError):
+        forks[0].build_index(10, False)
+    for f in forks:
+        f.close()
+
+
 def test_full_length_16s_geometry(oracle, gpu_ctx):
     """One full-length 16S-shaped problem (T=256,B=6 geometry, ~4.5 M cells)."""
     refs = synth.make_refs(600, length=1500, width=50000, seed=21)
