@@ -233,58 +233,100 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, 
     return base + x - v;
 }
 
+// Top-M of one query's score row, M = min(max, n_refs), order (score desc, id desc)
+// (kmer_search.cpp:405-418 partial_sort on pair<score, id>).  The cut score is found by bisection
+// on "how many scores are >= t" -- pure reductions over 16-byte vector loads of a row that sits in
+// L2 (200 KB for 100k references), no atomics on a histogram whose low bins every lane hits --
+// then one ordered pass emits everything above the cut plus the ties with the LARGEST ids.
 __global__ void __launch_bounds__(kSelThreads) kmer_select_kernel(SelectArgs a) {
-    __shared__ uint32_t hist[kMaxQueryLen + 1];
     __shared__ unsigned long long cand[kSelMax];
     __shared__ uint32_t wsum[kSelThreads / 64];
-    __shared__ uint32_t sh_cut, sh_need_eq, sh_skip_eq, sh_ncand;
+    __shared__ uint32_t sh_slot;
     const uint32_t q = blockIdx.x;
-    const int16_t *sc = a.scores + (size_t)q * a.stride;
-    const uint32_t M = min(a.max, a.n_refs);
+    const int tid = threadIdx.x;
+    const uint32_t n_refs = a.n_refs;
+    const int16_t *sc = a.scores + (size_t)q * a.stride;  // stride % 8 == 0: rows are 16-byte aligned
+    const uint4 *sc8 = reinterpret_cast<const uint4 *>(sc);
+    const uint32_t nvec = (n_refs + 7) / 8;
+    const uint32_t M = min(a.max, n_refs);
     const int top = (int)min(a.nkq[q], (uint32_t)kMaxQueryLen);  // no score can exceed the k-mer count
-    for (uint32_t i = threadIdx.x; i <= (uint32_t)top; i += kSelThreads) hist[i] = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < a.n_refs; i += kSelThreads) {
-        int v = sc[i];
-        v = v < 0 ? 0 : (v > top ? top : v);
-        atomicAdd(&hist[v], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        int t = top;
-        for (; t >= 0; t--) {
-            if (acc + hist[t] >= M) break;
-            acc += hist[t];
+
+    // f(value, index) over the 8 scores of vector i; entries past n_refs are skipped
+    auto for8 = [&](uint32_t i, auto &&f) {
+        const uint4 v = sc8[i];
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t base = 8 * i;
+        if (base + 8 <= n_refs) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                f((int)(int16_t)(wds[j] & 0xffffu), base + 2 * j);
+                f((int)(int16_t)(wds[j] >> 16), base + 2 * j + 1);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (base + 2 * j < n_refs) f((int)(int16_t)(wds[j] & 0xffffu), base + 2 * j);
+                if (base + 2 * j + 1 < n_refs) f((int)(int16_t)(wds[j] >> 16), base + 2 * j + 1);
+            }
         }
-        if (t < 0) t = 0;
-        sh_cut = (uint32_t)t;                 // scores > cut: all taken (acc of them)
-        sh_need_eq = M - acc;                 // ties at the cut still needed
-        sh_skip_eq = hist[t] - (M - acc);     // ties to skip (smallest ids)
-        sh_ncand = 0;
-    }
-    __syncthreads();
-    const int cut = (int)sh_cut;
-    const uint32_t skip_eq = sh_skip_eq;
-    uint32_t eq_seen = 0, out_base = 0;  // running totals (uniform)
-    for (uint32_t base = 0; base < a.n_refs; base += kSelThreads) {
-        const uint32_t i = base + threadIdx.x;
-        int v = -1;
-        if (i < a.n_refs) v = sc[i];
-        const uint32_t is_eq = (i < a.n_refs && v == cut) ? 1u : 0u;
-        uint32_t tot_eq;
-        const uint32_t eq_rank = eq_seen + block_excl_scan(is_eq, wsum, &tot_eq);
-        const uint32_t take = (i < a.n_refs && (v > cut || (is_eq && eq_rank >= skip_eq))) ? 1u : 0u;
-        uint32_t tot_take;
-        const uint32_t slot = out_base + block_excl_scan(take, wsum, &tot_take);
-        if (take && slot < kSelMax) {
-            // sort key: score (biased) high, id low -> descending order = (score desc, id desc)
-            cand[slot] = ((unsigned long long)(uint32_t)(v + 32768) << 32) | i;
+    };
+    auto block_sum = [&](uint32_t x) -> uint32_t {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        __syncthreads();  // wsum free again
+        if ((tid & 63) == 0) wsum[tid >> 6] = x;
+        __syncthreads();
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kSelThreads / 64; w++) t += wsum[w];
+        return t;
+    };
+    auto count_ge = [&](int t) -> uint32_t {
+        uint32_t c = 0;
+        for (uint32_t i = tid; i < nvec; i += kSelThreads) for8(i, [&](int v, uint32_t) { c += (v >= t) ? 1u : 0u; });
+        return block_sum(c);
+    };
+    // invariant: count(>= lo) >= M > count(>= hi)
+    int lo = 0, hi = top + 1;
+    uint32_t c_hi = 0;
+    for (int guard = 0; guard < 20 && hi - lo > 1; ++guard) {
+        const int mid = (lo + hi) >> 1;
+        const uint32_t c = count_ge(mid);
+        if (c >= M) {
+            lo = mid;
+        } else {
+            hi = mid;
+            c_hi = c;
         }
-        eq_seen += tot_eq;
-        out_base += tot_take;
     }
+    const int cut = lo;
+    const uint32_t acc = c_hi;  // scores > cut: all taken
+
+    // ordered pass over contiguous chunks: which ties (score == cut) to take
+    const uint32_t vc = (nvec + kSelThreads - 1) / kSelThreads;
+    const uint32_t v0 = min(nvec, (uint32_t)tid * vc), v1 = min(nvec, v0 + vc);
+    uint32_t my_eq = 0;
+    for (uint32_t i = v0; i < v1; i++) for8(i, [&](int v, uint32_t) { my_eq += (v == cut) ? 1u : 0u; });
+    uint32_t tot_eq;
+    uint32_t eq_rank = block_excl_scan(my_eq, wsum, &tot_eq);
+    const uint32_t skip_eq = tot_eq - (M - acc);  // ties to skip: the smallest ids
+    if (tid == 0) sh_slot = 0;
     __syncthreads();
+    for (uint32_t i = v0; i < v1; i++)
+        for8(i, [&](int v, uint32_t id) {
+            bool take = v > cut;
+            if (v == cut) {
+                take = eq_rank >= skip_eq;
+                eq_rank++;
+            }
+            if (take) {
+                const uint32_t slot = atomicAdd(&sh_slot, 1u);
+                // sort key: score (biased) high, id low -> descending order = (score desc, id desc)
+                if (slot < kSelMax) cand[slot] = ((unsigned long long)(uint32_t)(v + 32768) << 32) | id;
+            }
+        });
+    __syncthreads();
+    const uint32_t out_base = sh_slot;
     const uint32_t n = min(out_base, (uint32_t)kSelMax);
     uint32_t P = 1;
     while (P < n) P <<= 1;
@@ -329,7 +371,7 @@ static int index_ready(sina_hip_ctx *c) {
 static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint64_t *d_qoff, uint32_t nq,
                             uint32_t max, uint32_t max_qlen, bool want_scores_only) {
     hipStream_t s = c->stream;
-    const uint32_t stride = (c->st->n_refs + 1u) & ~1u;  // even: tiles are stored two scores per word
+    const uint32_t stride = (c->st->n_refs + 7u) & ~7u;  // rows 16-byte aligned (vector loads in the select kernel)
     if (c->k_scores.reserve((size_t)nq * stride * 2 + 64) || c->k_tmp2.reserve(8) || c->k_tmp0.reserve(4 * (size_t)nq))
         return 1;
     SH_CHECK(hipMemsetAsync(c->k_tmp2.p, 0, 8, s));

@@ -763,17 +763,34 @@ __global__ void backtrack_kernel(BtArgs a) {
         }
         return 0u;
     };
-    // :642-685 (a source node has no predecessors)
-    while (s != 0 && (rec[m].z & 0xffu) != 0) {
-        const uint32_t c = tb[(size_t)m * Lp + s];
+    // :642-685 (a source node has no predecessors).  Dependent loads dominate: per step the two
+    // trace-back cells are inherently serial; the row record / column of the node just reached and
+    // its NEXT cell are requested together.
+    uint32_t c = tb[(size_t)m * Lp + s];
+    uint32_t npred_m = rec[m].z & 0xffu;
+    while (s != 0 && npred_m != 0) {
         const uint32_t snew = c & kTbSMask;
         m = (c & kTbExt) ? gapm_idx(c >> 16, s) : (c >> 16);
         if (snew != 0) {
             const uint32_t c2 = tb[(size_t)m * Lp + snew];
             if (snew == (c2 & kTbSMask)) m = (c2 & kTbExt) ? gapm_idx(c2 >> 16, snew) : (c2 >> 16);
         }
-        pos = width - 1 - node_pos[m];
-        const float ms_w = mscore(m);
+        // everything below depends on m only: one round trip
+        c = tb[(size_t)m * Lp + snew];
+        const uint4 rm = rec[m];
+        const uint32_t np_pos = node_pos[m];
+        npred_m = rm.z & 0xffu;
+        pos = width - 1 - np_pos;
+        float ms_w;
+        {
+            const float wgt = __uint_as_float(rm.y);
+            if (a.weights != nullptr) {
+                const uint32_t nw1 = a.n_weights - 1;
+                ms_w = a.ms * a.weights[np_pos < nw1 ? np_pos : nw1] * wgt;
+            } else {
+                ms_w = a.ms * wgt;
+            }
+        }
         while (s != snew) {
             --s;
             out[n++] = pos;
