@@ -9,20 +9,24 @@
 //   * edge a->b whenever some reference has consecutive bases in nodes a, b; per node
 //     the predecessor ids ascending and unique; sources / sinks implicit.
 //
-// How it maps to the hardware: one workgroup per query, everything column-parallel.
+// How it maps to the hardware: one workgroup per query; the alignment is walked in tiles of
+// kTC occupied columns so that the [column][family member] tables stay in LDS:
 //   1. occupied-column bitmap in LDS (atomicOr per base), prefix-popcount -> dense
 //      column index ("rank") of every alignment column;
-//   2. a [column][family member] table in HBM scratch (one u32 per entry: base mask,
-//      local node index, dense column of that reference's previous base), filled with
-//      one store per base;
+//   2. per tile: every member's bases that fall into the tile (a contiguous stretch of its
+//      sequence, found with a per-member cursor) drop their mask into tabm[column][member];
 //   3. one thread per column scans its F entries in family order: first appearance of
 //      a mask opens a node (exact reference order), later ones count; block scans
-//      turn per-column node / raw-edge counts into node ids and CSR segments;
-//   4. one thread per column emits node records and, per node, inserts the
-//      predecessor ids (node base of the previous column + local index there) into a
-//      sorted unique list in its CSR segment; atomicMin collects the successor
-//      minimum column (for --insertion=forbid) and marks rows whose successors lie
-//      beyond the DP kernel's LDS ring (spill rows).
+//      turn per-column node / raw-edge counts into node ids and CSR segments (running totals
+//      carry across tiles);
+//   4. per base again: the node of the member's PREVIOUS base (same tile: table lookup; earlier
+//      tile: carried per member) goes into tabp[column][member];
+//   5. one thread per column emits node records and, per node, inserts the
+//      predecessor ids into a sorted unique list in its CSR segment; atomicMin / atomicMax
+//      collect the successor minimum column (for --insertion=forbid) and the last successor;
+//   6. sinks and fence flags; LDS-slot / spill-row assignment for the DP kernel by liveness
+//      (sequential over the rows: one wave, bookkeeping on the scalar unit); predecessor entries.
+// HBM traffic: the family's bases three times (bitmap, masks, previous nodes) and the DAG once.
 // All arithmetic is integer except the node weight, which is looked up in a table the
 // HOST computed with the reference's own mixed double/float expression.
 #include <algorithm>
@@ -37,23 +41,22 @@ namespace {
 constexpr int kGT = 256;          // threads per workgroup
 constexpr uint32_t kNoPrev = 0xFFFFu;
 constexpr int kMaxFam = 128;
+constexpr int kTC = 128;          // occupied columns per LDS tile
 
 struct GraphArgs {
     const uint32_t *ref_ab;
     const uint64_t *ref_off;
     const uint32_t *fam_ids;   // concatenated
     const uint64_t *fam_off;   // [nq+1]
-    const uint64_t *tab_off;   // [nq] offset of this query's column table (u32 units)
     const uint64_t *pred_off;  // [nq] offset of this query's pred area
     const float *wtab;         // [(kMaxFam+1) * (kMaxFam+1)]: weight for (F, count)
-    uint32_t *tab;             // scratch: [NC][F] per query
     uint4 *rec;                // [nq][ncap]
     uint32_t *node_pos;        // [nq][ncap]
     uint32_t *succ_min;        // [nq][ncap]
     uint32_t *far_mark;        // [nq][ncap] last successor row of every node (0: none)
     uint32_t *pred;            // per query area of total-family-bases entries
-    uint32_t *sizes;           // [nq][4]: N, raw edge entries, n_spill, status (0 ok, 1 NC cap, 2 N cap, 4 spill rows)
-    uint32_t width, nccap, ncap;
+    uint32_t *sizes;           // [nq][4]: N, raw edge entries, n_spill, status (0 ok, 2 N cap, 4 spill rows)
+    uint32_t width, ncap;
     int W;                     // DP ring depth: edges longer than this need a spill row
 };
 
@@ -96,26 +99,35 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
     __shared__ uint32_t s_ids[kMaxFam];
     __shared__ uint32_t s_len[kMaxFam];
     __shared__ uint64_t s_beg[kMaxFam];
+    __shared__ uint32_t s_cur[kMaxFam], s_curn[kMaxFam];      // first base of member j at/after the tile
+    __shared__ uint32_t s_carry[kMaxFam], s_carryn[kMaxFam];  // node of member j's last base before the tile
     __shared__ uint32_t s_tmp[8];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t nwords = (a.width + 31) / 32;
+    const uint64_t f0 = a.fam_off[q];
+    const uint32_t F = (uint32_t)(a.fam_off[q + 1] - f0);
+    const uint32_t FS = (F + 1) | 1u;  // table row stride (u16 units)
     // LDS carve
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(smem);                 // [nwords]
     uint16_t *wrank = reinterpret_cast<uint16_t *>(bitmap + nwords);        // [nwords]
-    uint32_t *cpos = reinterpret_cast<uint32_t *>(smem + ((6 * (size_t)nwords + 15) & ~(size_t)15));  // [nccap]
-    uint32_t *ebase = cpos + a.nccap;                                       // [nccap]
-    uint16_t *nbase = reinterpret_cast<uint16_t *>(ebase + a.nccap);        // [nccap]
-    uint8_t *nn = reinterpret_cast<uint8_t *>(nbase + a.nccap);             // [nccap] nodes per column
-    uint8_t *rc = nn + a.nccap;                                             // [nccap] raw edges per column
+    unsigned char *tile = smem + ((6 * (size_t)nwords + 15) & ~(size_t)15);
+    uint32_t *cposT = reinterpret_cast<uint32_t *>(tile);                   // [kTC] alignment column
+    uint32_t *nbaseT = cposT + kTC;                                         // [kTC] first node id
+    uint32_t *ebaseT = nbaseT + kTC;                                        // [kTC] first raw edge slot
+    uint8_t *nn = reinterpret_cast<uint8_t *>(ebaseT + kTC);                // [kTC] nodes per column
+    uint8_t *rc = nn + kTC;                                                 // [kTC] raw edges per column
+    // tabm[c][j]: mask (8) | local node index (5) << 8 | first base of the member << 13 ; 0 = absent
+    uint16_t *tabm = reinterpret_cast<uint16_t *>(rc + kTC);                // [kTC][FS]
+    uint16_t *tabp = tabm + (size_t)kTC * FS;                               // [kTC][FS] previous node, 0xFFFF none
 
-    const uint64_t f0 = a.fam_off[q];
-    const uint32_t F = (uint32_t)(a.fam_off[q + 1] - f0);
     uint32_t *sz = a.sizes + 4 * (size_t)q;
     for (uint32_t j = tid; j < F; j += kGT) {
         const uint32_t id = a.fam_ids[f0 + j];
         s_ids[j] = id;
         s_beg[j] = a.ref_off[id];
         s_len[j] = (uint32_t)(a.ref_off[id + 1] - a.ref_off[id]);
+        s_cur[j] = s_curn[j] = 0;
+        s_carry[j] = s_carryn[j] = kNoPrev;
     }
     for (uint32_t i = tid; i < nwords; i += kGT) bitmap[i] = 0;
     __syncthreads();
@@ -149,14 +161,6 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
             if (w < wave) base += s_tmp[w];
             total += s_tmp[w];
         }
-        if (total > a.nccap) {  // column table too small: the host retries with a larger cap
-            if (tid == 0) {
-                sz[0] = total;
-                sz[1] = sz[2] = 0;
-                sz[3] = 1;
-            }
-            return;
-        }
         uint32_t run = base + x - s;
         for (uint32_t i = b; i < e; i++) {
             wrank[i] = (uint16_t)run;
@@ -166,56 +170,153 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
     }
     __syncthreads();
     const uint32_t NC = s_tmp[4];
+    if (NC > 65535u) {  // (cannot be a valid DAG for the DP kernel anyway: more columns than row ids)
+        if (tid == 0) {
+            sz[0] = NC;
+            sz[1] = sz[2] = 0;
+            sz[3] = 2;
+        }
+        return;
+    }
     auto rank = [&](uint32_t pos) -> uint32_t {
         return (uint32_t)wrank[pos >> 5] + __popc(bitmap[pos >> 5] & ((1u << (pos & 31)) - 1u));
     };
-    // 3. column table: T[c][j] = mask | 0xFF << 8 | dense column of j's previous base << 16
-    uint32_t *T = a.tab + a.tab_off[q];
-    for (uint32_t i = tid; i < NC * F; i += kGT) T[i] = 0;
-    __syncthreads();
-    for (uint32_t j = 0; j < F; j++) {
-        const uint32_t *b = a.ref_ab + s_beg[j];
-        for (uint32_t i = tid; i < s_len[j]; i += kGT) {
+    uint4 *rec = a.rec + (size_t)q * a.ncap;
+    uint32_t *node_pos = a.node_pos + (size_t)q * a.ncap;
+    uint32_t *smin = a.succ_min + (size_t)q * a.ncap;
+    uint32_t *last = a.far_mark + (size_t)q * a.ncap;
+    uint32_t *pred = a.pred + a.pred_off[q];
+    for (uint32_t i = tid; i < a.ncap; i += kGT) {
+        smin[i] = 0xFFFFFFFFu;
+        last[i] = 0;
+    }
+    const float *wt = a.wtab + (size_t)F * (kMaxFam + 1);
+    uint32_t N = 0, E = 0;  // running totals (uniform)
+
+    for (uint32_t c0 = 0; c0 < NC; c0 += kTC) {
+        const uint32_t tc = min((uint32_t)kTC, NC - c0);
+        {   // clear the mask table (u32 stores; FS odd, kTC even: the element count is even)
+            uint32_t *z = reinterpret_cast<uint32_t *>(tabm);
+            for (uint32_t i = tid; i < (uint32_t)kTC * FS / 2; i += kGT) z[i] = 0;
+        }
+        __syncthreads();
+        // 3a. masks of this tile: member j's bases cur[j].. as long as their column is in the tile
+        for (uint32_t idx = tid; idx < F * (uint32_t)kTC; idx += kGT) {
+            const uint32_t j = idx / kTC, i = s_cur[j] + idx % kTC;
+            if (i >= s_len[j]) continue;
+            const uint32_t *b = a.ref_ab + s_beg[j];
             const uint32_t ab = b[i];
             const uint32_t pos = ab & 0xFFFFFFu;
-            const uint32_t c = rank(pos);
-            const uint32_t pc = (i > 0) ? rank(b[i - 1] & 0xFFFFFFu) : kNoPrev;
-            T[(size_t)c * F + j] = ((ab >> 24) & 0xFFu) | (0xFFu << 8) | (pc << 16);
-            cpos[c] = pos;
+            const uint32_t cl = rank(pos) - c0;
+            if (cl >= tc) continue;
+            tabm[cl * FS + j] = (uint16_t)(((ab >> 24) & 0xFFu) | (i == 0 ? (1u << 13) : 0u));
+            cposT[cl] = pos;
+            // the member's last base in this tile moves its cursor
+            if (i + 1 >= s_len[j] || rank(b[i + 1] & 0xFFFFFFu) - c0 >= tc) s_curn[j] = i + 1;
         }
-    }
-    __syncthreads();
-    // 4. per column: nodes in order of first appearance (family order), raw edge count
-    for (uint32_t c = tid; c < NC; c += kGT) {
-        uint32_t seen = 0;          // bit m: mask value m already has a node in this column
-        uint64_t idx0 = 0, idx1 = 0, idx2 = 0;  // local node index of mask m, 5 bits each (12/12/8 masks)
-        uint32_t k = 0, raw = 0;
-        uint32_t *row = T + (size_t)c * F;
-        for (uint32_t j = 0; j < F; j++) {
-            const uint32_t t = row[j];
-            const uint32_t m = t & 0x1Fu;
-            if ((t & 0xFFu) == 0) continue;
-            uint32_t li;
-            if (!((seen >> m) & 1u)) {
-                seen |= 1u << m;
-                li = k++;
-                if (m < 12) idx0 |= (uint64_t)li << (5 * m);
-                else if (m < 24) idx1 |= (uint64_t)li << (5 * (m - 12));
-                else idx2 |= (uint64_t)li << (5 * (m - 24));
-            } else {
-                li = (m < 12) ? (uint32_t)(idx0 >> (5 * m)) & 31u
-                     : (m < 24) ? (uint32_t)(idx1 >> (5 * (m - 12))) & 31u
-                                : (uint32_t)(idx2 >> (5 * (m - 24))) & 31u;
+        __syncthreads();
+        // 3b. per column: nodes in order of first appearance (family order), raw edge count
+        for (uint32_t c = tid; c < tc; c += kGT) {
+            uint32_t seen = 0;          // bit m: mask value m already has a node in this column
+            uint64_t idx0 = 0, idx1 = 0, idx2 = 0;  // local node index of mask m, 5 bits each (12/12/8 masks)
+            uint32_t k = 0, raw = 0;
+            uint16_t *row = tabm + c * FS;
+            for (uint32_t j = 0; j < F; j++) {
+                const uint32_t t = row[j];
+                const uint32_t m = t & 0x1Fu;
+                if ((t & 0xFFu) == 0) continue;
+                uint32_t li;
+                if (!((seen >> m) & 1u)) {
+                    seen |= 1u << m;
+                    li = k++;
+                    if (m < 12) idx0 |= (uint64_t)li << (5 * m);
+                    else if (m < 24) idx1 |= (uint64_t)li << (5 * (m - 12));
+                    else idx2 |= (uint64_t)li << (5 * (m - 24));
+                } else {
+                    li = (m < 12) ? (uint32_t)(idx0 >> (5 * m)) & 31u
+                         : (m < 24) ? (uint32_t)(idx1 >> (5 * (m - 12))) & 31u
+                                    : (uint32_t)(idx2 >> (5 * (m - 24))) & 31u;
+                }
+                row[j] = (uint16_t)(t | (li << 8));
+                if (!(t & (1u << 13))) raw++;
             }
-            row[j] = (t & 0xFFFF00FFu) | (li << 8);
-            if ((t >> 16) != kNoPrev) raw++;
+            nn[c] = (uint8_t)k;
+            rc[c] = (uint8_t)raw;
         }
-        nn[c] = (uint8_t)k;
-        rc[c] = (uint8_t)raw;
+        __syncthreads();
+        const uint32_t tn = block_exscan(nn, nbaseT, tc, s_tmp);
+        const uint32_t te = block_exscan(rc, ebaseT, tc, s_tmp);
+        // 4. node of every base's predecessor base
+        for (uint32_t idx = tid; idx < F * (uint32_t)kTC; idx += kGT) {
+            const uint32_t j = idx / kTC, i = s_cur[j] + idx % kTC;
+            if (i >= s_len[j]) continue;
+            const uint32_t *b = a.ref_ab + s_beg[j];
+            const uint32_t cl = rank(b[i] & 0xFFFFFFu) - c0;
+            if (cl >= tc) continue;
+            const uint32_t node = N + nbaseT[cl] + ((tabm[cl * FS + j] >> 8) & 31u);
+            uint32_t pn = kNoPrev;
+            if (i > 0) {
+                if (i > s_cur[j]) {
+                    const uint32_t pl = rank(b[i - 1] & 0xFFFFFFu) - c0;
+                    pn = N + nbaseT[pl] + ((tabm[pl * FS + j] >> 8) & 31u);
+                } else {
+                    pn = s_carry[j];
+                }
+            }
+            tabp[cl * FS + j] = (uint16_t)pn;
+            if (i + 1 == s_curn[j]) s_carryn[j] = node;
+        }
+        __syncthreads();
+        // 5. node records + sorted unique predecessor lists
+        for (uint32_t c = tid; c < tc; c += kGT) {
+            const uint16_t *rowm = tabm + c * FS;
+            const uint16_t *rowp = tabp + c * FS;
+            const uint32_t knodes = nn[c];
+            const uint32_t pos = cposT[c];
+            uint32_t seg = E + ebaseT[c];
+            for (uint32_t k = 0; k < knodes; k++) {
+                const uint32_t node = N + nbaseT[c] + k;
+                uint32_t cnt = 0, np = 0, rawk = 0, mask = 0;
+                for (uint32_t j = 0; j < F; j++) {
+                    const uint32_t t = rowm[j];
+                    if ((t & 0xFFu) == 0 || ((t >> 8) & 31u) != k) continue;
+                    mask = t & 0xFFu;
+                    cnt++;
+                    if (t & (1u << 13)) continue;
+                    rawk++;
+                    if (node >= a.ncap) continue;
+                    const uint32_t pa = rowp[j];
+                    // sorted unique insert into pred[seg .. seg+np)
+                    uint32_t x = 0;
+                    while (x < np && pred[seg + x] < pa) x++;
+                    if (x < np && pred[seg + x] == pa) continue;
+                    for (uint32_t y = np; y > x; y--) pred[seg + y] = pred[seg + y - 1];
+                    pred[seg + x] = pa;
+                    np++;
+                    atomicMin(&smin[pa], pos);
+                    atomicMax(&last[pa], node);
+                }
+                if (node < a.ncap) {
+                    uint4 r;
+                    r.x = seg;
+                    r.y = __float_as_uint(wt[cnt]);
+                    r.z = (np & 0xFFu) | (mask << 8);
+                    r.w = kRowNone;
+                    rec[node] = r;
+                    node_pos[node] = pos;
+                }
+                seg += rawk;
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = tid; j < F; j += kGT) {
+            s_cur[j] = s_curn[j];
+            s_carry[j] = s_carryn[j];
+        }
+        N += tn;
+        E += te;
+        __syncthreads();
     }
-    __syncthreads();
-    const uint32_t N = block_exscan(nn, nbase, NC, s_tmp);
-    const uint32_t E = block_exscan(rc, ebase, NC, s_tmp);
     if (N > a.ncap || N > 65535u) {
         if (tid == 0) {
             sz[0] = N;
@@ -224,57 +325,6 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         }
         return;
     }
-    uint4 *rec = a.rec + (size_t)q * a.ncap;
-    uint32_t *node_pos = a.node_pos + (size_t)q * a.ncap;
-    uint32_t *smin = a.succ_min + (size_t)q * a.ncap;
-    uint32_t *last = a.far_mark + (size_t)q * a.ncap;
-    uint32_t *pred = a.pred + a.pred_off[q];
-    for (uint32_t i = tid; i < N; i += kGT) {
-        smin[i] = 0xFFFFFFFFu;
-        last[i] = 0;
-    }
-    __syncthreads();
-    // 5. node records + sorted unique predecessor lists
-    const float *wt = a.wtab + (size_t)F * (kMaxFam + 1);
-    for (uint32_t c = tid; c < NC; c += kGT) {
-        const uint32_t *row = T + (size_t)c * F;
-        const uint32_t knodes = nn[c];
-        const uint32_t pos = cpos[c];
-        uint32_t seg = ebase[c];
-        for (uint32_t k = 0; k < knodes; k++) {
-            const uint32_t node = (uint32_t)nbase[c] + k;
-            uint32_t cnt = 0, np = 0, rawk = 0, mask = 0;
-            for (uint32_t j = 0; j < F; j++) {
-                const uint32_t t = row[j];
-                if ((t & 0xFFu) == 0 || ((t >> 8) & 0xFFu) != k) continue;
-                mask = t & 0xFFu;
-                cnt++;
-                const uint32_t pc = t >> 16;
-                if (pc == kNoPrev) continue;
-                rawk++;
-                const uint32_t pt = T[(size_t)pc * F + j];
-                const uint32_t pa = (uint32_t)nbase[pc] + ((pt >> 8) & 0xFFu);
-                // sorted unique insert into pred[seg .. seg+np)
-                uint32_t x = 0;
-                while (x < np && pred[seg + x] < pa) x++;
-                if (x < np && pred[seg + x] == pa) continue;
-                for (uint32_t y = np; y > x; y--) pred[seg + y] = pred[seg + y - 1];
-                pred[seg + x] = pa;
-                np++;
-                atomicMin(&smin[pa], pos);
-                atomicMax(&last[pa], node);
-            }
-            uint4 r;
-            r.x = seg;
-            r.y = __float_as_uint(wt[cnt]);
-            r.z = (np & 0xFFu) | (mask << 8);
-            r.w = kRowNone;
-            rec[node] = r;
-            node_pos[node] = pos;
-            seg += rawk;
-        }
-    }
-    __syncthreads();
     // 6. sinks, successor minimum, fence flag
     for (uint32_t i = tid; i < N; i += kGT) {
         uint32_t z = rec[i].z;
@@ -349,9 +399,10 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
     }
 }
 
-size_t graph_lds_bytes(uint32_t width, uint32_t nccap) {
+size_t graph_lds_bytes(uint32_t width, uint32_t max_family) {
     const size_t nwords = (width + 31) / 32;
-    return ((6 * nwords + 15) & ~(size_t)15) + (size_t)nccap * (4 + 4 + 2 + 1 + 1) + 64;
+    const size_t fs = (max_family + 1) | 1u;
+    return ((6 * nwords + 15) & ~(size_t)15) + (size_t)kTC * (4 + 4 + 4 + 1 + 1) + 2 * 2 * (size_t)kTC * fs + 64;
 }
 
 }  // namespace
@@ -362,7 +413,7 @@ using namespace sina_hip;
 namespace {
 
 struct BuiltGraphs {
-    uint32_t nccap = 0, ncap = 0;
+    uint32_t ncap = 0;
     std::vector<uint64_t> pred_off;  // per query, into c->pred
     std::vector<uint32_t> sizes;     // per query: N, raw edge entries, n_spill, status
 };
@@ -389,48 +440,43 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         SH_CHECK(hipStreamSynchronize(s));
         c->wtab_fs_weight = fs_weight;
     }
-    std::vector<uint64_t> foff(bq + 1), tab_off(bq), elems(bq, 0);
+    std::vector<uint64_t> foff(bq + 1), elems(bq, 0);
+    uint32_t max_f = 1;
     bg->pred_off.assign(bq, 0);
     for (uint32_t q = 0; q <= bq; q++) foff[q] = fam_off[q0 + q] - fam_off[q0];
     for (uint32_t q = 0; q < bq; q++) {
+        max_f = std::max<uint32_t>(max_f, (uint32_t)(foff[q + 1] - foff[q]));
         for (uint64_t x = fam_off[q0 + q]; x < fam_off[q0 + q + 1]; x++) {
             const uint32_t id = fam_ids[x];
             if (id >= c->st->n_refs) SH_FAIL("align_families: reference id out of range");
             elems[q] += c->st->ref_off_host[id + 1] - c->st->ref_off_host[id];
         }
     }
-    uint32_t nccap = std::min<uint32_t>(c->st->width, 4096);
-    uint32_t ncap = std::min<uint32_t>(65535, 3 * nccap);
+    uint32_t ncap = std::min<uint32_t>(65535, 12288);
     for (int attempt = 0;; attempt++) {
-        uint64_t tab_total = 0, pred_total = 0;
+        uint64_t pred_total = 0;
         for (uint32_t q = 0; q < bq; q++) {
-            tab_off[q] = tab_total;
-            tab_total += (uint64_t)nccap * (foff[q + 1] - foff[q]);
             bg->pred_off[q] = pred_total;
             pred_total += elems[q] + 8;  // +8: slack behind every list
         }
-        const size_t glds = graph_lds_bytes(c->st->width, nccap);
+        const size_t glds = graph_lds_bytes(c->st->width, max_f);
         if (glds > 160 * 1024) SH_FAIL("align_families: family too wide for the device DAG build");
         if (c->g_fam_ids.reserve(4 * std::max<uint64_t>(foff[bq], 1)) || c->g_fam_off.reserve(8 * ((uint64_t)bq + 1)) ||
-            c->g_tmp0.reserve(8 * (uint64_t)bq) || c->g_tmp1.reserve(8 * (uint64_t)bq) ||
-            c->g_tmp2.reserve(4 * std::max<uint64_t>(tab_total, 1)) ||
+            c->g_tmp1.reserve(8 * (uint64_t)bq) ||
             c->rec.reserve(sizeof(uint4) * (uint64_t)bq * ncap) || c->node_pos.reserve(4 * (uint64_t)bq * ncap) ||
             c->succ_minpos.reserve(4 * (uint64_t)bq * ncap) || c->g_tmp3.reserve(4 * (uint64_t)bq * ncap) ||
             c->pred.reserve(4 * pred_total) || c->g_sizes.reserve(16 * (uint64_t)bq))
             return 1;
         SH_CHECK(hipMemcpyAsync(c->g_fam_ids.p, fam_ids + fam_off[q0], 4 * foff[bq], hipMemcpyHostToDevice, s));
         SH_CHECK(hipMemcpyAsync(c->g_fam_off.p, foff.data(), 8 * ((uint64_t)bq + 1), hipMemcpyHostToDevice, s));
-        SH_CHECK(hipMemcpyAsync(c->g_tmp0.p, tab_off.data(), 8 * (uint64_t)bq, hipMemcpyHostToDevice, s));
         SH_CHECK(hipMemcpyAsync(c->g_tmp1.p, bg->pred_off.data(), 8 * (uint64_t)bq, hipMemcpyHostToDevice, s));
         GraphArgs ga;
         ga.ref_ab = c->st->ref_ab.as<uint32_t>();
         ga.ref_off = c->st->ref_off.as<uint64_t>();
         ga.fam_ids = c->g_fam_ids.as<uint32_t>();
         ga.fam_off = c->g_fam_off.as<uint64_t>();
-        ga.tab_off = c->g_tmp0.as<uint64_t>();
         ga.pred_off = c->g_tmp1.as<uint64_t>();
         ga.wtab = c->g_wtab.as<float>();
-        ga.tab = c->g_tmp2.as<uint32_t>();
         ga.rec = c->rec.as<uint4>();
         ga.node_pos = c->node_pos.as<uint32_t>();
         ga.succ_min = c->succ_minpos.as<uint32_t>();
@@ -438,7 +484,6 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         ga.pred = c->pred.as<uint32_t>();
         ga.sizes = c->g_sizes.as<uint32_t>();
         ga.width = c->st->width;
-        ga.nccap = nccap;
         ga.ncap = ncap;
         ga.W = W;
         SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(family_graph_kernel),
@@ -456,18 +501,15 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
             std::lock_guard<std::mutex> slk(c->st->stats_mu);
             c->st->stats.graph_ms += gms;
         }
-        uint32_t need_nc = 0, need_n = 0;
+        uint32_t need_n = 0;
         for (uint32_t q = 0; q < bq; q++) {
-            if (bg->sizes[4 * q + 3] == 1) need_nc = std::max(need_nc, bg->sizes[4 * q]);
             if (bg->sizes[4 * q + 3] == 2) need_n = std::max(need_n, bg->sizes[4 * q]);
             if (bg->sizes[4 * q + 3] == 4) SH_FAIL("align_families: too many spill rows for one query");
         }
-        if (!need_nc && !need_n) break;
+        if (!need_n) break;
         if (attempt >= 3 || need_n > 65535u) SH_FAIL("align_families: family DAG exceeds device limits");
-        if (need_nc) nccap = std::min<uint32_t>(c->st->width, need_nc + need_nc / 8 + 16);
-        ncap = std::min<uint32_t>(65535, std::max<uint32_t>(3 * nccap, need_n + need_n / 8 + 16));
+        ncap = std::min<uint32_t>(65535, need_n + need_n / 8 + 16);
     }
-    bg->nccap = nccap;
     bg->ncap = ncap;
     return 0;
 }
