@@ -37,13 +37,13 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="queries per step and rank")
     ap.add_argument("--refs", type=int, default=100000)
     ap.add_argument("--length", type=int, default=1500)
     ap.add_argument("--width", type=int, default=50000)
     ap.add_argument("--window", type=int, default=0, help="cut queries to this many bases (V4: 250)")
-    ap.add_argument("--inflight", type=int, default=3, help="batches worked on concurrently per rank")
+    ap.add_argument("--inflight", type=int, default=4, help="batches worked on concurrently per rank")
     ap.add_argument("--sub-batch", type=int, default=1024, help="queries per GPU launch inside a step")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

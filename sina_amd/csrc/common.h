@@ -33,12 +33,14 @@ void set_error(const std::string &msg);
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    // (hipFree / hipMalloc synchronise the whole device and stall every other context's stream:
+    // grow in big steps so that batch-to-batch size jitter never reallocates in steady state)
     int reserve(size_t bytes) {
         if (bytes <= cap) return 0;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        size_t want = bytes + bytes / 8 + 256;
+        size_t want = bytes + bytes / 4 + 4096;
         SH_CHECK(hipMalloc(&p, want));
         cap = want;
         return 0;

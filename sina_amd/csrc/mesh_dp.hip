@@ -840,10 +840,11 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, size_t l
 }  // namespace
 
 // Few, fat lanes win: the per-row fixed work of a wave (row record, hand-shake, chain exchange,
-// publish) is amortised over more cells.  Measured on MI355X (16S, 1024 queries, Gcell/s, before
-// the far-row prefetch): 128x12 152, 256x6 133, 512x3 97.  A variant that kept the ring of
-// recent rows in registers instead of LDS (deeper ring, but 2 waves/SIMD and scratch spills)
-// reached 82-90 and was dropped.
+// publish) is amortised over more cells -- up to the point where the registers of a lane allow
+// only one wave per SIMD.  Measured on MI355X (16S, 1024 queries, Gcell/s): 128x12 217 (2 waves/
+// SIMD), 192x8 135 (3 waves/SIMD), 64x24 159 (1 wave/SIMD, no cross-wave hand-shake at all); on an
+// earlier version 128x12 152, 256x6 133, 512x3 97.  A variant that kept the recent rows in
+// registers instead of LDS (deeper ring, but scratch spills) reached 82-90 and was dropped.
 static const DpGeom kGeoms[] = {{64, 4},  {64, 8},  {64, 12},  {128, 8}, {128, 12},
                                 {256, 8}, {256, 12}, {512, 8}, {512, 12}};
 
