@@ -39,6 +39,7 @@
 //   * the only per-cell HBM traffic is the write-once trace-back cell (4 bytes), row-major.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -64,6 +65,32 @@ __device__ __forceinline__ uint32_t lane_shr1(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 __device__ __forceinline__ float lane_shr1(float x) { return __uint_as_float(lane_shr1(__float_as_uint(x))); }
+
+// v_min_f32 / v_min3_f32 without the operand canonicalisation (v_max x, x) that fminf() drags in:
+// the values here are never NaN, and the extra instruction would sit on the cell-to-cell critical path
+__device__ __forceinline__ float min2_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// B consecutive floats as B/4 16-byte vectors: what a row read delivers, used in place (element
+// access with a compile-time index is a sub-register, no copy)
+template <int B>
+struct Cells {
+    using V = __attribute__((ext_vector_type(4))) float;
+    V v[B / 4];
+    __device__ __forceinline__ float operator[](int k) const { return v[k >> 2][k & 3]; }
+    __device__ __forceinline__ void load(const float *__restrict__ src) {
+#pragma unroll
+        for (int i = 0; i < B / 4; i++) v[i] = *reinterpret_cast<const V *>(src + 4 * i);
+    }
+};
 
 // B consecutive 4-byte cells starting at a 16-byte aligned address (B % 4 == 0) or 8-byte aligned
 // one (B % 2 == 0): wide loads/stores, both for LDS and for global memory
@@ -189,6 +216,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
     // end-cell search state (mesh.h:567-592)
     const bool own_last = (L - 1) / B == (uint32_t)j;
     const int k_last = (int)((L - 1) % B);
+    const int w_last = (int)(((L - 1) / B) >> 6);  // the wave that owns column L-1
     float lc_min = 0.f, lc_snk0 = 0.f;  // step 1: rows at column L-1 (lane own_last only)
     uint32_t lc_arg = 0;
     bool lc_any = false;
@@ -285,9 +313,9 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
     // of row m in between -- and the compiler sees load and use in one straight line, so it waits
     // for exactly that load instead of draining all outstanding trace-back stores.
     // Row 0 has no predecessors (they have smaller ids), its candidates are the initial values.
-    float pf_v[B], pf_g[B];  // spill row of the next row's first spilled predecessor, in flight
+    Cells<B> pf_v, pf_g;  // spill row of the next row's first spilled predecessor, in flight
 #pragma unroll
-    for (int k = 0; k < B; k++) pf_v[k] = pf_g[k] = 0.f;
+    for (int i = 0; i < B / 4; i++) pf_v.v[i] = pf_g.v[i] = 0.f;
     Row r = setup_row(rec[0], 0);
     handshake(0);
     init_cells(r);
@@ -310,6 +338,12 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 return gpe;
             }
         };
+        // One cell: gs = left value + gap cost; value = the smallest of {gs, deletion, match}.  Ties
+        // do not change the value (gs wins over the deletion, both win over the match: mesh.h:351-
+        // 374), so the value is a plain min3 and only the trace-back indices look at the order --
+        // that keeps the cell-to-cell dependency at add -> min3 -> compare -> select instead of
+        // seven dependent operations.  (No NaN and no -0 can occur among these values: they are
+        // sums that start at 1 or 1e6.)
         auto run_chain = [&](const ChainState &left) {
             ChainState c = left;
 #pragma unroll
@@ -320,29 +354,45 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 uint32_t vs = dvs[k];
                 float gs = 1.0f;  // init_edge at s == 0, no insertion step there
                 uint32_t gsi = 0, gmax = 0;
-                if (s > 0) {
-                    bool ins = true;
-                    float gi_cost = r.gi_open;  // opening gap (mesh.h:340-343 / :415-419)
-                    uint32_t gsi_n = s - 1, gmax_n = 0;
-                    if (FORBID) {
-                        ins = (r.smax >= 1) && (!c.e || c.gmax > 0);
-                        gmax_n = c.e ? c.gmax - 1 : r.smax - 1;
+                if constexpr (FORBID) {
+                    if (s > 0) {
+                        bool ins = (r.smax >= 1) && (!c.e || c.gmax > 0);
+                        const uint32_t gmax_n = c.e ? c.gmax - 1 : r.smax - 1;
+                        float gi_cost = r.gi_open;  // opening gap (mesh.h:415-419)
+                        uint32_t gsi_n = s - 1;
+                        if (c.e) {  // extending gap (:420-425); gaps_val == value here
+                            gi_cost = ext_cost(s, c.gsi);
+                            gsi_n = c.gsi;
+                        }
+                        gs = ins ? (c.v + gi_cost) : r.init_v;  // untouched cell keeps its initial gaps_*
+                        gsi = ins ? gsi_n : 0u;
+                        gmax = ins ? gmax_n : 0u;
+                        const bool take = ins && (gs <= v);  // mesh.h:351-357
+                        v = take ? gs : v;
+                        vm = take ? (m << 16) : vm;
+                        vs = take ? gsi : vs;
+                        const bool mtk = mt[k] < v;
+                        v = mtk ? mt[k] : v;
+                        vm = mtk ? mtp[k] : vm;
+                        vs = mtk ? s - 1 : vs;
                     }
-                    if (c.e) {  // extending gap (:344-349 / :420-425); gaps_val == value here
+                } else {
+                    const bool has_left = (k > 0) || (j > 0);  // s > 0
+                    float gi_cost = r.gi_open;  // opening gap (mesh.h:340-343)
+                    uint32_t gsi_n = s - 1;
+                    if (c.e) {  // extending gap (:344-349); gaps_val == value here
                         gi_cost = ext_cost(s, c.gsi);
                         gsi_n = c.gsi;
                     }
-                    gs = ins ? (c.v + gi_cost) : r.init_v;  // untouched cell keeps its initial gaps_*
-                    gsi = ins ? gsi_n : 0u;
-                    gmax = ins ? gmax_n : 0u;
-                    const bool take = ins && (gs <= v);  // mesh.h:351-357
-                    v = take ? gs : v;
-                    vm = take ? (m << 16) : vm;
-                    vs = take ? gsi : vs;
-                    const bool mtk = mt[k] < v;
-                    v = mtk ? mt[k] : v;
-                    vm = mtk ? mtp[k] : vm;
-                    vs = mtk ? s - 1 : vs;
+                    const float gsx = c.v + gi_cost;  // (left.v = +inf where nothing is to my left)
+                    const float a = min2_raw(gsx, dv[k]);
+                    v = min3_raw(gsx, dv[k], mt[k]);
+                    const bool take = gsx <= dv[k];    // mesh.h:351-357
+                    const bool mtk = mt[k] < a;        // :360-374
+                    vm = mtk ? mtp[k] : (take ? (m << 16) : vm);
+                    vs = mtk ? s - 1 : (take ? gsi_n : vs);
+                    gs = has_left ? gsx : 1.0f;
+                    gsi = has_left ? gsi_n : 0u;
                 }
                 fv[k] = v;
                 fvm[k] = vm;
@@ -355,14 +405,6 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
             ex = c;
         };
 
-        // speculative pass: pretend the cell to my left did not end in a gap and is so
-        // expensive that opening from it can never win.
-        ChainState left;
-        left.v = __builtin_inff();
-        left.e = 0;
-        left.gsi = 0;
-        left.gmax = 0;
-        run_chain(left);
         // lane 0 of wave > 0 knows its real left state already (published by the left wave)
         ChainState wave_left;
         wave_left.v = 0.f;
@@ -375,46 +417,59 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
             wave_left.gsi = pe_ & 0x7fffffffu;
             wave_left.gmax = FORBID ? xs_gmax[h] : 0u;
         }
-        // The speculation is exact unless the gap arriving from the left wins my first cell
-        // (gs <= value after deletions, and no match beats it): one add and two compares per
-        // lane verify that.  (With --insertion=forbid a cell that may NOT take a gap keeps its
-        // initial gaps_val, which the shortcut cannot see: always re-run there.)
-        bool rerun = true;
-        if constexpr (!FORBID) {
-            left.v = lane_shr1(ex.v);
-            left.e = lane_shr1(ex.e);
-            left.gsi = lane_shr1(ex.gsi);
-            if (lane == 0) left = wave_left;
-            bool take0 = false;
-            if (j > 0) {
-                const float g0 = left.v + (left.e ? ext_cost(s0, left.gsi) : r.gi_open);
-                take0 = (g0 <= dv[0]) && !(mt[0] < g0);
-            }
-            rerun = __any(take0);
-            if (SH_ABL(1)) rerun = false;
-        }
-        SH_PROF(4)
+        // "no gap enters from the left": the cell to my left did not end in a gap and is so
+        // expensive that opening from it can never win
+        ChainState none;
+        none.v = __builtin_inff();
+        none.e = none.gsi = none.gmax = 0;
+        ChainState left = none;
 #ifdef SINA_DP_PROFILE
         int it_ = 0;
 #endif
-        // Simple scheme: a gap that enters my cells from the left either runs through ALL of them
-        // (every cell: gap <= min(deletion, match) candidates) and leaves as the same gap, B adds
-        // later -- or it dies at some cell, and from that cell on everything is what the
-        // speculative pass computed (with gap_open >= gap_extend the speculative gap candidate of
-        // that cell is no smaller than the real one, so it lost there as well).  Exit states can
-        // therefore be propagated lane to lane with B adds and B compares per step instead of a
-        // full chain evaluation; one full evaluation with the converged left states finishes.
+        bool done = false;
+        // Simple scheme (gap_open >= gap_extend): a gap that enters my cells from the left either
+        // runs through ALL of them (every cell: gap <= min(deletion, match) candidates) and leaves
+        // as the same gap, B adds later -- or it dies at some cell, and from that cell on everything
+        // is what the cells compute without it (the gap candidate they see from their own left
+        // neighbour is no smaller than the real one, so it loses there as well).  So:
+        //   1. values only (no trace-back indices): my exit state sx if no gap enters;
+        //   2. exit states propagate lane to lane, B adds + B compares per step, until none changes
+        //      (to the right of the alignment diagonal whole stretches of a row are one insertion
+        //      run: 98 % of the rows need at least one step, 4.2 on average);
+        //   3. one full chain evaluation with the converged left states.
         if constexpr (!WEIGHTED && !FORBID) {
-            if (rerun && gp >= gpe) {
+            if (gp >= gpe && !SH_ABL(1)) {
                 float loc[B];
 #pragma unroll
-                for (int k = 0; k < B; k++) loc[k] = (mt[k] < dv[k]) ? mt[k] : dv[k];
-                const ChainState sx = ex;
+                for (int k = 0; k < B; k++) loc[k] = min2_raw(dv[k], mt[k]);
+                ChainState sx;
+                {
+                    float cv = __builtin_inff();
+                    uint32_t ce = 0, cgsi = 0;
+#pragma unroll
+                    for (int k = 0; k < B; k++) {
+                        const uint32_t s = s0 + k;
+                        const bool has_left = (k > 0) || (j > 0);
+                        const float gsx = cv + (ce ? gpe : gp);
+                        const uint32_t gsi_n = ce ? cgsi : s - 1;
+                        const float v = min2_raw(gsx, loc[k]);
+                        const float gs = has_left ? gsx : 1.0f;
+                        cv = v;
+                        ce = (gs == v) ? 1u : 0u;
+                        cgsi = has_left ? gsi_n : 0u;
+                    }
+                    sx.v = cv;
+                    sx.e = ce;
+                    sx.gsi = cgsi;
+                    sx.gmax = 0;
+                }
+                ex = sx;
+                SH_PROF(4)
                 for (int guard = 0; guard < (1 << 20); ++guard) {
-                    SH_PROF_CNT(10, 1)
-#ifdef SINA_DP_PROFILE
-                    it_++;
-#endif
+                    left.v = lane_shr1(ex.v);
+                    left.e = lane_shr1(ex.e);
+                    left.gsi = lane_shr1(ex.gsi);
+                    if (lane == 0) left = wave_left;
                     const ChainState prev = ex;
                     float g = left.v + (left.e ? gpe : gp);
                     bool pass = (j > 0) && (g <= loc[0]);
@@ -427,30 +482,54 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                     ex.e = pass ? 1u : sx.e;
                     ex.gsi = pass ? (left.e ? left.gsi : s0 - 1) : sx.gsi;
                     if (!__any(!same_state(ex, prev))) break;
-                    left.v = lane_shr1(ex.v);
-                    left.e = lane_shr1(ex.e);
-                    left.gsi = lane_shr1(ex.gsi);
-                    if (lane == 0) left = wave_left;
+                    SH_PROF_CNT(10, 1)
+#ifdef SINA_DP_PROFILE
+                    it_++;
+#endif
                 }
-                if (j > 0) run_chain(left);
-                rerun = false;
+                if (j == 0) left = none;
+                run_chain(left);
+                done = true;
             }
         }
-        // General case: re-run the chains with the real left states until no exit state changes.
-        if (rerun) {
-            for (int guard = 0; guard < (1 << 20); ++guard) {
-                SH_PROF_CNT(10, 1)
-#ifdef SINA_DP_PROFILE
-                it_++;
-#endif
-                const ChainState prev = ex;
+        // General case (weighted / forbid schemes): full chains, first without an incoming gap.
+        // The speculation is exact unless the gap arriving from the left wins my first cell
+        // (gs <= value after deletions, and no match beats it): one add and two compares per
+        // lane verify that.  (With --insertion=forbid a cell that may NOT take a gap keeps its
+        // initial gaps_val, which the shortcut cannot see: always re-run there.)  Then re-run the
+        // chains with the real left states until no exit state changes.
+        if (!done) {
+            run_chain(none);
+            bool rerun = true;
+            if constexpr (!FORBID) {
                 left.v = lane_shr1(ex.v);
                 left.e = lane_shr1(ex.e);
                 left.gsi = lane_shr1(ex.gsi);
-                left.gmax = FORBID ? lane_shr1(ex.gmax) : 0u;
                 if (lane == 0) left = wave_left;
-                if (j > 0) run_chain(left);
-                if (!__any(!same_state(ex, prev))) break;
+                bool take0 = false;
+                if (j > 0) {
+                    const float g0 = left.v + (left.e ? ext_cost(s0, left.gsi) : r.gi_open);
+                    take0 = (g0 <= dv[0]) && !(mt[0] < g0);
+                }
+                rerun = __any(take0);
+                if (SH_ABL(1)) rerun = false;
+            }
+            SH_PROF(4)
+            if (rerun) {
+                for (int guard = 0; guard < (1 << 20); ++guard) {
+                    SH_PROF_CNT(10, 1)
+#ifdef SINA_DP_PROFILE
+                    it_++;
+#endif
+                    const ChainState prev = ex;
+                    left.v = lane_shr1(ex.v);
+                    left.e = lane_shr1(ex.e);
+                    left.gsi = lane_shr1(ex.gsi);
+                    left.gmax = FORBID ? lane_shr1(ex.gmax) : 0u;
+                    if (lane == 0) left = wave_left;
+                    if (j > 0) run_chain(left);
+                    if (!__any(!same_state(ex, prev))) break;
+                }
             }
         }
 #ifdef SINA_DP_PROFILE
@@ -499,8 +578,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         const uint32_t n_ff = has_next ? (nrec.z >> 24) : 0u;
         if (n_ff != 0 && !SH_ABL(2)) {  // (no else: the registers keep their stale contents, never read)
             const float *row = spill + (size_t)((pred[nrec.x + n_ff - 1] >> 16) & 0x7FFFu) * (2 * Lp);
-            load_cells<B>(row + s0, pf_v);
-            load_cells<B>(row + Lp + s0, pf_g);
+            pf_v.load(row + s0);
+            pf_g.load(row + Lp + s0);
         }
 
         // ---- trace-back cells: the only per-cell HBM traffic
@@ -513,16 +592,16 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         if (dbg_value != nullptr && blockIdx.x == 0) store_cells<B>(dbg_value + (size_t)m * Lp + s0, fv);
 
         // ---- end-cell search, step 1: rows at the last query column (one lane)
-        if (own_last) {
+        if (w == w_last) {  // (wave-uniform: k_last is a scalar, one v_cndmask per cell)
             float v = fv[0];
 #pragma unroll
             for (int k = 1; k < B; k++) v = (k == k_last) ? fv[k] : v;
-            if (!lc_any || v < lc_min) {
+            if (own_last && (!lc_any || v < lc_min)) {
                 lc_min = v;
                 lc_arg = m;
                 lc_any = true;
             }
-            if (is_sink && !sk_any) lc_snk0 = v;  // value of sinks[0] at column L-1
+            if (own_last && is_sink && !sk_any) lc_snk0 = v;  // value of sinks[0] at column L-1
         }
         // step 2: sink rows x every column; each wave keeps the best of its own columns
         if (is_sink) {
@@ -560,11 +639,16 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         r = setup_row(nrec, mn);
         handshake(mn);
         SH_PROF(1)
-        init_cells(r);
+        if (r.npred == 0) init_cells(r);  // (otherwise the first predecessor's relax initialises)
         float csel[B];
 #pragma unroll
         for (int k = 0; k < B; k++) csel[k] = (r.mmask & qm[k]) ? r.cM : r.cX;  // comp(): optimistic IUPAC match (aligned_base.h:153)
-        auto relax = [&](uint32_t p, bool is_last, const float(&sv)[B], const float(&sg)[B], float svl) {
+        // (FIRST: the row's first predecessor meets the initial values -- constants -- instead of
+        // registers that would have to be initialised first)
+        const float iv0 = (j == 0) ? 1.0f : r.init_v;  // initial value of my cell 0 (column 0 starts at 1)
+        auto relax = [&](auto first_tag, uint32_t p, bool is_last, const Cells<B> &sv, const Cells<B> &sg,
+                         float svl) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             const uint32_t p_open = p << 16, p_ext = (p << 16) | kTbExt;
             uint32_t ob = 0;
 #pragma unroll
@@ -576,16 +660,18 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 const float cand = op ? v : g;
                 gm[k] = cand;
                 if (is_last) ob |= op ? (1u << k) : 0u;
-                const bool better = cand < dv[k];
-                dv[k] = better ? cand : dv[k];
-                dvm[k] = better ? (op ? p_open : p_ext) : dvm[k];
-                dvs[k] = better ? s0 + k : dvs[k];  // value_sidx of a deletion is the column itself
+                const float dv_old = FIRST ? (k == 0 ? iv0 : r.init_v) : dv[k];
+                const bool better = cand < dv_old;
+                dv[k] = better ? cand : dv_old;
+                dvm[k] = better ? (op ? p_open : p_ext) : (FIRST ? 0u : dvm[k]);
+                dvs[k] = better ? s0 + k : (FIRST ? 0u : dvs[k]);  // value_sidx of a deletion is the column itself
                 // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
                 const float pvv = (k == 0) ? svl : sv[k - 1];
                 const float mv = pvv + csel[k];
-                const bool mb = ((s0 + k) > 0) && (mv < mt[k]);
-                mt[k] = mb ? mv : mt[k];
-                mtp[k] = mb ? p_open : mtp[k];
+                const float mt_old = FIRST ? __builtin_inff() : mt[k];
+                const bool mb = ((s0 + k) > 0) && (mv < mt_old);
+                mt[k] = mb ? mv : mt_old;
+                mtp[k] = mb ? p_open : (FIRST ? 0u : mtp[k]);
             }
             if (is_last) oplast = ob;
         };
@@ -599,34 +685,32 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
             const uint32_t pe = pred[r.pb + e];
             const uint32_t p = pe & 0xffffu;
             const bool is_last = (e + 1 == r.npred);
-            float sv[B], sg[B];
+            Cells<B> sv, sg;
             float far_bnd = 0.f;
             if (pe & kPredSpilled) {
                 if (SH_ABL(2)) continue;
                 const float *row = spill + (size_t)((pe >> 16) & 0x7FFFu) * (2 * Lp);
                 if (e + 1 == r.first_far) {
-#pragma unroll
-                    for (int k = 0; k < B; k++) {
-                        sv[k] = pf_v[k];
-                        sg[k] = pf_g[k];
-                    }
+                    sv = pf_v;
+                    sg = pf_g;
                 } else {
-                    load_cells<B>(row + s0, sv);
-                    load_cells<B>(row + Lp + s0, sg);
+                    sv.load(row + s0);
+                    sg.load(row + Lp + s0);
                 }
                 if (lane == 0 && w > 0 && mn - p > (uint32_t)kFarLds) far_bnd = row[s0 - 1];
                 SH_PROF_CNT(9, 1)
             } else {
                 const unsigned char *slot = ring + (size_t)(pe >> 16) * kSlotBytes;
-                load_cells<B>(reinterpret_cast<const float *>(slot) + s0, sv);
-                load_cells<B>(reinterpret_cast<const float *>(slot + kValBytes) + s0, sg);
+                sv.load(reinterpret_cast<const float *>(slot) + s0);
+                sg.load(reinterpret_cast<const float *>(slot + kValBytes) + s0);
             }
             float svl = lane_shr1(sv[B - 1]);  // value[p][s0-1] lives in the lane to my left
             if (lane == 0 && w > 0) {
                 if (mn - p <= (uint32_t)kFarLds) svl = bnd_val[(w - 1) * kBndHist + (p & (kBndHist - 1))];
                 else svl = far_bnd;
             }
-            relax(p, is_last, sv, sg, svl);
+            if (e == 0) relax(std::true_type{}, p, is_last, sv, sg, svl);
+            else relax(std::false_type{}, p, is_last, sv, sg, svl);
         }
         SH_PROF(3)
     }
