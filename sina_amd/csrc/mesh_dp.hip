@@ -79,6 +79,20 @@ __device__ __forceinline__ float min3_raw(float a, float b, float c) {
     return r;
 }
 
+// plain v_add_f32 (the compiler otherwise pairs unrelated adds into v_pk_add_f32 and pays two
+// register moves per pair to line the operands up)
+__device__ __forceinline__ float add_raw(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// keeps a wave-uniform float in a VGPR as an opaque value (stops the compiler from re-deriving it
+// per use from its scalar inputs with vector multiplies)
+__device__ __forceinline__ float opaque_v(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // B consecutive floats as B/4 16-byte vectors: what a row read delivers, used in place (element
 // access with a compile-time index is a sub-register, no copy)
 template <int B>
@@ -640,9 +654,15 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         handshake(mn);
         SH_PROF(1)
         if (r.npred == 0) init_cells(r);  // (otherwise the first predecessor's relax initialises)
+        float gdo_v, gde_v;  // gap open / extend cost of a deletion, in VGPRs
         float csel[B];
+        {
+            const float vM = opaque_v(r.cM), vX = opaque_v(r.cX), vgo = opaque_v(r.gd_open), vge = opaque_v(r.gd_ext);
+            gdo_v = vgo;
+            gde_v = vge;
 #pragma unroll
-        for (int k = 0; k < B; k++) csel[k] = (r.mmask & qm[k]) ? r.cM : r.cX;  // comp(): optimistic IUPAC match (aligned_base.h:153)
+            for (int k = 0; k < B; k++) csel[k] = (r.mmask & qm[k]) ? vM : vX;  // comp(): optimistic IUPAC match (aligned_base.h:153)
+        }
         // (FIRST: the row's first predecessor meets the initial values -- constants -- instead of
         // registers that would have to be initialised first)
         const float iv0 = (j == 0) ? 1.0f : r.init_v;  // initial value of my cell 0 (column 0 starts at 1)
@@ -654,8 +674,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
 #pragma unroll
             for (int k = 0; k < B; k++) {
                 // deletion (mesh.h:307-330): gapm_* is overwritten by every predecessor
-                const float v = sv[k] + r.gd_open;
-                const float g = sg[k] + r.gd_ext;
+                const float v = add_raw(sv[k], gdo_v);
+                const float g = add_raw(sg[k], gde_v);
                 const bool op = v < g;
                 const float cand = op ? v : g;
                 gm[k] = cand;
@@ -667,7 +687,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                 dvs[k] = better ? s0 + k : (FIRST ? 0u : dvs[k]);  // value_sidx of a deletion is the column itself
                 // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
                 const float pvv = (k == 0) ? svl : sv[k - 1];
-                const float mv = pvv + csel[k];
+                const float mv = add_raw(pvv, csel[k]);
                 const float mt_old = FIRST ? __builtin_inff() : mt[k];
                 const bool mb = ((s0 + k) > 0) && (mv < mt_old);
                 mt[k] = mb ? mv : mt_old;
@@ -698,6 +718,15 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
                     sg.load(row + Lp + s0);
                 }
                 if (lane == 0 && w > 0 && mn - p > (uint32_t)kFarLds) far_bnd = row[s0 - 1];
+                // consume the global loads HERE: the compiler then waits for them (vmcnt) inside
+                // this rare branch instead of after the merge with the LDS path, where the wait
+                // would also drain the previous row's trace-back stores on every row
+#pragma unroll
+                for (int i = 0; i < B / 4; i++) {
+                    asm volatile("" : "+v"(sv.v[i]));
+                    asm volatile("" : "+v"(sg.v[i]));
+                }
+                asm volatile("" : "+v"(far_bnd));
                 SH_PROF_CNT(9, 1)
             } else {
                 const unsigned char *slot = ring + (size_t)(pe >> 16) * kSlotBytes;
