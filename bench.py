@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-graph", action="store_true", help="build family DAGs on the host")
+    ap.add_argument("--host-threads", type=int, default=0, help="threads of the host-side loop pool (0 = default)")
     return ap.parse_args()
 
 
@@ -121,7 +122,7 @@ def main():
         n_post = None
     idx_s = time.time() - t_idx
     al_opts = {"device-graph": not a.host_graph}
-    pl = pipeline.Pipeline(store, aligner=al_opts)
+    pl = pipeline.Pipeline(store, aligner=al_opts, host_threads=a.host_threads or None)
 
     def run_steps(first, count):
         lo, hi = qs.off[first * a.batch], qs.off[(first + count) * a.batch]

@@ -161,9 +161,13 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, uint32_t bq, uint64_t tb_ce
     a.gp = p->gap_penalty;
     a.gpe = p->gap_ext_penalty;
 
-    SH_CHECK(hipEventRecord(c->ev[0], s));
-    if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, s)) return 1;
-    SH_CHECK(hipEventRecord(c->ev[1], s));
+    {
+        std::lock_guard<std::mutex> token(c->st->dp_token);
+        SH_CHECK(hipEventRecord(c->ev[0], s));
+        if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, s)) return 1;
+        SH_CHECK(hipEventRecord(c->ev[1], s));
+        SH_CHECK(hipEventSynchronize(c->ev[1]));
+    }
     BtArgs b;
     b.qd = a.qd;
     b.rec = a.rec;
@@ -336,6 +340,7 @@ int sina_hip_fork(sina_hip_ctx *parent, sina_hip_ctx **ctx) {
     for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
     c->lds_budget = parent->lds_budget;
     c->tb_budget_bytes = parent->tb_budget_bytes;
+    if (c->adopt_hints()) return 1;
     *ctx = c;
     return 0;
 }
@@ -394,6 +399,7 @@ int sina_hip_align_graphs(sina_hip_ctx *c, const sina_hip_graph_batch *g, const 
                           uint32_t *out_pos) {
     if (!c) SH_FAIL("align_graphs: null ctx");
     std::lock_guard<std::mutex> lk(c->mu);
+    sina_hip_hint_guard hints(c);
     return align_graphs_impl(c, g, qmask, qoff, p, out, out_pos, nullptr, nullptr, nullptr);
 }
 

@@ -45,6 +45,15 @@ struct DevBuf {
         cap = want;
         return 0;
     }
+    int reserve_exact(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        SH_CHECK(hipMalloc(&p, bytes));
+        cap = bytes;
+        return 0;
+    }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;

@@ -14,6 +14,13 @@ struct sina_hip_store {
     uint64_t n_postings = 0, total_bases = 0;
     bool have_refs = false, have_index = false;
     std::mutex stats_mu;
+    // One DP kernel at a time per device: a DP launch fills every CU by itself, and contexts that
+    // all reach their DP phase together would otherwise run in lock-step (GPU idle while all of
+    // them are in their host phases).  Holding this while the DP kernel runs staggers them.
+    std::mutex dp_token;
+    // largest capacity any context has needed for each scratch buffer so far: a new fork reserves
+    // these at once (hipMalloc / hipFree synchronise the device; never in steady state)
+    size_t cap_hint[32] = {};
     sina_hip_stats stats;
 };
 
@@ -35,12 +42,38 @@ struct sina_hip_ctx {
     size_t lds_budget = 40 * 1024;
     uint64_t tb_budget_bytes = (uint64_t)24 << 30;
 
+    static constexpr int kNumScratch = 28;
+    void scratch(sina_hip::DevBuf **all) {
+        sina_hip::DevBuf *list[kNumScratch] = {&qd, &rec, &node_pos, &pred, &succ_minpos, &qmask, &tb, &spill, &res,
+                                               &weights, &out, &out_pos, &k_qoff, &k_scores, &k_out_ids,
+                                               &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2, &g_fam_ids,
+                                               &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab};
+        for (int i = 0; i < kNumScratch; i++) all[i] = list[i];
+    }
+    void publish_hints() {  // after a call: remember how big my buffers had to be
+        sina_hip::DevBuf *all[kNumScratch];
+        scratch(all);
+        std::lock_guard<std::mutex> lk(st->stats_mu);
+        for (int i = 0; i < kNumScratch; i++)
+            if (all[i]->cap > st->cap_hint[i]) st->cap_hint[i] = all[i]->cap;
+    }
+    int adopt_hints() {  // new fork: size everything like the biggest context so far
+        sina_hip::DevBuf *all[kNumScratch];
+        scratch(all);
+        size_t want[kNumScratch];
+        {
+            std::lock_guard<std::mutex> lk(st->stats_mu);
+            for (int i = 0; i < kNumScratch; i++) want[i] = st->cap_hint[i];
+        }
+        for (int i = 0; i < kNumScratch; i++)
+            if (want[i] > all[i]->cap && all[i]->reserve_exact(want[i])) return 1;
+        return 0;
+    }
     void free_all() {
-        sina_hip::DevBuf *all[] = {&qd, &rec, &node_pos, &pred, &succ_minpos,
-                                   &qmask, &tb, &spill, &res, &weights, &out, &out_pos, &dbg, &k_qoff,
-                                   &k_scores, &k_out_ids, &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2,
-                                   &g_fam_ids, &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab};
+        sina_hip::DevBuf *all[kNumScratch];
+        scratch(all);
         for (auto *b : all) b->release();
+        dbg.release();
         if (owns_store && st) {
             st->ref_ab.release();
             st->ref_off.release();
@@ -50,4 +83,11 @@ struct sina_hip_ctx {
         }
         st = nullptr;
     }
+};
+
+// publishes the context's scratch capacities when an API call ends (see sina_hip_store::cap_hint)
+struct sina_hip_hint_guard {
+    sina_hip_ctx *c;
+    explicit sina_hip_hint_guard(sina_hip_ctx *c) : c(c) {}
+    ~sina_hip_hint_guard() { c->publish_hints(); }
 };

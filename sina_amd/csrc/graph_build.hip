@@ -524,6 +524,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
     if (!c || !fam_ids || !fam_off || !qmask || !qoff || !p || !out || !out_pos)
         SH_FAIL("align_families: null argument");
     std::lock_guard<std::mutex> lk(c->mu);
+    sina_hip_hint_guard hints(c);
     if (!c->st->have_refs) SH_FAIL("align_families: upload references first");
     if (nq == 0) return 0;
     SH_CHECK(hipSetDevice(c->device));

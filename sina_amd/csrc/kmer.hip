@@ -532,6 +532,7 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
                        uint32_t *out_ids, float *out_scores, uint32_t *out_n) {
     if (!c || !qmask || !qoff || !out_ids || !out_scores || !out_n) SH_FAIL("kmer_topk: null argument");
     std::lock_guard<std::mutex> lk(c->mu);
+    sina_hip_hint_guard hints(c);
     if (index_ready(c)) return 1;
     if (nq == 0) return 0;
     SH_CHECK(hipSetDevice(c->device));
