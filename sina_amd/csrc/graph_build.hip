@@ -43,6 +43,18 @@ constexpr uint32_t kNoPrev = 0xFFFFu;
 constexpr int kMaxFam = 128;
 constexpr int kTC = 128;          // occupied columns per LDS tile
 
+#ifdef SINA_DP_PROFILE
+// profiling build (make PROFILE=1): per-phase s_memtime totals of thread 0, tools/perf_graph.py
+__device__ unsigned long long g_graph_prof[16];
+#define GP_DECL unsigned long long gp_[16] = {}; unsigned long long gt_ = __builtin_amdgcn_s_memtime();
+#define GP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); gp_[i] += t_ - gt_; gt_ = t_; }
+#define GP_FLUSH if (threadIdx.x == 0) { for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_graph_prof[i_], gp_[i_]); }
+#else
+#define GP_DECL
+#define GP(i)
+#define GP_FLUSH
+#endif
+
 struct GraphArgs {
     const uint32_t *ref_ab;
     const uint64_t *ref_off;
@@ -131,6 +143,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
     }
     for (uint32_t i = tid; i < nwords; i += kGT) bitmap[i] = 0;
     __syncthreads();
+    GP_DECL
 
     // 1. occupied columns
     for (uint32_t j = 0; j < F; j++) {
@@ -141,6 +154,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         }
     }
     __syncthreads();
+    GP(0)
     // 2. dense column index: rank(pos) = wrank[pos >> 5] + popc(bits below)
     {
         const uint32_t chunk = (nwords + kGT - 1) / kGT;
@@ -192,6 +206,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
     }
     const float *wt = a.wtab + (size_t)F * (kMaxFam + 1);
     uint32_t N = 0, E = 0;  // running totals (uniform)
+    GP(1)
 
     for (uint32_t c0 = 0; c0 < NC; c0 += kTC) {
         const uint32_t tc = min((uint32_t)kTC, NC - c0);
@@ -200,6 +215,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
             for (uint32_t i = tid; i < (uint32_t)kTC * FS / 2; i += kGT) z[i] = 0;
         }
         __syncthreads();
+        GP(2)
         // 3a. masks of this tile: member j's bases cur[j].. as long as their column is in the tile
         for (uint32_t idx = tid; idx < F * (uint32_t)kTC; idx += kGT) {
             const uint32_t j = idx / kTC, i = s_cur[j] + idx % kTC;
@@ -215,6 +231,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
             if (i + 1 >= s_len[j] || rank(b[i + 1] & 0xFFFFFFu) - c0 >= tc) s_curn[j] = i + 1;
         }
         __syncthreads();
+        GP(3)
         // 3b. per column: nodes in order of first appearance (family order), raw edge count
         for (uint32_t c = tid; c < tc; c += kGT) {
             uint32_t seen = 0;          // bit m: mask value m already has a node in this column
@@ -244,8 +261,10 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
             rc[c] = (uint8_t)raw;
         }
         __syncthreads();
+        GP(4)
         const uint32_t tn = block_exscan(nn, nbaseT, tc, s_tmp);
         const uint32_t te = block_exscan(rc, ebaseT, tc, s_tmp);
+        GP(5)
         // 4. node of every base's predecessor base
         for (uint32_t idx = tid; idx < F * (uint32_t)kTC; idx += kGT) {
             const uint32_t j = idx / kTC, i = s_cur[j] + idx % kTC;
@@ -267,6 +286,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
             if (i + 1 == s_curn[j]) s_carryn[j] = node;
         }
         __syncthreads();
+        GP(6)
         // 5. node records + sorted unique predecessor lists
         for (uint32_t c = tid; c < tc; c += kGT) {
             const uint16_t *rowm = tabm + c * FS;
@@ -277,6 +297,12 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
             for (uint32_t k = 0; k < knodes; k++) {
                 const uint32_t node = N + nbaseT[c] + k;
                 uint32_t cnt = 0, np = 0, rawk = 0, mask = 0;
+                // sorted unique predecessor ids, first in registers (8 cover all but freak
+                // columns): no read-modify-write round trips to the CSR segment in HBM
+                uint32_t pl[8];
+#pragma unroll
+                for (int t8 = 0; t8 < 8; t8++) pl[t8] = 0xFFFFFFFFu;
+                bool overflow = false;
                 for (uint32_t j = 0; j < F; j++) {
                     const uint32_t t = rowm[j];
                     if ((t & 0xFFu) == 0 || ((t >> 8) & 31u) != k) continue;
@@ -284,17 +310,44 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
                     cnt++;
                     if (t & (1u << 13)) continue;
                     rawk++;
-                    if (node >= a.ncap) continue;
-                    const uint32_t pa = rowp[j];
-                    // sorted unique insert into pred[seg .. seg+np)
-                    uint32_t x = 0;
-                    while (x < np && pred[seg + x] < pa) x++;
-                    if (x < np && pred[seg + x] == pa) continue;
-                    for (uint32_t y = np; y > x; y--) pred[seg + y] = pred[seg + y - 1];
-                    pred[seg + x] = pa;
-                    np++;
-                    atomicMin(&smin[pa], pos);
-                    atomicMax(&last[pa], node);
+                    uint32_t x = rowp[j];
+#pragma unroll
+                    for (int t8 = 0; t8 < 8; t8++) {  // bubble x into place; a duplicate turns into the pad value
+                        const uint32_t y = pl[t8];
+                        if (x == y) x = 0xFFFFFFFFu;
+                        const bool sw = x < y;
+                        pl[t8] = sw ? x : y;
+                        x = sw ? y : x;
+                    }
+                    overflow = overflow || (x != 0xFFFFFFFFu);
+                }
+                if (node < a.ncap) {
+                    if (!overflow) {
+#pragma unroll
+                        for (int t8 = 0; t8 < 8; t8++) {
+                            const uint32_t pa = pl[t8];
+                            if (pa != 0xFFFFFFFFu) {
+                                pred[seg + np] = pa;
+                                np++;
+                                atomicMin(&smin[pa], pos);
+                                atomicMax(&last[pa], node);
+                            }
+                        }
+                    } else {  // more than 8 distinct predecessors: insertion sort in the segment itself
+                        for (uint32_t j = 0; j < F; j++) {
+                            const uint32_t t = rowm[j];
+                            if ((t & 0xFFu) == 0 || ((t >> 8) & 31u) != k || (t & (1u << 13))) continue;
+                            const uint32_t pa = rowp[j];
+                            uint32_t x = 0;
+                            while (x < np && pred[seg + x] < pa) x++;
+                            if (x < np && pred[seg + x] == pa) continue;
+                            for (uint32_t y = np; y > x; y--) pred[seg + y] = pred[seg + y - 1];
+                            pred[seg + x] = pa;
+                            np++;
+                            atomicMin(&smin[pa], pos);
+                            atomicMax(&last[pa], node);
+                        }
+                    }
                 }
                 if (node < a.ncap) {
                     uint4 r;
@@ -316,6 +369,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         N += tn;
         E += te;
         __syncthreads();
+        GP(7)
     }
     if (N > a.ncap || N > 65535u) {
         if (tid == 0) {
@@ -325,6 +379,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         }
         return;
     }
+    GP(8)
     // 6. sinks, successor minimum, fence flag
     for (uint32_t i = tid; i < N; i += kGT) {
         uint32_t z = rec[i].z;
@@ -336,13 +391,14 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         rec[i].z = z;
     }
     __syncthreads();
+    GP(9)
     // 7. where every finished DP row is kept for its successors: LDS slots by liveness (first slot
     // whose row has seen its last successor), otherwise a spill row.  Inherently sequential over
     // the rows; one wave walks them 64 at a time (coalesced loads, wave-uniform bookkeeping).
     if (tid < 64) {
-        uint32_t free_at[8];
-#pragma unroll
-        for (int x = 0; x < 8; x++) free_at[x] = (x < a.W) ? 0u : 0xFFFFFFFFu;
+        // lane x < W holds free_at[x] = the last successor of the row in slot x (0: empty);
+        // "first free slot" is then one vector compare + find-first-set on the ballot
+        uint32_t fa = ((int)tid < a.W) ? 0u : 0xFFFFFFFFu;
         uint32_t nsp = 0;
         for (uint32_t m0 = 0; m0 < N; m0 += 64) {
             const uint32_t mi = m0 + tid;
@@ -357,17 +413,12 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
                 const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)s_c, (int)i);
                 if (sk == 1) continue;
                 const uint32_t m = m0 + i;
-                int slot = -1;
-                if (sk == 0) {  // (a row with a successor beyond kFarLds must be a spill row)
-#pragma unroll
-                    for (int x = 7; x >= 0; x--)
-                        if (free_at[x] <= m) slot = x;
-                }
+                const unsigned long long free_mask = __ballot(fa <= m);
                 uint32_t wv;
-                if (slot >= 0) {
-#pragma unroll
-                    for (int x = 0; x < 8; x++) free_at[x] = (x == slot) ? li : free_at[x];
-                    wv = (uint32_t)slot;
+                if (sk == 0 && free_mask != 0ull) {  // (a row with a successor beyond kFarLds must be a spill row)
+                    const uint32_t slot = (uint32_t)__ffsll((long long)free_mask) - 1u;
+                    fa = (tid == slot) ? li : fa;
+                    wv = slot;
                 } else {
                     wv = kRowSpilled | nsp++;
                 }
@@ -383,6 +434,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         }
     }
     __syncthreads();
+    GP(10)
     // 8. predecessor entries for the DP kernel: id | (LDS slot or spill row) << 16 | spilled << 31
     for (uint32_t i = tid; i < N; i += kGT) {
         const uint4 r = rec[i];
@@ -397,6 +449,8 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         }
         rec[i].z = r.z | (first_far << 24);
     }
+    GP(11)
+    GP_FLUSH
 }
 
 size_t graph_lds_bytes(uint32_t width, uint32_t max_family) {
@@ -585,6 +639,17 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
     }
     return 0;
 }
+
+#ifdef SINA_DP_PROFILE
+int sina_hip_debug_graph_profile(unsigned long long *out16, int reset) {
+    SH_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_graph_prof), sizeof(unsigned long long) * 16));
+    if (reset) {
+        unsigned long long z[16] = {};
+        SH_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_graph_prof), z, sizeof z));
+    }
+    return 0;
+}
+#endif
 
 int sina_hip_debug_family_graph(sina_hip_ctx *c, const uint32_t *fam_ids, uint32_t F, float fs_weight,
                                 uint32_t ring_depth, uint32_t *n_nodes, uint32_t *n_edges, uint32_t *pos,
