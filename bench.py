@@ -36,7 +36,7 @@ DP_BYTES_PER_CELL = 8          # two u32 trace-back indices per me
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="queries per step and rank")
     ap.add_argument("--refs", type=int, default=100000)
@@ -164,6 +164,14 @@ def main():
     dp_launches = s1["dp_launches"] - s0["dp_launches"]
     achieved = DP_BYTES_PER_CELL * dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
 
+    # HBM bytes per DP launch from the PMC passes of this same command (tools/prof_bench.sh ->
+    # profiles/r01_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); null if not collected
+    dp_traffic = None
+    try:
+        tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")))
+        dp_traffic = tj["mesh_dp_kernel"]["hbm_bytes"]
+    except Exception:
+        pass
     if rank == 0 and os.environ.get("SINA_HOST_PROFILE"):
         print(pl.profile(), file=sys.stderr)
     if rank == 0:
@@ -199,7 +207,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": dp_traffic,
+                "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_traffic.json)",
+                "algorithmic_bytes_per_launch": DP_BYTES_PER_CELL * dp_cells / dp_launches if dp_launches else 0,
                 "cells_per_launch": dp_cells / dp_launches if dp_launches else 0,
                 "ms_per_launch": dp_ms / dp_launches if dp_launches else 0,
                 "gcells_per_s": dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0,

@@ -37,3 +37,14 @@ for k in sorted(agg):
 out = "\n".join(lines)
 print(out)
 open(os.path.join(d, "summary.txt"), "w").write(out + "\n")
+# machine-readable per-launch HBM bytes (FETCH_SIZE x2-corrected + WRITE_SIZE) for bench.py's roofline.traffic
+import json
+js = {}
+for k in agg:
+    f = agg[k].get("FETCH_SIZE", 0.0) * 1024 / max(1, len(cnt[(k, "FETCH_SIZE")]))
+    w = agg[k].get("WRITE_SIZE", 0.0) * 1024 / max(1, len(cnt[(k, "WRITE_SIZE")]))
+    name = next((n for n in ("mesh_dp_kernel", "backtrack_kernel", "family_graph_kernel", "kmer_count_kernel",
+                             "kmer_select_kernel", "ref_kmer_keys", "mark_unique", "scatter_unique") if n in k), k[:48])
+    js[name] = {"fetch_bytes_raw": f, "fetch_bytes_x2": 2 * f, "write_bytes": w, "hbm_bytes": 2 * f + w,
+                "launches": len(cnt[(k, "WRITE_SIZE")])}
+json.dump(js, open(os.path.join(d, "traffic.json"), "w"), indent=1)
