@@ -1,0 +1,173 @@
+"""GPU parity at the edges of the path: degenerate sizes, the largest DP geometry, error returns of
+the C ABI, and size-independent properties at full-length scale (self-alignment, determinism)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from sina_amd import capi, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _cseq(name, masks):
+    m = np.asarray(masks, np.uint8)
+    ab = np.arange(len(m), dtype=np.uint32) | (m.astype(np.uint32) << 24)
+    return po.Cseq.from_packed(name, ab, len(m)), m
+
+
+def _planes_equal(oracle, gpu_ctx, fam, q, qm, width, **opts):
+    cells = oracle.mesh_compute(fam, q, oracle.align_opts(**opts) if opts else None)
+    gb = gpu_ctx.graph_batch([util.graph_dict(fam)], width)
+    vm, vs, val = gpu_ctx.debug_mesh(gb, qm, gpu_ctx.params(**opts) if opts else None)
+    assert (util.f32_bits(val) == util.f32_bits(cells["value"])).all()
+    assert (vm == cells["value_midx"]).all() and (vs == cells["value_sidx"]).all()
+
+
+def test_tiny_queries_and_tiny_families(oracle, gpu_ctx):
+    """Queries of 1, 2, 3, 5 and 13 bases; families of one and of two (identical) references."""
+    refs = synth.make_refs(30, length=120, width=900, seed=301)
+    cs = util.cseqs_from_refs(refs)
+    rng = np.random.default_rng(302)
+    n_aligned = 0
+    for L in (1, 2, 3, 5, 13, 14):
+        q, qm = _cseq("tiny%d" % L, rng.choice([1, 2, 4, 8], size=L))
+        for fam in ([cs[3]], [cs[4], cs[4]], [cs[i] for i in (1, 7, 9, 20)]):
+            _planes_equal(oracle, gpu_ctx, fam, q, qm, refs.width)
+            want = oracle.align(fam, q, oracle.align_opts(realign=1))
+            gb = gpu_ctx.graph_batch([util.graph_dict(fam)], refs.width)
+            out, pos = gpu_ctx.align_graphs(gb, qm, np.array([0, L], np.uint64), gpu_ctx.params())
+            assert out[0]["status"] == 0
+            if want["status"] != 0:
+                continue  # the aligner drops family members that CONTAIN the query (align.cpp:337-348)
+            n_aligned += 1
+            aligned, _ = util.finish_alignment(qm, out[0], pos[:L], refs.width)
+            assert aligned == want["aligned"]
+    assert n_aligned >= 3
+
+
+def test_ragged_batch_mixed_lengths(oracle, gpu_ctx):
+    """One launch with query lengths from 17 to 700 against families of 1..40: every query picks its
+    own rows of the batch-wide geometry."""
+    refs = synth.make_refs(200, length=600, width=5000, seed=311, amb_rate=0.01)
+    cs = util.cseqs_from_refs(refs)
+    rng = np.random.default_rng(312)
+    graphs, qms, fams, qcs = [], [], [], []
+    for i, L in enumerate((19, 700, 17, 350, 33, 512, 64, 129)):
+        src = (refs.seq(int(rng.integers(refs.n))) >> 24) & 0x0f
+        # (short ones random: a piece of a reference would be CONTAINED in family members, which the
+        # aligner then removes from the family, align.cpp:337-348 -- not what this test is about)
+        m = np.resize(src, L).astype(np.uint8) if L >= 100 else rng.choice([1, 2, 4, 8], size=L).astype(np.uint8)
+        m[m == 0] = 1
+        q, qm = _cseq("rag%d" % i, m)
+        fam = [cs[j] for j in rng.choice(refs.n, size=int(rng.integers(1, 41)), replace=False)]
+        graphs.append(util.graph_dict(fam)); qms.append(qm); fams.append(fam); qcs.append(q)
+    qoff = np.zeros(len(qms) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(m) for m in qms])
+    out, pos = gpu_ctx.align_graphs(gpu_ctx.graph_batch(graphs, refs.width), np.concatenate(qms), qoff,
+                                    gpu_ctx.params())
+    for i, (fam, q) in enumerate(zip(fams, qcs)):
+        want = oracle.align(fam, q, oracle.align_opts(realign=1))
+        assert out[i]["status"] == want["status"] == 0
+        assert util.f32_bits(np.float32(out[i]["raw"]) / np.float32(out[i]["sum_weight"])) == util.f32_bits(want["score"])
+        aligned, _ = util.finish_alignment(qms[i], out[i], pos[int(qoff[i]):int(qoff[i + 1])], refs.width)
+        assert aligned == want["aligned"]
+
+
+def test_largest_geometry(oracle, gpu_ctx):
+    """A 5800-base query (the 512x12 geometry, 6144 columns) against a 3-member family of
+    6000-base references: ~70 M cells, planes bit-exact."""
+    refs = synth.make_refs(6, length=6000, width=40000, seed=321, n_clades=2)
+    cs = util.cseqs_from_refs(refs)
+    src = (refs.seq(2) >> 24) & 0x0f
+    q, qm = _cseq("long", src[100:5900])
+    _planes_equal(oracle, gpu_ctx, [cs[0], cs[2], cs[5]], q, qm, refs.width)
+
+
+def test_error_returns(oracle, gpu_ctx):
+    """The C ABI reports what it cannot do instead of computing something else."""
+    refs = synth.make_refs(140, length=100, width=700, seed=331)
+    cs = util.cseqs_from_refs(refs)
+    g = util.graph_dict([cs[0], cs[1]])
+    too_long = np.ones(6145, np.uint8)
+    with pytest.raises(capi.SinaHipError):
+        gpu_ctx.align_graphs(gpu_ctx.graph_batch([g], refs.width), too_long, np.array([0, 6145], np.uint64),
+                             gpu_ctx.params())
+    with pytest.raises(capi.SinaHipError):   # empty query
+        gpu_ctx.align_graphs(gpu_ctx.graph_batch([g], refs.width), np.ones(1, np.uint8), np.array([0, 0], np.uint64),
+                             gpu_ctx.params())
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    ids = np.arange(129, dtype=np.uint32)     # families are capped at 128 members
+    with pytest.raises(capi.SinaHipError):
+        gpu_ctx.align_families(ids, np.array([0, 129], np.uint64), np.ones(20, np.uint8),
+                               np.array([0, 20], np.uint64), gpu_ctx.params())
+    with pytest.raises(capi.SinaHipError):   # reference id out of range
+        gpu_ctx.align_families(np.array([5, 9999], np.uint32), np.array([0, 2], np.uint64), np.ones(20, np.uint8),
+                               np.array([0, 20], np.uint64), gpu_ctx.params())
+    fresh = capi.Context(0)
+    with pytest.raises(capi.SinaHipError):   # k-mer search without an index
+        fresh.kmer_topk(np.ones(30, np.uint8), np.array([0, 30], np.uint64), 5)
+    fresh.close()
+
+
+def test_kmer_search_degenerate_queries(oracle, gpu_ctx):
+    """Queries shorter than k, all-ambiguous queries, a query that IS a reference, and max larger
+    than the store: scores and (score desc, id desc) order as the oracle's."""
+    refs = synth.make_refs(300, length=200, width=1500, seed=341, amb_rate=0.02)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    gpu_ctx.build_index(10, False)
+    rng = np.random.default_rng(342)
+    masks = [rng.choice([1, 2, 4, 8], size=5), rng.choice([1, 2, 4, 8], size=10), np.full(40, 15),
+             (refs.seq(17) >> 24) & 0x0f, rng.choice([1, 2, 4, 8, 5, 15], size=90)]
+    qoff = np.zeros(len(masks) + 1, np.int64)
+    qoff[1:] = np.cumsum([len(m) for m in masks])
+    flat = np.concatenate(masks).astype(np.uint8)
+    for mx in (1, 7, 300, 1000):
+        gi, gs, gn = gpu_ctx.kmer_topk(flat, qoff, mx)
+        for qi, m in enumerate(masks):
+            q, _ = _cseq("d%d" % qi, m)
+            oi, os_ = idx.find(q, mx)
+            assert gn[qi] == len(oi)
+            assert (gi[qi, :gn[qi]] == oi).all() and (gs[qi, :gn[qi]] == os_).all()
+    assert gpu_ctx.kmer_topk(flat, qoff, 1)[0][3, 0] == 17     # the reference finds itself first
+
+
+def test_full_length_properties(oracle, gpu_ctx):
+    """Size-independent properties on full-length 16S-shaped inputs (no oracle run: too large to be
+    quick on the CPU): a reference aligned against a family that contains it lands (almost
+    entirely) on its own columns, in order; the same batch twice gives identical bytes; results do not
+    depend on how the batch is cut into launches."""
+    refs = synth.make_refs(3000, length=1500, width=50000, seed=351)
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    gpu_ctx.build_index(10, False)
+    pick = np.arange(0, 3000, 125)                        # 24 references as queries
+    masks = [((refs.seq(int(i)) >> 24) & 0x0f).astype(np.uint8) for i in pick]
+    qoff = np.zeros(len(masks) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(m) for m in masks])
+    flat = np.concatenate(masks)
+    ids, sc, n = gpu_ctx.kmer_topk(flat, qoff, 40)
+    assert all(ids[q, 0] == pick[q] for q in range(len(pick)))          # each finds itself first
+    fam = [np.asarray(ids[q, :n[q]], np.uint32) for q in range(len(pick))]
+    foff = np.zeros(len(pick) + 1, np.uint64)
+    foff[1:] = np.cumsum([len(f) for f in fam])
+    out, pos = gpu_ctx.align_families(np.concatenate(fam), foff, flat, qoff, gpu_ctx.params())
+    for q, i in enumerate(pick):
+        cols = (refs.seq(int(i)) & 0xFFFFFF).astype(np.uint32)
+        a, b = int(qoff[q]), int(qoff[q + 1])
+        assert out[q]["status"] == 0 and out[q]["n_out"] == b - a
+        # backtrack emits the columns from the last base to the first, counted from the right edge.
+        # (Not necessarily ALL on its own columns: a better-conserved neighbouring column can score
+        # higher than the reference's own, the node weight grows with the members sharing it.)
+        got = refs.width - 1 - pos[a:b][::-1]
+        assert (got == cols).mean() > 0.98
+        assert (np.diff(got.astype(np.int64)) >= 0).all()
+        assert out[q]["cutoff_head"] == 0 and out[q]["cutoff_tail"] == 0
+    out2, pos2 = gpu_ctx.align_families(np.concatenate(fam), foff, flat, qoff, gpu_ctx.params())
+    assert out.tobytes() == out2.tobytes() and (pos == pos2).all()
+    for q in (0, 7, 23):                                                   # one query per launch
+        o1, p1 = gpu_ctx.align_families(fam[q], np.array([0, len(fam[q])], np.uint64), masks[q],
+                                        np.array([0, len(masks[q])], np.uint64), gpu_ctx.params())
+        assert o1[0].tobytes() == out[q].tobytes()
+        assert (p1[:len(masks[q])] == pos[int(qoff[q]):int(qoff[q + 1])]).all()
