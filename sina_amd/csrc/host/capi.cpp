@@ -8,6 +8,8 @@
 
 #include "stages.h"
 
+#include <memory>
+
 using namespace sina;
 
 namespace {
@@ -152,8 +154,10 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                     const uint32_t b1 = std::min(nq, b0 + batch);
                     const auto t_in = std::chrono::steady_clock::now();
                     std::vector<tray> trays(b1 - b0);
-                    for (uint32_t q = b0; q < b1; q++) {
-                        tray &t = trays[q - b0];
+                    std::unique_ptr<host_phase> hp(new host_phase("drv.build_trays"));
+                    parallel_for(b1 - b0, [&](size_t i) {  // (what SINA's reader stage does per sequence)
+                        const uint32_t q = b0 + (uint32_t)i;
+                        tray &t = trays[i];
                         t.seqno = q;
                         const std::string name = "query" + std::to_string(q);
                         t.input_sequence = new cseq(name.c_str());
@@ -161,7 +165,8 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                             t.input_sequence->append(
                                 aligned_base((uint32_t)(x - qoff[q]), base_iupac::from_mask(qmask[x])));
                         t.input_sequence->setWidth((uint32_t)(qoff[q + 1] - qoff[q]));
-                    }
+                    });
+                    hp.reset();
                     const auto a = std::chrono::steady_clock::now();
                     p->ff(trays);
                     const auto b = std::chrono::steady_clock::now();
@@ -169,8 +174,10 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                     const auto c = std::chrono::steady_clock::now();
                     ff_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
                     al_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(c - b).count();
-                    for (uint32_t q = b0; q < b1; q++) {
-                        tray &t = trays[q - b0];
+                    hp.reset(new host_phase("drv.extract"));
+                    parallel_for(b1 - b0, [&](size_t i) {  // (what SINA's writer stage does per sequence)
+                        const uint32_t q = b0 + (uint32_t)i;
+                        tray &t = trays[i];
                         result &r = p->results[q];
                         r.log = t.log.str();
                         r.family = t.input_sequence->get_attr<std::string>(fn::family);
@@ -184,7 +191,8 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                             r.status = (r.log.find("copied alignment from") != std::string::npos) ? 1 : 0;
                         }
                         t.destroy();
-                    }
+                    });
+                    hp.reset();
                 }
             } catch (...) {
                 std::lock_guard<std::mutex> lk(err_mu);

@@ -27,6 +27,16 @@ struct prof_state {
     std::mutex mu;
     std::map<std::string, std::pair<double, uint64_t>> acc;
     bool on = getenv("SINA_HOST_PROFILE") != nullptr;
+    // SINA_HOST_TRACE=<file>: every phase as "thread name t0 t1" (seconds), to see what the batches
+    // in flight are doing while the GPU idles
+    const char *trace_path = getenv("SINA_HOST_TRACE");
+    struct ev {
+        size_t tid;
+        const char *name;
+        double t0, t1;
+    };
+    std::vector<ev> events;
+    std::chrono::steady_clock::time_point origin = std::chrono::steady_clock::now();
 };
 prof_state &prof() {
     static prof_state p;
@@ -38,15 +48,24 @@ struct scoped_phase {
     explicit scoped_phase(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
     ~scoped_phase() {
         prof_state &p = prof();
-        if (!p.on) return;
-        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (!p.on && !p.trace_path) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        const double s = std::chrono::duration<double>(t1 - t0).count();
         std::lock_guard<std::mutex> lk(p.mu);
+        if (p.trace_path)
+            p.events.push_back({std::hash<std::thread::id>()(std::this_thread::get_id()) % 9973, name,
+                                std::chrono::duration<double>(t0 - p.origin).count(),
+                                std::chrono::duration<double>(t1 - p.origin).count()});
+        if (!p.on) return;
         auto &e = p.acc[name];
         e.first += s;
         e.second++;
     }
 };
 }  // namespace
+
+host_phase::host_phase(const char *n) : impl(new scoped_phase(n)) {}
+host_phase::~host_phase() { delete static_cast<scoped_phase *>(impl); }
 
 std::string host_profile_dump(bool reset) {
     prof_state &p = prof();
@@ -59,6 +78,12 @@ std::string host_profile_dump(bool reset) {
         out += buf;
     }
     if (reset) p.acc.clear();
+    if (p.trace_path && !p.events.empty()) {
+        if (FILE *f = fopen(p.trace_path, "w")) {
+            for (auto &e : p.events) fprintf(f, "%zu %s %.6f %.6f\n", e.tid, e.name, e.t0, e.t1);
+            fclose(f);
+        }
+    }
     return out;
 }
 

@@ -322,6 +322,15 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn);
 void set_host_threads(unsigned n);
 unsigned host_threads();
 std::string host_profile_dump(bool reset);  // per-phase wall time when SINA_HOST_PROFILE is set
+class host_phase {                           // a named phase of the calling thread (profile / SINA_HOST_TRACE)
+public:
+    explicit host_phase(const char *name);
+    ~host_phase();
+    host_phase(const host_phase &) = delete;
+
+private:
+    void *impl;
+};
 
 // Family DAG on the host (flat CSR) -- used when aligner option device_graph is off
 // and by tests; see src/mseq.cpp:47-118 for the behaviour it reproduces.
