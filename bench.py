@@ -43,8 +43,8 @@ def parse():
     ap.add_argument("--length", type=int, default=1500)
     ap.add_argument("--width", type=int, default=50000)
     ap.add_argument("--window", type=int, default=0, help="cut queries to this many bases (V4: 250)")
-    ap.add_argument("--inflight", type=int, default=4, help="batches worked on concurrently per rank")
-    ap.add_argument("--sub-batch", type=int, default=1024, help="queries per GPU launch inside a step")
+    ap.add_argument("--inflight", type=int, default=3, help="batches worked on concurrently per rank")
+    ap.add_argument("--sub-batch", type=int, default=2048, help="queries per GPU launch inside a step")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-graph", action="store_true", help="build family DAGs on the host")

@@ -124,7 +124,7 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
 
 // Runs DP + backtrack for bq queries whose graphs (qd, rec, pred, node_pos, succ_minpos) and
 // query masks are already in the context's device buffers; copies results back.
-int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, uint32_t bq, uint64_t tb_cells, uint64_t spill_rows,
+int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint32_t bq, uint64_t tb_cells, uint64_t spill_rows,
                   uint64_t cells, uint64_t nqm, const sina_hip_align_params *p, uint32_t width,
                   sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value) {
     hipStream_t s = c->stream;
@@ -143,8 +143,17 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, uint32_t bq, uint64_t tb_ce
         c->out_pos.reserve(4 * std::max<uint64_t>(nqm, 1)))
         return 1;
     if (want_dbg_value && c->dbg.reserve(4 * tb_cells)) return 1;
+    // longest queries first (workgroups start in index order; see mesh_dp_kernel)
+    std::vector<uint32_t> order(bq);
+    for (uint32_t q = 0; q < bq; q++) order[q] = q;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        return (uint64_t)qd_host[x].N * qd_host[x].L > (uint64_t)qd_host[y].N * qd_host[y].L;
+    });
+    if (c->order.reserve(4 * (size_t)bq)) return 1;
+    SH_CHECK(hipMemcpyAsync(c->order.p, order.data(), 4 * (size_t)bq, hipMemcpyHostToDevice, s));
     DpArgs a;
     a.qd = c->qd.as<QDesc>();
+    a.order = c->order.as<uint32_t>();
     a.rec = c->rec.as<uint4>();
     a.pred = c->pred.as<uint32_t>();
     a.node_pos = c->node_pos.as<uint32_t>();
@@ -262,7 +271,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         if (g->succ_minpos)
             SH_CHECK(hipMemcpyAsync(c->succ_minpos.p, g->succ_minpos + nbase, 4 * nn, hipMemcpyHostToDevice, s));
         SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qbase, nqm, hipMemcpyHostToDevice, s));
-        if (run_dp_device(c, pl, bq, hp.tb_cells, hp.spill_rows, hp.cells, nqm, p, g->width, out + q0,
+        if (run_dp_device(c, pl, hp.qd.data(), bq, hp.tb_cells, hp.spill_rows, hp.cells, nqm, p, g->width, out + q0,
                           out_pos + qbase, dbg_value_host != nullptr))
             return 1;
         if (dbg_vm) {  // single-query debug: unpack the planes
@@ -323,7 +332,7 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
     SH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
     c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 40) * 1024;
-    c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 24) << 30;
+    c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 48) << 30;
     memset(&c->st->stats, 0, sizeof(c->st->stats));
     *ctx = c;
     return 0;

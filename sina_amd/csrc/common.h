@@ -117,6 +117,7 @@ struct DpResult {
 
 struct DpArgs {
     const QDesc *qd;
+    const uint32_t *order;      // workgroup -> query (decreasing N*L)
     const uint4 *rec;
     const uint32_t *pred;
     const uint32_t *node_pos;
@@ -174,7 +175,7 @@ struct sina_hip_ctx;
 namespace sina_hip {
 int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl);
 int upload_weights(sina_hip_ctx *c, const sina_hip_align_params *p);
-int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, uint32_t bq, uint64_t tb_cells, uint64_t spill_rows,
+int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint32_t bq, uint64_t tb_cells, uint64_t spill_rows,
                   uint64_t cells, uint64_t nqm, const sina_hip_align_params *p, uint32_t width,
                   sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value);
 

@@ -34,20 +34,20 @@ struct sina_hip_ctx {
     bool owns_store = false;
 
     // per-batch scratch, grown on demand and reused
-    sina_hip::DevBuf qd, rec, node_pos, pred, succ_minpos, qmask, tb, spill, res, weights, out, out_pos, dbg;
+    sina_hip::DevBuf qd, order, rec, node_pos, pred, succ_minpos, qmask, tb, spill, res, weights, out, out_pos, dbg;
     sina_hip::DevBuf k_qoff, k_scores, k_out_ids, k_out_scores, k_out_n, k_tmp0, k_tmp1, k_tmp2;
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes, g_wtab;
     float wtab_fs_weight = NAN;  // fs_weight the device weight table was computed for
 
     size_t lds_budget = 40 * 1024;
-    uint64_t tb_budget_bytes = (uint64_t)24 << 30;
+    uint64_t tb_budget_bytes = (uint64_t)48 << 30;
 
-    static constexpr int kNumScratch = 28;
+    static constexpr int kNumScratch = 29;
     void scratch(sina_hip::DevBuf **all) {
         sina_hip::DevBuf *list[kNumScratch] = {&qd, &rec, &node_pos, &pred, &succ_minpos, &qmask, &tb, &spill, &res,
                                                &weights, &out, &out_pos, &k_qoff, &k_scores, &k_out_ids,
                                                &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2, &g_fam_ids,
-                                               &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab};
+                                               &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab, &order};
         for (int i = 0; i < kNumScratch; i++) all[i] = list[i];
     }
     void publish_hints() {  // after a call: remember how big my buffers had to be

@@ -180,7 +180,7 @@ __device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p) {
 
 template <int T, int B, bool WEIGHTED, bool FORBID>
 __global__ void __launch_bounds__(T, (B <= 4 ? 4 : (B <= 8 ? 3 : 2)))
-mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, const uint32_t *__restrict__ predv,
+mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ orderv, const uint4 *__restrict__ recv, const uint32_t *__restrict__ predv,
                const uint32_t *__restrict__ node_posv, const uint32_t *__restrict__ succ_minposv,
                const uint8_t *__restrict__ qmaskv, const float *__restrict__ weights, uint32_t n_weights,
                uint32_t *__restrict__ tbv, float *__restrict__ dbg_value, float *spillv,
@@ -194,7 +194,10 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
     const int j = threadIdx.x;
     const int lane = j & 63;
     const int w = j >> 6;
-    const QDesc d = qdv[blockIdx.x];
+    // workgroups are dispatched in blockIdx order: the launch lists the queries by decreasing work
+    // (longest first), so that a launch of more workgroups than the GPU holds at once ends evenly
+    const uint32_t qi = orderv[blockIdx.x];
+    const QDesc d = qdv[qi];
     const uint32_t N = d.N, L = d.L;
     const uint32_t s0 = (uint32_t)j * B;
 
@@ -603,7 +606,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
             for (int k = 0; k < B; k++) tc[k] = fvm[k] | fvs[k] | (((oplast >> k) & 1u) << 14);
             store_cells<B>(tb + (size_t)m * Lp + s0, tc);
         }
-        if (dbg_value != nullptr && blockIdx.x == 0) store_cells<B>(dbg_value + (size_t)m * Lp + s0, fv);
+        if (dbg_value != nullptr && qi == 0) store_cells<B>(dbg_value + (size_t)m * Lp + s0, fv);
 
         // ---- end-cell search, step 1: rows at the last query column (one lane)
         if (w == w_last) {  // (wave-uniform: k_last is a scalar, one v_cndmask per cell)
@@ -801,7 +804,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint4 *__restrict__ recv, co
         r.end_m = em;
         r.end_s = es;
         r.raw = ev;
-        resv[blockIdx.x] = r;
+        resv[qi] = r;
     }
 }
 
@@ -937,7 +940,7 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, size_t l
         auto kfn = mesh_dp_kernel<T, B, WG, FB>;                                                            \
         SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                               \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-        hipLaunchKernelGGL(kfn, dim3(nq), dim3(T), lds, s, a.qd, a.rec, a.pred, a.node_pos, a.succ_minpos, \
+        hipLaunchKernelGGL(kfn, dim3(nq), dim3(T), lds, s, a.qd, a.order, a.rec, a.pred, a.node_pos, a.succ_minpos, \
                            a.qmask, a.weights, a.n_weights, a.tb, a.dbg_value, a.spill, a.res, a.ms, a.mms, \
                            a.gp, a.gpe);                                                           \
     } while (0)
