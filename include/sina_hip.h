@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SINA_HIP_ABI_VERSION 1
+#define SINA_HIP_ABI_VERSION 2
 
 typedef struct sina_hip_ctx sina_hip_ctx;
 
@@ -110,6 +110,31 @@ int sina_hip_kmer_topk(sina_hip_ctx *ctx, const uint8_t *qmask, const uint64_t *
 /* Full score vector (score+offset of src/kmer_search.cpp:405-409) of one query
  * against every reference; for tests and the search_filter stage. */
 int sina_hip_kmer_scores(sina_hip_ctx *ctx, const uint8_t *qmask, uint32_t qlen, int16_t *scores);
+
+/* ------------------------------------------------------------- search stage
+ * Replaces the per-candidate cseq_comparator::operator() calls of search_filter::operator()
+ * (src/search_filter.cpp:311-313 and :274-276; traverse + match_counter,
+ * src/cseq_comparator.cpp:56-240): for every query (an ALIGNED sequence: packed aligned bases
+ * u32 = column | mask << 24, bit 4 of the mask = lower case) and every candidate reference of
+ * the store, the six counters the comparator derives its score from.  The float score itself
+ * ((float)match / base, Jukes-Cantor) stays with the caller, as in the reference.
+ *
+ *   q_ab/q_off     : concatenated packed aligned bases of the queries, offsets [nq+1]
+ *   cand_ids/off   : concatenated candidate reference ids per query, offsets [nq+1]
+ *   iupac_rule     : SINA_CMP_IUPAC_* (base_comp_optimistic / pessimistic / exact, query first)
+ *   filter_lowercase : filter_lowercase instead of filter_none
+ *   out            : [cand_off[nq]] counters
+ * Columns must ascend strictly within a sequence; a side without any unfiltered base gives
+ * all-zero counters (the reference dereferences end() there). */
+#define SINA_CMP_IUPAC_OPTIMISTIC 0
+#define SINA_CMP_IUPAC_PESSIMISTIC 1
+#define SINA_CMP_IUPAC_EXACT 2
+typedef struct sina_hip_match_counts {
+    int32_t only_a_overhang, only_b_overhang, only_a, only_b, match, mismatch;
+} sina_hip_match_counts;
+int sina_hip_compare(sina_hip_ctx *ctx, const uint32_t *q_ab, const uint64_t *q_off, uint32_t nq,
+                     const uint32_t *cand_ids, const uint64_t *cand_off, int iupac_rule, int filter_lowercase,
+                     sina_hip_match_counts *out);
 
 /* ------------------------------------------------------------- alignment
  * Replaces, for a batch of queries: mseq::mseq + sort + reduce_edges
@@ -214,6 +239,9 @@ typedef struct sina_hip_stats {
     uint64_t dp_cells;     /* sum of N*L over the batch               */
     uint64_t postings;     /* postings visited by the count kernel    */
     uint32_t dp_launches, kmer_launches;
+    double compare_ms;       /* search-stage comparison kernel            */
+    uint64_t compare_bases;  /* candidate bases streamed by it            */
+    uint32_t compare_launches, reserved;
 } sina_hip_stats;
 int sina_hip_get_stats(sina_hip_ctx *ctx, sina_hip_stats *s);
 

@@ -54,6 +54,22 @@ class Graph(C.Structure):
                 ("n_src", C.c_uint32), ("src", u32p), ("n_snk", C.c_uint32), ("snk", u32p)]
 
 
+class MatchCounts(C.Structure):
+    _fields_ = [("only_a_overhang", C.c_int), ("only_b_overhang", C.c_int), ("only_a", C.c_int),
+                ("only_b", C.c_int), ("match", C.c_int), ("mismatch", C.c_int)]
+
+
+class SearchOpts(C.Structure):
+    _fields_ = [("kmer_candidates", C.c_uint32), ("max_result", C.c_uint32), ("min_sim", C.c_float),
+                ("lca_quorum", C.c_float), ("ignore_super", C.c_int), ("search_all", C.c_int),
+                ("iupac", C.c_int), ("dist", C.c_int), ("cover", C.c_int), ("filter_lc", C.c_int)]
+
+
+IUPAC_RULES = {"optimistic": 0, "pessimistic": 1, "exact": 2}
+DIST_RULES = {"none": 0, "jc": 1}
+COVER_RULES = {"abs": 0, "query": 1, "target": 2, "overlap": 3, "all": 4, "average": 5, "min": 6, "max": 7,
+               "nogap": 8}
+
 CELL_DTYPE = np.dtype([("value_midx", "<u4"), ("value_sidx", "<u4"), ("gapm_idx", "<u4"),
                        ("gaps_idx", "<u4"), ("value", "<f4"), ("gapm_val", "<f4"), ("gaps_val", "<f4"),
                        ("gaps_max", "<u4")])
@@ -135,6 +151,18 @@ def lib():
                                    C.POINTER(AlignOpts), C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.so_log_init.argtypes = [C.POINTER(Log)]
         L.so_log_free.argtypes = [C.POINTER(Log)]
+        L.so_compare_counts.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(MatchCounts)]
+        L.so_compare_score.restype = C.c_float
+        L.so_compare_score.argtypes = [C.POINTER(MatchCounts), C.c_int, C.c_int]
+        L.so_compare.restype = C.c_float
+        L.so_compare.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.so_search_opts_default.argtypes = [C.POINTER(SearchOpts)]
+        L.so_search.restype = C.c_int
+        L.so_search.argtypes = [vp, C.POINTER(vp), C.c_uint32, vp, C.POINTER(SearchOpts), u32p, f32p, C.c_uint32,
+                                C.POINTER(Log)]
+        cpp = C.POINTER(C.c_char_p)
+        L.so_search_nearest.argtypes = [cpp, cpp, cpp, cpp, u32p, f32p, C.c_uint32, C.POINTER(Log)]
+        L.so_search_lca.argtypes = [cpp, C.c_uint32, C.c_float, C.POINTER(Log)]
         _lib = L
     return _lib
 
@@ -391,3 +419,80 @@ def bench_run(index, queries, threads, ff=None, al=None):
     sec = lib().so_bench_run(index.h, index._h, qh, len(queries), C.byref(ff), C.byref(al), threads,
                              C.byref(cells), C.byref(aligned))
     return dict(seconds=sec, cells=cells.value, aligned=aligned.value)
+
+
+# ---- section 8f-1: cseq_comparator + search_filter
+
+def compare_counts(a, b, iupac="optimistic", filter_lc=False):
+    """match_counter of traverse(a, b): (only_a_overhang, only_b_overhang, only_a, only_b, match, mismatch)."""
+    m = MatchCounts()
+    lib().so_compare_counts(a.h, b.h, IUPAC_RULES[iupac], int(filter_lc), C.byref(m))
+    return (m.only_a_overhang, m.only_b_overhang, m.only_a, m.only_b, m.match, m.mismatch)
+
+
+def compare(a, b, iupac="optimistic", dist="none", cover="query", filter_lc=False):
+    return np.float32(lib().so_compare(a.h, b.h, IUPAC_RULES[iupac], DIST_RULES[dist], COVER_RULES[cover],
+                                       int(filter_lc)))
+
+
+def compare_score(counts, cover="query", dist="none"):
+    m = MatchCounts(*[int(x) for x in counts])
+    return np.float32(lib().so_compare_score(C.byref(m), COVER_RULES[cover], DIST_RULES[dist]))
+
+
+def search_opts(**kw):
+    o = SearchOpts()
+    lib().so_search_opts_default(C.byref(o))
+    for k, v in kw.items():
+        if k == "iupac":
+            v = IUPAC_RULES[v]
+        elif k == "dist":
+            v = DIST_RULES[v]
+        elif k == "cover":
+            v = COVER_RULES[v]
+        setattr(o, k, v)
+    return o
+
+
+def search(index, query_aligned, opts=None):
+    """search_filter::operator() up to the result vector: (ids, scores, log) best first; ids is None when
+    the stage bails out (sequence too short)."""
+    opts = opts or search_opts()
+    cap = max(len(index.refs), 1)
+    ids = np.zeros(cap, np.uint32)
+    sc = np.zeros(cap, np.float32)
+    lg = new_log()
+    n = lib().so_search(index.h, index._h, len(index.refs), query_aligned.h, C.byref(opts), _p(ids, u32p),
+                        _p(sc, f32p), cap, C.byref(lg))
+    txt = log_text(lg)
+    lib().so_log_free(C.byref(lg))
+    if n < 0:
+        return None, None, txt
+    return ids[:n].copy(), sc[:n].copy(), txt
+
+
+def _cstrs(strings):
+    arr = (C.c_char_p * max(len(strings), 1))()
+    for i, x in enumerate(strings):
+        arr[i] = x.encode()
+    return arr
+
+
+def search_nearest(acc, version, start, stop, ids, scores):
+    lg = new_log()
+    ids = np.ascontiguousarray(ids, np.uint32)
+    scores = np.ascontiguousarray(scores, np.float32)
+    lib().so_search_nearest(_cstrs(acc), _cstrs(version), _cstrs(start), _cstrs(stop), _p(ids, u32p),
+                            _p(scores, f32p), len(ids), C.byref(lg))
+    txt = log_text(lg)
+    lib().so_log_free(C.byref(lg))
+    return txt
+
+
+def search_lca(tax_of_results, quorum=0.7):
+    lg = new_log()
+    lib().so_search_lca(_cstrs(tax_of_results), len(tax_of_results), quorum, C.byref(lg))
+    txt = log_text(lg)
+    lib().so_log_free(C.byref(lg))
+    return txt
+

@@ -9,6 +9,7 @@
 #include "sina_oracle.h"
 
 #include <ctype.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1313,3 +1314,314 @@ done:
     free(bases);
     so_cseq_free(c);
 }
+
+/* ------------------------------------------------------------ cseq_comparator (section 8f-1) */
+
+static int cmp_filtered(uint32_t ab, int filter_lc) { /* filter_lowercase / filter_none, :128-138 */
+    return filter_lc && (((ab >> 24) & 0x10) != 0);      /* aligned_base isLowerCase: bit 4 of the mask byte */
+}
+static int cmp_bases(uint32_t a, uint32_t b, int iupac) { /* base_comp_*, :113-129; a = query base */
+    const uint8_t ma = (uint8_t)((a >> 24) & 0xf), mb = (uint8_t)((b >> 24) & 0xf);
+    switch (iupac) {
+    case SO_CMP_IUPAC_OPTIMISTIC: return (ma & mb) != 0;                 /* aligned_base.h:153-155 */
+    case SO_CMP_IUPAC_PESSIMISTIC: return !is_ambig(ma) && ma == mb;     /* :163-165 */
+    default: return ma == mb;                                            /* :167-169 */
+    }
+}
+
+/* traverse(), cseq_comparator.cpp:56-111, with match_counter::counter :165-206 */
+void so_compare_counts(const so_cseq *A, const so_cseq *B, int iupac, int filter_lc, so_match_counts *m) {
+    memset(m, 0, sizeof(*m));
+    const uint32_t *a = A->ab, *a_end = A->ab + A->n;
+    const uint32_t *b = B->ab, *b_end = B->ab + B->n;
+#define POS(x) ((x) & 0xFFFFFFu)
+    /* skip filtered bases at beginning */
+    while (a != a_end && cmp_filtered(*a, filter_lc)) ++a;
+    while (b != b_end && cmp_filtered(*b, filter_lc)) ++b;
+    /* skip filtered bases at end */
+    while (a != a_end && cmp_filtered(*(a_end - 1), filter_lc)) --a_end;
+    while (b != b_end && cmp_filtered(*(b_end - 1), filter_lc)) --b_end;
+    if (a == a_end || b == b_end) return; /* (the reference dereferences end() here) */
+    /* count left overhang */
+    if (POS(*a) < POS(*b)) {
+        while (a != a_end && POS(*a) < POS(*b)) {
+            if (!cmp_filtered(*a, filter_lc)) m->only_a_overhang++;
+            ++a;
+        }
+    } else {
+        while (b != b_end && POS(*a) > POS(*b)) {
+            if (!cmp_filtered(*b, filter_lc)) m->only_b_overhang++;
+            ++b;
+        }
+    }
+    /* count overlapping zone */
+    while (a != a_end && b != b_end) {
+        const int diff = (int)POS(*a) - (int)POS(*b);
+        if (diff > 0) {
+            if (!cmp_filtered(*b, filter_lc)) m->only_b++;
+            ++b;
+        } else if (diff < 0) {
+            if (!cmp_filtered(*a, filter_lc)) m->only_a++;
+            ++a;
+        } else {
+            const int fa = cmp_filtered(*a, filter_lc), fb = cmp_filtered(*b, filter_lc);
+            if (!fa && !fb) {
+                if (cmp_bases(*a, *b, iupac)) m->match++;
+                else m->mismatch++;
+            } else if (!fa) {
+                m->only_a++;
+            } else if (!fb) {
+                m->only_b++;
+            }
+            ++a;
+            ++b;
+        }
+    }
+    /* count right overhang */
+    while (a != a_end) {
+        if (!cmp_filtered(*a, filter_lc)) m->only_a_overhang++;
+        ++a;
+    }
+    while (b != b_end) {
+        if (!cmp_filtered(*b, filter_lc)) m->only_b_overhang++;
+        ++b;
+    }
+#undef POS
+}
+
+/* cseq_comparator::operator() :240-296 */
+float so_compare_score(const so_match_counts *m, int cover, int dist_rule) {
+    int base;
+    switch (cover) {
+    case SO_CMP_COVER_ABS: base = 1; break;
+    case SO_CMP_COVER_QUERY: base = m->match + m->mismatch + m->only_a + m->only_a_overhang; break;
+    case SO_CMP_COVER_TARGET: base = m->match + m->mismatch + m->only_b + m->only_b_overhang; break;
+    case SO_CMP_COVER_OVERLAP: base = m->match + m->mismatch + m->only_a + m->only_b; break;
+    case SO_CMP_COVER_ALL:
+        base = m->match + m->mismatch + m->only_a + m->only_b + m->only_a_overhang + m->only_b_overhang;
+        break;
+    case SO_CMP_COVER_AVERAGE:
+        base = m->match + m->mismatch + (m->only_a + m->only_b + m->only_a_overhang + m->only_b_overhang) / 2;
+        break;
+    case SO_CMP_COVER_MIN: {
+        const int x = m->only_a + m->only_a_overhang, y = m->only_b + m->only_b_overhang;
+        base = m->match + m->mismatch + (x < y ? x : y);
+        break;
+    }
+    case SO_CMP_COVER_MAX: {
+        const int x = m->only_a + m->only_a_overhang, y = m->only_b + m->only_b_overhang;
+        base = m->match + m->mismatch + (x > y ? x : y);
+        break;
+    }
+    default: base = m->match + m->mismatch; break; /* NOGAP */
+    }
+    float dist = (float)m->match / base;
+    if (dist_rule == SO_CMP_DIST_JC) dist = (float)(-3.0 / 4 * log(1.0 - 4.0 / 3 * dist)); /* jukes_cantor :42-44 */
+    return dist;
+}
+
+float so_compare(const so_cseq *a, const so_cseq *b, int iupac, int dist, int cover, int filter_lc) {
+    so_match_counts m;
+    so_compare_counts(a, b, iupac, filter_lc, &m);
+    return so_compare_score(&m, cover, dist);
+}
+
+/* ------------------------------------------------------------ search_filter (section 8f-1) */
+
+void so_search_opts_default(so_search_opts *o) { /* search_filter.cpp:91-126, cseq_comparator.cpp:434-464 */
+    o->kmer_candidates = 1000;
+    o->max_result = 10;
+    o->min_sim = .7f;
+    o->lca_quorum = .7f;
+    o->ignore_super = 0;
+    o->search_all = 0;
+    o->iupac = SO_CMP_IUPAC_OPTIMISTIC;
+    o->dist = SO_CMP_DIST_NONE;
+    o->cover = SO_CMP_COVER_QUERY;
+    o->filter_lc = 0;
+}
+
+typedef struct {
+    float score;
+    uint32_t id;
+    const char *name;
+} search_item;
+/* std::greater<result_item>: a > b == !(a < b), with a < b = score, then name (search.h:58-66) */
+static int item_less(const search_item *a, const search_item *b) {
+    if (a->score < b->score) return 1;
+    if (a->score > b->score) return 0;
+    return strcmp(a->name, b->name) < 0;
+}
+static int item_cmp_desc(const void *x, const void *y) {
+    const search_item *a = (const search_item *)x, *b = (const search_item *)y;
+    if (item_less(b, a)) return -1;
+    if (item_less(a, b)) return 1;
+    return 0;
+}
+/* boost::algorithm::contains(ref aligned bases, query aligned bases, a.comp(b)) :264-268 */
+static int seq_contains(const so_cseq *hay, const so_cseq *needle) {
+    if (needle->n == 0) return 1;
+    if (needle->n > hay->n) return 0;
+    for (uint32_t i = 0; i + needle->n <= hay->n; i++) {
+        uint32_t j = 0;
+        while (j < needle->n && (((hay->ab[i + j] >> 24) & (needle->ab[j] >> 24) & 0xf) != 0)) j++;
+        if (j == needle->n) return 1;
+    }
+    return 0;
+}
+
+int so_search(const so_index *idx, const so_cseq *const *refs, uint32_t n_refs, const so_cseq *c,
+              const so_search_opts *o, uint32_t *out_ids, float *out_scores, uint32_t cap, so_log *log) {
+    if (c->n < 20) {
+        so_logf(log, "search:sequence too short (<20 bases);");
+        return -1;
+    }
+    search_item *vc = NULL;
+    uint32_t nvc = 0;
+    uint32_t n_out = 0;
+    if (o->search_all) { /* :271-296 */
+        vc = (search_item *)malloc(sizeof(search_item) * (n_refs ? n_refs : 1));
+        for (uint32_t r = 0; r < n_refs; r++) {
+            vc[r].score = so_compare(c, refs[r], o->iupac, o->dist, o->cover, o->filter_lc);
+            vc[r].id = r;
+            vc[r].name = refs[r]->name;
+        }
+        /* partial_sort / partition rounds: the top max_result that do not contain the query.
+         * (The element ORDER inside std::partition's groups is unspecified, but every round
+         * re-sorts, and (score, name) is a total order: the outcome is the sorted list of
+         * the best non-containing candidates.) */
+        qsort(vc, n_refs, sizeof(search_item), item_cmp_desc);
+        search_item *top = (search_item *)malloc(sizeof(search_item) * (o->max_result ? o->max_result : 1));
+        uint32_t ntop = 0;
+        for (uint32_t r = 0; r < n_refs && ntop < o->max_result; r++) {
+            if (o->ignore_super && seq_contains(refs[vc[r].id], c)) continue;
+            top[ntop++] = vc[r];
+        }
+        for (uint32_t r = 0; r < ntop && top[r].score > o->min_sim; r++) {
+            if (n_out < cap) {
+                out_ids[n_out] = top[r].id;
+                out_scores[n_out] = top[r].score;
+            }
+            n_out++;
+        }
+        free(top);
+    } else { /* :297-331 */
+        uint32_t kc = o->kmer_candidates < n_refs ? o->kmer_candidates : n_refs;
+        uint32_t *ids = (uint32_t *)malloc(sizeof(uint32_t) * (kc ? kc : 1));
+        float *sc = (float *)malloc(sizeof(float) * (kc ? kc : 1));
+        kc = so_index_find(idx, c, kc, ids, sc);
+        vc = (search_item *)malloc(sizeof(search_item) * (kc ? kc : 1));
+        for (uint32_t i = 0; i < kc; i++) {
+            if (o->ignore_super && !seq_contains(refs[ids[i]], c)) continue; /* sic: partition + erase keeps the
+                                                                                 containing ones (:307-310) */
+            vc[nvc].id = ids[i];
+            vc[nvc].name = refs[ids[i]]->name;
+            vc[nvc].score = so_compare(c, refs[ids[i]], o->iupac, o->dist, o->cover, o->filter_lc);
+            nvc++;
+        }
+        qsort(vc, nvc, sizeof(search_item), item_cmp_desc); /* partial_sort of the first max_result: same prefix */
+        uint32_t middle = o->max_result < nvc ? o->max_result : nvc;
+        for (uint32_t r = 0; r < middle && vc[r].score > o->min_sim; r++) {
+            if (n_out < cap) {
+                out_ids[n_out] = vc[r].id;
+                out_scores[n_out] = vc[r].score;
+            }
+            n_out++;
+        }
+        free(ids);
+        free(sc);
+    }
+    free(vc);
+    return (int)n_out;
+}
+
+void so_search_nearest(const char *const *acc, const char *const *version, const char *const *start,
+                       const char *const *stop, const uint32_t *ids, const float *scores, uint32_t n, so_log *out) {
+    for (uint32_t i = 0; i < n; i++) /* fmt "{}.{}.{}.{}~{:.3f} " :357-363 */
+        so_logf(out, "%s.%s.%s.%s~%.3f ", acc[ids[i]], version[ids[i]], start[ids[i]], stop[ids[i]],
+                (double)scores[i]);
+}
+
+/* :339-352 (split) and :374-409 (vote) */
+void so_search_lca(const char *const *tax, uint32_t n_results, float quorum, so_log *out) {
+    /* group_names: one vector of names per result whose path is not "Unclassified;" */
+    typedef struct {
+        char **v;
+        int n;
+    } names;
+    names *g = (names *)calloc(n_results ? n_results : 1, sizeof(names));
+    int ng = 0;
+    for (uint32_t i = 0; i < n_results; i++) {
+        const char *p = tax[i];
+        if (strcmp(p, "Unclassified;") == 0) continue;
+        /* boost::split on ';' (no token compression): k delimiters give k+1 tokens */
+        int ntok = 1;
+        for (const char *q = p; *q; q++) ntok += (*q == ';');
+        names nm;
+        nm.v = (char **)malloc(sizeof(char *) * ntok);
+        nm.n = 0;
+        const char *tok = p;
+        for (const char *q = p;; q++) {
+            if (*q == ';' || *q == 0) {
+                size_t len = (size_t)(q - tok);
+                char *t = (char *)malloc(len + 1);
+                memcpy(t, tok, len);
+                t[len] = 0;
+                nm.v[nm.n++] = t;
+                tok = q + 1;
+                if (*q == 0) break;
+            }
+        }
+        if (nm.n > 0 && (nm.v[nm.n - 1][0] == 0 || strcmp(nm.v[nm.n - 1], " ") == 0)) free(nm.v[--nm.n]);
+        /* reverse(vs): back() becomes the root; keep the order and pop from the FRONT instead */
+        g[ng++] = nm;
+    }
+    int *front = (int *)calloc(ng ? ng : 1, sizeof(int)); /* index of the current "back()" of each vector */
+    uint8_t *alive = (uint8_t *)malloc(ng ? ng : 1);
+    memset(alive, 1, ng ? ng : 1);
+    int n_alive = ng;
+    so_log res;
+    so_log_init(&res);
+    int outliers = (int)((double)((float)n_results * (1 - quorum)) + .5);
+#define EMPTY(i) (front[i] >= g[i].n)
+    while (outliers >= 0 && n_alive > 0) {
+        int first = 0;
+        while (!alive[first]) first++;
+        if (EMPTY(first)) {
+            alive[first] = 0;
+            n_alive--;
+            outliers--;
+            continue;
+        }
+        const char *name = g[first].v[front[first]];
+        int it = first + 1;
+        for (; it < ng; it++) {
+            if (!alive[it]) continue;
+            if (EMPTY(it) || strcmp(g[it].v[front[it]], name) != 0) break;
+        }
+        if (it < ng) {
+            alive[it] = 0;
+            n_alive--;
+            outliers--;
+            continue;
+        }
+        for (int i = 0; i < ng; i++)
+            if (alive[i]) front[i]++;
+        so_logf(&res, "%s;", name);
+    }
+#undef EMPTY
+    const char *r = so_log_str(&res);
+    size_t rl = strlen(r);
+    if (rl > 1 && r[rl - 2] == ';' && r[rl - 1] == ';') r = r + rl - 1; /* res.substr(res.size()-1) */
+    if (r[0] == 0 || strcmp(r, ";") == 0) r = "Unclassified;";
+    so_logf(out, "%s", r);
+    so_log_free(&res);
+    for (int i = 0; i < ng; i++) {
+        for (int x = 0; x < g[i].n; x++) free(g[i].v[x]);
+        free(g[i].v);
+    }
+    free(g);
+    free(front);
+    free(alive);
+}
+

@@ -193,6 +193,41 @@ typedef struct so_align_result {
 void so_align(const so_cseq *const *family, uint32_t F, const so_cseq *query,
               const so_align_opts *o, so_cseq *out, so_align_result *res, so_log *log);
 
+/* ---- cseq_comparator: src/cseq_comparator.cpp:56-296 */
+enum { SO_CMP_IUPAC_OPTIMISTIC = 0, SO_CMP_IUPAC_PESSIMISTIC = 1, SO_CMP_IUPAC_EXACT = 2 };
+enum { SO_CMP_DIST_NONE = 0, SO_CMP_DIST_JC = 1 };
+enum {
+    SO_CMP_COVER_ABS = 0, SO_CMP_COVER_QUERY, SO_CMP_COVER_TARGET, SO_CMP_COVER_OVERLAP, SO_CMP_COVER_ALL,
+    SO_CMP_COVER_AVERAGE, SO_CMP_COVER_MIN, SO_CMP_COVER_MAX, SO_CMP_COVER_NOGAP
+};
+typedef struct so_match_counts {  /* match_counter, cseq_comparator.cpp:146-163 */
+    int only_a_overhang, only_b_overhang, only_a, only_b, match, mismatch;
+} so_match_counts;
+/* traverse() with the counter functor; a = query, b = target.  Both must keep at least one
+ * unfiltered base (the reference dereferences end() otherwise). */
+void so_compare_counts(const so_cseq *a, const so_cseq *b, int iupac, int filter_lc, so_match_counts *m);
+float so_compare_score(const so_match_counts *m, int cover, int dist);
+float so_compare(const so_cseq *a, const so_cseq *b, int iupac, int dist, int cover, int filter_lc);
+
+/* ---- search_filter::operator(): src/search_filter.cpp:244-412 */
+typedef struct so_search_opts {
+    uint32_t kmer_candidates, max_result;
+    float min_sim, lca_quorum;
+    int ignore_super, search_all;
+    int iupac, dist, cover, filter_lc;
+} so_search_opts;
+void so_search_opts_default(so_search_opts *o);
+/* the result_vector after scoring, sorting and the min_sim cut (ids into refs, best first).
+ * returns -1 (and the reference's log text) when the query is shorter than 20 bases. */
+int so_search(const so_index *idx, const so_cseq *const *refs, uint32_t n_refs, const so_cseq *query_aligned,
+              const so_search_opts *o, uint32_t *out_ids, float *out_scores, uint32_t cap, so_log *log);
+/* "acc.version.start.stop~score " per result (search_filter.cpp:357-363) */
+void so_search_nearest(const char *const *acc, const char *const *version, const char *const *start,
+                       const char *const *stop, const uint32_t *ids, const float *scores, uint32_t n, so_log *out);
+/* the lowest-common-ancestor vote over one taxonomy field of the results (:374-409);
+ * tax[i] = that field of result i */
+void so_search_lca(const char *const *tax, uint32_t n_results, float quorum, so_log *out);
+
 #ifdef __cplusplus
 }
 #endif

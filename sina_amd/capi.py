@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "sina_hip_abi_version", "sina_hip_last_error", "sina_hip_init", "sina_hip_fork", "sina_hip_destroy",
     "sina_hip_sync",
     "sina_hip_upload_refs", "sina_hip_build_index", "sina_hip_upload_index", "sina_hip_store_view_get",
-    "sina_hip_store_alloc_like", "sina_hip_kmer_topk", "sina_hip_kmer_scores",
+    "sina_hip_store_alloc_like", "sina_hip_kmer_topk", "sina_hip_kmer_scores", "sina_hip_compare",
     "sina_hip_align_params_default", "sina_hip_align_graphs", "sina_hip_align_families",
     "sina_hip_debug_mesh", "sina_hip_debug_family_graph", "sina_hip_get_stats",
 ]
@@ -65,7 +65,9 @@ class StoreView(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("dp_ms", C.c_double), ("backtrack_ms", C.c_double), ("graph_ms", C.c_double),
                 ("kmer_count_ms", C.c_double), ("kmer_select_ms", C.c_double), ("dp_cells", C.c_uint64),
-                ("postings", C.c_uint64), ("dp_launches", C.c_uint32), ("kmer_launches", C.c_uint32)]
+                ("postings", C.c_uint64), ("dp_launches", C.c_uint32), ("kmer_launches", C.c_uint32),
+                ("compare_ms", C.c_double), ("compare_bases", C.c_uint64), ("compare_launches", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 _lib = None
@@ -95,6 +97,7 @@ def load():
     L.sina_hip_store_alloc_like.argtypes = [vp, C.POINTER(StoreView)]
     L.sina_hip_kmer_topk.argtypes = [vp, u8p, u64p, C.c_uint32, C.c_uint32, u32p, f32p, u32p]
     L.sina_hip_kmer_scores.argtypes = [vp, u8p, C.c_uint32, i16p]
+    L.sina_hip_compare.argtypes = [vp, u32p, u64p, C.c_uint32, u32p, u64p, C.c_int, C.c_int, C.c_void_p]
     L.sina_hip_align_params_default.argtypes = [C.POINTER(AlignParams)]
     L.sina_hip_align_params_default.restype = None
     L.sina_hip_align_graphs.argtypes = [vp, C.POINTER(GraphBatch), u8p, u64p, C.POINTER(AlignParams),
@@ -254,6 +257,19 @@ class Context:
                                                  C.byref(params), out.ctypes.data_as(C.POINTER(AlignOut)),
                                                  _ptr(pos, u32p)))
         return out, pos
+
+    def compare(self, q_ab, q_off, cand_ids, cand_off, iupac=0, filter_lc=False):
+        """Search-stage comparison: int32 [n candidates][6] = only_a_overhang, only_b_overhang, only_a,
+        only_b, match, mismatch of every (query, candidate) pair."""
+        q_ab = _c(q_ab, np.uint32)
+        q_off = _c(q_off, np.uint64)
+        cand_ids = _c(cand_ids, np.uint32)
+        cand_off = _c(cand_off, np.uint64)
+        out = np.zeros((max(len(cand_ids), 1), 6), np.int32)
+        self._check(self.L.sina_hip_compare(self.h, _ptr(q_ab, u32p), _ptr(q_off, u64p), len(q_off) - 1,
+                                            _ptr(cand_ids, u32p), _ptr(cand_off, u64p), int(iupac),
+                                            int(filter_lc), out.ctypes.data_as(C.c_void_p)))
+        return out[:len(cand_ids)]
 
     def align_families(self, fam_ids, fam_off, qmask, qoff, params=None):
         params = params or self.params()

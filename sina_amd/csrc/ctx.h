@@ -37,17 +37,19 @@ struct sina_hip_ctx {
     sina_hip::DevBuf qd, order, rec, node_pos, pred, succ_minpos, qmask, tb, spill, res, weights, out, out_pos, dbg;
     sina_hip::DevBuf k_qoff, k_scores, k_out_ids, k_out_scores, k_out_n, k_tmp0, k_tmp1, k_tmp2;
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes, g_wtab;
+    sina_hip::DevBuf s_qab, s_qoff, s_cand, s_coff, s_out;  // search-stage comparison
     float wtab_fs_weight = NAN;  // fs_weight the device weight table was computed for
 
     size_t lds_budget = 40 * 1024;
     uint64_t tb_budget_bytes = (uint64_t)48 << 30;
 
-    static constexpr int kNumScratch = 29;
+    static constexpr int kNumScratch = 34;
     void scratch(sina_hip::DevBuf **all) {
         sina_hip::DevBuf *list[kNumScratch] = {&qd, &rec, &node_pos, &pred, &succ_minpos, &qmask, &tb, &spill, &res,
                                                &weights, &out, &out_pos, &k_qoff, &k_scores, &k_out_ids,
                                                &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2, &g_fam_ids,
-                                               &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab, &order};
+                                               &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab, &order,
+                                               &s_qab, &s_qoff, &s_cand, &s_coff, &s_out};
         for (int i = 0; i < kNumScratch; i++) all[i] = list[i];
     }
     void publish_hints() {  // after a call: remember how big my buffers had to be

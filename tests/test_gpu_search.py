@@ -1,0 +1,83 @@
+"""GPU parity for the search stage: the comparison kernel's counters against the
+oracle's literal traverse(), for every iupac rule, with and without the lower-case filter."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from sina_amd import capi, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _aligned_queries(refs, n, seed, lower_rate=0.0, amb_rate=0.0):
+    """Aligned query sequences: references with substitutions, a trimmed window, some bases moved to
+    a free neighbouring column and some dropped -- strictly ascending columns."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        ab = refs.seq(int(rng.integers(refs.n))).copy()
+        a, b = sorted(rng.integers(0, len(ab), size=2))
+        if b - a < 30:
+            a, b = 0, len(ab)
+        ab = ab[a:b]
+        keep = rng.random(len(ab)) > 0.03
+        ab = ab[keep]
+        pos = (ab & 0xFFFFFF).astype(np.int64)
+        mask = (ab >> 24).astype(np.uint32)
+        sub = rng.random(len(ab)) < 0.05
+        mask[sub] = rng.choice([1, 2, 4, 8], size=int(sub.sum()))
+        amb = rng.random(len(ab)) < amb_rate
+        mask[amb] = rng.choice([3, 5, 7, 15, 12], size=int(amb.sum()))
+        low = rng.random(len(ab)) < lower_rate
+        mask[low] |= 0x10
+        # shift a few bases one column to the right when that column is free
+        for x in np.nonzero(rng.random(len(ab)) < 0.04)[0]:
+            nxt = pos[x + 1] if x + 1 < len(pos) else refs.width
+            if pos[x] + 1 < nxt:
+                pos[x] += 1
+        out.append((pos.astype(np.uint32) | (mask << 24)).astype(np.uint32))
+    return out
+
+
+@pytest.mark.parametrize("filter_lc", [False, True])
+def test_compare_counts_equal_traverse(oracle, gpu_ctx, filter_lc):
+    refs = synth.make_refs(150, length=300, width=2500, seed=401, amb_rate=0.02, lower_rate=0.1)
+    cs = util.cseqs_from_refs(refs)
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    qs = _aligned_queries(refs, 9, 402, lower_rate=0.15, amb_rate=0.03)
+    # one query without any upper-case base in the middle of a run, one fully lower case at both ends
+    qs[3] = qs[3] | np.uint32(0)
+    qs[4][:7] |= np.uint32(0x10 << 24)
+    qs[4][-5:] |= np.uint32(0x10 << 24)
+    rng = np.random.default_rng(403)
+    cand = [rng.choice(refs.n, size=int(k), replace=False).astype(np.uint32) for k in (150, 1, 40, 7, 99, 3, 64, 20, 150)]
+    q_off = np.zeros(len(qs) + 1, np.uint64)
+    q_off[1:] = np.cumsum([len(x) for x in qs])
+    c_off = np.zeros(len(qs) + 1, np.uint64)
+    c_off[1:] = np.cumsum([len(x) for x in cand])
+    for rule, name in enumerate(("optimistic", "pessimistic", "exact")):
+        got = gpu_ctx.compare(np.concatenate(qs), q_off, np.concatenate(cand), c_off, rule, filter_lc)
+        for qi, q_ab in enumerate(qs):
+            q = po.Cseq.from_packed("q%d" % qi, q_ab, refs.width)
+            for x, rid in enumerate(cand[qi]):
+                want = po.compare_counts(q, cs[int(rid)], name, filter_lc)
+                assert tuple(got[int(c_off[qi]) + x]) == want, (name, qi, int(rid))
+
+
+def test_compare_reference_against_itself(oracle, gpu_ctx):
+    """Properties that need no oracle: a sequence against itself is all matches; swapping a base
+    for a different one moves exactly one count from match to mismatch."""
+    refs = synth.make_refs(60, length=1500, width=50000, seed=411)
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    ids = np.arange(0, 60, 7, dtype=np.uint32)
+    qs = [refs.seq(int(i)).copy() for i in ids]
+    for q in qs[::2]:
+        m = (q[100] >> 24) & 0xf
+        q[100] = (q[100] & 0xFFFFFF) | (np.uint32(8 if m != 8 else 1) << 24)
+    q_off = np.zeros(len(qs) + 1, np.uint64)
+    q_off[1:] = np.cumsum([len(x) for x in qs])
+    got = gpu_ctx.compare(np.concatenate(qs), q_off, ids, np.arange(len(ids) + 1, dtype=np.uint64), 2, False)
+    for x, q in enumerate(qs):
+        changed = 1 if x % 2 == 0 else 0
+        assert tuple(got[x]) == (0, 0, 0, 0, len(q) - changed, changed)
