@@ -1470,6 +1470,82 @@ static int seq_contains(const so_cseq *hay, const so_cseq *needle) {
     return 0;
 }
 
+/* libstdc++'s std::partial_sort with std::greater<result_item> (bits/stl_heap.h, bits/stl_algo.h:
+ * __heap_select + __sort_heap) and std::partition for bidirectional iterators, restated so that the
+ * UNSORTED remainder they leave is the one a GCC build of the reference sees. */
+static int item_gt(const search_item *a, const search_item *b) { return !item_less(a, b); }
+static void gnu_push_heap(search_item *first, long hole, long top, search_item value) {
+    long parent = (hole - 1) / 2;
+    while (hole > top && item_gt(first + parent, &value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+static void gnu_adjust_heap(search_item *first, long hole, long len, search_item value) {
+    const long top = hole;
+    long second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (item_gt(first + second, first + (second - 1))) second--;
+        first[hole] = first[second];
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        first[hole] = first[second - 1];
+        hole = second - 1;
+    }
+    gnu_push_heap(first, hole, top, value);
+}
+static void gnu_pop_heap(search_item *first, search_item *last, search_item *result) {
+    search_item value = *result;
+    *result = *first;
+    gnu_adjust_heap(first, 0, last - first, value);
+}
+static void gnu_partial_sort(search_item *first, search_item *middle, search_item *last) {
+    const long len = middle - first;
+    if (len >= 2) { /* __make_heap */
+        long parent = (len - 2) / 2;
+        for (;;) {
+            search_item value = first[parent];
+            gnu_adjust_heap(first, parent, len, value);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    for (search_item *i = middle; i < last; ++i) /* __heap_select */
+        if (item_gt(i, first)) gnu_pop_heap(first, middle, i);
+    while (middle - first > 1) { /* __sort_heap */
+        --middle;
+        gnu_pop_heap(first, middle, middle);
+    }
+}
+static int seq_contains(const so_cseq *hay, const so_cseq *needle);
+/* std::partition(first, last, contains_query); returns the number of elements in the first group */
+static uint32_t gnu_partition_contains(search_item *first, search_item *last, const so_cseq *const *refs,
+                                       const so_cseq *c) {
+    search_item *const begin = first;
+    for (;;) {
+        for (;;) {
+            if (first == last) return (uint32_t)(first - begin);
+            else if (seq_contains(refs[first->id], c)) ++first;
+            else break;
+        }
+        --last;
+        for (;;) {
+            if (first == last) return (uint32_t)(first - begin);
+            else if (!seq_contains(refs[last->id], c)) --last;
+            else break;
+        }
+        search_item t = *first;
+        *first = *last;
+        *last = t;
+        ++first;
+    }
+}
+
 int so_search(const so_index *idx, const so_cseq *const *refs, uint32_t n_refs, const so_cseq *c,
               const so_search_opts *o, uint32_t *out_ids, float *out_scores, uint32_t cap, so_log *log) {
     if (c->n < 20) {
@@ -1486,17 +1562,23 @@ int so_search(const so_index *idx, const so_cseq *const *refs, uint32_t n_refs, 
             vc[r].id = r;
             vc[r].name = refs[r]->name;
         }
-        /* partial_sort / partition rounds: the top max_result that do not contain the query.
-         * (The element ORDER inside std::partition's groups is unspecified, but every round
-         * re-sorts, and (score, name) is a total order: the outcome is the sorted list of
-         * the best non-containing candidates.) */
-        qsort(vc, n_refs, sizeof(search_item), item_cmp_desc);
-        search_item *top = (search_item *)malloc(sizeof(search_item) * (o->max_result ? o->max_result : 1));
-        uint32_t ntop = 0;
-        for (uint32_t r = 0; r < n_refs && ntop < o->max_result; r++) {
-            if (o->ignore_super && seq_contains(refs[vc[r].id], c)) continue;
-            top[ntop++] = vc[r];
-        }
+        /* :279-290, literally -- including what libstdc++'s partial_sort and partition leave
+         * behind: when containing sequences are removed from the top, the second round sorts only
+         * the slots that are left, and the range then handed to partition() extends into elements
+         * partial_sort never ordered.  (A reference built with GCC behaves exactly like this.) */
+        search_item *top = vc;
+        uint32_t it = 0, end = n_refs;
+        uint32_t middle = o->max_result < n_refs ? o->max_result : n_refs;
+        do {
+            gnu_partial_sort(vc + it, vc + middle, vc + end);
+            if (o->ignore_super) {
+                middle = it + o->max_result;
+                if (middle > end) middle = end; /* (the reference would run past the end here) */
+                it += gnu_partition_contains(vc + it, vc + middle, refs, c);
+            }
+        } while (middle != end && it + o->max_result > middle);
+        top = vc + it;
+        const uint32_t ntop = middle - it;
         for (uint32_t r = 0; r < ntop && top[r].score > o->min_sim; r++) {
             if (n_out < cap) {
                 out_ids[n_out] = top[r].id;
@@ -1504,7 +1586,6 @@ int so_search(const so_index *idx, const so_cseq *const *refs, uint32_t n_refs, 
             }
             n_out++;
         }
-        free(top);
     } else { /* :297-331 */
         uint32_t kc = o->kmer_candidates < n_refs ? o->kmer_candidates : n_refs;
         uint32_t *ids = (uint32_t *)malloc(sizeof(uint32_t) * (kc ? kc : 1));

@@ -8,6 +8,7 @@
 
 #include "stages.h"
 
+#include <map>
 #include <memory>
 
 using namespace sina;
@@ -25,11 +26,18 @@ struct result {
     uint32_t width = 0;
     std::vector<uint32_t> ab;
     std::string log, family;
+    bool searched = false;          // search stage ran and produced a result vector
+    std::vector<uint32_t> sr_ids;   // search results, best first
+    std::vector<float> sr_scores;
+    std::map<std::string, std::string> attrs;  // nearest_slv, lca_*, copy_*
 };
 
 struct pipeline {
     famfinder ff;
     aligner al;
+    std::unique_ptr<search_filter> sf;  // only with sina_host_pipeline_create_search()
+    std::shared_ptr<reference_store> search_store;
+    double sf_s = 0;
     std::vector<result> results;
     double wall_s = 0, ff_s = 0, al_s = 0;
 };
@@ -104,13 +112,25 @@ int sina_host_store_index_ready(const char *key, unsigned k, int nofast) {
 int sina_host_reset_options(void) {
     famfinder::reset_options();
     aligner::reset_options();
+    search_filter::reset_options();
     return 0;
+}
+
+// field of a reference sequence (stands in for the ARB database fields the search stage loads)
+int sina_host_store_set_attr(const char *key, uint32_t id, const char *field, const char *value) {
+    try {
+        reference_store::get(key)->set_attr(id, field, value);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
 }
 
 int sina_host_set_option(const char *stage, const char *name, const char *value) {
     try {
         if (!strcmp(stage, "famfinder")) famfinder::set_option(name, value);
         else if (!strcmp(stage, "aligner")) aligner::set_option(name, value);
+        else if (!strcmp(stage, "search")) search_filter::set_option(name, value);
         else if (!strcmp(stage, "host") && !strcmp(name, "threads")) set_host_threads((unsigned)atoi(value));
         else throw std::logic_error(std::string("unknown stage ") + stage);
         return 0;
@@ -129,6 +149,21 @@ void *sina_host_pipeline_create(void) {
         return nullptr;
     }
 }
+// the same with the search stage behind the aligner (sina --search)
+void *sina_host_pipeline_create_search(void) {
+    try {
+        famfinder::validate_options();
+        aligner::validate_options();
+        search_filter::validate_options();
+        std::unique_ptr<pipeline> p(new pipeline());
+        p->sf.reset(new search_filter());
+        p->search_store = reference_store::get(search_filter_database());
+        return p.release();
+    } catch (const std::exception &e) {
+        fail(e);
+        return nullptr;
+    }
+}
 void sina_host_pipeline_destroy(void *p) { delete (pipeline *)p; }
 
 // Feeds nq unaligned queries (iupac masks) through famfinder -> aligner in batches
@@ -142,7 +177,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
         if (batch == 0) batch = nq ? nq : 1;
         if (inflight == 0) inflight = 1;
         std::atomic<uint32_t> next{0};
-        std::atomic<uint64_t> ff_ns{0}, al_ns{0};
+        std::atomic<uint64_t> ff_ns{0}, al_ns{0}, sf_ns{0};
         std::exception_ptr err;
         std::mutex err_mu;
         const auto t0 = std::chrono::steady_clock::now();
@@ -172,6 +207,12 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                     const auto b = std::chrono::steady_clock::now();
                     p->al(trays);
                     const auto c = std::chrono::steady_clock::now();
+                    if (p->sf) {
+                        (*p->sf)(trays);
+                        sf_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                                     std::chrono::steady_clock::now() - c)
+                                     .count();
+                    }
                     ff_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
                     al_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(c - b).count();
                     hp.reset(new host_phase("drv.extract"));
@@ -189,6 +230,19 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                             r.width = c.getWidth();
                             r.ab.assign(c.packed(), c.packed() + c.size());
                             r.status = (r.log.find("copied alignment from") != std::string::npos) ? 1 : 0;
+                            for (const auto &kv : c.get_attrs()) {
+                                const std::string &k = kv.first;
+                                if (k == search_filter::fn_nearest || k.compare(0, 4, "lca_") == 0 ||
+                                    k.compare(0, 5, "copy_") == 0)
+                                    r.attrs[k] = c.get_attr<std::string>(k);
+                            }
+                        }
+                        if (t.search_result) {
+                            r.searched = true;
+                            for (const auto &it : *t.search_result) {
+                                r.sr_ids.push_back(p->search_store->id_of(it.sequence));
+                                r.sr_scores.push_back(it.score);
+                            }
                         }
                         t.destroy();
                     });
@@ -206,6 +260,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
         p->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         p->ff_s = ff_ns.load() * 1e-9;
         p->al_s = al_ns.load() * 1e-9;
+        p->sf_s = sf_ns.load() * 1e-9;
         if (err) std::rethrow_exception(err);
         return 0;
     } catch (const std::exception &e) {
@@ -229,6 +284,23 @@ int sina_host_result(void *pp, uint32_t q, int *status, int *head, int *tail, in
 const uint32_t *sina_host_result_bases(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].ab.data(); }
 const char *sina_host_result_log(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].log.c_str(); }
 const char *sina_host_result_family(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].family.c_str(); }
+// search stage: number of results (-1: stage did not run for this query), ids/scores best first,
+// string attributes it set on the sequence (nearest_slv, lca_<field>, copy_<acc>_<field>; "" if absent)
+int sina_host_result_search(void *pp, uint32_t q, uint32_t *ids, float *scores, uint32_t cap) {
+    const result &r = ((pipeline *)pp)->results[q];
+    if (!r.searched) return -1;
+    for (size_t i = 0; i < r.sr_ids.size() && i < cap; i++) {
+        ids[i] = r.sr_ids[i];
+        scores[i] = r.sr_scores[i];
+    }
+    return (int)r.sr_ids.size();
+}
+const char *sina_host_result_attr(void *pp, uint32_t q, const char *name) {
+    const result &r = ((pipeline *)pp)->results[q];
+    const auto it = r.attrs.find(name);
+    return it == r.attrs.end() ? "" : it->second.c_str();
+}
+double sina_host_search_seconds(void *pp) { return ((pipeline *)pp)->sf_s; }
 void sina_host_timings(void *pp, double *wall_s, double *famfinder_s, double *aligner_s) {
     pipeline *p = (pipeline *)pp;
     *wall_s = p->wall_s;
@@ -262,6 +334,24 @@ int sina_host_build_graph(const char *key, const uint32_t *ids, uint32_t F, floa
         std::copy(g.pred_off.begin(), g.pred_off.end(), pred_off);
         std::copy(g.pred.begin(), g.pred.end(), pred);
         std::copy(g.succ_minpos.begin(), g.succ_minpos.end(), succ_minpos);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+// cseq_comparator on two aligned strings, for CPU-only tests against the reference's KAT table
+// (src/unit_tests/cseq_comparator_test.cpp); also returns the six counters
+int sina_host_compare(const char *a_aligned, const char *b_aligned, int iupac, int dist, int cover, int filter_lc,
+                      float *score, int32_t *counts6) {
+    try {
+        cseq a("", a_aligned), b("", b_aligned);
+        cseq_comparator cmp((CMP_IUPAC_TYPE)iupac, (CMP_DIST_TYPE)dist, (CMP_COVER_TYPE)cover, filter_lc != 0);
+        sina_hip_match_counts m;
+        cseq_comparator::counts(a, b, (CMP_IUPAC_TYPE)iupac, filter_lc != 0, &m);
+        *score = cmp.score(m);
+        const int32_t v[6] = {m.only_a_overhang, m.only_b_overhang, m.only_a, m.only_b, m.match, m.mismatch};
+        memcpy(counts6, v, sizeof v);
         return 0;
     } catch (const std::exception &e) {
         return fail(e);

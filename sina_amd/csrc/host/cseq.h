@@ -48,6 +48,7 @@ public:
     int ambig_order() const { return __builtin_popcount(_data & 0xf); }
     bool is_ambig() const { return ambig_order() > 1; }
     bool comp(const base_iupac &rhs) const { return (0xf & _data & rhs._data) != 0; }
+    bool comp_pessimistic(const base_iupac &rhs) const { return !is_ambig() && (0xf & _data) == (0xf & rhs._data); }
     bool comp_exact(const base_iupac &rhs) const { return (0xf & _data) == (0xf & rhs._data); }
 
 private:

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
@@ -1170,6 +1171,445 @@ void aligner::operator()(std::vector<tray> &batch) {
             t.aligned_sequence = &c;
         });
     }
+}
+
+// ================================================================ cseq_comparator (src/cseq_comparator.cpp)
+
+// traverse() + match_counter::counter, src/cseq_comparator.cpp:56-111,165-206 (host restatement for
+// single pairs and for the CPU-side tests; batches go through sina_hip_compare)
+void cseq_comparator::counts(const cseq &A, const cseq &B, CMP_IUPAC_TYPE iupac, bool filter_lc,
+                             sina_hip_match_counts *m) {
+    memset(m, 0, sizeof(*m));
+    const auto &av = A.getAlignedBases();
+    const auto &bv = B.getAlignedBases();
+    auto filtered = [&](const aligned_base &x) { return filter_lc && x.getBase().isLowerCase(); };
+    auto cmp = [&](const aligned_base &x, const aligned_base &y) {
+        switch (iupac) {
+        case CMP_IUPAC_OPTIMISTIC: return x.getBase().comp(y.getBase());
+        case CMP_IUPAC_PESSIMISTIC: return x.getBase().comp_pessimistic(y.getBase());
+        default: return x.getBase().comp_exact(y.getBase());
+        }
+    };
+    auto a = av.begin(), a_end = av.end();
+    auto b = bv.begin(), b_end = bv.end();
+    while (a != a_end && filtered(*a)) ++a;
+    while (b != b_end && filtered(*b)) ++b;
+    while (a != a_end && filtered(*(a_end - 1))) --a_end;
+    while (b != b_end && filtered(*(b_end - 1))) --b_end;
+    if (a == a_end || b == b_end) return;  // (the reference dereferences end() here)
+    if (a->getPosition() < b->getPosition()) {
+        while (a != a_end && a->getPosition() < b->getPosition()) {
+            if (!filtered(*a)) m->only_a_overhang++;
+            ++a;
+        }
+    } else {
+        while (b != b_end && a->getPosition() > b->getPosition()) {
+            if (!filtered(*b)) m->only_b_overhang++;
+            ++b;
+        }
+    }
+    while (a != a_end && b != b_end) {
+        const int diff = (int)a->getPosition() - (int)b->getPosition();
+        if (diff > 0) {
+            if (!filtered(*b)) m->only_b++;
+            ++b;
+        } else if (diff < 0) {
+            if (!filtered(*a)) m->only_a++;
+            ++a;
+        } else {
+            if (!filtered(*a) && !filtered(*b)) {
+                if (cmp(*a, *b)) m->match++;
+                else m->mismatch++;
+            } else if (!filtered(*a)) {
+                m->only_a++;
+            } else if (!filtered(*b)) {
+                m->only_b++;
+            }
+            ++a;
+            ++b;
+        }
+    }
+    for (; a != a_end; ++a)
+        if (!filtered(*a)) m->only_a_overhang++;
+    for (; b != b_end; ++b)
+        if (!filtered(*b)) m->only_b_overhang++;
+}
+
+// src/cseq_comparator.cpp:240-296
+float cseq_comparator::score(const sina_hip_match_counts &m) const {
+    int base;
+    switch (cover_rule) {
+    case CMP_COVER_ABS: base = 1; break;
+    case CMP_COVER_QUERY: base = m.match + m.mismatch + m.only_a + m.only_a_overhang; break;
+    case CMP_COVER_TARGET: base = m.match + m.mismatch + m.only_b + m.only_b_overhang; break;
+    case CMP_COVER_OVERLAP: base = m.match + m.mismatch + m.only_a + m.only_b; break;
+    case CMP_COVER_ALL:
+        base = m.match + m.mismatch + m.only_a + m.only_b + m.only_a_overhang + m.only_b_overhang;
+        break;
+    case CMP_COVER_AVERAGE:
+        base = m.match + m.mismatch + (m.only_a + m.only_b + m.only_a_overhang + m.only_b_overhang) / 2;
+        break;
+    case CMP_COVER_MIN:
+        base = m.match + m.mismatch + std::min(m.only_a + m.only_a_overhang, m.only_b + m.only_b_overhang);
+        break;
+    case CMP_COVER_MAX:
+        base = m.match + m.mismatch + std::max(m.only_a + m.only_a_overhang, m.only_b + m.only_b_overhang);
+        break;
+    case CMP_COVER_NOGAP: base = m.match + m.mismatch; break;
+    default: throw std::logic_error("unknown cover rule");
+    }
+    float dist = (float)m.match / base;
+    if (dist_rule == CMP_DIST_JC) dist = (float)(-3.0 / 4 * log(1.0 - 4.0 / 3 * dist));  // jukes_cantor :42-44
+    return dist;
+}
+float cseq_comparator::operator()(const cseq &query, const cseq &target) const {
+    sina_hip_match_counts m;
+    counts(query, target, iupac_rule, filter_lc_rule, &m);
+    return score(m);
+}
+
+// ================================================================ search_filter (src/search_filter.cpp)
+
+const char *search_filter::fn_nearest = "nearest_slv";
+
+struct search_filter::options {
+    std::string pt_database;
+    bool search_all;
+    bool fs_no_fast;
+    int fs_kmer_len;
+    int kmer_candidates;
+    float min_sim;
+    bool ignore_super;
+    int max_result;
+    std::string lca_fields;
+    std::vector<std::string> v_lca_fields;
+    float lca_quorum;
+    std::string copy_fields;
+    std::vector<std::string> v_copy_fields;
+    cseq_comparator comparator;
+};
+search_filter::options *search_filter::opts = nullptr;
+
+static search_filter::options sf_defaults() {  // src/search_filter.cpp:91-126, cseq_comparator.cpp:434-464
+    search_filter::options o;
+    o.search_all = false;
+    o.fs_no_fast = false;
+    o.fs_kmer_len = 10;
+    o.kmer_candidates = 1000;
+    o.min_sim = .7f;
+    o.ignore_super = false;
+    o.max_result = 10;
+    o.lca_quorum = .7f;
+    return o;
+}
+static search_filter::options &sf_opts() {
+    if (!search_filter::opts) search_filter::opts = new search_filter::options(sf_defaults());
+    return *search_filter::opts;
+}
+void search_filter::reset_options() { sf_opts() = sf_defaults(); }
+std::string search_filter_database() { return sf_opts().pt_database; }
+
+void search_filter::set_option(const std::string &name, const std::string &value) {
+    options &o = sf_opts();
+    const std::string v = lower(value);
+    if (name == "search-db" || (name == "db" && o.pt_database.empty())) o.pt_database = value;
+    else if (name == "db") {}
+    else if (name == "search-min-sim") o.min_sim = std::stof(value);
+    else if (name == "search-max-result") o.max_result = std::stoi(value);
+    else if (name == "lca-fields") o.lca_fields = value;
+    else if (name == "lca-quorum") o.lca_quorum = std::stof(value);
+    else if (name == "search-all") o.search_all = to_bool(value);
+    else if (name == "search-no-fast") o.fs_no_fast = to_bool(value);
+    else if (name == "search-kmer-candidates") o.kmer_candidates = std::stoi(value);
+    else if (name == "search-kmer-len") o.fs_kmer_len = std::stoi(value);
+    else if (name == "search-ignore-super") o.ignore_super = to_bool(value);
+    else if (name == "search-copy-fields") o.copy_fields = value;
+    else if (name == "search-iupac") {  // validate(), cseq_comparator.cpp:301-318: istarts_with(name, value)
+        auto starts = [&](const char *full) { return !v.empty() && std::string(full).compare(0, v.size(), v) == 0; };
+        if (starts("optimistic")) o.comparator.iupac_rule = CMP_IUPAC_OPTIMISTIC;
+        else if (starts("pessimistic")) o.comparator.iupac_rule = CMP_IUPAC_PESSIMISTIC;
+        else if (starts("exact")) o.comparator.iupac_rule = CMP_IUPAC_EXACT;
+        else throw std::logic_error("iupac matching must be either optimistic or pessimistic");
+    } else if (name == "search-correction") {
+        if (v == "none") o.comparator.dist_rule = CMP_DIST_NONE;
+        else if (v == "jc") o.comparator.dist_rule = CMP_DIST_JC;
+        else throw std::logic_error("distance correction must be either none or jc");
+    } else if (name == "search-cover") {
+        static const char *names[] = {"abs", "query", "target", "overlap", "all", "average", "min", "max", "nogap"};
+        int found = -1;
+        for (int i = 0; i < 9; i++)
+            if (v == names[i]) found = i;
+        if (found < 0)
+            throw std::logic_error("coverage type must be one of abs, query, target, overlap,"
+                                   "average, nogap, min or max");
+        o.comparator.cover_rule = (CMP_COVER_TYPE)found;
+    } else if (name == "search-filter-lowercase") o.comparator.filter_lc_rule = to_bool(value);
+    else if (name == "search-engine") {
+        if (v != "internal" && v != "sina_kmer" && v != "kmer")
+            throw std::logic_error("search: only the internal k-mer engine is accelerated");
+    } else if (name == "search-kmer-mm") {
+        if (std::stoi(value) != 0) throw std::logic_error("search: --search-kmer-mm is a PT-server option");
+    } else if (name == "search-kmer-norel") {
+        if (to_bool(value)) throw std::logic_error("search: --search-kmer-norel is a PT-server option");
+    } else throw std::logic_error("search: unknown option " + name);
+}
+
+void search_filter::validate_options() {  // src/search_filter.cpp:130-168
+    options &o = sf_opts();
+    if (o.pt_database.empty()) throw std::logic_error("need search-db to search");
+    if (o.comparator.cover_rule == CMP_COVER_ABS && o.comparator.dist_rule != CMP_DIST_NONE)
+        throw std::logic_error("only fractional identity can be distance corrected");  // cseq_comparator.cpp:476-479
+    auto split = [](const std::string &s, std::vector<std::string> &out) {  // boost::split on ":,"
+        out.clear();
+        std::string cur;
+        for (char ch : s) {
+            if (ch == ':' || ch == ',') {
+                out.push_back(cur);
+                cur.clear();
+            } else {
+                cur += ch;
+            }
+        }
+        out.push_back(cur);
+        if (out.back().empty()) out.pop_back();
+    };
+    split(o.lca_fields, o.v_lca_fields);
+    split(o.copy_fields, o.v_copy_fields);
+}
+
+struct search_filter::priv_data {
+    std::shared_ptr<reference_store> arb;
+    kmer_search *index = nullptr;
+};
+
+search_filter::search_filter() : data(new priv_data) {
+    options &o = sf_opts();
+    if (o.pt_database.empty()) throw std::logic_error("need search-db to search");
+    data->arb = reference_store::get(o.pt_database);
+    if (!o.search_all) data->index = kmer_search::get_kmer_search(o.pt_database, o.fs_kmer_len, o.fs_no_fast);
+}
+search_filter::search_filter(const search_filter &) = default;
+search_filter &search_filter::operator=(const search_filter &) = default;
+search_filter::~search_filter() = default;
+
+tray search_filter::operator()(tray t) {
+    std::vector<tray> b{t};
+    (*this)(b);
+    return b[0];
+}
+
+namespace {
+// boost::algorithm::contains(ref aligned bases, query aligned bases, a.comp(b)), search_filter.cpp:264-268
+bool contains_query(const cseq &ref, const cseq &q) {
+    const auto &h = ref.getAlignedBases();
+    const auto &n = q.getAlignedBases();
+    if (n.empty()) return true;
+    if (n.size() > h.size()) return false;
+    for (size_t i = 0; i + n.size() <= h.size(); i++) {
+        size_t j = 0;
+        while (j < n.size() && h[i + j].getBase().comp(n[j].getBase())) j++;
+        if (j == n.size()) return true;
+    }
+    return false;
+}
+
+// the LCA vote of search_filter.cpp:374-409 over the taxonomy paths of the results
+std::string lca_vote(std::vector<std::vector<std::string>> group_names, size_t n_results, float quorum) {
+    std::stringstream result;
+    for (auto &vs : group_names) std::reverse(vs.begin(), vs.end());
+    int outliers = n_results * (1 - quorum) + .5;
+    while (outliers >= 0 && !group_names.empty()) {
+        auto it = group_names.begin();
+        if (it->empty()) {
+            group_names.erase(it);
+            outliers--;
+            continue;
+        }
+        std::string name = it->back();
+        ++it;
+        for (; it != group_names.end(); ++it)
+            if (it->empty() || it->back() != name) break;
+        if (it != group_names.end()) {
+            group_names.erase(it);
+            outliers--;
+            continue;
+        }
+        for (auto &vs : group_names) vs.pop_back();
+        result << name << ";";
+    }
+    std::string res = result.str();
+    if (res.size() > 1 && res.substr(res.size() - 2) == ";;") res = res.substr(res.size() - 1);
+    if (res.empty() || res == ";") res = "Unclassified;";
+    return res;
+}
+}  // namespace
+
+// src/search_filter.cpp:244-412 for a batch of trays: the k-mer search and the comparisons of the
+// whole batch are one GPU call each (sina_hip_kmer_topk, sina_hip_compare).
+void search_filter::operator()(std::vector<tray> &batch) {
+    const options &o = sf_opts();
+    reference_store &st = *data->arb;
+    std::vector<size_t> idx;  // trays that are searched
+    for (size_t i = 0; i < batch.size(); i++) {
+        tray &t = batch[i];
+        if (t.aligned_sequence == nullptr) {
+            t.log << "search: no sequence?!;";
+            continue;
+        }
+        if (t.aligned_sequence->size() < 20) {
+            t.log << "search:sequence too short (<20 bases);";
+            continue;
+        }
+        t.search_result = new search::result_vector();
+        idx.push_back(i);
+    }
+    if (idx.empty()) return;
+    const size_t nq = idx.size();
+    const unsigned n_refs = st.size();
+
+    // ---- candidates
+    std::vector<search::result_vector> cand(nq);
+    if (!o.search_all) {
+        scoped_phase ph("sf.find_batch");
+        std::vector<const cseq *> qs(nq);
+        for (size_t x = 0; x < nq; x++) qs[x] = batch[idx[x]].aligned_sequence;
+        data->index->find_batch(qs, cand, (unsigned)o.kmer_candidates);
+        if (o.ignore_super) {  // sic: partition() moves the containing ones to the front and the REST is erased
+            parallel_for(nq, [&](size_t x) {
+                const cseq &c = *batch[idx[x]].aligned_sequence;
+                search::result_vector kept;
+                for (auto &r : cand[x])
+                    if (contains_query(*r.sequence, c)) kept.push_back(r);
+                cand[x].swap(kept);
+            });
+        }
+    }
+
+    // ---- scores: one comparison launch per slice of the batch
+    {
+        scoped_phase ph("sf.compare(C-ABI)");
+        auto dev = st.worker_device();
+        const uint64_t max_pairs = 8u << 20;
+        size_t x0 = 0;
+        while (x0 < nq) {
+            size_t x1 = x0;
+            uint64_t pairs = 0;
+            while (x1 < nq) {
+                const uint64_t k = o.search_all ? n_refs : cand[x1].size();
+                if (x1 > x0 && pairs + k > max_pairs) break;
+                pairs += k;
+                x1++;
+            }
+            std::vector<uint64_t> qoff(x1 - x0 + 1, 0), coff(x1 - x0 + 1, 0);
+            for (size_t x = x0; x < x1; x++) {
+                qoff[x - x0 + 1] = qoff[x - x0] + batch[idx[x]].aligned_sequence->size();
+                coff[x - x0 + 1] = coff[x - x0] + (o.search_all ? n_refs : cand[x].size());
+            }
+            std::vector<uint32_t> qab(qoff.back() ? qoff.back() : 1), cids(coff.back() ? coff.back() : 1);
+            for (size_t x = x0; x < x1; x++) {
+                const cseq &c = *batch[idx[x]].aligned_sequence;
+                memcpy(qab.data() + qoff[x - x0], c.packed(), 4 * (size_t)c.size());
+                uint32_t *dst = cids.data() + coff[x - x0];
+                if (o.search_all) {
+                    for (unsigned r = 0; r < n_refs; r++) dst[r] = r;
+                } else {
+                    for (size_t r = 0; r < cand[x].size(); r++) dst[r] = st.id_of(cand[x][r].sequence);
+                }
+            }
+            std::vector<sina_hip_match_counts> counts(coff.back() ? coff.back() : 1);
+            if (coff.back())
+                hip_check(sina_hip_compare(dev.get(), qab.data(), qoff.data(), (uint32_t)(x1 - x0), cids.data(),
+                                           coff.data(), (int)o.comparator.iupac_rule,
+                                           o.comparator.filter_lc_rule ? 1 : 0, counts.data()),
+                          "sina_hip_compare");
+            for (size_t x = x0; x < x1; x++) {
+                const sina_hip_match_counts *m = counts.data() + coff[x - x0];
+                if (o.search_all) {
+                    cand[x].clear();
+                    cand[x].reserve(n_refs);
+                    for (unsigned r = 0; r < n_refs; r++) cand[x].emplace_back(o.comparator.score(m[r]), &st.getCseq(r));
+                } else {
+                    for (size_t r = 0; r < cand[x].size(); r++) cand[x][r].score = o.comparator.score(m[r]);
+                }
+            }
+            x0 = x1;
+        }
+    }
+
+    // ---- ranking + attributes, per tray
+    scoped_phase ph("sf.rank+lca");
+    parallel_for(nq, [&](size_t x) {
+        tray &t = batch[idx[x]];
+        cseq *c = t.aligned_sequence;
+        auto &vc = *t.search_result;
+        if (o.search_all) {  // :271-296
+            search::result_vector &result = cand[x];
+            auto it = result.begin();
+            auto middle = it + std::min<size_t>((size_t)o.max_result, result.size());
+            auto end = result.end();
+            do {
+                std::partial_sort(it, middle, end, std::greater<search::result_item>());
+                if (o.ignore_super) {
+                    middle = it + std::min<size_t>((size_t)o.max_result, (size_t)(end - it));
+                    it = std::partition(it, middle, [&](search::result_item &item) {
+                        return contains_query(*item.sequence, *c);
+                    });
+                }
+            } while (middle != end && it + o.max_result > middle);
+            while (it != middle && it->score > o.min_sim) {
+                vc.push_back(*it);
+                ++it;
+            }
+        } else {  // :297-331
+            vc.swap(cand[x]);
+            auto it = vc.begin();
+            auto middle = vc.begin() + std::min<size_t>((size_t)o.max_result, vc.size());
+            auto end = vc.end();
+            std::partial_sort(it, middle, end, std::greater<search::result_item>());
+            while (it != middle && it->score > o.min_sim) ++it;
+            vc.erase(it, vc.end());
+        }
+
+        std::string nearest;
+        std::map<std::string, std::vector<std::vector<std::string>>> group_names_map;
+        for (auto &i : vc) {
+            const cseq &r = *i.sequence;
+            st.loadKey(r, "acc");
+            st.loadKey(r, "version");
+            st.loadKey(r, "start");
+            st.loadKey(r, "stop");
+            for (const std::string &s : o.v_lca_fields) {
+                st.loadKey(r, s);
+                std::string tax_path = r.get_attr<std::string>(s);
+                if (tax_path == "Unclassified;") continue;
+                std::vector<std::string> group_names;  // boost::split(..., is_any_of(";"))
+                std::string cur;
+                for (char ch : tax_path) {
+                    if (ch == ';') {
+                        group_names.push_back(cur);
+                        cur.clear();
+                    } else {
+                        cur += ch;
+                    }
+                }
+                group_names.push_back(cur);
+                if (group_names.back().empty() || group_names.back() == " ") group_names.pop_back();
+                group_names_map[s].push_back(group_names);
+            }
+            char buf[64];
+            snprintf(buf, sizeof buf, "~%.3f ", (double)i.score);  // fmt "{}.{}.{}.{}~{:.3f} "
+            nearest += r.get_attr<std::string>("acc") + "." + r.get_attr<std::string>("version") + "." +
+                       r.get_attr<std::string>("start") + "." + r.get_attr<std::string>("stop") + buf;
+            const std::string acc = r.get_attr<std::string>("acc");
+            for (const std::string &s : o.v_copy_fields) {
+                st.loadKey(r, s);
+                c->set_attr<std::string>(std::string("copy_") + acc + std::string("_") + s, r.get_attr<std::string>(s));
+            }
+        }
+        c->set_attr<std::string>(fn_nearest, nearest);
+        for (const std::string &s : o.v_lca_fields)
+            c->set_attr<std::string>(std::string("lca_") + s, lca_vote(group_names_map[s], vc.size(), o.lca_quorum));
+    });
 }
 
 }  // namespace sina

@@ -124,6 +124,9 @@ public:
     std::vector<std::string> getSequenceNames() const;
     void loadKey(const cseq &c, const std::string &key) const;  // acc := name, start := "0" if absent
     std::vector<alignment_stats> &getAlignmentStats() { return vastats; }
+    // field of a reference sequence (what loadKey would fetch from the ARB database: version, start,
+    // stop, taxonomy paths ...); set before the stages run
+    void set_attr(unsigned int id, const std::string &key, const std::string &value) { seqs.at(id).set_attr(key, value); }
 
     // device side
     void set_device(int device) { device_id = device; }
@@ -247,6 +250,57 @@ public:
     static void reset_options();
     static void validate_options();
 };
+
+// ---------------------------------------------------------------- search_filter
+// src/search_filter.{h,cpp}: for an ALIGNED query, 1000 k-mer candidates -> identity against each
+// (cseq_comparator) -> best 10 above min-sim -> nearest_slv / lca_<field> / copy_* attributes.
+enum CMP_IUPAC_TYPE { CMP_IUPAC_OPTIMISTIC, CMP_IUPAC_PESSIMISTIC, CMP_IUPAC_EXACT };
+enum CMP_DIST_TYPE { CMP_DIST_NONE, CMP_DIST_JC };
+enum CMP_COVER_TYPE {
+    CMP_COVER_ABS, CMP_COVER_QUERY, CMP_COVER_TARGET, CMP_COVER_OVERLAP, CMP_COVER_ALL, CMP_COVER_AVERAGE,
+    CMP_COVER_MIN, CMP_COVER_MAX, CMP_COVER_NOGAP
+};
+// src/cseq_comparator.{h,cpp}: the score from the six counters (the counting itself is
+// sina_hip_compare on the GPU; counts() is the host restatement used for single pairs)
+class cseq_comparator {
+public:
+    cseq_comparator() = default;
+    cseq_comparator(CMP_IUPAC_TYPE iupac, CMP_DIST_TYPE dist, CMP_COVER_TYPE cover, bool filter_lc)
+        : iupac_rule(iupac), dist_rule(dist), cover_rule(cover), filter_lc_rule(filter_lc) {}
+    float operator()(const cseq &query, const cseq &target) const;
+    float score(const sina_hip_match_counts &m) const;
+    static void counts(const cseq &query, const cseq &target, CMP_IUPAC_TYPE iupac, bool filter_lc,
+                       sina_hip_match_counts *m);
+    CMP_IUPAC_TYPE iupac_rule{CMP_IUPAC_OPTIMISTIC};
+    CMP_DIST_TYPE dist_rule{CMP_DIST_NONE};
+    CMP_COVER_TYPE cover_rule{CMP_COVER_QUERY};
+    bool filter_lc_rule{false};
+};
+
+class search_filter {
+    struct priv_data;
+    std::shared_ptr<priv_data> data;
+
+public:
+    struct options;
+    static options *opts;
+    search_filter();
+    search_filter(const search_filter &);
+    search_filter &operator=(const search_filter &);
+    ~search_filter();
+    tray operator()(tray t);
+    void operator()(std::vector<tray> &batch);
+
+    // "search-db", "search-min-sim", "search-max-result", "lca-fields", "lca-quorum", "search-all",
+    // "search-no-fast", "search-kmer-candidates", "search-kmer-len", "search-ignore-super",
+    // "search-copy-fields", "search-iupac", "search-correction", "search-cover",
+    // "search-filter-lowercase", "db" (fallback for search-db)
+    static void set_option(const std::string &name, const std::string &value);
+    static void reset_options();
+    static void validate_options();
+    static const char *fn_nearest;  // "nearest_slv" (query_arb.cpp:126)
+};
+std::string search_filter_database();  // the store the search stage was configured for
 
 // ---------------------------------------------------------------- batching shim
 // SINA calls a stage once per tray from many TBB workers (function_node with

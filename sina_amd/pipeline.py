@@ -56,6 +56,15 @@ def load_host():
     H.sina_host_store_ctx.argtypes = [C.c_char_p]
     H.sina_host_store_build_index.argtypes = [C.c_char_p, C.c_uint, C.c_int]
     H.sina_host_store_index_ready.argtypes = [C.c_char_p, C.c_uint, C.c_int]
+    H.sina_host_store_set_attr.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p]
+    H.sina_host_compare.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    H.sina_host_pipeline_create_search.restype = vp
+    H.sina_host_result_search.argtypes = [vp, C.c_uint32, capi.u32p, capi.f32p, C.c_uint32]
+    H.sina_host_result_attr.restype = C.c_char_p
+    H.sina_host_result_attr.argtypes = [vp, C.c_uint32, C.c_char_p]
+    H.sina_host_search_seconds.restype = C.c_double
+    H.sina_host_search_seconds.argtypes = [vp]
     _host = H
     return H
 
@@ -110,6 +119,10 @@ class Store:
             raise HostError(self.H.sina_host_last_error().decode())
         return C.c_void_p(h)
 
+    def set_attr(self, ref_id, field, value):
+        """A database field of one reference (version, start, stop, a taxonomy path ...)."""
+        _chk(self.H.sina_host_store_set_attr(self.key.encode(), ref_id, field.encode(), value.encode()))
+
     def build_index(self, k=10, nofast=False):
         _chk(self.H.sina_host_store_build_index(self.key.encode(), k, int(nofast)))
 
@@ -127,9 +140,10 @@ class Store:
 
 
 class Pipeline:
-    """famfinder + aligner over one Store.  Options use SINA's command-line names."""
+    """famfinder + aligner (+ search_filter when `search` is given, as `sina --search`) over one Store.
+    Options use SINA's command-line names."""
 
-    def __init__(self, store, famfinder=None, aligner=None, host_threads=None):
+    def __init__(self, store, famfinder=None, aligner=None, host_threads=None, search=None):
         self.H = load_host()
         self.store = store
         self.H.sina_host_reset_options()
@@ -141,7 +155,14 @@ class Pipeline:
             self._set("aligner", k, v)
         if host_threads:
             self._set("host", "threads", host_threads)
-        self.h = self.H.sina_host_pipeline_create()
+        self.has_search = search is not None
+        if self.has_search:
+            self._set("search", "search-db", store.key)
+            for k, v in search.items():
+                self._set("search", k, v)
+            self.h = self.H.sina_host_pipeline_create_search()
+        else:
+            self.h = self.H.sina_host_pipeline_create()
         if not self.h:
             raise HostError(self.H.sina_host_last_error().decode())
 
@@ -174,9 +195,24 @@ class Pipeline:
                                      C.byref(n)))
         ab = np.ctypeslib.as_array(self.H.sina_host_result_bases(self.h, q), shape=(n.value,)).copy() \
             if n.value else np.zeros(0, np.uint32)
-        return dict(status=st.value, head=hd.value, tail=tl.value, qual=ql.value, width=w.value, packed=ab,
-                    log=self.H.sina_host_result_log(self.h, q).decode(),
-                    family=self.H.sina_host_result_family(self.h, q).decode())
+        d = dict(status=st.value, head=hd.value, tail=tl.value, qual=ql.value, width=w.value, packed=ab,
+                 log=self.H.sina_host_result_log(self.h, q).decode(),
+                 family=self.H.sina_host_result_family(self.h, q).decode())
+        if self.has_search:
+            ids = np.zeros(4096, np.uint32)
+            sc = np.zeros(4096, np.float32)
+            n = self.H.sina_host_result_search(self.h, q, ids.ctypes.data_as(capi.u32p),
+                                               sc.ctypes.data_as(capi.f32p), len(ids))
+            d["search_ids"] = ids[:n].copy() if n >= 0 else None
+            d["search_scores"] = sc[:n].copy() if n >= 0 else None
+        return d
+
+    def attr(self, q, name):
+        """String attribute the search stage set on query q's sequence (nearest_slv, lca_<field>, ...)."""
+        return self.H.sina_host_result_attr(self.h, q, name.encode()).decode()
+
+    def search_seconds(self):
+        return self.H.sina_host_search_seconds(self.h)
 
     def close(self):
         if self.h:
@@ -188,3 +224,14 @@ class Pipeline:
             self.close()
         except Exception:
             pass
+
+
+def host_compare(a_aligned, b_aligned, iupac=0, dist=0, cover=1, filter_lc=False):
+    """The host stage's cseq_comparator on two aligned strings: (score, six counters)."""
+    H = load_host()
+    sc = C.c_float()
+    cnt = (C.c_int32 * 6)()
+    _chk(H.sina_host_compare(a_aligned.encode(), b_aligned.encode(), iupac, dist, cover, int(filter_lc),
+                             C.byref(sc), cnt))
+    return np.float32(sc.value), tuple(cnt)
+

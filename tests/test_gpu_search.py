@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle as po
-from sina_amd import capi, synth
+from sina_amd import capi, pipeline, synth
 from tests import util
 
 pytestmark = pytest.mark.gpu
@@ -81,3 +81,76 @@ def test_compare_reference_against_itself(oracle, gpu_ctx):
     for x, q in enumerate(qs):
         changed = 1 if x % 2 == 0 else 0
         assert tuple(got[x]) == (0, 0, 0, 0, len(q) - changed, changed)
+
+
+def _taxonomy(i):
+    phyla = ["Proteobacteria", "Firmicutes", "Bacteroidota"]
+    return "Bacteria;%s;class%d;order%d;" % (phyla[i % 3], i % 6, i % 12)
+
+
+@pytest.mark.parametrize("sopts,oopts", [
+    ({}, {}),
+    ({"search-min-sim": 0.5, "search-max-result": 7, "search-iupac": "pessimistic", "search-cover": "overlap",
+      "lca-quorum": 0.5},
+     dict(min_sim=0.5, max_result=7, iupac="pessimistic", cover="overlap", lca_quorum=0.5)),
+    # (no --search-correction jc here: Jukes-Cantor of an IDENTITY above 0.75 is NaN, and the order
+    # partial_sort leaves NaN scores in is unspecified in the reference itself)
+    ({"search-kmer-candidates": 40, "search-cover": "all", "search-min-sim": -1, "search-filter-lowercase": True,
+      "search-iupac": "exact"},
+     dict(kmer_candidates=40, cover="all", min_sim=-1, filter_lc=1, iupac="exact")),
+    ({"search-all": True, "search-ignore-super": True, "search-max-result": 5},
+     dict(search_all=1, ignore_super=1, max_result=5)),
+    ({"search-ignore-super": True, "search-min-sim": 0.0}, dict(ignore_super=1, min_sim=0.0)),
+])
+def test_pipeline_with_search_stage(oracle, sopts, oopts):
+    """tray -> famfinder -> aligner -> search_filter through the C++ stage mirror (k-mer search, DP and the
+    1000-candidate comparison on the GPU) vs the oracle run query by query: result ids, score bits,
+    nearest_slv and the LCA classification."""
+    refs = synth.make_refs(420, length=300, width=3000, seed=451, amb_rate=0.01, lower_rate=0.03)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    st = pipeline.Store(":mem:gpu-search", refs)
+    acc = ["ref%d" % i for i in range(refs.n)]
+    ver = [str(1 + i % 3) for i in range(refs.n)]
+    start = [str(i % 7) for i in range(refs.n)]
+    stop = [str(1400 + i) for i in range(refs.n)]
+    for i in range(refs.n):
+        st.set_attr(i, "version", ver[i])
+        st.set_attr(i, "start", start[i])
+        st.set_attr(i, "stop", stop[i])
+        st.set_attr(i, "tax_slv", _taxonomy(i))
+    qs = synth.make_queries(refs, 24, seed=452, amb_rate=0.01, lower_rate=0.05)
+    # three more queries that are exact pieces of references (contained: --search-ignore-super matters)
+    extra = [((refs.seq(i) >> 24) & 0xff).astype(np.uint8)[a:b] for i, a, b in ((5, 10, 250), (77, 0, 200), (300, 40, 290))]
+    masks = [qs.seq(i) for i in range(qs.n)] + extra
+    off = np.zeros(len(masks) + 1, np.int64)
+    off[1:] = np.cumsum([len(m) for m in masks])
+    qs = synth.QuerySet(mask=np.concatenate(masks), off=off, src=np.zeros(len(masks), np.int64))
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    pl = pipeline.Pipeline(st, famfinder=ff, aligner={"realign": True},
+                           search=dict({"lca-fields": "tax_slv"}, **sopts))
+    pl.run(qs.mask, qs.off, batch=10, inflight=2)
+    so = oracle.search_opts(**oopts)
+    n_hits = 0
+    for qi in range(qs.n):
+        got = pl.result(qi)
+        q = util.query_cseq(qs, qi, upper=False)
+        ids, sc, _ = idx.famfinder(q, oracle.ff_opts(fs_min_len=100, fs_full_len=250))
+        if len(ids) == 0:
+            assert got["search_ids"] is None
+            continue
+        al = oracle.align([cs[i] for i in ids], q, oracle.align_opts(realign=1))
+        if al["status"] not in (0, 1):
+            assert got["search_ids"] is None
+            continue
+        aligned = po.Cseq.from_packed("query%d" % qi, al["packed"], al["width"])
+        want_ids, want_sc, _ = oracle.search(idx, aligned, so)
+        assert (got["search_ids"] == want_ids).all(), qi
+        assert (util.f32_bits(got["search_scores"]) == util.f32_bits(want_sc)).all(), qi
+        assert pl.attr(qi, "nearest_slv") == po.search_nearest(acc, ver, start, stop, want_ids, want_sc)
+        assert pl.attr(qi, "lca_tax_slv") == po.search_lca([_taxonomy(int(i)) for i in want_ids], so.lca_quorum)
+        n_hits += len(want_ids)
+    assert n_hits > 0
+    pl.close()
+    st.close()
+

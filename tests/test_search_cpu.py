@@ -1,0 +1,96 @@
+"""CPU tests of the search stage: the oracle's cseq_comparator and the host
+stage's restatement against the reference's own known-answer table
+(src/unit_tests/cseq_comparator_test.cpp, extracted to tests/golden/cseq_comparator_kat.json), and the
+pieces of search_filter::operator() that need no GPU (ranking order, nearest string, LCA vote)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from sina_amd import pipeline
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KAT = json.load(open(os.path.join(GOLD, "cseq_comparator_kat.json")))
+
+
+def _bits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+def test_oracle_comparator_reference_kats(oracle):
+    cs = {k: po.Cseq(k, v) for k, v in KAT["sequences"].items()}
+    assert len(KAT["checks"]) == 121
+    for c in KAT["checks"]:
+        got = po.compare(cs[c["a"]], cs[c["b"]], c["iupac"], c["dist"], c["cover"], c["filter_lc"])
+        if "same_as" in c:
+            o = c["same_as"]
+            want = po.compare(cs[o["a"]], cs[o["b"]], o["iupac"], o["dist"], o["cover"], o["filter_lc"])
+            assert _bits(got) == _bits(want), c
+        else:
+            assert _bits(got) == c["expect_bits"], c
+
+
+def test_host_comparator_reference_kats():
+    seqs = KAT["sequences"]
+    for c in KAT["checks"]:
+        args = (po.IUPAC_RULES[c["iupac"]], po.DIST_RULES[c["dist"]], po.COVER_RULES[c["cover"]], c["filter_lc"])
+        got, _ = pipeline.host_compare(seqs[c["a"]], seqs[c["b"]], *args)
+        if "same_as" in c:
+            o = c["same_as"]
+            want, _ = pipeline.host_compare(seqs[o["a"]], seqs[o["b"]], po.IUPAC_RULES[o["iupac"]],
+                                            po.DIST_RULES[o["dist"]], po.COVER_RULES[o["cover"]], o["filter_lc"])
+            assert _bits(got) == _bits(want), c
+        else:
+            assert _bits(got) == c["expect_bits"], c
+
+
+def test_host_and_oracle_counters_agree_on_random_pairs(oracle):
+    rng = np.random.default_rng(7)
+    alphabet = np.array(list("ACGUacgu-----MRN"))
+    for it in range(300):
+        n = int(rng.integers(8, 60))
+        a = "".join(rng.choice(alphabet, size=n))
+        b = "".join(rng.choice(alphabet, size=n))
+        if not any(ch.isupper() for ch in a) or not any(ch.isupper() for ch in b):
+            continue  # (the reference dereferences end() when a side has no unfiltered base)
+        for iupac in range(3):
+            for flc in (False, True):
+                _, got = pipeline.host_compare(a, b, iupac, 0, 4, flc)
+                want = po.compare_counts(po.Cseq("a", a), po.Cseq("b", b), list(po.IUPAC_RULES)[iupac], flc)
+                assert got == want, (a, b, iupac, flc)
+
+
+def test_jukes_cantor_and_cover_rules(oracle):
+    counts = (3, 5, 2, 7, 80, 9)  # only_a_overhang, only_b_overhang, only_a, only_b, match, mismatch
+    base = {"query": 80 + 9 + 2 + 3, "target": 80 + 9 + 7 + 5, "overlap": 80 + 9 + 2 + 7, "all": 80 + 9 + 17,
+            "average": 80 + 9 + 17 // 2, "min": 89 + 5, "max": 89 + 12, "nogap": 89}
+    for cover, b in base.items():
+        frac = np.float32(80) / np.float32(b)
+        assert _bits(po.compare_score(counts, cover, "none")) == _bits(frac)
+        with np.errstate(invalid="ignore"):  # (identity > 0.75: log of a negative number, NaN on both sides)
+            jc = np.float32(-3.0 / 4 * np.log(1.0 - 4.0 / 3 * float(frac)))
+        assert _bits(po.compare_score(counts, cover, "jc")) == _bits(jc)
+    assert po.compare_score(counts, "abs", "none") == 80
+
+
+def test_lca_vote(oracle):
+    A = "Bacteria;Proteobacteria;Gamma;Entero;"
+    B = "Bacteria;Proteobacteria;Gamma;Pseudo;"
+    C_ = "Bacteria;Firmicutes;Bacilli;"
+    assert po.search_lca([A, A, A], 0.7) == A
+    assert po.search_lca([A, B, A, B], 0.7) == "Bacteria;Proteobacteria;Gamma;"
+    # quorum .7 of 10 results tolerates 3 outliers
+    assert po.search_lca([A] * 7 + [C_] * 3, 0.7) == A
+    assert po.search_lca([A] * 6 + [C_] * 4, 0.7) == "Bacteria;"
+    assert po.search_lca([], 0.7) == "Unclassified;"
+    assert po.search_lca(["Unclassified;", "Unclassified;"], 0.7) == "Unclassified;"
+    assert po.search_lca([A, "Archaea;Eury;"], 1.0) == "Unclassified;"
+    assert po.search_lca(["Bacteria; ", "Bacteria; "], 0.7) == "Bacteria;"
+
+
+def test_nearest_string(oracle):
+    txt = po.search_nearest(["AB1", "CD2"], ["1", "2"], ["5", "0"], ["1500", "1400"], [1, 0],
+                            np.array([0.98765, 0.5], np.float32))
+    assert txt == "CD2.2.0.1400~0.988 AB1.1.5.1500~0.500 "
