@@ -131,13 +131,6 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     const int Lp = pl.geom.Lp();
     const bool weighted = p->weights != nullptr && p->n_weights > 0;
     const bool forbid = p->insertion == SINA_INSERTION_FORBID;
-    // the trace-back plane is the one big allocation: take the whole per-launch budget at once
-    // (if the device has room) instead of growing with the largest batch seen so far
-    if (c->tb.cap < 4 * tb_cells && 4 * tb_cells <= c->tb_budget_bytes) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 2 * c->tb_budget_bytes)
-            if (c->tb.reserve(c->tb_budget_bytes - c->tb_budget_bytes / 4 - 8192)) return 1;
-    }
     if (c->tb.reserve(4 * tb_cells) || c->spill.reserve(std::max<uint64_t>(spill_rows, 1) * 8 * (uint64_t)Lp) ||
         c->res.reserve(sizeof(DpResult) * bq) || c->out.reserve(sizeof(sina_hip_align_out) * bq) ||
         c->out_pos.reserve(4 * std::max<uint64_t>(nqm, 1)))

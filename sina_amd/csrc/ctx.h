@@ -20,7 +20,7 @@ struct sina_hip_store {
     std::mutex dp_token;
     // largest capacity any context has needed for each scratch buffer so far: a new fork reserves
     // these at once (hipMalloc / hipFree synchronise the device; never in steady state)
-    size_t cap_hint[32] = {};
+    size_t cap_hint[64] = {};  // (indexed like sina_hip_ctx::scratch(): kNumScratch entries)
     sina_hip_stats stats;
 };
 
@@ -44,6 +44,7 @@ struct sina_hip_ctx {
     uint64_t tb_budget_bytes = (uint64_t)48 << 30;
 
     static constexpr int kNumScratch = 34;
+    static_assert(kNumScratch <= 64, "sina_hip_store::cap_hint is too short");
     void scratch(sina_hip::DevBuf **all) {
         sina_hip::DevBuf *list[kNumScratch] = {&qd, &rec, &node_pos, &pred, &succ_minpos, &qmask, &tb, &spill, &res,
                                                &weights, &out, &out_pos, &k_qoff, &k_scores, &k_out_ids,
