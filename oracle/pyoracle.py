@@ -45,7 +45,7 @@ class AlignOpts(C.Structure):
 
 class AlignResult(C.Structure):
     _fields_ = [("status", C.c_int), ("head", C.c_int), ("tail", C.c_int), ("qual", C.c_int),
-                ("score", C.c_float), ("cells", C.c_uint64)]
+                ("score", C.c_float), ("cells", C.c_uint64), ("idty", C.c_float)]
 
 
 class Graph(C.Structure):
@@ -404,7 +404,7 @@ def align(fam, query, opts=None):
     txt = log_text(lg)
     lib().so_log_free(C.byref(lg))
     d = dict(status=res.status, head=res.head, tail=res.tail, qual=res.qual, score=np.float32(res.score),
-             cells=res.cells, log=txt, packed=out.packed(), width=out.width)
+             cells=res.cells, log=txt, packed=out.packed(), width=out.width, idty=np.float32(res.idty))
     d["aligned"] = out.aligned() if res.status in (0, 1) else None
     return d
 

@@ -1262,6 +1262,7 @@ part_done:;
             so_cseq_set_width(c, vc[begin_containing]->width);
             so_cseq_set_data(out, c->ab, c->n, c->width);
             res->status = 1;
+            res->idty = 100.f; /* :380-382 */
             res->qual = 100;
             res->head = res->tail = 0;
             res->score = 1.0f;
@@ -1303,6 +1304,14 @@ part_done:;
             if (v < 0.f) v = 0.f;   /* std::max(0.f, v) */
             if (100.f < v) v = 100.f; /* std::min(100.f, .) */
             res->qual = (int)v;
+        }
+        { /* :443-453 calc_idty */
+            float idty = 0;
+            for (uint32_t i = 0; i < nfam; i++) {
+                const float x = so_compare(out, vc[i], SO_CMP_IUPAC_OPTIMISTIC, SO_CMP_DIST_NONE, SO_CMP_COVER_OVERLAP, 0);
+                if (idty < x) idty = x; /* std::max(idty, x) */
+            }
+            res->idty = 100.f * idty;
         }
         res->status = 0;
     }

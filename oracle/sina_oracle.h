@@ -189,6 +189,8 @@ typedef struct so_align_result {
     int head, tail, qual;
     float score;
     uint64_t cells; /* N*L of the mesh that was filled (0 if none) */
+    float idty;     /* --calc-idty (align.cpp:380-382,443-453): 100 * best overlap identity with a family
+                       member; always computed here (40 merge walks, nothing beside the mesh) */
 } so_align_result;
 void so_align(const so_cseq *const *family, uint32_t F, const so_cseq *query,
               const so_align_opts *o, so_cseq *out, so_align_result *res, so_log *log);

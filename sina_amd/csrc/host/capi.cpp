@@ -26,6 +26,7 @@ struct result {
     uint32_t width = 0;
     std::vector<uint32_t> ab;
     std::string log, family;
+    float idty = -1.f;              // align_ident_slv (--calc-idty), -1 if not computed
     bool searched = false;          // search stage ran and produced a result vector
     std::vector<uint32_t> sr_ids;   // search results, best first
     std::vector<float> sr_scores;
@@ -236,6 +237,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                                     k.compare(0, 5, "copy_") == 0)
                                     r.attrs[k] = c.get_attr<std::string>(k);
                             }
+                            r.idty = c.has_attr(fn::idty) ? c.get_attr<float>(fn::idty) : -1.f;
                         }
                         if (t.search_result) {
                             r.searched = true;
@@ -301,6 +303,7 @@ const char *sina_host_result_attr(void *pp, uint32_t q, const char *name) {
     return it == r.attrs.end() ? "" : it->second.c_str();
 }
 double sina_host_search_seconds(void *pp) { return ((pipeline *)pp)->sf_s; }
+float sina_host_result_idty(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].idty; }
 void sina_host_timings(void *pp, double *wall_s, double *famfinder_s, double *aligner_s) {
     pipeline *p = (pipeline *)pp;
     *wall_s = p->wall_s;

@@ -907,7 +907,8 @@ void aligner::set_option(const std::string &name, const std::string &value) {
     else if (name == "pen-gap") o.gap_penalty = std::stof(value);
     else if (name == "pen-gapext") o.gap_ext_penalty = std::stof(value);
     else if (name == "write-used-rels") o.write_used_rels = to_bool(value);
-    else if (name == "fs-no-graph" || name == "use-subst-matrix" || name == "debug-graph" || name == "calc-idty") {
+    else if (name == "calc-idty") o.calc_idty = to_bool(value);
+    else if (name == "fs-no-graph" || name == "use-subst-matrix" || name == "debug-graph") {
         if (to_bool(value)) throw std::logic_error("aligner: --" + name + " is outside the accelerated path");
     } else if (name == "device-graph") o.device_graph = to_bool(value);
     else if (name == "db") o.database = value;
@@ -1170,6 +1171,35 @@ void aligner::operator()(std::vector<tray> &batch) {
             c.set_attr(fn::filter, t.astats->getName());
             t.aligned_sequence = &c;
         });
+
+        // --calc-idty (src/align.cpp:443-453): best overlap identity of the aligned query with a member
+        // of its family -- one comparison launch for the group (sina_hip_compare)
+        if (o.calc_idty) {
+            scoped_phase ph_idty("al.calc_idty(C-ABI)");
+            std::vector<uint64_t> qoff(nq + 1, 0), coff(nq + 1, 0);
+            for (size_t x = 0; x < nq; x++) {
+                qoff[x + 1] = qoff[x] + jobs[idx[x]].c->size();
+                coff[x + 1] = coff[x] + jobs[idx[x]].family.size();
+            }
+            std::vector<uint32_t> qab(qoff.back() ? qoff.back() : 1), cids(coff.back() ? coff.back() : 1);
+            for (size_t x = 0; x < nq; x++) {
+                const cseq &c = *jobs[idx[x]].c;
+                memcpy(qab.data() + qoff[x], c.packed(), 4 * (size_t)c.size());
+                for (size_t y = 0; y < jobs[idx[x]].family.size(); y++)
+                    cids[coff[x] + y] = store->id_of(jobs[idx[x]].family[y]);
+            }
+            std::vector<sina_hip_match_counts> counts(coff.back() ? coff.back() : 1);
+            auto dev = store->worker_device();
+            hip_check(sina_hip_compare(dev.get(), qab.data(), qoff.data(), (uint32_t)nq, cids.data(), coff.data(),
+                                       SINA_CMP_IUPAC_OPTIMISTIC, 0, counts.data()),
+                      "sina_hip_compare");
+            const cseq_comparator calc_id(CMP_IUPAC_OPTIMISTIC, CMP_DIST_NONE, CMP_COVER_OVERLAP, false);
+            for (size_t x = 0; x < nq; x++) {
+                float idty = 0;
+                for (uint64_t y = coff[x]; y < coff[x + 1]; y++) idty = std::max(idty, calc_id.score(counts[y]));
+                jobs[idx[x]].c->set_attr(fn::idty, 100.f * idty);
+            }
+        }
     }
 }
 

@@ -64,6 +64,8 @@ def load_host():
     H.sina_host_result_attr.restype = C.c_char_p
     H.sina_host_result_attr.argtypes = [vp, C.c_uint32, C.c_char_p]
     H.sina_host_search_seconds.restype = C.c_double
+    H.sina_host_result_idty.restype = C.c_float
+    H.sina_host_result_idty.argtypes = [vp, C.c_uint32]
     H.sina_host_search_seconds.argtypes = [vp]
     _host = H
     return H
@@ -197,7 +199,8 @@ class Pipeline:
             if n.value else np.zeros(0, np.uint32)
         d = dict(status=st.value, head=hd.value, tail=tl.value, qual=ql.value, width=w.value, packed=ab,
                  log=self.H.sina_host_result_log(self.h, q).decode(),
-                 family=self.H.sina_host_result_family(self.h, q).decode())
+                 family=self.H.sina_host_result_family(self.h, q).decode(),
+                 idty=np.float32(self.H.sina_host_result_idty(self.h, q)))
         if self.has_search:
             ids = np.zeros(4096, np.uint32)
             sc = np.zeros(4096, np.float32)

@@ -82,6 +82,32 @@ def test_pipeline_aligner_options(oracle, world, al, oal):
     pl.close()
 
 
+def test_pipeline_calc_idty(oracle, world):
+    """--calc-idty (align.cpp:380-382,443-453): align_ident_slv = 100 x the best overlap identity of the
+    aligned query with a member of its family (one comparison launch per batch); 100 for copied
+    alignments; absent without the option."""
+    refs, cs, idx, st = world
+    some = synth.make_queries(refs, 20, seed=58, amb_rate=0.01, lower_rate=0.05)
+    exact = synth.make_queries(refs, 6, seed=59, sub=0.0, dele=0.0, ins=0.0)
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    for qs in (some, exact):
+        pl = pipeline.Pipeline(st, famfinder=ff, aligner={"calc-idty": True})
+        pl.run(qs.mask, qs.off, batch=8, inflight=2)
+        n = 0
+        for qi in range(qs.n):
+            want = _oracle_run(oracle, cs, idx, qs, qi, dict(fs_min_len=100, fs_full_len=250))
+            got = pl.result(qi)
+            if want["status"] in (0, 1):
+                assert util.f32_bits(got["idty"]) == util.f32_bits(want["idty"]), qi
+                n += 1
+        assert n >= 5
+        pl.close()
+    pl = pipeline.Pipeline(st, famfinder=ff)
+    pl.run(some.mask, some.off)
+    assert pl.result(0)["idty"] == -1
+    pl.close()
+
+
 def test_pipeline_copy_shortcut_and_realign(oracle, world):
     """Queries that ARE (substrings of) references: alignment is copied (align.cpp:349-388) unless --realign."""
     refs, cs, idx, st = world
