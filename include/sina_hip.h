@@ -68,6 +68,11 @@ int sina_hip_upload_refs(sina_hip_ctx *ctx, const uint32_t *ab, const uint64_t *
  * is a storage optimisation with identical scores and is not reproduced. */
 int sina_hip_build_index(sina_hip_ctx *ctx, unsigned k, int nofast);
 
+/* Copies the device index back to the host (offsets [4^k+1], ids [n_postings as reported by
+ * sina_hip_store_view_get]); used to write the reference's .sidx cache file after a device build
+ * (kmer_search::impl::store, src/kmer_search.cpp:279-304). */
+int sina_hip_download_index(sina_hip_ctx *ctx, uint32_t *offsets, uint32_t *ids);
+
 /* Alternative to build_index: adopt a host-built CSR index. */
 int sina_hip_upload_index(sina_hip_ctx *ctx, unsigned k, int nofast, const uint32_t *offsets,
                           const uint32_t *ids, uint64_t n_postings);

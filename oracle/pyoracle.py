@@ -151,6 +151,9 @@ def lib():
                                    C.POINTER(AlignOpts), C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.so_log_init.argtypes = [C.POINTER(Log)]
         L.so_log_free.argtypes = [C.POINTER(Log)]
+        L.so_index_write.argtypes = [vp, C.POINTER(C.c_char_p), C.c_char_p]
+        L.so_index_read.restype = vp
+        L.so_index_read.argtypes = [C.c_char_p, C.c_uint, C.c_int]
         L.so_compare_counts.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(MatchCounts)]
         L.so_compare_score.restype = C.c_float
         L.so_compare_score.argtypes = [C.POINTER(MatchCounts), C.c_int, C.c_int]
@@ -343,6 +346,26 @@ class Index:
         ids = np.zeros(max(int(total), 1), np.uint32)
         lib().so_index_csr(self.h, _p(off, u32p), _p(ids, u32p))
         return off, ids[:total]
+
+    def write_sidx(self, path, names=None):
+        """The reference's on-disk index cache for this index (kmer_search::impl::store)."""
+        names = names or ["ref%d" % i for i in range(len(self.refs))]
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        if lib().so_index_write(self.h, arr, path.encode()) != 0:
+            raise IOError(path)
+
+    @classmethod
+    def read_sidx(cls, path, refs, k=10, nofast=False):
+        """kmer_search::impl::try_load; None when the header does not fit."""
+        h = lib().so_index_read(path.encode(), k, int(nofast))
+        if not h:
+            return None
+        self = cls.__new__(cls)
+        self.refs = refs
+        self._h = handles(refs)
+        self.h = C.c_void_p(h)
+        self.k = k
+        return self
 
     def famfinder(self, q, opts=None):
         opts = opts or ff_opts()

@@ -615,6 +615,100 @@ uint32_t so_index_find(const so_index *idx, const so_cseq *query, uint32_t max, 
     return max;
 }
 
+/* ---- .sidx (kmer_search.cpp:66-88: idx_header is {u64 magic; u16 vers; [2 pad]; u32 n_sequences;
+ * u16 flags = k | nofast << 8; [6 pad]} = 24 bytes, the padding is whatever the stack held) */
+static void vlimap_write(const so_vlimap *v, FILE *f) { /* idset.h:390-398 */
+    uint32_t head[4] = {(uint32_t)(int32_t)v->inc, v->last, (uint32_t)v->nbytes, (uint32_t)v->size};
+    fwrite(head, 4, 4, f);
+    fwrite(v->data, 1, v->nbytes, f);
+}
+static so_vlimap *vlimap_read(uint32_t maxsize, FILE *f) { /* :400-409 */
+    uint32_t head[4];
+    if (fread(head, 4, 4, f) != 4) return NULL;
+    so_vlimap *v = so_vlimap_new(maxsize);
+    v->inc = (int16_t)head[0];
+    v->last = head[1];
+    v->size = head[3];
+    v->nbytes = head[2];
+    v->cap = head[2] ? head[2] : 1;
+    free(v->data);
+    v->data = (uint8_t *)malloc(v->cap);
+    if (fread(v->data, 1, v->nbytes, f) != v->nbytes) {
+        so_vlimap_free(v);
+        return NULL;
+    }
+    return v;
+}
+int so_index_write(const so_index *idx, const char *const *names, const char *path) { /* :279-304 */
+    FILE *f = fopen(path, "wb");
+    if (!f) return 1;
+    unsigned char header[24];
+    memset(header, 0, sizeof header);
+    const uint64_t magic = 0x5844494b414e4953ull; /* SINAKIDX */
+    const uint16_t vers = 0, flags = (uint16_t)((idx->k & 0xff) | ((idx->nofast ? 1 : 0) << 8));
+    memcpy(header, &magic, 8);
+    memcpy(header + 8, &vers, 2);
+    memcpy(header + 12, &idx->n_sequences, 4);
+    memcpy(header + 16, &flags, 2);
+    fwrite(header, 1, 24, f);
+    for (uint32_t i = 0; i < idx->n_sequences; i++) fprintf(f, "%s\n", names[i]);
+    so_vlimap *emptymap = so_vlimap_new(idx->n_sequences);
+    for (uint32_t i = 0; i < idx->n_kmers; i++)
+        if (idx->kmer_idx[i] && idx->kmer_idx[i]->size > 0) so_vlimap_push_back(emptymap, i);
+    vlimap_write(emptymap, f);
+    size_t it = 0, idxno = 0;
+    while (it < emptymap->nbytes) {
+        idxno += vl_decode(emptymap, &it);
+        vlimap_write(idx->kmer_idx[idxno], f);
+    }
+    so_vlimap_free(emptymap);
+    fclose(f);
+    return 0;
+}
+so_index *so_index_read(const char *path, unsigned k, int nofast) { /* :306-351 */
+    FILE *f = fopen(path, "rb");
+    if (!f) return NULL;
+    unsigned char header[24];
+    uint64_t magic;
+    uint16_t vers, flags;
+    uint32_t nseq;
+    if (fread(header, 1, 24, f) != 24) goto bad;
+    memcpy(&magic, header, 8);
+    memcpy(&vers, header + 8, 2);
+    memcpy(&nseq, header + 12, 4);
+    memcpy(&flags, header + 16, 2);
+    if (magic != 0x5844494b414e4953ull || vers != 0 || (flags & 0xff) != k || ((flags >> 8) & 1) != (nofast ? 1 : 0))
+        goto bad;
+    {
+        so_index *idx = (so_index *)calloc(1, sizeof(so_index));
+        idx->k = k;
+        idx->n_kmers = 1u << (k * 2);
+        idx->n_sequences = nseq;
+        idx->nofast = nofast;
+        idx->kmer_idx = (so_vlimap **)calloc(idx->n_kmers, sizeof(so_vlimap *));
+        for (uint32_t i = 0; i < nseq; i++) { /* getline per name */
+            int ch;
+            while ((ch = fgetc(f)) != EOF && ch != '\n') {}
+        }
+        so_vlimap *emptymap = vlimap_read(nseq, f);
+        if (!emptymap) {
+            so_index_free(idx);
+            goto bad;
+        }
+        size_t it = 0, idxno = 0;
+        while (it < emptymap->nbytes) {
+            idxno += vl_decode(emptymap, &it);
+            idx->kmer_idx[idxno] = vlimap_read(nseq, f);
+        }
+        so_vlimap_free(emptymap);
+        fclose(f);
+        return idx;
+    }
+bad:
+    fclose(f);
+    return NULL;
+}
+
 /* plain CSR of "ref r contains k-mer v" (SURVEY Appendix A.1): inverted lists
  * are expanded back.  offsets has n_kmers+1 entries. */
 uint64_t so_index_csr(const so_index *idx, uint32_t *offsets, uint32_t *ids) {

@@ -121,6 +121,11 @@ void so_index_scores(const so_index *idx, const so_cseq *query, int16_t *scores)
 /* find(): top-`max` by (score desc, id desc). out arrays must hold min(max,n) entries */
 uint32_t so_index_find(const so_index *idx, const so_cseq *query, uint32_t max,
                        uint32_t *out_ids, float *out_scores);
+/* the reference's on-disk index cache (.sidx): kmer_search::impl::store / try_load,
+ * src/kmer_search.cpp:66-88,279-351 + vlimap::write/read, src/idset.h:386-410.
+ * write: 0 ok.  read: NULL on wrong magic / version / k / nofast. */
+int so_index_write(const so_index *idx, const char *const *names, const char *path);
+so_index *so_index_read(const char *path, unsigned k, int nofast);
 /* CSR export of the (un-inverted) index for loading the device index in tests */
 uint64_t so_index_csr(const so_index *idx, uint32_t *offsets /* 4^k+1 or NULL */,
                       uint32_t *ids /* or NULL */);

@@ -23,7 +23,7 @@ i16p = C.POINTER(C.c_int16)
 ABI_SYMBOLS = [
     "sina_hip_abi_version", "sina_hip_last_error", "sina_hip_init", "sina_hip_fork", "sina_hip_destroy",
     "sina_hip_sync",
-    "sina_hip_upload_refs", "sina_hip_build_index", "sina_hip_upload_index", "sina_hip_store_view_get",
+    "sina_hip_upload_refs", "sina_hip_build_index", "sina_hip_download_index", "sina_hip_upload_index", "sina_hip_store_view_get",
     "sina_hip_store_alloc_like", "sina_hip_kmer_topk", "sina_hip_kmer_scores", "sina_hip_compare",
     "sina_hip_align_params_default", "sina_hip_align_graphs", "sina_hip_align_families",
     "sina_hip_debug_mesh", "sina_hip_debug_family_graph", "sina_hip_get_stats",
@@ -93,6 +93,7 @@ def load():
     L.sina_hip_upload_refs.argtypes = [vp, u32p, u64p, C.c_uint32, C.c_uint32]
     L.sina_hip_build_index.argtypes = [vp, C.c_uint, C.c_int]
     L.sina_hip_upload_index.argtypes = [vp, C.c_uint, C.c_int, u32p, u32p, C.c_uint64]
+    L.sina_hip_download_index.argtypes = [vp, u32p, u32p]
     L.sina_hip_store_view_get.argtypes = [vp, C.POINTER(StoreView)]
     L.sina_hip_store_alloc_like.argtypes = [vp, C.POINTER(StoreView)]
     L.sina_hip_kmer_topk.argtypes = [vp, u8p, u64p, C.c_uint32, C.c_uint32, u32p, f32p, u32p]

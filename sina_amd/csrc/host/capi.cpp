@@ -99,6 +99,56 @@ int sina_host_store_build_index(const char *key, unsigned k, int nofast) {
         return fail(e);
     }
 }
+// .sidx <-> CSR without a GPU (tests): load into caller buffers / store from caller arrays
+int sina_host_sidx_load(const char *path, unsigned k, int nofast, uint32_t *n_sequences, uint32_t *offsets,
+                        uint32_t *ids, uint64_t ids_cap, uint64_t *n_ids) {
+    try {
+        std::vector<std::string> names;
+        std::vector<uint32_t> off, id;
+        std::string why;
+        if (!sidx_load(path, k, nofast != 0, &names, &off, &id, &why)) throw std::runtime_error("sidx_load: " + why);
+        *n_sequences = (uint32_t)names.size();
+        *n_ids = id.size();
+        if (id.size() > ids_cap) throw std::runtime_error("sidx_load: ids buffer too small");
+        memcpy(offsets, off.data(), 4 * off.size());
+        if (!id.empty()) memcpy(ids, id.data(), 4 * id.size());
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+int sina_host_sidx_store(const char *path, unsigned k, int nofast, uint32_t n_sequences, const uint32_t *offsets,
+                         const uint32_t *ids, uint64_t n_ids) {
+    try {
+        std::vector<std::string> names;
+        for (uint32_t i = 0; i < n_sequences; i++) names.push_back("ref" + std::to_string(i));
+        sidx_store(path, k, nofast != 0, names, std::vector<uint32_t>(offsets, offsets + ((size_t)1 << (2 * k)) + 1),
+                   std::vector<uint32_t>(ids, ids + n_ids));
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+// opens an aligned-FASTA database by path (its index is cached in <path minus extension>.sidx)
+int sina_host_store_open(const char *path, int device) {
+    try {
+        auto s = reference_store::get(path);
+        s->set_device(device);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+const char *sina_host_store_index_origin(const char *key) {
+    static thread_local std::string s;
+    try {
+        s = reference_store::get(key)->index_origin();
+    } catch (const std::exception &e) {
+        fail(e);
+        s.clear();
+    }
+    return s.c_str();
+}
 // After the index arrived by broadcast (sina_hip_store_alloc_like + RCCL): tell the store
 // not to rebuild it.
 int sina_host_store_index_ready(const char *key, unsigned k, int nofast) {

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <ctime>
 #include <fstream>
+#include <sys/stat.h>
 #include <chrono>
 #include <map>
 
@@ -373,7 +374,49 @@ void reference_store::ensure_index(unsigned k, bool nofast) {
     sina_hip_ctx *c = device();
     std::lock_guard<std::mutex> lk(gpu_mu);
     if (idx_k == (int)k && idx_nofast == nofast) return;
-    hip_check(sina_hip_build_index(c, k, nofast ? 1 : 0), "build_index");
+    // kmer_search::impl::impl (src/kmer_search.cpp:213-243): a file-backed database keeps its index
+    // in <db>.sidx -- load it if it is not older than the database, else build and store it.
+    // (":..." names are in-memory stores: always built.)
+    std::string idxpath;
+    if (!path.empty() && path[0] != ':') {
+        const size_t dot = path.find_last_of('.'), slash = path.find_last_of('/');
+        idxpath = (dot != std::string::npos && (slash == std::string::npos || dot > slash) ? path.substr(0, dot) : path) +
+                  ".sidx";
+    }
+    bool loaded = false;
+    if (!idxpath.empty()) {
+        struct stat si, sd;
+        if (stat(idxpath.c_str(), &si) == 0 && stat(path.c_str(), &sd) == 0 &&
+            (si.st_mtim.tv_sec > sd.st_mtim.tv_sec ||
+             (si.st_mtim.tv_sec == sd.st_mtim.tv_sec && si.st_mtim.tv_nsec >= sd.st_mtim.tv_nsec))) {
+            std::vector<std::string> names;
+            std::vector<uint32_t> offsets, ids;
+            if (sidx_load(idxpath, k, nofast, &names, &offsets, &ids) && names.size() == seqs.size()) {
+                hip_check(sina_hip_upload_index(c, k, nofast ? 1 : 0, offsets.data(), ids.data(), ids.size()),
+                          "upload_index");
+                loaded = true;
+                idx_origin = "loaded " + idxpath;
+            }
+        }
+    }
+    if (!loaded) {
+        hip_check(sina_hip_build_index(c, k, nofast ? 1 : 0), "build_index");
+        idx_origin = "built";
+        if (!idxpath.empty()) {
+            sina_hip_store_view v;
+            hip_check(sina_hip_store_view_get(c, &v), "store_view_get");
+            std::vector<uint32_t> offsets(((size_t)1 << (2 * k)) + 1), ids(v.n_postings ? v.n_postings : 1);
+            hip_check(sina_hip_download_index(c, offsets.data(), ids.data()), "download_index");
+            ids.resize(v.n_postings);
+            std::vector<std::string> names;
+            for (const auto &sq : seqs) names.push_back(sq.getName());
+            try {
+                sidx_store(idxpath, k, nofast, names, offsets, ids);
+            } catch (const std::exception &) {
+                // (a read-only database directory: keep the in-memory index, like a failed ofstream)
+            }
+        }
+    }
     idx_k = (int)k;
     idx_nofast = nofast;
 }

@@ -138,6 +138,8 @@ public:
         idx_nofast = nofast;
     }
     std::mutex &gpu_mutex() { return gpu_mu; }
+    // how the current index came to be: "built" (on the GPU), "loaded <file>", "adopted" (broadcast)
+    const std::string &index_origin() const { return idx_origin; }
 
     // A forked context (own stream + scratch, shared store/index: sina_hip_fork) for the duration
     // of one GPU call, so that batches in flight on different host threads overlap on the GPU.
@@ -166,8 +168,18 @@ private:
     std::vector<sina_hip_ctx *> idle_forks;  // guarded by gpu_mu
     int idx_k{-1};
     bool idx_nofast{false};
+    std::string idx_origin;
     std::mutex gpu_mu;
 };
+
+// ---------------------------------------------------------------- .sidx index cache
+// The reference's on-disk k-mer index (src/kmer_search.cpp:279-351, src/idset.h:386-410) to and from
+// the CSR form the GPU uses (host/sidx.cpp).  sidx_load returns false (and why) when the file does
+// not fit, as try_load does.
+void sidx_store(const std::string &path, unsigned k, bool nofast, const std::vector<std::string> &names,
+                const std::vector<uint32_t> &offsets, const std::vector<uint32_t> &ids);
+bool sidx_load(const std::string &path, unsigned k, bool nofast, std::vector<std::string> *names,
+               std::vector<uint32_t> *offsets, std::vector<uint32_t> *ids, std::string *why = nullptr);
 
 // ---------------------------------------------------------------- kmer_search
 class kmer_search : public search {

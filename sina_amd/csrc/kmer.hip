@@ -441,6 +441,18 @@ int sina_hip_upload_index(sina_hip_ctx *c, unsigned k, int nofast, const uint32_
     return 0;
 }
 
+int sina_hip_download_index(sina_hip_ctx *c, uint32_t *offsets, uint32_t *ids) {
+    if (!c || !offsets) SH_FAIL("download_index: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->st->have_index) SH_FAIL("download_index: no index");
+    if (!ids && c->st->n_postings) SH_FAIL("download_index: null ids");
+    SH_CHECK(hipSetDevice(c->device));
+    const uint64_t nk = 1ull << (2 * c->st->k);
+    SH_CHECK(hipMemcpy(offsets, c->st->idx_off.p, 4 * (nk + 1), hipMemcpyDeviceToHost));
+    if (c->st->n_postings) SH_CHECK(hipMemcpy(ids, c->st->idx_ids.p, 4 * c->st->n_postings, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int sina_hip_build_index(sina_hip_ctx *c, unsigned k, int nofast) {
     if (!c) SH_FAIL("build_index: null ctx");
     if (k < 1 || k > 12) SH_FAIL("build_index: k must be in 1..12");

@@ -57,6 +57,12 @@ def load_host():
     H.sina_host_store_build_index.argtypes = [C.c_char_p, C.c_uint, C.c_int]
     H.sina_host_store_index_ready.argtypes = [C.c_char_p, C.c_uint, C.c_int]
     H.sina_host_store_set_attr.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p]
+    H.sina_host_sidx_load.argtypes = [C.c_char_p, C.c_uint, C.c_int, capi.u32p, capi.u32p, capi.u32p, C.c_uint64,
+                                      C.POINTER(C.c_uint64)]
+    H.sina_host_sidx_store.argtypes = [C.c_char_p, C.c_uint, C.c_int, C.c_uint32, capi.u32p, capi.u32p, C.c_uint64]
+    H.sina_host_store_open.argtypes = [C.c_char_p, C.c_int]
+    H.sina_host_store_index_origin.restype = C.c_char_p
+    H.sina_host_store_index_origin.argtypes = [C.c_char_p]
     H.sina_host_compare.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     H.sina_host_pipeline_create_search.restype = vp
@@ -90,6 +96,19 @@ class Store:
         off = np.ascontiguousarray(refs.off, np.uint64)
         _chk(self.H.sina_host_store_from_packed(key.encode(), ab.ctypes.data_as(capi.u32p),
                                                 off.ctypes.data_as(capi.u64p), refs.n, refs.width, device))
+
+    @classmethod
+    def open(cls, path, device=0):
+        """An aligned-FASTA database file; its k-mer index is cached beside it as <name>.sidx in the
+        reference's own format (kmer_search.cpp:213-243)."""
+        self = cls.__new__(cls)
+        self.H = load_host()
+        self.key = path
+        _chk(self.H.sina_host_store_open(path.encode(), device))
+        return self
+
+    def index_origin(self):
+        return self.H.sina_host_store_index_origin(self.key.encode()).decode()
 
     def add_filter(self, name, weights):
         w = np.ascontiguousarray(weights, np.float32)
@@ -237,4 +256,24 @@ def host_compare(a_aligned, b_aligned, iupac=0, dist=0, cover=1, filter_lc=False
     _chk(H.sina_host_compare(a_aligned.encode(), b_aligned.encode(), iupac, dist, cover, int(filter_lc),
                              C.byref(sc), cnt))
     return np.float32(sc.value), tuple(cnt)
+
+
+def sidx_load(path, k=10, nofast=False, ids_cap=1 << 26):
+    """The reference's .sidx index cache as CSR: (n_sequences, offsets[4^k+1], ids)."""
+    H = load_host()
+    off = np.zeros((1 << (2 * k)) + 1, np.uint32)
+    ids = np.zeros(ids_cap, np.uint32)
+    n, nid = C.c_uint32(), C.c_uint64()
+    _chk(H.sina_host_sidx_load(path.encode(), k, int(nofast), C.byref(n), off.ctypes.data_as(capi.u32p),
+                               ids.ctypes.data_as(capi.u32p), ids_cap, C.byref(nid)))
+    return n.value, off, ids[:nid.value].copy()
+
+
+def sidx_store(path, n_sequences, offsets, ids, k=10, nofast=False):
+    """Writes a CSR index as the reference's .sidx file (names ref0, ref1, ...)."""
+    H = load_host()
+    offsets = np.ascontiguousarray(offsets, np.uint32)
+    ids = np.ascontiguousarray(ids, np.uint32)
+    _chk(H.sina_host_sidx_store(path.encode(), k, int(nofast), n_sequences, offsets.ctypes.data_as(capi.u32p),
+                                ids.ctypes.data_as(capi.u32p), len(ids)))
 

@@ -154,3 +154,48 @@ def test_pipeline_with_search_stage(oracle, sopts, oopts):
     pl.close()
     st.close()
 
+
+
+def test_fasta_database_keeps_its_index_in_a_sidx_file(oracle, tmp_path):
+    """a file-backed database builds its index on the GPU once, writes it beside the
+    database as <name>.sidx in the reference's format (equal to the oracle's writer), and loads it from
+    there the next time -- with the same search results either way."""
+    import os
+    refs = synth.make_refs(260, length=300, width=2600, seed=471, amb_rate=0.01)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    db = str(tmp_path / "refs.fasta")
+    with open(db, "w") as f:
+        for i in range(refs.n):
+            f.write(">ref%d some description\n%s\n" % (i, synth.aligned_string(refs.seq(i), refs.width)))
+    qs = synth.make_queries(refs, 12, seed=472)
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+
+    def run():
+        st = pipeline.Store.open(db)
+        pl = pipeline.Pipeline(st, famfinder=ff)
+        pl.run(qs.mask, qs.off)
+        fam = [pl.result(q)["family"] for q in range(qs.n)]
+        origin = st.index_origin()
+        pl.close()
+        st.close()
+        return fam, origin
+
+    fam1, origin1 = run()
+    sidx = str(tmp_path / "refs.sidx")
+    assert origin1 == "built" and os.path.exists(sidx)
+    want = str(tmp_path / "want.sidx")
+    idx.write_sidx(want)
+    a, b = open(want, "rb").read(), open(sidx, "rb").read()
+    keep = lambda x: x[:10] + x[12:18] + x[24:]
+    assert keep(a) == keep(b)
+    fam2, origin2 = run()
+    assert origin2 == "loaded " + sidx
+    assert fam1 == fam2
+    for q in range(qs.n):
+        ids, sc, _ = idx.famfinder(util.query_cseq(qs, q, upper=False), oracle.ff_opts(fs_min_len=100, fs_full_len=250))
+        assert fam1[q] == "".join("ref%d.0:%.2f " % (i, s) for i, s in zip(ids, sc))
+    # an index file older than the database is not trusted
+    os.utime(sidx, (1, 1))
+    _, origin3 = run()
+    assert origin3 == "built"

@@ -94,3 +94,40 @@ def test_nearest_string(oracle):
     txt = po.search_nearest(["AB1", "CD2"], ["1", "2"], ["5", "0"], ["1500", "1400"], [1, 0],
                             np.array([0.98765, 0.5], np.float32))
     assert txt == "CD2.2.0.1400~0.988 AB1.1.5.1500~0.500 "
+
+
+# ---- the reference's .sidx index cache
+
+@pytest.mark.parametrize("k,nofast", [(4, False), (4, True), (6, True), (10, False)])
+def test_sidx_files_match_the_oracle_writer_and_reader(oracle, tmp_path, k, nofast):
+    """The host's writer produces the bytes kmer_search::impl::store would (restated in the oracle,
+    whose vlimaps are byte-exact against the real idset.h) -- inverted lists included -- and its reader
+    recovers the CSR index from the oracle's file."""
+    from sina_amd import synth
+    from tests import util
+    refs = synth.make_refs(90, length=220, width=1600, seed=77 + k, amb_rate=0.01)
+    cs = util.cseqs_from_refs(refs)
+    idx = po.Index(cs, k=k, nofast=nofast)
+    off, ids = idx.csr()
+    want = str(tmp_path / "want.sidx")
+    got = str(tmp_path / "got.sidx")
+    idx.write_sidx(want)
+    pipeline.sidx_store(got, refs.n, off, ids, k=k, nofast=nofast)
+    a, b = open(want, "rb").read(), open(got, "rb").read()
+    assert len(a) == len(b)
+    # bytes 10-11 and 18-23 of the header are struct padding (uninitialised in the reference)
+    keep = lambda x: x[:10] + x[12:18] + x[24:]
+    assert keep(a) == keep(b)
+    n, off2, ids2 = pipeline.sidx_load(want, k=k, nofast=nofast)
+    assert n == refs.n and (off2 == off).all() and (ids2 == ids).all()
+    if k == 4:  # short k-mers: many lists are longer than n/2 and stored inverted
+        assert b.count(b"\xff\xff\xff\xff") > 20
+    # wrong k / fast setting are refused, as try_load does
+    with pytest.raises(pipeline.HostError):
+        pipeline.sidx_load(want, k=k + 1, nofast=nofast)
+    with pytest.raises(pipeline.HostError):
+        pipeline.sidx_load(want, k=k, nofast=not nofast)
+    # and the oracle's reader accepts the host's file
+    again = po.Index.read_sidx(got, cs, k=k, nofast=nofast)
+    o3, i3 = again.csr()
+    assert (o3 == off).all() and (i3 == ids).all()
