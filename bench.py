@@ -136,12 +136,16 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.time()
     timing = run_steps(a.warmup, a.steps)
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
     elapsed = time.time() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_cores = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / elapsed
     s1 = store.stats()
 
     n_done = a.batch * a.steps
@@ -230,6 +234,7 @@ def main():
                 "mesh_dp_kernel": iso["dp_ms"],
                 "backtrack_kernel": iso["backtrack_ms"],
             },
+            "host_cores_busy": host_cores,  # CPU seconds per wall second of this rank in the timed region
             "stages_ms_per_step": {
                 "famfinder_host_wall": 1e3 * timing["famfinder_s"] / a.steps,
                 "aligner_host_wall": 1e3 * timing["aligner_s"] / a.steps,

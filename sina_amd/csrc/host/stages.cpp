@@ -374,6 +374,13 @@ void reference_store::ensure_index(unsigned k, bool nofast) {
     sina_hip_ctx *c = device();
     std::lock_guard<std::mutex> lk(gpu_mu);
     if (idx_k == (int)k && idx_nofast == nofast) return;
+    // One index per store on the device: a second (k, fast) combination would replace the index
+    // under the feet of the batches in flight (the reference keeps one kmer_search object per
+    // combination; use a second store for that).
+    if (idx_k != -1)
+        throw std::logic_error("reference store " + path + " already has a k-mer index for k=" + std::to_string(idx_k) +
+                               (idx_nofast ? " (no-fast)" : " (fast)") +
+                               "; famfinder and search must use the same --fs-kmer-len / --fs-kmer-no-fast");
     // kmer_search::impl::impl (src/kmer_search.cpp:213-243): a file-backed database keeps its index
     // in <db>.sidx -- load it if it is not older than the database, else build and store it.
     // (":..." names are in-memory stores: always built.)

@@ -292,12 +292,16 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         return o;
     };
     // wave pipeline hand-shake for row m (LDS flags, no barrier)
+    // (the neighbours' counters only grow: the last value read stays a valid lower bound, and LDS is
+    // asked again only when that bound no longer suffices -- most rows cost no LDS round trip here)
+    uint32_t left_done = 0, right_done = 0;
     auto handshake = [&](uint32_t m) {
-        if (w > 0 && !SH_ABL(8)) {  // the wave to my left must have published row m
-            while (lds_load_relaxed(&progress[w - 1]) <= m) __builtin_amdgcn_s_sleep(1);
+        if (w > 0 && !SH_ABL(8) && left_done <= m) {  // the wave to my left must have published row m
+            while ((left_done = lds_load_relaxed(&progress[w - 1])) <= m) __builtin_amdgcn_s_sleep(1);
         }
-        if (w < NW - 1 && !SH_ABL(8)) {  // do not lap the history slots the wave to my right still needs
-            while (m >= lds_load_relaxed(&progress[w + 1]) + throttle) __builtin_amdgcn_s_sleep(1);
+        if (w < NW - 1 && !SH_ABL(8) && m >= right_done + throttle) {  // do not lap the history slots the
+            // wave to my right still needs
+            while (m >= (right_done = lds_load_relaxed(&progress[w + 1])) + throttle) __builtin_amdgcn_s_sleep(1);
         }
         // LDS is in-order per CU: everything the publishing wave wrote before its progress
         // store is visible once the counter is; only the compiler must not hoist loads.
