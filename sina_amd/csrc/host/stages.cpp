@@ -342,6 +342,17 @@ const cseq &reference_store::getCseq(const std::string &name) const {
         if (c.getName() == name) return c;
     throw std::runtime_error("no such sequence: " + name);
 }
+const std::string &reference_store::upper_bases(unsigned int id) {
+    std::call_once(ubases_once, [this] {
+        ubases.resize(seqs.size());
+        parallel_for(seqs.size(), [this](size_t i) {
+            std::string b = seqs[i].getBases();
+            for (auto &ch : b) ch = (char)toupper((unsigned char)ch);
+            ubases[i].swap(b);
+        });
+    });
+    return ubases[id];
+}
 std::vector<std::string> reference_store::getSequenceNames() const {
     std::vector<std::string> v;
     v.reserve(seqs.size());
@@ -1010,6 +1021,17 @@ void aligner::operator()(std::vector<tray> &batch) {
     std::vector<char> need_dp(batch.size(), 0);
 
     std::unique_ptr<scoped_phase> ph(new scoped_phase("al.prepare(partition)"));
+    std::shared_ptr<reference_store> prep_store;
+    {
+        const std::string db = o.database.empty() ? ff_opts.database : o.database;
+        if (!db.empty()) {
+            try {
+                prep_store = reference_store::get(db);
+            } catch (const std::exception &) {
+            }
+            if (prep_store && !batch.empty() && prep_store->size() > 0) prep_store->upper_bases(0);  // (fills the cache outside the loop)
+        }
+    }
     parallel_for(batch.size(), [&](size_t i) {
         tray &t = batch[i];
         if (t.input_sequence == nullptr || t.alignment_reference == nullptr || t.astats == nullptr) return;  // :310-318
@@ -1019,8 +1041,15 @@ void aligner::operator()(std::vector<tray> &batch) {
         const std::string ubases = upper_copy(bases);
         if (o.lowercase != LOWERCASE_ORIGINAL) c.upperCaseAll();
 
+        // upper-case bases of a family member: cached per store (40 members x every query)
+        auto ref_ubases = [&](const cseq *r, std::string &tmp) -> const std::string & {
+            if (prep_store && prep_store->owns(r)) return prep_store->upper_bases(prep_store->id_of(r));
+            tmp = upper_copy(r->getBases());
+            return tmp;
+        };
         auto not_contains_query = [&](search::result_item &item) {
-            return upper_copy(item.sequence->getBases()).find(ubases) == std::string::npos;
+            std::string tmp;
+            return ref_ubases(item.sequence, tmp).find(ubases) == std::string::npos;
         };
         auto begin_containing = std::partition(vc.begin(), vc.end(), not_contains_query);
         if (begin_containing != vc.end()) {
@@ -1037,7 +1066,8 @@ void aligner::operator()(std::vector<tray> &batch) {
                 }
             } else {  // :349-388 steal the alignment
                 auto same_as_query = [&](search::result_item &item) {
-                    return upper_copy(item.sequence->getBases()) == ubases;
+                    std::string tmp;
+                    return ref_ubases(item.sequence, tmp) == ubases;
                 };
                 auto exact = std::find_if(begin_containing, vc.end(), same_as_query);
                 if (exact != vc.end()) {
@@ -1047,7 +1077,8 @@ void aligner::operator()(std::vector<tray> &batch) {
                           << exact->sequence->get_attr<std::string>(fn::start, "0") << "; ";
                 } else {
                     const auto &refal = begin_containing->sequence->getAlignedBases();
-                    const size_t at = upper_copy(begin_containing->sequence->getBases()).find(ubases);
+                    std::string tmp;
+                    const size_t at = ref_ubases(begin_containing->sequence, tmp).find(ubases);
                     std::vector<aligned_base> sub(refal.begin() + at, refal.begin() + at + bases.size());
                     c.setAlignedBases(sub);
                     t.log << "copied alignment from (longer) template sequence "

@@ -121,6 +121,10 @@ public:
     const cseq &getCseq(unsigned int id) const { return seqs[id]; }
     const cseq &getCseq(const std::string &name) const;
     unsigned int id_of(const cseq *c) const { return (unsigned int)(c - seqs.data()); }
+    bool owns(const cseq *c) const { return c >= seqs.data() && c < seqs.data() + seqs.size(); }
+    // getBases() of a reference in upper case, computed once for the whole store (the aligner asks
+    // for it for every family member of every query: icontains(), src/align.cpp:329-333)
+    const std::string &upper_bases(unsigned int id);
     std::vector<std::string> getSequenceNames() const;
     void loadKey(const cseq &c, const std::string &key) const;  // acc := name, start := "0" if absent
     std::vector<alignment_stats> &getAlignmentStats() { return vastats; }
@@ -169,6 +173,8 @@ private:
     int idx_k{-1};
     bool idx_nofast{false};
     std::string idx_origin;
+    std::vector<std::string> ubases;
+    std::once_flag ubases_once;
     std::mutex gpu_mu;
 };
 
