@@ -20,7 +20,7 @@
 //     successors in W LDS slots (8 B per column) that only that wave touches; slots
 //     are handed out by liveness when the graph is built, and a row that finds every
 //     slot busy goes to a per-query spill area in HBM instead (read back by the lane
-//     that wrote it, the first such row of the next DP row prefetched);
+//     that wrote it; 3 % of the predecessor reads at three slots);
 //   * gapm_idx is not carried at all: the trace-back cell records whether a deletion
 //     extends its predecessor's gap and whether the row's own gap was opened from its
 //     last predecessor, and backtrack() resolves the index for the few cells on the
@@ -308,43 +308,117 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         asm volatile("" ::: "memory");
     };
 
-    // phase-1 results of the current row: deletion / match candidates of my B cells
-    // (dvm / mtp hold value_midx already shifted into its trace-back position, dvm with kTbExt)
-    float dv[B], gm[B], mt[B];
-    uint32_t dvm[B], dvs[B], mtp[B];
-    uint32_t oplast = 0;  // bit k: gapm of cell k was opened from the row's last predecessor
-    auto init_cells = [&](const Row &r) {
-#pragma unroll
-        for (int k = 0; k < B; k++) {
-            const float iv = (s0 + k == 0) ? 1.0f : r.init_v;
-            dv[k] = iv;
-            gm[k] = iv;
-            mt[k] = __builtin_inff();
-            dvm[k] = 0;
-            dvs[k] = 0;
-            mtp[k] = 0;
-        }
-        oplast = 0;
-    };
-
-    // Rows are software-pipelined across loop iterations: iteration m finishes row m (insertion
-    // chain, publish, trace-back) and then starts row m+1 (hand-shake, candidates from its
-    // predecessors).  That way the spill row of row m+1's first far predecessor can be requested
-    // in the middle of the iteration and is consumed at its end, with the chain-independent tail
-    // of row m in between -- and the compiler sees load and use in one straight line, so it waits
-    // for exactly that load instead of draining all outstanding trace-back stores.
-    // Row 0 has no predecessors (they have smaller ids), its candidates are the initial values.
-    Cells<B> pf_v, pf_g;  // spill row of the next row's first spilled predecessor, in flight
-#pragma unroll
-    for (int i = 0; i < B / 4; i++) pf_v.v[i] = pf_g.v[i] = 0.f;
-    Row r = setup_row(rec[0], 0);
-    handshake(0);
-    init_cells(r);
+    uint4 cur = rec[0];
     for (uint32_t m = 0; m < N; ++m) {
-        const bool has_next = m + 1 < N;
-        const uint4 nrec = rec[has_next ? m + 1 : m];  // scalar load, used after the chain
+        const uint4 nrec = rec[m + 1 < N ? m + 1 : m];  // scalar prefetch of the next row record
+        // phase-1 results of the current row: deletion / match candidates of my B cells
+        // (dvm / mtp hold value_midx already shifted into its trace-back position, dvm with kTbExt)
+        float dv[B], gm[B], mt[B];
+        uint32_t dvm[B], dvs[B], mtp[B];
+        uint32_t oplast = 0;  // bit k: gapm of cell k was opened from the row's last predecessor
+        auto init_cells = [&](const Row &r) {
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                const float iv = (s0 + k == 0) ? 1.0f : r.init_v;
+                dv[k] = iv;
+                gm[k] = iv;
+                mt[k] = __builtin_inff();
+                dvm[k] = 0;
+                dvs[k] = 0;
+                mtp[k] = 0;
+            }
+            oplast = 0;
+        };
+
+        // ---- phase 1: deletion / match candidates of my B cells from the predecessor rows
+        const Row r = setup_row(cur, m);
+        handshake(m);
+        SH_PROF(1)
+        if (r.npred == 0) init_cells(r);  // (otherwise the first predecessor's relax initialises)
+        float gdo_v, gde_v;  // gap open / extend cost of a deletion, in VGPRs
+        float csel[B];
+        {
+            const float vM = opaque_v(r.cM), vX = opaque_v(r.cX), vgo = opaque_v(r.gd_open), vge = opaque_v(r.gd_ext);
+            gdo_v = vgo;
+            gde_v = vge;
+#pragma unroll
+            for (int k = 0; k < B; k++) csel[k] = (r.mmask & qm[k]) ? vM : vX;  // comp(): optimistic IUPAC match (aligned_base.h:153)
+        }
+        // (FIRST: the row's first predecessor meets the initial values -- constants -- instead of
+        // registers that would have to be initialised first)
+        const float iv0 = (j == 0) ? 1.0f : r.init_v;  // initial value of my cell 0 (column 0 starts at 1)
+        auto relax = [&](auto first_tag, uint32_t p, bool is_last, const Cells<B> &sv, const Cells<B> &sg,
+                         float svl) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const uint32_t p_open = p << 16, p_ext = (p << 16) | kTbExt;
+            uint32_t ob = 0;
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                // deletion (mesh.h:307-330): gapm_* is overwritten by every predecessor
+                const float v = add_raw(sv[k], gdo_v);
+                const float g = add_raw(sg[k], gde_v);
+                const bool op = v < g;
+                const float cand = op ? v : g;
+                gm[k] = cand;
+                if (is_last) ob |= op ? (1u << k) : 0u;
+                const float dv_old = FIRST ? (k == 0 ? iv0 : r.init_v) : dv[k];
+                const bool better = cand < dv_old;
+                dv[k] = better ? cand : dv_old;
+                dvm[k] = better ? (op ? p_open : p_ext) : (FIRST ? 0u : dvm[k]);
+                dvs[k] = better ? s0 + k : (FIRST ? 0u : dvs[k]);  // value_sidx of a deletion is the column itself
+                // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
+                const float pvv = (k == 0) ? svl : sv[k - 1];
+                const float mv = add_raw(pvv, csel[k]);
+                const float mt_old = FIRST ? __builtin_inff() : mt[k];
+                const bool mb = ((s0 + k) > 0) && (mv < mt_old);
+                mt[k] = mb ? mv : mt_old;
+                mtp[k] = mb ? p_open : (FIRST ? 0u : mtp[k]);
+            }
+            if (is_last) oplast = ob;
+        };
+        // Predecessors in ascending id order (the reference's order: the first minimum wins, the
+        // last one defines gapm).  Entry = id | (LDS slot or spill row) << 16 | spilled << 31.
+        // My own columns of a spill row were written by me; the single value I need from the wave
+        // to my left (column s0-1, lane 0 only) comes from its boundary history in LDS, or -- for
+        // predecessors further back than kFarLds rows -- from the spill row itself, which such rows
+        // publish with a workgroup-scope release (kRecFence; such rows are made to spill: see below).
+        for (uint32_t e = 0; e < r.npred; ++e) {
+            const uint32_t pe = pred[r.pb + e];
+            const uint32_t p = pe & 0xffffu;
+            const bool is_last = (e + 1 == r.npred);
+            Cells<B> sv, sg;
+            float far_bnd = 0.f;
+            if (pe & kPredSpilled) {
+                if (SH_ABL(2)) continue;
+                const float *row = spill + (size_t)((pe >> 16) & 0x7FFFu) * (2 * Lp);
+                sv.load(row + s0);
+                sg.load(row + Lp + s0);
+                if (lane == 0 && w > 0 && m - p > (uint32_t)kFarLds) far_bnd = row[s0 - 1];
+                // consume the global loads HERE: the compiler then waits for them (vmcnt) inside
+                // this rare branch instead of after the merge with the LDS path, where the wait
+                // would also drain the previous row's trace-back stores on every row
+#pragma unroll
+                for (int i = 0; i < B / 4; i++) {
+                    asm volatile("" : "+v"(sv.v[i]));
+                    asm volatile("" : "+v"(sg.v[i]));
+                }
+                asm volatile("" : "+v"(far_bnd));
+                SH_PROF_CNT(9, 1)
+            } else {
+                const unsigned char *slot = ring + (size_t)(pe >> 16) * kSlotBytes;
+                sv.load(reinterpret_cast<const float *>(slot) + s0);
+                sg.load(reinterpret_cast<const float *>(slot + kValBytes) + s0);
+            }
+            float svl = lane_shr1(sv[B - 1]);  // value[p][s0-1] lives in the lane to my left
+            if (lane == 0 && w > 0) {
+                if (m - p <= (uint32_t)kFarLds) svl = bnd_val[(w - 1) * kBndHist + (p & (kBndHist - 1))];
+                else svl = far_bnd;
+            }
+            if (e == 0) relax(std::true_type{}, p, is_last, sv, sg, svl);
+            else relax(std::false_type{}, p, is_last, sv, sg, svl);
+        }
+        SH_PROF(3)
         const bool is_sink = (r.z & kRecSink) != 0;
-        SH_PROF(0)
 
         // ---- phase 2: insertion chain along my B cells
         float fv[B];
@@ -594,15 +668,6 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         if (lane == 0) __hip_atomic_store(&progress[w], m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         SH_PROF(6)
 
-        // ---- request the spill row of the first spilled predecessor of row m+1 (after my own spill
-        // stores, so that waiting for it later does not wait for them; before the trace-back stores)
-        const uint32_t n_ff = has_next ? (nrec.z >> 24) : 0u;
-        if (n_ff != 0 && !SH_ABL(2)) {  // (no else: the registers keep their stale contents, never read)
-            const float *row = spill + (size_t)((pred[nrec.x + n_ff - 1] >> 16) & 0x7FFFu) * (2 * Lp);
-            pf_v.load(row + s0);
-            pf_g.load(row + Lp + s0);
-        }
-
         // ---- trace-back cells: the only per-cell HBM traffic
         if (!SH_ABL(4)) {
             uint32_t tc[B];
@@ -653,102 +718,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         }
         SH_PROF(7)
         SH_PROF_CNT(8, 1)
-        if (!has_next) break;
-
-        // ================= row m+1: candidates from its predecessor rows =================
-        const uint32_t mn = m + 1;
-        r = setup_row(nrec, mn);
-        handshake(mn);
-        SH_PROF(1)
-        if (r.npred == 0) init_cells(r);  // (otherwise the first predecessor's relax initialises)
-        float gdo_v, gde_v;  // gap open / extend cost of a deletion, in VGPRs
-        float csel[B];
-        {
-            const float vM = opaque_v(r.cM), vX = opaque_v(r.cX), vgo = opaque_v(r.gd_open), vge = opaque_v(r.gd_ext);
-            gdo_v = vgo;
-            gde_v = vge;
-#pragma unroll
-            for (int k = 0; k < B; k++) csel[k] = (r.mmask & qm[k]) ? vM : vX;  // comp(): optimistic IUPAC match (aligned_base.h:153)
-        }
-        // (FIRST: the row's first predecessor meets the initial values -- constants -- instead of
-        // registers that would have to be initialised first)
-        const float iv0 = (j == 0) ? 1.0f : r.init_v;  // initial value of my cell 0 (column 0 starts at 1)
-        auto relax = [&](auto first_tag, uint32_t p, bool is_last, const Cells<B> &sv, const Cells<B> &sg,
-                         float svl) {
-            constexpr bool FIRST = decltype(first_tag)::value;
-            const uint32_t p_open = p << 16, p_ext = (p << 16) | kTbExt;
-            uint32_t ob = 0;
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-                // deletion (mesh.h:307-330): gapm_* is overwritten by every predecessor
-                const float v = add_raw(sv[k], gdo_v);
-                const float g = add_raw(sg[k], gde_v);
-                const bool op = v < g;
-                const float cand = op ? v : g;
-                gm[k] = cand;
-                if (is_last) ob |= op ? (1u << k) : 0u;
-                const float dv_old = FIRST ? (k == 0 ? iv0 : r.init_v) : dv[k];
-                const bool better = cand < dv_old;
-                dv[k] = better ? cand : dv_old;
-                dvm[k] = better ? (op ? p_open : p_ext) : (FIRST ? 0u : dvm[k]);
-                dvs[k] = better ? s0 + k : (FIRST ? 0u : dvs[k]);  // value_sidx of a deletion is the column itself
-                // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
-                const float pvv = (k == 0) ? svl : sv[k - 1];
-                const float mv = add_raw(pvv, csel[k]);
-                const float mt_old = FIRST ? __builtin_inff() : mt[k];
-                const bool mb = ((s0 + k) > 0) && (mv < mt_old);
-                mt[k] = mb ? mv : mt_old;
-                mtp[k] = mb ? p_open : (FIRST ? 0u : mtp[k]);
-            }
-            if (is_last) oplast = ob;
-        };
-        // Predecessors in ascending id order (the reference's order: the first minimum wins, the
-        // last one defines gapm).  Entry = id | (LDS slot or spill row) << 16 | spilled << 31.
-        // My own columns of a spill row were written by me; the single value I need from the wave
-        // to my left (column s0-1, lane 0 only) comes from its boundary history in LDS, or -- for
-        // predecessors further back than kFarLds rows -- from the spill row itself, which such rows
-        // publish with a workgroup-scope release (kRecFence; such rows are made to spill: see below).
-        for (uint32_t e = 0; e < r.npred; ++e) {
-            const uint32_t pe = pred[r.pb + e];
-            const uint32_t p = pe & 0xffffu;
-            const bool is_last = (e + 1 == r.npred);
-            Cells<B> sv, sg;
-            float far_bnd = 0.f;
-            if (pe & kPredSpilled) {
-                if (SH_ABL(2)) continue;
-                const float *row = spill + (size_t)((pe >> 16) & 0x7FFFu) * (2 * Lp);
-                if (e + 1 == r.first_far) {
-                    sv = pf_v;
-                    sg = pf_g;
-                } else {
-                    sv.load(row + s0);
-                    sg.load(row + Lp + s0);
-                }
-                if (lane == 0 && w > 0 && mn - p > (uint32_t)kFarLds) far_bnd = row[s0 - 1];
-                // consume the global loads HERE: the compiler then waits for them (vmcnt) inside
-                // this rare branch instead of after the merge with the LDS path, where the wait
-                // would also drain the previous row's trace-back stores on every row
-#pragma unroll
-                for (int i = 0; i < B / 4; i++) {
-                    asm volatile("" : "+v"(sv.v[i]));
-                    asm volatile("" : "+v"(sg.v[i]));
-                }
-                asm volatile("" : "+v"(far_bnd));
-                SH_PROF_CNT(9, 1)
-            } else {
-                const unsigned char *slot = ring + (size_t)(pe >> 16) * kSlotBytes;
-                sv.load(reinterpret_cast<const float *>(slot) + s0);
-                sg.load(reinterpret_cast<const float *>(slot + kValBytes) + s0);
-            }
-            float svl = lane_shr1(sv[B - 1]);  // value[p][s0-1] lives in the lane to my left
-            if (lane == 0 && w > 0) {
-                if (mn - p <= (uint32_t)kFarLds) svl = bnd_val[(w - 1) * kBndHist + (p & (kBndHist - 1))];
-                else svl = far_bnd;
-            }
-            if (e == 0) relax(std::true_type{}, p, is_last, sv, sg, svl);
-            else relax(std::false_type{}, p, is_last, sv, sg, svl);
-        }
-        SH_PROF(3)
+        cur = nrec;
     }
     SH_PROF_FLUSH
 
