@@ -8,7 +8,9 @@
 
 #include "stages.h"
 
+#include <fstream>
 #include <map>
+#include <sstream>
 #include <memory>
 
 using namespace sina;
@@ -99,6 +101,88 @@ int sina_host_store_build_index(const char *key, unsigned k, int nofast) {
         return fail(e);
     }
 }
+// sina -i in.fasta -o out.fasta --db <key> [--search] [--show-dist]: FASTA reader -> famfinder -> aligner
+// [-> search_filter] -> log printer -> FASTA writer, in batches of `batch` sequences.  The stage
+// options are whatever sina_host_set_option set.  summary: n_read, n_aligned, n_written, n_skipped,
+// then avg_sps, avg_cpm, avg_idty (as Log::printer prints them at exit).
+int sina_host_run_fasta(const char *in_path, const char *out_path, const char *log_path, int do_search,
+                        int show_dist, uint32_t batch, double *summary7) {
+    try {
+        famfinder::validate_options();
+        aligner::validate_options();
+        if (do_search) search_filter::validate_options();
+        famfinder ff;
+        aligner al;
+        std::unique_ptr<search_filter> sf;
+        if (do_search) sf.reset(new search_filter());
+        rw_fasta::reader rd(in_path);
+        rw_fasta::writer wr(out_path);
+        log_printer lp(show_dist != 0);
+        std::ofstream logf;
+        if (log_path && *log_path) logf.open(log_path);
+        std::ostringstream sink;
+        std::ostream &log = logf.is_open() ? static_cast<std::ostream &>(logf) : sink;
+        if (batch == 0) batch = 1024;
+        int n_read = 0, n_aligned = 0;
+        for (;;) {
+            std::vector<tray> trays;
+            while (trays.size() < batch) {
+                tray t;
+                if (!rd(t)) break;
+                trays.push_back(t);
+            }
+            if (trays.empty()) break;
+            n_read += (int)trays.size();
+            ff(trays);
+            al(trays);
+            if (sf) (*sf)(trays);
+            for (auto &t : trays) {  // serial, in input order (Log::printer and the writer are serial nodes)
+                if (t.aligned_sequence) n_aligned++;
+                t = lp(t, log);
+                t = wr(t);
+                t.destroy();
+                sink.str("");
+            }
+        }
+        wr.flush();
+        const log_printer::summary sm = lp.totals();
+        summary7[0] = n_read;
+        summary7[1] = n_aligned;
+        summary7[2] = wr.written();
+        summary7[3] = rd.skipped();
+        summary7[4] = sm.avg_sps;
+        summary7[5] = sm.avg_cpm;
+        summary7[6] = sm.avg_idty;
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+// FASTA reader + writer alone (no GPU): reads every sequence of in_path and writes it back, the
+// input sequence standing in for the aligned one; returns the counts.  For CPU tests of the I/O rules.
+int sina_host_fasta_roundtrip(const char *in_path, const char *out_path, int *n_read, int *n_skipped) {
+    try {
+        rw_fasta::reader rd(in_path);
+        rw_fasta::writer wr(out_path);
+        int n = 0;
+        for (;;) {
+            tray t;
+            if (!rd(t)) break;
+            n++;
+            t.aligned_sequence = new cseq(*t.input_sequence);
+            t = wr(t);
+            t.destroy();
+        }
+        wr.flush();
+        *n_read = n;
+        *n_skipped = rd.skipped();
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
 // .sidx <-> CSR without a GPU (tests): load into caller buffers / store from caller arrays
 int sina_host_sidx_load(const char *path, unsigned k, int nofast, uint32_t *n_sequences, uint32_t *offsets,
                         uint32_t *ids, uint64_t ids_cap, uint64_t *n_ids) {
@@ -164,6 +248,7 @@ int sina_host_reset_options(void) {
     famfinder::reset_options();
     aligner::reset_options();
     search_filter::reset_options();
+    rw_fasta::reset_options();
     return 0;
 }
 
@@ -182,6 +267,7 @@ int sina_host_set_option(const char *stage, const char *name, const char *value)
         if (!strcmp(stage, "famfinder")) famfinder::set_option(name, value);
         else if (!strcmp(stage, "aligner")) aligner::set_option(name, value);
         else if (!strcmp(stage, "search")) search_filter::set_option(name, value);
+        else if (!strcmp(stage, "fasta")) rw_fasta::set_option(name, value);
         else if (!strcmp(stage, "host") && !strcmp(name, "threads")) set_host_threads((unsigned)atoi(value));
         else throw std::logic_error(std::string("unknown stage ") + stage);
         return 0;

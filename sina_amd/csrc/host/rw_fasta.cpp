@@ -1,0 +1,365 @@
+// FASTA source / sink stages and the --show-dist accuracy metrics.
+//
+// Restates reference src/rw_fasta.cpp (reader::operator() :229-315, writer :332-541) and
+// Log::printer (src/log.cpp:279-325 show_dist, :364-430 operator()) on std::fstream: name / full_name
+// split, ";key=value" comment attributes, skipping of sequences with characters outside the IUPAC
+// alphabet, --fasta-idx/--fasta-block slicing; on output the three text meta formats and the csv
+// side file, dots vs dashes, DNA vs RNA, line wrapping, the --min-idty filter, --add-relatives.
+// gzip in/out (boost::iostreams filters in the reference) is not provided.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <unordered_set>
+
+#include "stages.h"
+
+namespace sina {
+
+// ---------------------------------------------------------------- options
+
+struct rw_fasta::options {
+    FASTA_META_TYPE fastameta = FASTA_META_NONE;
+    int line_length = 0;
+    float min_idty = 0.f;
+    long fasta_block = 0, fasta_idx = 0;
+    bool out_dots = false, out_dna = false;
+};
+rw_fasta::options *rw_fasta::opts = nullptr;
+static rw_fasta::options &fa_opts() {
+    if (!rw_fasta::opts) rw_fasta::opts = new rw_fasta::options();
+    return *rw_fasta::opts;
+}
+void rw_fasta::reset_options() { fa_opts() = options(); }
+void rw_fasta::set_option(const std::string &name, const std::string &value) {
+    options &o = fa_opts();
+    std::string v(value);
+    for (auto &c : v) c = (char)tolower((unsigned char)c);
+    auto to_bool = [&]() { return v == "1" || v == "true" || v == "yes" || v == "on" || v.empty(); };
+    if (name == "meta-fmt") {
+        if (v == "none") o.fastameta = FASTA_META_NONE;
+        else if (v == "header") o.fastameta = FASTA_META_HEADER;
+        else if (v == "comment") o.fastameta = FASTA_META_COMMENT;
+        else if (v == "csv") o.fastameta = FASTA_META_CSV;
+        else throw std::logic_error("must be one of 'none', 'header', 'comment' or 'cvs'");
+    } else if (name == "line-length") o.line_length = std::stoi(value);
+    else if (name == "min-idty") o.min_idty = std::stof(value);
+    else if (name == "fasta-write-dna") o.out_dna = to_bool();
+    else if (name == "fasta-write-dots") o.out_dots = to_bool();
+    else if (name == "fasta-idx") o.fasta_idx = std::stol(value);
+    else if (name == "fasta-block") o.fasta_block = std::stol(value);
+    else throw std::logic_error("fasta: unknown option " + name);
+}
+
+// ---------------------------------------------------------------- reader
+
+struct rw_fasta::reader::priv_data {
+    std::ifstream in;
+    std::string filename;
+    int lineno = 0, seqno = 0, skipped = 0;
+};
+
+rw_fasta::reader::reader(const std::string &infile) : data(new priv_data) {
+    data->filename = infile;
+    data->in.open(infile, std::ios_base::binary);
+    if (!data->in.is_open()) throw std::runtime_error("Unable to open file \"" + infile + "\" for reading.");
+    if (fa_opts().fasta_block > 0) data->in.seekg(fa_opts().fasta_block * fa_opts().fasta_idx);
+}
+rw_fasta::reader::reader(const reader &) = default;
+rw_fasta::reader &rw_fasta::reader::operator=(const reader &) = default;
+rw_fasta::reader::~reader() = default;
+int rw_fasta::reader::skipped() const { return data->skipped; }
+
+static std::string trim(const std::string &s) {  // boost::trim
+    size_t a = 0, b = s.size();
+    while (a < b && isspace((unsigned char)s[a])) a++;
+    while (b > a && isspace((unsigned char)s[b - 1])) b--;
+    return s.substr(a, b - a);
+}
+
+bool rw_fasta::reader::operator()(tray &t) {  // :229-315
+    const options &o = fa_opts();
+    for (;;) {
+        t.seqno = ++data->seqno;
+        t.input_sequence = new cseq();
+        cseq &c = *t.input_sequence;
+        auto give_up = [&]() {
+            delete t.input_sequence;
+            t.input_sequence = nullptr;
+            return false;
+        };
+        if (data->in.fail()) return give_up();
+        // if fasta blocking enabled, check if we've passed block boundary in last sequence
+        if (o.fasta_block > 0 && data->in.tellg() > o.fasta_block * (o.fasta_idx + 1)) return give_up();
+
+        std::string line;
+        // skip lines not beginning with '>'
+        while (data->in.peek() != '>' && std::getline(data->in, line).good()) data->lineno++;
+
+        // parse title
+        data->lineno++;
+        if (std::getline(data->in, line).good()) {
+            if (!line.empty() && line[line.size() - 1] == '\r') line.resize(line.size() - 1);
+            // set name to text between first '>' and first ' '
+            unsigned int blank = (unsigned int)line.find_first_of(" \t");
+            if (blank == 0) blank = (unsigned int)line.size();
+            c.setName(line.substr(1, blank - 1));
+            if (blank < line.size()) c.set_attr<std::string>(fn::fullname, line.substr(blank + 1));
+        } else {  // didn't get a title
+            return give_up();
+        }
+
+        // handle comments: "; key = value" becomes an attribute, others are ignored
+        while (data->in.peek() == ';' && std::getline(data->in, line).good()) {
+            data->lineno++;
+            const size_t equalsign = line.find_first_of('=');
+            if (equalsign != std::string::npos)
+                c.set_attr(trim(line.substr(1, equalsign - 1)), trim(line.substr(equalsign + 1)));
+        }
+
+        try {
+            // all lines until eof or next /^>/ are data
+            while (data->in.peek() != '>' && data->in.good()) {
+                std::getline(data->in, line);
+                data->lineno++;
+                c.append(line);
+            }
+        } catch (base_iupac::bad_character_exception &) {
+            // "Skipping sequence N (>name) at file:line (contains character 'x')"
+            while (data->in.peek() != '>' && std::getline(data->in, line).good()) data->lineno++;
+            delete t.input_sequence;
+            t.input_sequence = nullptr;
+            data->skipped++;
+            continue;  // (the reference recurses here)
+        }
+        return true;
+    }
+}
+
+// ---------------------------------------------------------------- writer
+
+// boost::apply_visitor(lexical_cast_visitor<string>(), variant<string, char, int, float>)
+static std::string attr_to_string(const cseq::variant &v) {
+    if (const auto *s = std::get_if<std::string>(&v)) return *s;
+    if (const auto *c = std::get_if<char>(&v)) return std::string(1, *c);
+    if (const auto *i = std::get_if<int>(&v)) return std::to_string(*i);
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.9g", (double)std::get<float>(v));  // lexical_cast<string>(float): 9 digits
+    return buf;
+}
+
+static std::string escape_string(const std::string &in) {  // :378-392
+    if (in.find_first_of("\",\r\n") == std::string::npos) return in;
+    std::stringstream tmp;
+    tmp << "\"";
+    size_t j = 0;
+    for (size_t i = in.find('"'); i != std::string::npos; j = i + 1, i = in.find('"', i + 1))
+        tmp << in.substr(j, i - j) << "\"\"";
+    tmp << in.substr(j) << "\"";
+    return tmp.str();
+}
+
+struct rw_fasta::writer::priv_data {
+    std::ofstream out, out_csv;
+    int count = 0, excluded = 0;
+    std::unordered_set<std::string> relatives_written;
+    unsigned long copy_relatives = 0;
+    void write(const cseq &c);
+};
+
+rw_fasta::writer::writer(const std::string &outfile, unsigned int copy_relatives) : data(new priv_data) {
+    data->copy_relatives = copy_relatives;
+    data->out.open(outfile, std::ios_base::binary);
+    if (!data->out.is_open()) throw std::runtime_error("Unable to open file \"" + outfile + "\" for writing.");
+    if (fa_opts().fastameta == FASTA_META_CSV) {
+        const size_t dot = outfile.find_last_of('.'), slash = outfile.find_last_of('/');
+        const std::string stem =
+            (dot != std::string::npos && (slash == std::string::npos || dot > slash)) ? outfile.substr(0, dot) : outfile;
+        data->out_csv.open(stem + ".csv");
+        if (data->out_csv.fail()) throw std::runtime_error("Unable to open file \"" + outfile + ".csv\" for writing.");
+    }
+}
+rw_fasta::writer::writer(const writer &) = default;
+rw_fasta::writer &rw_fasta::writer::operator=(const writer &) = default;
+rw_fasta::writer::~writer() = default;
+int rw_fasta::writer::written() const { return data->count; }
+int rw_fasta::writer::excluded() const { return data->excluded; }
+void rw_fasta::writer::flush() {
+    data->out.flush();
+    if (data->out_csv.is_open()) data->out_csv.flush();
+}
+
+tray rw_fasta::writer::operator()(tray t) {  // :394-435
+    if (t.input_sequence == nullptr) throw std::runtime_error("Received broken tray in rw_fasta");
+    if (t.aligned_sequence == nullptr) {  // "Not writing sequence N (>name): not aligned"
+        ++data->excluded;
+        return t;
+    }
+    if (fa_opts().min_idty > 0) {
+        const float idty = t.aligned_sequence->get_attr<float>(fn::idty, 0);
+        if (fa_opts().min_idty > idty) {  // "below identity threshold"
+            ++data->excluded;
+            return t;
+        }
+    }
+    data->write(*t.aligned_sequence);
+    if (data->copy_relatives != 0u) {
+        auto *relatives = t.search_result != nullptr ? t.search_result : t.alignment_reference;
+        if (relatives != nullptr) {
+            int i = (int)data->copy_relatives;
+            for (auto &item : *relatives) {
+                if (data->relatives_written.insert(item.sequence->getName()).second) data->write(*item.sequence);
+                if (--i == 0) break;
+            }
+        }
+    }
+    return t;
+}
+
+void rw_fasta::writer::priv_data::write(const cseq &c) {  // :437-541
+    const options &o = fa_opts();
+    const auto &attrs = c.get_attrs();
+    out << ">" << c.getName();
+    const std::string fname = c.get_attr<std::string>(fn::fullname, "");
+    if (!fname.empty()) out << " " << fname;
+    switch (o.fastameta) {
+    case FASTA_META_NONE: out << "\n"; break;
+    case FASTA_META_HEADER:
+        for (auto &ap : attrs) {
+            if (ap.first == fn::family) continue;    // alignment family is too much
+            if (ap.first == fn::fullname) continue;  // already written as description in header
+            const std::string val = attr_to_string(ap.second);
+            if (!val.empty()) out << " [" << ap.first << "=" << val << "]";
+        }
+        out << "\n";
+        break;
+    case FASTA_META_COMMENT:
+        out << "\n";
+        for (auto &ap : attrs) {
+            if (ap.first == fn::family) continue;
+            if (ap.first == fn::fullname) continue;
+            out << "; " << ap.first << "=" << attr_to_string(ap.second) << "\n";
+        }
+        break;
+    case FASTA_META_CSV:
+        out << "\n";
+        if (count == 0) {  // print header
+            out_csv << "name";
+            for (auto &ap : attrs) {
+                if (ap.first == fn::family) continue;
+                out_csv << "," << escape_string(ap.first);
+            }
+            out_csv << "\r\n";
+        }
+        out_csv << c.getName();
+        for (auto &ap : attrs) {
+            if (ap.first == fn::family) continue;
+            out_csv << "," << escape_string(attr_to_string(ap.second));
+        }
+        out_csv << "\r\n";
+        break;
+    default: throw std::runtime_error("Unknown meta-fmt output option");
+    }
+    const std::string seq = c.getAligned(!o.out_dots, o.out_dna);
+    const int len = (int)seq.size();
+    if (o.line_length > 0) {
+        for (int i = 0; i < len; i += o.line_length) out << seq.substr(i, o.line_length) << "\n";
+    } else {
+        out << seq << "\n";
+    }
+    count++;
+}
+
+// ---------------------------------------------------------------- Log::printer (--show-dist)
+
+struct log_printer::priv_data {
+    int sequence_num = 0;
+    // data for computing alignment quality based on a reference (src/log.cpp:262-266)
+    double total_sps = 0, total_cpm = 0, total_idty = 0, total_bps = 0;
+    bool show_dist = false;
+    void show(cseq &orig, cseq &aligned, search::result_vector &ref, std::ostream &log);
+};
+log_printer::log_printer(bool show_dist) : data(new priv_data) { data->show_dist = show_dist; }
+log_printer::log_printer(const log_printer &) = default;
+log_printer &log_printer::operator=(const log_printer &) = default;
+log_printer::~log_printer() = default;
+
+// src/log.cpp:279-325 (without a comparison database: orig = the input sequence as it was read)
+void log_printer::priv_data::show(cseq &orig, cseq &aligned, search::result_vector &ref, std::ostream &log) {
+    char buf[96];
+    if (orig.getWidth() != aligned.getWidth()) {
+        log << "Cannot show dist - " << orig.getName() << " and " << aligned.getName() << " have lengths "
+            << orig.getWidth() << " and " << aligned.getWidth() << "\n";
+        return;
+    }
+    const cseq_comparator cmp_exact(CMP_IUPAC_EXACT, CMP_DIST_NONE, CMP_COVER_QUERY, false);
+    const float sps = cmp_exact(orig, aligned);
+    snprintf(buf, sizeof buf, "orig_idty: %.6f\n", (double)sps);
+    log << buf;
+    total_sps += sps;
+    if (ref.empty()) {
+        log << "reference / search result empty?\n";
+        return;
+    }
+    const cseq_comparator cmp_optimistic(CMP_IUPAC_OPTIMISTIC, CMP_DIST_NONE, CMP_COVER_QUERY, false);
+    auto scored = ref;  // copy
+    for (auto &item : scored) item.score = cmp_optimistic(orig, *item.sequence);
+    std::sort(scored.begin(), scored.end());
+    auto &closest = *scored.rbegin();
+    const float orig_idty = closest.score;
+    total_idty += orig_idty;
+    snprintf(buf, sizeof buf, "orig_closest_idty: %.6f\n", (double)orig_idty);
+    log << buf;
+    const float aligned_idty = cmp_optimistic(aligned, *closest.sequence);
+    snprintf(buf, sizeof buf, "closest_idty: %.6f\n", (double)aligned_idty);
+    log << buf;
+    const float cpm = orig_idty - aligned_idty;
+    snprintf(buf, sizeof buf, "cpm: %.6f\n", (double)cpm);
+    log << buf;
+    total_cpm += cpm;
+}
+
+tray log_printer::operator()(tray t, std::ostream &log) {  // src/log.cpp:364-430
+    if (t.input_sequence == nullptr) throw std::runtime_error("Received broken tray in log printer");
+    log << "sequence_number: " << t.seqno << "\n";
+    log << "sequence_identifier: " << t.input_sequence->getName() << "\n";
+    if (t.aligned_sequence == nullptr) {
+        log << fn::align_log << ": " << t.log.str() << "\n";
+        log << fn::fullname << ": " << t.input_sequence->get_attr<std::string>(fn::fullname) << "\n";
+        log << "alignment failed!\n";
+        return t;
+    }
+    ++data->sequence_num;
+    cseq &aligned = *t.aligned_sequence;
+    // (helix pairing comes from the ARB database: no pairs, bp score 0)
+    aligned.set_attr("align_bp_score_slv", 0);
+    aligned.set_attr(fn::align_log, t.log.str());
+    aligned.set_attr("nuc", (int)aligned.size());
+    if (aligned.size() != 0u) {
+        aligned.set_attr("align_startpos_slv", (int)aligned.begin()->getPosition());
+        aligned.set_attr("align_stoppos_slv", (int)((--aligned.end())->getPosition()));
+    } else {
+        aligned.set_attr("align_startpos_slv", 0);
+        aligned.set_attr("align_stoppos_slv", 0);
+    }
+    for (auto &ap : aligned.get_attrs()) log << ap.first << ": " << attr_to_string(ap.second) << "\n";
+    search::result_vector ref;
+    if (t.search_result != nullptr) ref = *t.search_result;
+    else if (t.alignment_reference != nullptr) ref = *t.alignment_reference;
+    if (data->show_dist) data->show(*t.input_sequence, aligned, ref, log);
+    return t;
+}
+
+log_printer::summary log_printer::totals() const {  // ~priv_data, src/log.cpp:350-358
+    summary s;
+    s.sequences = data->sequence_num;
+    const double n = data->sequence_num;
+    s.avg_sps = data->total_sps / n;
+    s.avg_cpm = data->total_cpm / n;
+    s.avg_idty = data->total_idty / n;
+    s.avg_bps = data->total_bps / n;
+    return s;
+}
+
+}  // namespace sina

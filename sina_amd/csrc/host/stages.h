@@ -320,6 +320,66 @@ public:
 };
 std::string search_filter_database();  // the store the search stage was configured for
 
+// ---------------------------------------------------------------- FASTA I/O + accuracy metrics
+enum FASTA_META_TYPE { FASTA_META_NONE = 0, FASTA_META_HEADER = 1, FASTA_META_COMMENT = 2, FASTA_META_CSV = 3 };
+
+// src/rw_fasta.{h,cpp}: source and sink of the pipeline for FASTA files (host/rw_fasta.cpp)
+class rw_fasta {
+public:
+    struct options;
+    static options *opts;
+    // "meta-fmt", "line-length", "min-idty", "fasta-write-dna", "fasta-write-dots", "fasta-idx", "fasta-block"
+    static void set_option(const std::string &name, const std::string &value);
+    static void reset_options();
+
+    class reader {
+        struct priv_data;
+        std::shared_ptr<priv_data> data;
+
+    public:
+        explicit reader(const std::string &infile);
+        reader(const reader &);
+        reader &operator=(const reader &);
+        ~reader();
+        bool operator()(tray &t);  // false at end of input; fills seqno and input_sequence
+        int skipped() const;       // sequences dropped for characters outside the IUPAC alphabet
+    };
+    class writer {
+        struct priv_data;
+        std::shared_ptr<priv_data> data;
+
+    public:
+        explicit writer(const std::string &outfile, unsigned int copy_relatives = 0);
+        writer(const writer &);
+        writer &operator=(const writer &);
+        ~writer();
+        tray operator()(tray t);
+        int written() const;
+        int excluded() const;
+        void flush();
+    };
+};
+
+// src/log.cpp Log::printer: per-sequence report and the --show-dist accuracy metrics (sps: identity
+// of the new alignment with the input's own alignment; cpm: loss of identity with the closest
+// reference; idty: identity of the input with that reference)
+class log_printer {
+    struct priv_data;
+    std::shared_ptr<priv_data> data;
+
+public:
+    struct summary {
+        int sequences = 0;
+        double avg_sps = 0, avg_cpm = 0, avg_idty = 0, avg_bps = 0;
+    };
+    explicit log_printer(bool show_dist);
+    log_printer(const log_printer &);
+    log_printer &operator=(const log_printer &);
+    ~log_printer();
+    tray operator()(tray t, std::ostream &log);  // serial stage: call in sequence order
+    summary totals() const;
+};
+
 // ---------------------------------------------------------------- batching shim
 // SINA calls a stage once per tray from many TBB workers (function_node with
 // unlimited concurrency, src/sina.cpp:497-519); the GPU wants thousands of

@@ -61,6 +61,9 @@ def load_host():
                                       C.POINTER(C.c_uint64)]
     H.sina_host_sidx_store.argtypes = [C.c_char_p, C.c_uint, C.c_int, C.c_uint32, capi.u32p, capi.u32p, C.c_uint64]
     H.sina_host_store_open.argtypes = [C.c_char_p, C.c_int]
+    H.sina_host_run_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint32,
+                                      C.POINTER(C.c_double)]
+    H.sina_host_fasta_roundtrip.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     H.sina_host_store_index_origin.restype = C.c_char_p
     H.sina_host_store_index_origin.argtypes = [C.c_char_p]
     H.sina_host_compare.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -276,4 +279,39 @@ def sidx_store(path, n_sequences, offsets, ids, k=10, nofast=False):
     ids = np.ascontiguousarray(ids, np.uint32)
     _chk(H.sina_host_sidx_store(path.encode(), k, int(nofast), n_sequences, offsets.ctypes.data_as(capi.u32p),
                                 ids.ctypes.data_as(capi.u32p), len(ids)))
+
+
+def _set_options(H, stage, opts):
+    for k, v in (opts or {}).items():
+        if isinstance(v, bool):
+            v = "1" if v else "0"
+        _chk(H.sina_host_set_option(stage.encode(), k.encode(), str(v).encode()))
+
+
+def run_fasta(store, in_path, out_path, famfinder=None, aligner=None, search=None, fasta=None, show_dist=False,
+              log_path="", batch=1024):
+    """`sina -i in_path -o out_path --db <store> [--search] [--show-dist]`: FASTA in, aligned FASTA out, through
+    the stage mirror.  Returns dict(read, aligned, written, skipped, avg_sps, avg_cpm, avg_idty)."""
+    H = load_host()
+    H.sina_host_reset_options()
+    _set_options(H, "famfinder", dict({"db": store.key}, **(famfinder or {})))
+    _set_options(H, "aligner", dict({"db": store.key}, **(aligner or {})))
+    if search is not None:
+        _set_options(H, "search", dict({"search-db": store.key}, **search))
+    _set_options(H, "fasta", fasta)
+    out = (C.c_double * 7)()
+    _chk(H.sina_host_run_fasta(in_path.encode(), out_path.encode(), log_path.encode(), int(search is not None),
+                               int(show_dist), batch, out))
+    return dict(read=int(out[0]), aligned=int(out[1]), written=int(out[2]), skipped=int(out[3]), avg_sps=out[4],
+                avg_cpm=out[5], avg_idty=out[6])
+
+
+def fasta_roundtrip(in_path, out_path, fasta=None):
+    """FASTA reader -> writer only (no GPU): (sequences read, sequences skipped for bad characters)."""
+    H = load_host()
+    H.sina_host_reset_options()
+    _set_options(H, "fasta", fasta)
+    n, sk = C.c_int(), C.c_int()
+    _chk(H.sina_host_fasta_roundtrip(in_path.encode(), out_path.encode(), C.byref(n), C.byref(sk)))
+    return n.value, sk.value
 

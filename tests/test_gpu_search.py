@@ -199,3 +199,48 @@ def test_fasta_database_keeps_its_index_in_a_sidx_file(oracle, tmp_path):
     os.utime(sidx, (1, 1))
     _, origin3 = run()
     assert origin3 == "built"
+
+
+def test_fasta_pipeline_and_show_dist_metrics(oracle, tmp_path):
+    """FASTA in -> famfinder -> aligner -> FASTA out with --show-dist, run the way the
+    reference's accuracy test does (tests/accuracy_kmer.test: the database's own sequences, --realign
+    --fs-leave-query-out): written alignments and avg_sps / avg_cpm / avg_idty against the oracle."""
+    refs = synth.make_refs(300, length=320, width=3200, seed=481, amb_rate=0.01)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    st = pipeline.Store(":mem:gpu-fasta", refs)
+    pick = list(range(0, 300, 12))
+    src = str(tmp_path / "in.fasta")
+    with open(src, "w") as f:
+        for i in pick:
+            f.write(">ref%d\n%s\n" % (i, synth.aligned_string(refs.seq(i), refs.width)))
+    dst = str(tmp_path / "out.fasta")
+    ffo = {"fs-min-len": 100, "fs-full-len": 250, "fs-leave-query-out": True}
+    got = pipeline.run_fasta(st, src, dst, famfinder=ffo, aligner={"realign": True}, show_dist=True, batch=7,
+                             log_path=str(tmp_path / "log.txt"))
+    assert got["read"] == len(pick) and got["skipped"] == 0
+    out_lines = open(dst).read().splitlines()
+    tot_sps = tot_cpm = tot_idty = 0.0
+    n = 0
+    for i in pick:
+        orig = cs[i]
+        ids, sc, _ = idx.famfinder(orig, oracle.ff_opts(fs_min_len=100, fs_full_len=250, fs_leave_query_out=1))
+        assert i not in ids
+        al = oracle.align([cs[j] for j in ids], orig, oracle.align_opts(realign=1))
+        assert al["status"] == 0 and "removed from family" not in al["log"]
+        assert out_lines[2 * n] == ">ref%d" % i and out_lines[2 * n + 1] == al["aligned"].replace(".", "-")
+        aligned = po.Cseq.from_packed("ref%d" % i, al["packed"], al["width"])
+        sps = po.compare(orig, aligned, "exact", "none", "query")
+        scored = sorted((float(po.compare(orig, cs[int(j)], "optimistic", "none", "query")), "ref%d" % j, int(j))
+                        for j in ids)
+        closest = scored[-1]
+        orig_idty = np.float32(closest[0])
+        aligned_idty = po.compare(aligned, cs[closest[2]], "optimistic", "none", "query")
+        tot_sps += float(sps)
+        tot_idty += float(orig_idty)
+        tot_cpm += float(np.float32(orig_idty - aligned_idty))
+        n += 1
+    assert got["aligned"] == n and got["written"] == n
+    assert got["avg_sps"] == tot_sps / n and got["avg_cpm"] == tot_cpm / n and got["avg_idty"] == tot_idty / n
+    assert got["avg_sps"] > 0.97   # (the reference's own accuracy test asks for > 0.996 on real rRNA)
+    st.close()

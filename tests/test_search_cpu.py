@@ -131,3 +131,39 @@ def test_sidx_files_match_the_oracle_writer_and_reader(oracle, tmp_path, k, nofa
     again = po.Index.read_sidx(got, cs, k=k, nofast=nofast)
     o3, i3 = again.csr()
     assert (o3 == off).all() and (i3 == ids).all()
+
+
+# ---- FASTA reader / writer rules (src/rw_fasta.cpp:229-315,437-541)
+
+def test_fasta_reader_and_writer_rules(tmp_path):
+    src = str(tmp_path / "in.fasta")
+    open(src, "w").write(
+        "junk before the first record\n"
+        ">seq1 Escherichia coli K12\r\n"
+        "; acc = AB000001 \n"
+        ";just a remark\n"
+        "--AGCU\n"
+        "agcu..\n"
+        ">seq2\n"
+        "ACGTNRY-acgu\n"
+        ">bad has a digit\n"
+        "ACG7ACG\n"
+        "ACGU\n"
+        ">seq3\tdescription after a tab\n"
+        "A-C\n")
+    dst = str(tmp_path / "out.fasta")
+    assert pipeline.fasta_roundtrip(src, dst) == (3, 1)
+    assert open(dst).read() == (">seq1 Escherichia coli K12\n--AGCUagcu--\n"
+                                ">seq2\nACGUNRY-acgu\n"
+                                ">seq3 description after a tab\nA-C\n")
+    # dots for leading/trailing gaps, DNA alphabet, wrapped lines, attributes as comments
+    assert pipeline.fasta_roundtrip(src, dst, {"fasta-write-dots": True, "fasta-write-dna": True, "line-length": 5,
+                                               "meta-fmt": "comment"}) == (3, 1)
+    assert open(dst).read() == (">seq1 Escherichia coli K12\n; acc=AB000001\n..AGC\nTagct\n..\n"
+                                ">seq2\nACGTN\nRY-ac\ngt\n"
+                                ">seq3 description after a tab\nA-C\n")
+    assert pipeline.fasta_roundtrip(src, dst, {"meta-fmt": "header"}) == (3, 1)
+    assert open(dst).read().splitlines()[0] == ">seq1 Escherichia coli K12 [acc=AB000001]"
+    assert pipeline.fasta_roundtrip(src, dst, {"meta-fmt": "csv"}) == (3, 1)
+    csv = open(str(tmp_path / "out.csv"), newline="").read()
+    assert csv.startswith("name,acc,full_name\r\nseq1,AB000001,Escherichia coli K12\r\nseq2\r\n")
