@@ -27,11 +27,13 @@
 //     final path (common.h, kTbExt / kTbOpLast);
 //   * the only dependencies between column blocks are (a) the insertion chain
 //     along the query (cell (m,s) needs the final (m,s-1)) and (b) the match
-//     candidate from (p,s-1).  Inside a wave both travel by lane shuffle: each
-//     lane runs the chain over its B cells serially (exact reference order),
-//     first assuming that no gap enters from the left, then again with the left
-//     lane's real exit state, repeated only while some exit state still changed
-//     (wave vote, no barrier).  Between waves they travel through two small LDS
+//     candidate from (p,s-1).  Inside a wave both travel by lane shuffle (DPP).  For
+//     the chain each lane first finds its exit state as if no gap entered from the
+//     left; then the exit states are propagated lane to lane -- a gap either runs
+//     through all B cells of a lane or dies inside it, B adds + B compares per step
+//     -- until none changes (wave vote, no barrier), and one full pass over the B
+//     cells with the converged left states finishes the row (weighted / forbid
+//     schemes: full chain passes are iterated instead).  Between waves they travel through two small LDS
 //     histories (boundary value and exit state per row) guarded by a per-wave
 //     progress counter: wave w starts row m once wave w-1 has published it.  The
 //     waves of a workgroup thus form a software pipeline skewed by one row and
@@ -106,31 +108,8 @@ struct Cells {
     }
 };
 
-// B consecutive 4-byte cells starting at a 16-byte aligned address (B % 4 == 0) or 8-byte aligned
-// one (B % 2 == 0): wide loads/stores, both for LDS and for global memory
-template <int B, typename T>
-__device__ __forceinline__ void load_cells(const T *__restrict__ src, T (&dst)[B]) {
-    static_assert(sizeof(T) == 4 && B % 2 == 0, "4-byte cells, even count");
-    if constexpr (B % 4 == 0) {
-        using V = __attribute__((ext_vector_type(4))) T;
-#pragma unroll
-        for (int k = 0; k < B; k += 4) {
-            const V v = *reinterpret_cast<const V *>(src + k);
-            dst[k] = v.x;
-            dst[k + 1] = v.y;
-            dst[k + 2] = v.z;
-            dst[k + 3] = v.w;
-        }
-    } else {
-        using V = __attribute__((ext_vector_type(2))) T;
-#pragma unroll
-        for (int k = 0; k < B; k += 2) {
-            const V v = *reinterpret_cast<const V *>(src + k);
-            dst[k] = v.x;
-            dst[k + 1] = v.y;
-        }
-    }
-}
+// B consecutive 4-byte cells to a 16-byte aligned address (B % 4 == 0) or 8-byte aligned one
+// (B % 2 == 0): wide stores, both for LDS and for global memory
 template <int B, typename T>
 __device__ __forceinline__ void store_cells(T *__restrict__ dst, const T (&src)[B]) {
     static_assert(sizeof(T) == 4 && B % 2 == 0, "4-byte cells, even count");
@@ -315,7 +294,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         // (dvm / mtp hold value_midx already shifted into its trace-back position, dvm with kTbExt)
         float dv[B], gm[B], mt[B];
         uint32_t dvm[B], dvs[B], mtp[B];
-        uint32_t oplast = 0;  // bit k: gapm of cell k was opened from the row's last predecessor
+        bool oplast[B];  // gapm of cell k was opened from the row's last predecessor (lane masks in SGPRs)
         auto init_cells = [&](const Row &r) {
 #pragma unroll
             for (int k = 0; k < B; k++) {
@@ -326,8 +305,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 dvm[k] = 0;
                 dvs[k] = 0;
                 mtp[k] = 0;
+                oplast[k] = false;
             }
-            oplast = 0;
         };
 
         // ---- phase 1: deletion / match candidates of my B cells from the predecessor rows
@@ -351,7 +330,6 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                          float svl) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const uint32_t p_open = p << 16, p_ext = (p << 16) | kTbExt;
-            uint32_t ob = 0;
 #pragma unroll
             for (int k = 0; k < B; k++) {
                 // deletion (mesh.h:307-330): gapm_* is overwritten by every predecessor
@@ -360,7 +338,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 const bool op = v < g;
                 const float cand = op ? v : g;
                 gm[k] = cand;
-                if (is_last) ob |= op ? (1u << k) : 0u;
+                oplast[k] = op;  // (every predecessor overwrites: the last one stays)
                 const float dv_old = FIRST ? (k == 0 ? iv0 : r.init_v) : dv[k];
                 const bool better = cand < dv_old;
                 dv[k] = better ? cand : dv_old;
@@ -374,7 +352,6 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 mt[k] = mb ? mv : mt_old;
                 mtp[k] = mb ? p_open : (FIRST ? 0u : mtp[k]);
             }
-            if (is_last) oplast = ob;
         };
         // Predecessors in ascending id order (the reference's order: the first minimum wins, the
         // last one defines gapm).  Entry = id | (LDS slot or spill row) << 16 | spilled << 31.
@@ -672,7 +649,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         if (!SH_ABL(4)) {
             uint32_t tc[B];
 #pragma unroll
-            for (int k = 0; k < B; k++) tc[k] = fvm[k] | fvs[k] | (((oplast >> k) & 1u) << 14);
+            for (int k = 0; k < B; k++) tc[k] = fvm[k] | fvs[k] | (oplast[k] ? kTbOpLast : 0u);
             store_cells<B>(tb + (size_t)m * Lp + s0, tc);
         }
         if (dbg_value != nullptr && qi == 0) store_cells<B>(dbg_value + (size_t)m * Lp + s0, fv);
