@@ -335,13 +335,15 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 // deletion (mesh.h:307-330): gapm_* is overwritten by every predecessor
                 const float v = add_raw(sv[k], gdo_v);
                 const float g = add_raw(sg[k], gde_v);
+                // (values by v_min -- the same number as the reference's compare-and-assign, there are
+                // no NaNs -- so that only the trace-back tags wait for the compares)
                 const bool op = v < g;
-                const float cand = op ? v : g;
+                const float cand = min2_raw(v, g);
                 gm[k] = cand;
                 oplast[k] = op;  // (every predecessor overwrites: the last one stays)
                 const float dv_old = FIRST ? (k == 0 ? iv0 : r.init_v) : dv[k];
                 const bool better = cand < dv_old;
-                dv[k] = better ? cand : dv_old;
+                dv[k] = min2_raw(cand, dv_old);
                 dvm[k] = better ? (op ? p_open : p_ext) : (FIRST ? 0u : dvm[k]);
                 dvs[k] = better ? s0 + k : (FIRST ? 0u : dvs[k]);  // value_sidx of a deletion is the column itself
                 // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
@@ -349,7 +351,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 const float mv = add_raw(pvv, csel[k]);
                 const float mt_old = FIRST ? __builtin_inff() : mt[k];
                 const bool mb = ((s0 + k) > 0) && (mv < mt_old);
-                mt[k] = mb ? mv : mt_old;
+                mt[k] = (k == 0) ? (mb ? mv : mt_old) : min2_raw(mv, mt_old);
                 mtp[k] = mb ? p_open : (FIRST ? 0u : mtp[k]);
             }
         };
