@@ -560,6 +560,44 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
 #ifdef SINA_DP_PROFILE
                     it_++;
 #endif
+                    if (guard == 0 && !SH_ABL(8)) {
+                        // A gap does enter some lane.  Stepping lane by lane costs one iteration per
+                        // lane a run crosses, so first GUESS all exit states with a log-step scan and
+                        // let the iterations above verify the guess (any start converges to the one
+                        // consistent set of states, so this only changes the number of iterations).
+                        // A stretch of lanes acts on the gap candidate x arriving at its first cell
+                        // as  x <= th ? (x + cells * gpe, extending, same origin) : C  with a constant
+                        // state C; two stretches compose to one of the same form.  th and the sums
+                        // are computed with single adds where the cells do repeated ones, which is
+                        // the same float except at rare roundings -- hence a guess, not the result.
+                        float th = loc[0];
+#pragma unroll
+                        for (int k = 1; k < B; k++) th = min2_raw(th, loc[k] - (float)k * gpe);
+                        float th1 = lane_shr1(th);               // (the step just done was offset 1:
+                        th = min2_raw(th1, th - (float)B * gpe);  //  ex = lane (i) after lane (i-1)'s sx)
+                        if (lane <= 1) th = -__builtin_inff();  // lane 0's left state is known: constant
+                        float cv = ex.v;
+                        uint32_t ceg = (ex.e << 31) | ex.gsi;
+                        // (unrolled, the 8-column variants no longer fit 3 waves per SIMD)
+                        constexpr int kScanUnroll = B > 8 ? 5 : 1;
+#pragma unroll kScanUnroll
+                        for (int o = 2; o < 64; o *= 2) {
+                            const int src = (lane - o) << 2;
+                            const float pth = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(th)));
+                            const float pv = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(cv)));
+                            const uint32_t peg = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ceg);
+                            const bool valid = lane >= o;
+                            const bool pe = (peg >> 31) != 0;
+                            const float x = pv + (pe ? gpe : gp);
+                            const bool hit = valid && (x <= th);
+                            cv = hit ? x + (float)(o * B - 1) * gpe : cv;
+                            ceg = hit ? (pe ? peg : (0x80000000u | (s0 - (uint32_t)((o - 1) * B) - 1u))) : ceg;
+                            th = valid ? min2_raw(pth, th - (float)(o * B) * gpe) : th;
+                        }
+                        ex.v = cv;
+                        ex.e = ceg >> 31;
+                        ex.gsi = ceg & 0x7fffffffu;
+                    }
                 }
                 if (j == 0) left = none;
                 run_chain(left);

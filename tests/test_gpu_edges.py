@@ -171,3 +171,33 @@ def test_full_length_properties(oracle, gpu_ctx):
                                         np.array([0, len(masks[q])], np.uint64), gpu_ctx.params())
         assert o1[0].tobytes() == out[q].tobytes()
         assert (p1[:len(masks[q])] == pos[int(qoff[q]):int(qoff[q + 1])]).all()
+
+
+@pytest.mark.parametrize("scores", [
+    (2.0, -1.0, 5.0, 2.0),          # the defaults
+    (1.7, -0.9, 3.3, 0.7),          # nothing exactly representable: every sum rounds
+    (2.0, -1.0, 2.0, 2.0),          # open == extend: ties between opening and extending everywhere
+    (0.1, -0.1, 0.3, 0.1),          # small values, long runs of equal-cost choices
+    (3.0, -2.0, 1.0, 0.25),         # cheap gaps: insertion runs cross many lanes
+    (2.0, -1.0, 1.0, 3.0),          # extend > open: the general chain path
+])
+def test_scoring_parameter_sets_planes(oracle, gpu_ctx, scores):
+    """All three planes bit-equal for scoring parameters that are not small integers (the insertion
+    chain guesses run structure with single adds and must still end at the reference's repeated
+    float adds), for a query with long insertions against its family, in a one-wave and a two-wave
+    geometry."""
+    ms, mms, gp, gpe = scores
+    for length, width, seed in ((500, 4000, 331), (1450, 50000, 332)):
+        refs = synth.make_refs(120, length=length, width=width, seed=seed)
+        cs = util.cseqs_from_refs(refs)
+        rng = np.random.default_rng(seed + 1)
+        fam = [cs[i] for i in rng.choice(refs.n, size=12, replace=False)]
+        src = ((refs.seq(int(rng.integers(refs.n))) >> 24) & 0x0f).astype(np.uint8)
+        # two inserted stretches (40 and 150 bases) and one deleted stretch
+        ins1 = rng.choice([1, 2, 4, 8], size=40).astype(np.uint8)
+        ins2 = rng.choice([1, 2, 4, 8], size=150).astype(np.uint8)
+        a, b, c = len(src) // 5, len(src) // 2, (3 * len(src)) // 4
+        qmask = np.concatenate([src[:a], ins1, src[a:b], ins2, src[b:c], src[c + 60:]])
+        q, qm = _cseq("ins%d" % length, qmask)
+        _planes_equal(oracle, gpu_ctx, fam, q, qm, refs.width, match_score=ms, mismatch_score=mms,
+                      gap_penalty=gp, gap_ext_penalty=gpe)
