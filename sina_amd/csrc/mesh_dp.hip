@@ -212,6 +212,9 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     // end-cell search state (mesh.h:567-592)
     const bool own_last = (L - 1) / B == (uint32_t)j;
     const int k_last = (int)((L - 1) % B);
+    const int kg_last = k_last >> 2, kr_last = k_last & 3;
+    const uint32_t kr_is1 = kr_last == 1 ? ~0u : 0u, kr_is2 = kr_last == 2 ? ~0u : 0u,
+                   kr_is3 = kr_last == 3 ? ~0u : 0u;  // select masks
     const int w_last = (int)(((L - 1) / B) >> 6);  // the wave that owns column L-1
     float lc_min = 0.f, lc_snk0 = 0.f;  // step 1: rows at column L-1 (lane own_last only)
     uint32_t lc_arg = 0;
@@ -695,10 +698,31 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         if (dbg_value != nullptr && qi == 0) store_cells<B>(dbg_value + (size_t)m * Lp + s0, fv);
 
         // ---- end-cell search, step 1: rows at the last query column (one lane)
-        if (w == w_last) {  // (wave-uniform: k_last is a scalar, one v_cndmask per cell)
-            float v = fv[0];
-#pragma unroll
-            for (int k = 1; k < B; k++) v = (k == k_last) ? fv[k] : v;
+        if (w == w_last) {
+            // fv[k_last], k_last wave-uniform: a scalar branch picks the group of four, three selects
+            // the cell (B select masks would not fit the SGPR budget and come back from spill lanes
+            // every row)
+            float v = 0.f;
+            auto pick4 = [&](auto g4_tag) {
+                constexpr int g4 = decltype(g4_tag)::value;
+                if constexpr (4 * g4 < B) {
+                    if (g4 == kg_last) {
+                        // (bit-field inserts with 32-bit all-or-nothing masks instead of selects, and a
+                        // volatile asm to keep the branch: otherwise the compiler turns the whole
+                        // construct into a dynamically indexed array in scratch memory)
+                        uint32_t t = __float_as_uint(fv[4 * g4]);
+                        t = (kr_is1 & __float_as_uint(fv[4 * g4 + 1])) | (~kr_is1 & t);
+                        t = (kr_is2 & __float_as_uint(fv[4 * g4 + 2])) | (~kr_is2 & t);
+                        t = (kr_is3 & __float_as_uint(fv[4 * g4 + 3])) | (~kr_is3 & t);
+                        asm volatile("" : "+v"(t));
+                        v = __uint_as_float(t);
+                    }
+                }
+            };
+            pick4(std::integral_constant<int, 0>{});
+            pick4(std::integral_constant<int, 1>{});
+            pick4(std::integral_constant<int, 2>{});
+            static_assert(B <= 12, "pick4 covers three groups of four");
             if (own_last && (!lc_any || v < lc_min)) {
                 lc_min = v;
                 lc_arg = m;
