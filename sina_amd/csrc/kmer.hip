@@ -32,6 +32,7 @@ namespace {
 
 constexpr int kCountThreads = 1024;
 constexpr int kTileRefs = 32768;            // refs per LDS histogram tile (64 KiB)
+constexpr int kWide = 2;                    // 1 KiB loads a wave of the count kernel keeps in flight
 constexpr int kMaxQueryLen = 8192;          // k-mer list capacity in LDS (32 KiB)
 constexpr int kSelThreads = 256;
 constexpr int kSelMax = 4096;               // candidates sortable in LDS
@@ -118,10 +119,10 @@ struct CountArgs {
 // One workgroup (16 waves) per query.  Every query k-mer keeps a cursor into its (ascending)
 // posting list; the reference range is processed in tiles of kTileRefs whose int16 counters
 // live in LDS (two per 32-bit word).  For a tile, a wave takes a k-mer, streams postings from
-// its cursor with four independent coalesced 256-byte loads in flight, bumps the LDS counters of
-// those below the tile end (a prefix, the lists being sorted) and advances the cursor: every
-// posting is read exactly once, there is no search, and the tile is written out once.
-__global__ void __launch_bounds__(kCountThreads) kmer_count_kernel(CountArgs a) {
+// its cursor (kWide loads of 1 KiB in flight, four consecutive postings per lane), bumps the LDS
+// counters of those below the tile end (a prefix, the lists being sorted) and advances the
+// cursor: there is no search, and the tile is written out once.  (64 VGPRs: two workgroups per CU.)
+__global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) kmer_count_kernel(CountArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t n_kmers, next_kmer;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);                 // [kTileRefs/2]
@@ -165,25 +166,41 @@ __global__ void __launch_bounds__(kCountThreads) kmer_count_kernel(CountArgs a) 
             if (i >= nk) break;
             uint32_t c = cur[i];
             const uint32_t e = end[i];
+            // kWide x 1 KiB in flight per wave: every lane reads four consecutive postings per load
+            // (most postings sit in a few hundred long lists -- k-mers of conserved regions -- and
+            // one wave streams each of them: bytes in flight are what bounds it)
             for (uint32_t g2 = 0; c < e && g2 < (1u << 22); g2++) {
-                uint32_t id[4];
+                uint32_t id[kWide][4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t x = c + (uint32_t)lane + 64u * u;
-                    id[u] = (x < e) ? a.idx_ids[x] : 0xFFFFFFFFu;
-                }
-                uint32_t n_in = 0;
+                for (int u = 0; u < kWide; u++) {
+                    const uint32_t x = c + 4u * (uint32_t)lane + 256u * u;
+                    if (x + 4u <= e) {
+                        const uint32_t *src = a.idx_ids + x;  // (4-byte aligned: three dwords + one, or one 16-byte load)
+                        id[u][0] = src[0];
+                        id[u][1] = src[1];
+                        id[u][2] = src[2];
+                        id[u][3] = src[3];
+                    } else {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const bool in = id[u] < tile_hi;
-                    if (in) {
-                        const uint32_t r = id[u] - tile_lo;
-                        atomicAdd(&hist[r >> 1], 1u << (16 * (r & 1)));
+                        for (int v = 0; v < 4; v++) id[u][v] = (x + v < e) ? a.idx_ids[x + v] : 0xFFFFFFFFu;
                     }
-                    n_in += (uint32_t)__popcll(__ballot(in));
                 }
-                c += n_in;
-                if (n_in < 256u) break;
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int u = 0; u < kWide; u++) {
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        if (id[u][v] < tile_hi) {
+                            const uint32_t r = id[u][v] - tile_lo;
+                            atomicAdd(&hist[r >> 1], 1u << (16 * (r & 1)));
+                            cnt++;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+                c += cnt;
+                if (cnt < 256u * kWide) break;
             }
             if (lane == 0) cur[i] = c;
         }
