@@ -186,6 +186,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     b.Lp = (uint32_t)Lp;
     b.ms = a.ms;
     b.overhang = p->overhang;
+    b.lazy_sidx = forbid ? 0 : 1;
     if (launch_backtrack(b, s)) return 1;
     SH_CHECK(hipEventRecord(c->ev[2], s));
     SH_CHECK(hipMemcpyAsync(out, c->out.p, sizeof(sina_hip_align_out) * bq, hipMemcpyDeviceToHost, s));
@@ -294,7 +295,19 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
                     uint32_t vm = cell >> 16;
                     if (cell & kTbExt) vm = gapm_idx(vm, x);
                     dbg_vm[(size_t)m * d.L + x] = vm;
-                    dbg_vs[(size_t)m * d.L + x] = cell & kTbSMask;
+                    uint32_t vs = cell & kTbSMask;
+                    if (!forbid) {  // type code instead of value_sidx (common.h, kTbTypeMask)
+                        const uint32_t t = cell & kTbTypeMask;
+                        if (t == kTbNone) vs = 0;
+                        else if (t == kTbMatch) vs = x - 1;
+                        else if (t == kTbDel) vs = x;
+                        else {  // insertion: where the run of insertion cells to the left ends
+                            uint32_t k = x - 1;
+                            while (k > 0 && (tbh[(size_t)m * Lp + k] & kTbTypeMask) == kTbIns) --k;
+                            vs = k;
+                        }
+                    }
+                    dbg_vs[(size_t)m * d.L + x] = vs;
                     if (dbg_value_host) dbg_value_host[(size_t)m * d.L + x] = vh[(size_t)m * Lp + x];
                 }
         }

@@ -105,9 +105,16 @@ constexpr int kFarLds = 192;   // predecessors up to this distance find their le
 //   kTbOpLast: this row's own gapm at this column was OPENED from its last predecessor, i.e.
 //              gapm_idx = last predecessor; otherwise gapm_idx = the last predecessor's gapm_idx.
 // backtrack resolves kTbExt by walking last predecessors until a kTbOpLast cell (resolve_gapm_idx).
+// All scoring schemes except --insertion=forbid store a TYPE CODE in place of value_sidx (it follows
+// from the type: a match came from column s-1, a deletion from s, an untouched cell keeps 0, and an
+// insertion from the column where the run of insertion cells to its left ends -- a cell's
+// gaps_val == value, the reference's "extend" condition, holds exactly for insertion cells), so the
+// recurrence carries no column indices at all; backtrack walks the few insertion runs on the path.
 constexpr uint32_t kTbSMask = 0x1FFFu;
 constexpr uint32_t kTbExt = 1u << 13;
 constexpr uint32_t kTbOpLast = 1u << 14;
+constexpr uint32_t kTbTypeMask = 3u;  // lazy format only
+constexpr uint32_t kTbDel = 0u, kTbMatch = 1u, kTbIns = 2u, kTbNone = 3u;
 
 struct DpResult {
     uint32_t end_m, end_s;
@@ -146,6 +153,7 @@ struct BtArgs {
     uint32_t nq, width, Lp;
     float ms;
     int overhang;
+    int lazy_sidx;  // trace-back cells hold a type code, not value_sidx (see kTbTypeMask)
 };
 
 // Picks the (threads, cells per thread) geometry for the longest query of a batch.

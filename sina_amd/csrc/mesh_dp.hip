@@ -58,8 +58,12 @@ struct ChainState {  // canonical exit state of cell (m, s): what cell (m, s+1) 
     uint32_t gmax;   // gaps_max (FORBID only, only meaningful when e)
 };
 
+// (GSI: the variant reads gaps_idx / gaps_max -- weighted gap costs, --insertion=forbid; the
+// simple scheme never looks at them)
+template <bool GSI>
 __device__ __forceinline__ bool same_state(const ChainState &a, const ChainState &b) {
-    return a.v == b.v && a.e == b.e && (!a.e || (a.gsi == b.gsi && a.gmax == b.gmax));
+    if constexpr (GSI) return a.v == b.v && a.e == b.e && (!a.e || (a.gsi == b.gsi && a.gmax == b.gmax));
+    else return a.v == b.v && a.e == b.e;
 }
 
 // value of `x` in lane-1 (lane 0 gets an unspecified value): one DPP move, no LDS round trip
@@ -228,6 +232,11 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     const uint32_t throttle = (uint32_t)(kHist - 2);
     static_assert(kFarLds + kHist <= kBndHist, "boundary history too short");
     SH_PROF_DECL
+    // kLazy: trace-back cells carry a type code, value_sidx is derived in backtrack (common.h);
+    // kGsi: gaps_idx is read by the recurrence itself (gap costs by length, --insertion=forbid)
+    constexpr bool kLazy = !FORBID;
+    constexpr bool kGsi = WEIGHTED || FORBID;
+    constexpr uint32_t kTagNone = kLazy ? kTbNone : 0u;
 #ifdef SINA_DP_PROFILE
     const int abl_ = g_dp_abl;
 #endif
@@ -305,7 +314,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 dv[k] = iv;
                 gm[k] = iv;
                 mt[k] = __builtin_inff();
-                dvm[k] = 0;
+                dvm[k] = kTagNone;
                 dvs[k] = 0;
                 mtp[k] = 0;
                 oplast[k] = false;
@@ -332,7 +341,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         auto relax = [&](auto first_tag, uint32_t p, bool is_last, const Cells<B> &sv, const Cells<B> &sg,
                          float svl) {
             constexpr bool FIRST = decltype(first_tag)::value;
-            const uint32_t p_open = p << 16, p_ext = (p << 16) | kTbExt;
+            const uint32_t p_open = p << 16, p_ext = (p << 16) | kTbExt;  // (type code kTbDel == 0)
+            const uint32_t p_match = kLazy ? (p_open | kTbMatch) : p_open;
 #pragma unroll
             for (int k = 0; k < B; k++) {
                 // deletion (mesh.h:307-330): gapm_* is overwritten by every predecessor
@@ -347,7 +357,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 const float dv_old = FIRST ? (k == 0 ? iv0 : r.init_v) : dv[k];
                 const bool better = cand < dv_old;
                 dv[k] = min2_raw(cand, dv_old);
-                dvm[k] = better ? (op ? p_open : p_ext) : (FIRST ? 0u : dvm[k]);
+                dvm[k] = better ? (op ? p_open : p_ext) : (FIRST ? kTagNone : dvm[k]);
                 dvs[k] = better ? s0 + k : (FIRST ? 0u : dvs[k]);  // value_sidx of a deletion is the column itself
                 // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
                 const float pvv = (k == 0) ? svl : sv[k - 1];
@@ -355,7 +365,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 const float mt_old = FIRST ? __builtin_inff() : mt[k];
                 const bool mb = ((s0 + k) > 0) && (mv < mt_old);
                 mt[k] = (k == 0) ? (mb ? mv : mt_old) : min2_raw(mv, mt_old);
-                mtp[k] = mb ? p_open : (FIRST ? 0u : mtp[k]);
+                mtp[k] = mb ? p_match : (FIRST ? 0u : mtp[k]);
             }
         };
         // Predecessors in ascending id order (the reference's order: the first minimum wins, the
@@ -421,6 +431,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         // that keeps the cell-to-cell dependency at add -> min3 -> compare -> select instead of
         // seven dependent operations.  (No NaN and no -0 can occur among these values: they are
         // sums that start at 1 or 1e6.)
+        const uint32_t m_ins = (m << 16) | (kLazy ? kTbIns : 0u);  // tag of an insertion cell
         auto run_chain = [&](const ChainState &left) {
             ChainState c = left;
 #pragma unroll
@@ -446,7 +457,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                         gmax = ins ? gmax_n : 0u;
                         const bool take = ins && (gs <= v);  // mesh.h:351-357
                         v = take ? gs : v;
-                        vm = take ? (m << 16) : vm;
+                        vm = take ? m_ins : vm;
                         vs = take ? gsi : vs;
                         const bool mtk = mt[k] < v;
                         v = mtk ? mt[k] : v;
@@ -466,7 +477,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                     v = min3_raw(gsx, dv[k], mt[k]);
                     const bool take = gsx <= dv[k];    // mesh.h:351-357
                     const bool mtk = mt[k] < a;        // :360-374
-                    vm = mtk ? mtp[k] : (take ? (m << 16) : vm);
+                    vm = mtk ? mtp[k] : (take ? m_ins : vm);
                     vs = mtk ? s - 1 : (take ? gsi_n : vs);
                     gs = has_left ? gsx : 1.0f;
                     gsi = has_left ? gsi_n : 0u;
@@ -521,23 +532,21 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 for (int k = 0; k < B; k++) loc[k] = min2_raw(dv[k], mt[k]);
                 ChainState sx;
                 {
+                    // (this scheme never reads gaps_idx: the states are {value, extending?} only)
                     float cv = __builtin_inff();
-                    uint32_t ce = 0, cgsi = 0;
+                    uint32_t ce = 0;
 #pragma unroll
                     for (int k = 0; k < B; k++) {
-                        const uint32_t s = s0 + k;
                         const bool has_left = (k > 0) || (j > 0);
                         const float gsx = cv + (ce ? gpe : gp);
-                        const uint32_t gsi_n = ce ? cgsi : s - 1;
                         const float v = min2_raw(gsx, loc[k]);
                         const float gs = has_left ? gsx : 1.0f;
                         cv = v;
                         ce = (gs == v) ? 1u : 0u;
-                        cgsi = has_left ? gsi_n : 0u;
                     }
                     sx.v = cv;
                     sx.e = ce;
-                    sx.gsi = cgsi;
+                    sx.gsi = 0;
                     sx.gmax = 0;
                 }
                 ex = sx;
@@ -545,7 +554,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 for (int guard = 0; guard < (1 << 20); ++guard) {
                     left.v = lane_shr1(ex.v);
                     left.e = lane_shr1(ex.e);
-                    left.gsi = lane_shr1(ex.gsi);
+                    left.gsi = 0;
                     if (lane == 0) left = wave_left;
                     const ChainState prev = ex;
                     float g = left.v + (left.e ? gpe : gp);
@@ -557,8 +566,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                     }
                     ex.v = pass ? g : sx.v;
                     ex.e = pass ? 1u : sx.e;
-                    ex.gsi = pass ? (left.e ? left.gsi : s0 - 1) : sx.gsi;
-                    if (!__any(!same_state(ex, prev))) break;
+                    if (!__any(!same_state<kGsi>(ex, prev))) break;
                     SH_PROF_CNT(10, 1)
 #ifdef SINA_DP_PROFILE
                     it_++;
@@ -569,7 +577,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                         // let the iterations above verify the guess (any start converges to the one
                         // consistent set of states, so this only changes the number of iterations).
                         // A stretch of lanes acts on the gap candidate x arriving at its first cell
-                        // as  x <= th ? (x + cells * gpe, extending, same origin) : C  with a constant
+                        // as  x <= th ? (x + cells * gpe, extending) : C  with a constant
                         // state C; two stretches compose to one of the same form.  th and the sums
                         // are computed with single adds where the cells do repeated ones, which is
                         // the same float except at rare roundings -- hence a guess, not the result.
@@ -580,7 +588,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                         th = min2_raw(th1, th - (float)B * gpe);  //  ex = lane (i) after lane (i-1)'s sx)
                         if (lane <= 1) th = -__builtin_inff();  // lane 0's left state is known: constant
                         float cv = ex.v;
-                        uint32_t ceg = (ex.e << 31) | ex.gsi;
+                        uint32_t ce = ex.e;
                         // (unrolled, the 8-column variants no longer fit 3 waves per SIMD)
                         constexpr int kScanUnroll = B > 8 ? 5 : 1;
 #pragma unroll kScanUnroll
@@ -588,18 +596,16 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                             const int src = (lane - o) << 2;
                             const float pth = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(th)));
                             const float pv = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(cv)));
-                            const uint32_t peg = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ceg);
+                            const bool pe = __builtin_amdgcn_ds_bpermute(src, (int)ce) != 0;
                             const bool valid = lane >= o;
-                            const bool pe = (peg >> 31) != 0;
                             const float x = pv + (pe ? gpe : gp);
                             const bool hit = valid && (x <= th);
                             cv = hit ? x + (float)(o * B - 1) * gpe : cv;
-                            ceg = hit ? (pe ? peg : (0x80000000u | (s0 - (uint32_t)((o - 1) * B) - 1u))) : ceg;
+                            ce = hit ? 1u : ce;
                             th = valid ? min2_raw(pth, th - (float)(o * B) * gpe) : th;
                         }
                         ex.v = cv;
-                        ex.e = ceg >> 31;
-                        ex.gsi = ceg & 0x7fffffffu;
+                        ex.e = ce;
                     }
                 }
                 if (j == 0) left = none;
@@ -643,7 +649,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                     left.gmax = FORBID ? lane_shr1(ex.gmax) : 0u;
                     if (lane == 0) left = wave_left;
                     if (j > 0) run_chain(left);
-                    if (!__any(!same_state(ex, prev))) break;
+                    if (!__any(!same_state<kGsi>(ex, prev))) break;
                 }
             }
         }
@@ -661,7 +667,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             const int h = w * kHist + (int)(m & (kHist - 1));
             bnd_val[w * kBndHist + (int)(m & (kBndHist - 1))] = fv[B - 1];
             xs_v[h] = ex.v;
-            xs_e[h] = (ex.e << 31) | ex.gsi;
+            xs_e[h] = (ex.e << 31) | (kGsi ? ex.gsi : 0u);
             if (FORBID) xs_gmax[h] = ex.gmax;
         }
         if (r.keep != kRowNone) {
@@ -692,7 +698,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         if (!SH_ABL(4)) {
             uint32_t tc[B];
 #pragma unroll
-            for (int k = 0; k < B; k++) tc[k] = fvm[k] | fvs[k] | (oplast[k] ? kTbOpLast : 0u);
+            for (int k = 0; k < B; k++)
+                tc[k] = kLazy ? (fvm[k] | (oplast[k] ? kTbOpLast : 0u)) : (fvm[k] | fvs[k] | (oplast[k] ? kTbOpLast : 0u));
             store_cells<B>(tb + (size_t)m * Lp + s0, tc);
         }
         if (dbg_value != nullptr && qi == 0) store_cells<B>(dbg_value + (size_t)m * Lp + s0, fv);
@@ -897,14 +904,29 @@ __global__ void backtrack_kernel(BtArgs a) {
     // :642-685 (a source node has no predecessors).  Dependent loads dominate: per step the two
     // trace-back cells are inherently serial; the row record / column of the node just reached and
     // its NEXT cell are requested together.
+    // value_sidx of cell c = (row, col): stored, or (type-code cells, common.h) what the type implies
+    const bool lazy = a.lazy_sidx != 0;
+    auto sidx_of = [&](uint32_t c, uint32_t row, uint32_t col) -> uint32_t {
+        if (!lazy) return c & kTbSMask;
+        const uint32_t t = c & kTbTypeMask;
+        if (t == kTbNone) return 0u;
+        if (t == kTbMatch) return col - 1;
+        if (t == kTbDel) return col;
+        uint32_t k = col - 1;  // insertion: the gap began where the run of insertion cells to the left ends
+        while (k > 0 && (tb[(size_t)row * Lp + k] & kTbTypeMask) == kTbIns) --k;
+        return k;
+    };
+    auto is_deletion_at = [&](uint32_t c, uint32_t col) -> bool {  // value_sidx == own column
+        return lazy ? (c & kTbTypeMask) == kTbDel : (c & kTbSMask) == col;
+    };
     uint32_t c = tb[(size_t)m * Lp + s];
     uint32_t npred_m = rec[m].z & 0xffu;
     while (s != 0 && npred_m != 0) {
-        const uint32_t snew = c & kTbSMask;
+        const uint32_t snew = sidx_of(c, m, s);
         m = (c & kTbExt) ? gapm_idx(c >> 16, s) : (c >> 16);
         if (snew != 0) {
             const uint32_t c2 = tb[(size_t)m * Lp + snew];
-            if (snew == (c2 & kTbSMask)) m = (c2 & kTbExt) ? gapm_idx(c2 >> 16, snew) : (c2 >> 16);
+            if (is_deletion_at(c2, snew)) m = (c2 & kTbExt) ? gapm_idx(c2 >> 16, snew) : (c2 >> 16);
         }
         // everything below depends on m only: one round trip
         c = tb[(size_t)m * Lp + snew];
