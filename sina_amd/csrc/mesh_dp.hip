@@ -520,36 +520,19 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         // as the same gap, B adds later -- or it dies at some cell, and from that cell on everything
         // is what the cells compute without it (the gap candidate they see from their own left
         // neighbour is no smaller than the real one, so it loses there as well).  So:
-        //   1. values only (no trace-back indices): my exit state sx if no gap enters;
-        //   2. exit states propagate lane to lane, B adds + B compares per step, until none changes
-        //      (to the right of the alignment diagonal whole stretches of a row are one insertion
-        //      run: 98 % of the rows need at least one step, 4.2 on average);
-        //   3. one full chain evaluation with the converged left states.
+        //   1. my cells without any gap from the left: values, trace-back tags, exit state sx;
+        //   2. exit states propagate lane to lane, B adds + B compares per step (after the first
+        //      step a log-step scan guesses all of them, the steps then verify), until none changes;
+        //   3. the cells the entering gap wins -- a prefix of my cells -- are overwritten.
         if constexpr (!WEIGHTED && !FORBID) {
             if (gp >= gpe && !SH_ABL(1)) {
+                // 1. the cells as if no gap entered: values, tags and my exit state sx
+                run_chain(none);
+                const ChainState sx = ex;
                 float loc[B];
 #pragma unroll
                 for (int k = 0; k < B; k++) loc[k] = min2_raw(dv[k], mt[k]);
-                ChainState sx;
-                {
-                    // (this scheme never reads gaps_idx: the states are {value, extending?} only)
-                    float cv = __builtin_inff();
-                    uint32_t ce = 0;
-#pragma unroll
-                    for (int k = 0; k < B; k++) {
-                        const bool has_left = (k > 0) || (j > 0);
-                        const float gsx = cv + (ce ? gpe : gp);
-                        const float v = min2_raw(gsx, loc[k]);
-                        const float gs = has_left ? gsx : 1.0f;
-                        cv = v;
-                        ce = (gs == v) ? 1u : 0u;
-                    }
-                    sx.v = cv;
-                    sx.e = ce;
-                    sx.gsi = 0;
-                    sx.gmax = 0;
-                }
-                ex = sx;
+                bool enter = false;  // the gap from my left wins at least my first cell
                 SH_PROF(4)
                 for (int guard = 0; guard < (1 << 20); ++guard) {
                     left.v = lane_shr1(ex.v);
@@ -558,7 +541,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                     if (lane == 0) left = wave_left;
                     const ChainState prev = ex;
                     float g = left.v + (left.e ? gpe : gp);
-                    bool pass = (j > 0) && (g <= loc[0]);
+                    enter = (j > 0) && (g <= loc[0]);
+                    bool pass = enter;
 #pragma unroll
                     for (int k = 1; k < B; k++) {
                         g = g + gpe;
@@ -608,8 +592,23 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                         ex.e = ce;
                     }
                 }
-                if (j == 0) left = none;
-                run_chain(left);
+                // 3. cells the entering gap wins (a prefix of my cells: it extends while it is no
+                // worse than the local candidates) become insertion cells; behind the cell where it
+                // loses everything is as computed in 1.  (The last iteration above ran with the
+                // final left states: `enter` is current.)
+                if (__any(enter)) {
+                    float g = left.v + (left.e ? gpe : gp);
+                    bool alive = enter;
+#pragma unroll
+                    for (int k = 0; k < B; k++) {
+                        if (k > 0) {
+                            g = g + gpe;
+                            alive = alive && (g <= loc[k]);
+                        }
+                        fv[k] = alive ? g : fv[k];
+                        fvm[k] = alive ? m_ins : fvm[k];
+                    }
+                }
                 done = true;
             }
         }
