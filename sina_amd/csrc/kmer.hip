@@ -298,50 +298,97 @@ __global__ void __launch_bounds__(kSelThreads) kmer_select_kernel(SelectArgs a) 
         for (int w = 0; w < kSelThreads / 64; w++) t += wsum[w];
         return t;
     };
-    auto count_ge = [&](int t) -> uint32_t {
-        uint32_t c = 0;
-        for (uint32_t i = tid; i < nvec; i += kSelThreads) for8(i, [&](int v, uint32_t) { c += (v >= t) ? 1u : 0u; });
-        return block_sum(c);
-    };
-    // invariant: count(>= lo) >= M > count(>= hi)
+    // invariant: count(>= lo) >= M > count(>= hi).  Each pass over the row (it sits in L2) counts
+    // against kWays - 1 thresholds at once: log_8 instead of log_2 passes.
+    constexpr int kWays = 8;
     int lo = 0, hi = top + 1;
     uint32_t c_hi = 0;
     for (int guard = 0; guard < 20 && hi - lo > 1; ++guard) {
-        const int mid = (lo + hi) >> 1;
-        const uint32_t c = count_ge(mid);
-        if (c >= M) {
-            lo = mid;
-        } else {
-            hi = mid;
-            c_hi = c;
+        int th[kWays - 1];
+        uint32_t c[kWays - 1];
+#pragma unroll
+        for (int x = 0; x < kWays - 1; x++) {
+            // ascending thresholds strictly inside (lo, hi); duplicates at the top when the gap is small
+            const int t = lo + (int)(((long long)(hi - lo) * (x + 1)) / kWays);
+            th[x] = t > lo ? t : lo + 1;
+            c[x] = 0;
         }
+        for (uint32_t i = tid; i < nvec; i += kSelThreads)
+            for8(i, [&](int v, uint32_t) {
+#pragma unroll
+                for (int x = 0; x < kWays - 1; x++) c[x] += (v >= th[x]) ? 1u : 0u;
+            });
+#pragma unroll
+        for (int x = 0; x < kWays - 1; x++) c[x] = block_sum(c[x]);
+        // the largest threshold that still has M scores at or above it becomes lo, the next one hi
+        int nlo = lo, nhi = hi;
+        uint32_t nc_hi = c_hi;
+        bool hi_set = false;
+#pragma unroll
+        for (int x = 0; x < kWays - 1; x++) {
+            if (th[x] >= hi) continue;
+            if (c[x] >= M) {
+                nlo = th[x];
+            } else if (!hi_set) {
+                nhi = th[x];
+                nc_hi = c[x];
+                hi_set = true;
+            }
+        }
+        lo = nlo;
+        hi = nhi;
+        c_hi = nc_hi;
     }
     const int cut = lo;
     const uint32_t acc = c_hi;  // scores > cut: all taken
 
-    // ordered pass over contiguous chunks: which ties (score == cut) to take
-    const uint32_t vc = (nvec + kSelThreads - 1) / kSelThreads;
-    const uint32_t v0 = min(nvec, (uint32_t)tid * vc), v1 = min(nvec, v0 + vc);
+    // Ordered pass: which ties (score == cut) to take -- those with the largest ids.  A wave owns
+    // a contiguous range of vectors and reads it 64 vectors (1 KiB, coalesced) at a time; the rank
+    // of a tie in id order is (ties in earlier waves) + (earlier iterations) + (lower lanes).
+    constexpr int kSelWaves = kSelThreads / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t vw = ((nvec + kSelWaves - 1) / kSelWaves + 63) / 64 * 64;  // vectors per wave
+    const uint32_t w0 = min(nvec, (uint32_t)wave * vw), w1 = min(nvec, w0 + vw);
     uint32_t my_eq = 0;
-    for (uint32_t i = v0; i < v1; i++) for8(i, [&](int v, uint32_t) { my_eq += (v == cut) ? 1u : 0u; });
-    uint32_t tot_eq;
-    uint32_t eq_rank = block_excl_scan(my_eq, wsum, &tot_eq);
-    const uint32_t skip_eq = tot_eq - (M - acc);  // ties to skip: the smallest ids
+    for (uint32_t i = w0 + lane; i < w1; i += 64) for8(i, [&](int v, uint32_t) { my_eq += (v == cut) ? 1u : 0u; });
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) my_eq += __shfl_xor(my_eq, off);  // ties in my wave's range
+    __syncthreads();
+    if (lane == 0) wsum[wave] = my_eq;
     if (tid == 0) sh_slot = 0;
     __syncthreads();
-    for (uint32_t i = v0; i < v1; i++)
-        for8(i, [&](int v, uint32_t id) {
-            bool take = v > cut;
-            if (v == cut) {
-                take = eq_rank >= skip_eq;
-                eq_rank++;
-            }
-            if (take) {
-                const uint32_t slot = atomicAdd(&sh_slot, 1u);
-                // sort key: score (biased) high, id low -> descending order = (score desc, id desc)
-                if (slot < kSelMax) cand[slot] = ((unsigned long long)(uint32_t)(v + 32768) << 32) | id;
-            }
-        });
+    uint32_t tot_eq = 0, run = 0;  // run: ties before the vectors of this iteration
+    for (int w = 0; w < kSelWaves; w++) {
+        if (w < wave) run += wsum[w];
+        tot_eq += wsum[w];
+    }
+    const uint32_t skip_eq = tot_eq - (M - acc);  // ties to skip: the smallest ids
+    for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        uint32_t c = 0;
+        if (i < w1) for8(i, [&](int v, uint32_t) { c += (v == cut) ? 1u : 0u; });
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
+        }
+        uint32_t eq_rank = run + incl - c;
+        run += __shfl(incl, 63);
+        if (i < w1)
+            for8(i, [&](int v, uint32_t id) {
+                bool take = v > cut;
+                if (v == cut) {
+                    take = eq_rank >= skip_eq;
+                    eq_rank++;
+                }
+                if (take) {
+                    const uint32_t slot = atomicAdd(&sh_slot, 1u);
+                    // sort key: score (biased) high, id low -> descending order = (score desc, id desc)
+                    if (slot < kSelMax) cand[slot] = ((unsigned long long)(uint32_t)(v + 32768) << 32) | id;
+                }
+            });
+    }
     __syncthreads();
     const uint32_t out_base = sh_slot;
     const uint32_t n = min(out_base, (uint32_t)kSelMax);

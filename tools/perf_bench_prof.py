@@ -28,7 +28,8 @@ run(0)
 a = (ctypes.c_ulonglong * 32)()
 if hasattr(lib, "sina_hip_debug_dp_profile"):
     lib.sina_hip_debug_dp_profile(a, 1)
-run(nq)
+for rep in range(int(os.environ.get("REPS", "1"))):
+    run(nq)
 if hasattr(lib, "sina_hip_debug_dp_profile"):
     lib.sina_hip_debug_dp_profile(a, 1)
     names = ["setup", "handshake", "far preds", "near preds", "chain+verify", "rerun", "publish", "tb+end"]
