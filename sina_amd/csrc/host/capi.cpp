@@ -324,7 +324,6 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                     const uint32_t b0 = next.fetch_add(batch);
                     if (b0 >= nq) break;
                     const uint32_t b1 = std::min(nq, b0 + batch);
-                    const auto t_in = std::chrono::steady_clock::now();
                     std::vector<tray> trays(b1 - b0);
                     std::unique_ptr<host_phase> hp(new host_phase("drv.build_trays"));
                     parallel_for(b1 - b0, [&](size_t i) {  // (what SINA's reader stage does per sequence)
