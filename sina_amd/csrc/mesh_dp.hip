@@ -362,10 +362,18 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
                 const float pvv = (k == 0) ? svl : sv[k - 1];
                 const float mv = add_raw(pvv, csel[k]);
-                const float mt_old = FIRST ? __builtin_inff() : mt[k];
-                const bool mb = ((s0 + k) > 0) && (mv < mt_old);
-                mt[k] = (k == 0) ? (mb ? mv : mt_old) : min2_raw(mv, mt_old);
-                mtp[k] = mb ? p_match : (FIRST ? 0u : mtp[k]);
+                if constexpr (FIRST) {
+                    // against the initial +inf every candidate wins: values are finite (a cell never
+                    // exceeds its finite deletion candidates or initial value), so mv < inf always
+                    const bool mb = (k > 0) || (j > 0);  // s > 0
+                    mt[k] = mb ? mv : __builtin_inff();
+                    mtp[k] = mb ? p_match : 0u;
+                } else {
+                    const float mt_old = mt[k];
+                    const bool mb = ((s0 + k) > 0) && (mv < mt_old);
+                    mt[k] = (k == 0) ? (mb ? mv : mt_old) : min2_raw(mv, mt_old);
+                    mtp[k] = mb ? p_match : mtp[k];
+                }
             }
         };
         // Predecessors in ascending id order (the reference's order: the first minimum wins, the
