@@ -162,6 +162,11 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     a.mms = -p->mismatch_score;
     a.gp = p->gap_penalty;
     a.gpe = p->gap_ext_penalty;
+    {
+        uint32_t max_n = 0;
+        for (uint32_t q = 0; q < bq; q++) max_n = std::max<uint32_t>(max_n, qd_host[q].N);
+        a.below_init = (!weighted && !forbid && dp_below_init(max_n, a.gp, a.gpe)) ? 1 : 0;
+    }
 
     {
         std::lock_guard<std::mutex> token(c->st->dp_token);

@@ -122,6 +122,14 @@ struct DpResult {
     int32_t status;
 };
 
+// Every cell is at most its deletion candidate from any predecessor, value[p][s] + gap_open, and rows
+// without predecessors start at 1: no value exceeds 1 + N * gap_open (the float sums stay within
+// 0.1 % of that).  True if that is well below the 1e6 initial value of rows WITH predecessors for
+// the longest DAG of a launch (constant gap costs only: not for the weighted scheme).
+inline bool dp_below_init(uint32_t max_n, float gp, float gpe) {
+    return gp >= 0.f && gpe >= 0.f && 1.0f + (float)max_n * gp * 1.01f + gp + gpe < 900000.0f;
+}
+
 struct DpArgs {
     const QDesc *qd;
     const uint32_t *order;      // workgroup -> query (decreasing N*L)
@@ -130,6 +138,7 @@ struct DpArgs {
     const uint32_t *node_pos;
     const uint32_t *succ_minpos;
     const uint8_t *qmask;
+    int below_init;             // see dp_below_init()
     uint32_t *tb;               // trace-back cells (kTb* above)
     float *dbg_value;           // optional [N*Lp] plane of the first query
     float *spill;               // spill rows: value[Lp] | gapm_val[Lp]

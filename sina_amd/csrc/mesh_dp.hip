@@ -161,7 +161,7 @@ __device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int T, int B, bool WEIGHTED, bool FORBID>
+template <int T, int B, bool WEIGHTED, bool FORBID, bool BELOW_INIT>
 __global__ void __launch_bounds__(T, (B <= 4 ? 4 : (B <= 8 ? 3 : 2)))
 mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ orderv, const uint4 *__restrict__ recv, const uint32_t *__restrict__ predv,
                const uint32_t *__restrict__ node_posv, const uint32_t *__restrict__ succ_minposv,
@@ -237,6 +237,9 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     constexpr bool kLazy = !FORBID;
     constexpr bool kGsi = WEIGHTED || FORBID;
     constexpr uint32_t kTagNone = kLazy ? kTbNone : 0u;
+    // BELOW_INIT (chosen by the host per launch, dp_below_init()): no value of this launch can reach
+    // the 1e6 initial value of rows with predecessors, so their first deletion candidate always
+    // replaces it and needs no compare.
 #ifdef SINA_DP_PROFILE
     const int abl_ = g_dp_abl;
 #endif
@@ -340,7 +343,11 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         const float iv0 = (j == 0) ? 1.0f : r.init_v;  // initial value of my cell 0 (column 0 starts at 1)
         auto relax = [&](auto first_tag, uint32_t p, bool is_last, const Cells<B> &sv, const Cells<B> &sg,
                          float svl) {
-            constexpr bool FIRST = decltype(first_tag)::value;
+            // first_tag: 0 = a later predecessor, 1 = the first one, 2 = the first one in a launch whose
+            // values provably stay below the 1e6 initial value (below_init): every deletion candidate
+            // then beats the initial value and needs no compare (column 0, initial value 1, excepted)
+            constexpr bool FIRST = decltype(first_tag)::value != 0;
+            constexpr bool BELOW = decltype(first_tag)::value == 2;
             const uint32_t p_open = p << 16, p_ext = (p << 16) | kTbExt;  // (type code kTbDel == 0)
             const uint32_t p_match = kLazy ? (p_open | kTbMatch) : p_open;
 #pragma unroll
@@ -355,10 +362,16 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 gm[k] = cand;
                 oplast[k] = op;  // (every predecessor overwrites: the last one stays)
                 const float dv_old = FIRST ? (k == 0 ? iv0 : r.init_v) : dv[k];
-                const bool better = cand < dv_old;
-                dv[k] = min2_raw(cand, dv_old);
-                dvm[k] = better ? (op ? p_open : p_ext) : (FIRST ? kTagNone : dvm[k]);
-                dvs[k] = better ? s0 + k : (FIRST ? 0u : dvs[k]);  // value_sidx of a deletion is the column itself
+                if (BELOW && k > 0) {  // (cell 0 of lane 0 is column 0: its initial value is 1)
+                    dv[k] = cand;
+                    dvm[k] = op ? p_open : p_ext;
+                    dvs[k] = s0 + k;
+                } else {
+                    const bool better = cand < dv_old;
+                    dv[k] = min2_raw(cand, dv_old);
+                    dvm[k] = better ? (op ? p_open : p_ext) : (FIRST ? kTagNone : dvm[k]);
+                    dvs[k] = better ? s0 + k : (FIRST ? 0u : dvs[k]);  // value_sidx of a deletion is the column itself
+                }
                 // match from (p, s-1) (mesh.h:360-374); first predecessor with the minimum wins
                 const float pvv = (k == 0) ? svl : sv[k - 1];
                 const float mv = add_raw(pvv, csel[k]);
@@ -414,8 +427,11 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 if (m - p <= (uint32_t)kFarLds) svl = bnd_val[(w - 1) * kBndHist + (p & (kBndHist - 1))];
                 else svl = far_bnd;
             }
-            if (e == 0) relax(std::true_type{}, p, is_last, sv, sg, svl);
-            else relax(std::false_type{}, p, is_last, sv, sg, svl);
+            if (e == 0) {
+                relax(std::integral_constant<int, BELOW_INIT ? 2 : 1>{}, p, is_last, sv, sg, svl);
+            } else {
+                relax(std::integral_constant<int, 0>{}, p, is_last, sv, sg, svl);
+            }
         }
         SH_PROF(3)
         const bool is_sink = (r.z & kRecSink) != 0;
@@ -979,19 +995,20 @@ __global__ void backtrack_kernel(BtArgs a) {
 
 template <int T, int B>
 int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, size_t lds, hipStream_t s) {
-#define SH_LAUNCH(WG, FB)                                                                               \
+#define SH_LAUNCH(WG, FB, BL)                                                                              \
     do {                                                                                                \
-        auto kfn = mesh_dp_kernel<T, B, WG, FB>;                                                            \
+        auto kfn = mesh_dp_kernel<T, B, WG, FB, BL>;                                                        \
         SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                               \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(T), lds, s, a.qd, a.order, a.rec, a.pred, a.node_pos, a.succ_minpos, \
                            a.qmask, a.weights, a.n_weights, a.tb, a.dbg_value, a.spill, a.res, a.ms, a.mms, \
                            a.gp, a.gpe);                                                           \
     } while (0)
-    if (!weighted && !forbid) SH_LAUNCH(false, false);
-    else if (weighted && !forbid) SH_LAUNCH(true, false);
-    else if (!weighted && forbid) SH_LAUNCH(false, true);
-    else SH_LAUNCH(true, true);
+    if (!weighted && !forbid && a.below_init) SH_LAUNCH(false, false, true);
+    else if (!weighted && !forbid) SH_LAUNCH(false, false, false);
+    else if (weighted && !forbid) SH_LAUNCH(true, false, false);
+    else if (!weighted && forbid) SH_LAUNCH(false, true, false);
+    else SH_LAUNCH(true, true, false);
 #undef SH_LAUNCH
     SH_CHECK(hipGetLastError());
     return 0;

@@ -180,6 +180,7 @@ def test_full_length_properties(oracle, gpu_ctx):
     (0.1, -0.1, 0.3, 0.1),          # small values, long runs of equal-cost choices
     (3.0, -2.0, 1.0, 0.25),         # cheap gaps: insertion runs cross many lanes
     (2.0, -1.0, 1.0, 3.0),          # extend > open: the general chain path
+    (2.0, -1.0, 2000.0, 700.0),     # gap costs so large that values reach the 1e6 initial value of a cell
 ])
 def test_scoring_parameter_sets_planes(oracle, gpu_ctx, scores):
     """All three planes bit-equal for scoring parameters that are not small integers (the insertion
