@@ -26,6 +26,12 @@ import time
 
 import numpy as np
 
+# The pipeline keeps 6 HIP streams busy (3 aligner, 2 k-mer search contexts, the store's own).  With
+# the runtime's default of 4 hardware queues, streams share a queue and a DP launch waits for an
+# unrelated backtrack / k-mer kernel queued before it (rocprofv3 kernel trace: 10 % of the time no DP
+# kernel resident).  Must be set before the HIP runtime starts, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

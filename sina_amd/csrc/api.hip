@@ -131,6 +131,15 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     const int Lp = pl.geom.Lp();
     const bool weighted = p->weights != nullptr && p->n_weights > 0;
     const bool forbid = p->insertion == SINA_INSERTION_FORBID;
+    // The trace-back plane is the one buffer whose size follows the batch (tens of GB for 16S): a
+    // context that needs a big one gets the whole budget at once instead of growing again and again
+    // -- a reallocation of that size stalls every stream of the device for milliseconds.
+    if (4 * tb_cells > c->tb.cap && 4 * tb_cells > ((uint64_t)4 << 30) && c->tb_budget_bytes >= 4 * tb_cells) {
+        if (c->tb.reserve_exact(c->tb_budget_bytes)) {  // (not enough memory for the whole budget: grow as usual)
+            (void)hipGetLastError();
+            set_error("");
+        }
+    }
     if (c->tb.reserve(4 * tb_cells) || c->spill.reserve(std::max<uint64_t>(spill_rows, 1) * 8 * (uint64_t)Lp) ||
         c->res.reserve(sizeof(DpResult) * bq) || c->out.reserve(sizeof(sina_hip_align_out) * bq) ||
         c->out_pos.reserve(4 * std::max<uint64_t>(nqm, 1)))
@@ -194,9 +203,12 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     b.lazy_sidx = forbid ? 0 : 1;
     if (launch_backtrack(b, s)) return 1;
     SH_CHECK(hipEventRecord(c->ev[2], s));
-    SH_CHECK(hipMemcpyAsync(out, c->out.p, sizeof(sina_hip_align_out) * bq, hipMemcpyDeviceToHost, s));
-    SH_CHECK(hipMemcpyAsync(out_pos, c->out_pos.p, 4 * nqm, hipMemcpyDeviceToHost, s));
+    if (c->h_out.reserve(sizeof(sina_hip_align_out) * bq) || c->h_out_pos.reserve(4 * std::max<uint64_t>(nqm, 1))) return 1;
+    SH_CHECK(hipMemcpyAsync(c->h_out.p, c->out.p, sizeof(sina_hip_align_out) * bq, hipMemcpyDeviceToHost, s));
+    SH_CHECK(hipMemcpyAsync(c->h_out_pos.p, c->out_pos.p, 4 * nqm, hipMemcpyDeviceToHost, s));
     SH_CHECK(hipStreamSynchronize(s));
+    memcpy(out, c->h_out.p, sizeof(sina_hip_align_out) * bq);
+    memcpy(out_pos, c->h_out_pos.p, 4 * nqm);
     float ms = 0;
     SH_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     std::lock_guard<std::mutex> slk(c->st->stats_mu);

@@ -8,6 +8,10 @@
 #include <string>
 #include <vector>
 
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
+
 #include "sina_hip.h"
 
 namespace sina_hip {
@@ -41,21 +45,57 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
         size_t want = bytes + bytes / 4 + 4096;
+        trace_alloc(want);
         SH_CHECK(hipMalloc(&p, want));
         cap = want;
         return 0;
+    }
+    // SINA_HIP_TRACE_ALLOC=1: one line per device allocation (there should be none in steady state)
+    static void trace_alloc(size_t bytes) {
+        static const bool on = getenv("SINA_HIP_TRACE_ALLOC") != nullptr;
+        if (on) {
+            timespec ts;
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            fprintf(stderr, "[sina_hip] %.3f hipMalloc %.1f MB\n", ts.tv_sec % 1000 + ts.tv_nsec * 1e-9, bytes / 1048576.0);
+        }
     }
     int reserve_exact(size_t bytes) {
         if (bytes <= cap) return 0;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        trace_alloc(bytes);
         SH_CHECK(hipMalloc(&p, bytes));
         cap = bytes;
         return 0;
     }
     void release() {
         if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Growable pinned host staging buffer.  Copies between the device and PAGEABLE host memory make the
+// runtime wait for the stream inside the call, under locks that other threads' kernel launches need
+// (a result copy queued behind a 5 ms backtrack kernel held up the next batch's DP launch for as
+// long): results come back into pinned memory and are copied out after the stream has finished.
+struct HostBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        SH_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
     }

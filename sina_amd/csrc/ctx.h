@@ -38,6 +38,7 @@ struct sina_hip_ctx {
     sina_hip::DevBuf k_qoff, k_scores, k_out_ids, k_out_scores, k_out_n, k_tmp0, k_tmp1, k_tmp2;
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes, g_wtab;
     sina_hip::DevBuf s_qab, s_qoff, s_cand, s_coff, s_out;  // search-stage comparison
+    sina_hip::HostBuf h_out, h_out_pos;  // pinned staging for the DP results
     float wtab_fs_weight = NAN;  // fs_weight the device weight table was computed for
 
     size_t lds_budget = 40 * 1024;
@@ -77,6 +78,8 @@ struct sina_hip_ctx {
         scratch(all);
         for (auto *b : all) b->release();
         dbg.release();
+        h_out.release();
+        h_out_pos.release();
         if (owns_store && st) {
             st->ref_ab.release();
             st->ref_off.release();

@@ -3,6 +3,8 @@
 // and the famfinder/aligner classes above it); this only lets Python feed trays
 // through the stages and read the results back.
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <chrono>
 #include <cstring>
 
@@ -318,82 +320,204 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
         std::exception_ptr err;
         std::mutex err_mu;
         const auto t0 = std::chrono::steady_clock::now();
-        auto worker = [&]() {
-            try {
-                for (;;) {
-                    const uint32_t b0 = next.fetch_add(batch);
-                    if (b0 >= nq) break;
-                    const uint32_t b1 = std::min(nq, b0 + batch);
-                    std::vector<tray> trays(b1 - b0);
-                    std::unique_ptr<host_phase> hp(new host_phase("drv.build_trays"));
-                    parallel_for(b1 - b0, [&](size_t i) {  // (what SINA's reader stage does per sequence)
-                        const uint32_t q = b0 + (uint32_t)i;
-                        tray &t = trays[i];
-                        t.seqno = q;
-                        const std::string name = "query" + std::to_string(q);
-                        t.input_sequence = new cseq(name.c_str());
-                        for (uint64_t x = qoff[q]; x < qoff[q + 1]; x++)
-                            t.input_sequence->append(
-                                aligned_base((uint32_t)(x - qoff[q]), base_iupac::from_mask(qmask[x])));
-                        t.input_sequence->setWidth((uint32_t)(qoff[q + 1] - qoff[q]));
-                    });
-                    hp.reset();
-                    const auto a = std::chrono::steady_clock::now();
-                    p->ff(trays);
-                    const auto b = std::chrono::steady_clock::now();
-                    p->al(trays);
-                    const auto c = std::chrono::steady_clock::now();
-                    if (p->sf) {
-                        (*p->sf)(trays);
-                        sf_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
-                                     std::chrono::steady_clock::now() - c)
-                                     .count();
+        // One batch travelling through the stages (what a tray is in SINA's TBB flow graph, times `batch`).
+        struct item {
+            uint32_t b0 = 0, b1 = 0;
+            std::vector<tray> trays;
+        };
+        auto build_and_find = [&](item &it) {  // source + famfinder node
+            it.trays.resize(it.b1 - it.b0);
+            {
+                host_phase hp("drv.build_trays");
+                parallel_for(it.b1 - it.b0, [&](size_t i) {  // (what SINA's reader stage does per sequence)
+                    const uint32_t q = it.b0 + (uint32_t)i;
+                    tray &t = it.trays[i];
+                    t.seqno = q;
+                    const std::string name = "query" + std::to_string(q);
+                    t.input_sequence = new cseq(name.c_str());
+                    for (uint64_t x = qoff[q]; x < qoff[q + 1]; x++)
+                        t.input_sequence->append(
+                            aligned_base((uint32_t)(x - qoff[q]), base_iupac::from_mask(qmask[x])));
+                    t.input_sequence->setWidth((uint32_t)(qoff[q + 1] - qoff[q]));
+                });
+            }
+            const auto a = std::chrono::steady_clock::now();
+            p->ff(it.trays);
+            ff_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - a)
+                         .count();
+        };
+        auto align_and_search = [&](item &it) {  // aligner node (+ search node)
+            const auto b = std::chrono::steady_clock::now();
+            p->al(it.trays);
+            const auto c = std::chrono::steady_clock::now();
+            al_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(c - b).count();
+            if (p->sf) {
+                (*p->sf)(it.trays);
+                sf_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                             std::chrono::steady_clock::now() - c)
+                             .count();
+            }
+        };
+        auto extract = [&](item &it) {  // sink
+            host_phase hp("drv.extract");
+            const uint32_t b0 = it.b0;
+            std::vector<tray> &trays = it.trays;
+            parallel_for(it.b1 - it.b0, [&](size_t i) {  // (what SINA's writer stage does per sequence)
+                const uint32_t q = b0 + (uint32_t)i;
+                tray &t = trays[i];
+                result &r = p->results[q];
+                r.log = t.log.str();
+                r.family = t.input_sequence->get_attr<std::string>(fn::family);
+                if (t.aligned_sequence) {
+                    const cseq &c = *t.aligned_sequence;
+                    r.qual = c.get_attr<int>(fn::qual);
+                    r.head = c.get_attr<int>(fn::head);
+                    r.tail = c.get_attr<int>(fn::tail);
+                    r.width = c.getWidth();
+                    r.ab.assign(c.packed(), c.packed() + c.size());
+                    r.status = (r.log.find("copied alignment from") != std::string::npos) ? 1 : 0;
+                    for (const auto &kv : c.get_attrs()) {
+                        const std::string &k = kv.first;
+                        if (k == search_filter::fn_nearest || k.compare(0, 4, "lca_") == 0 ||
+                            k.compare(0, 5, "copy_") == 0)
+                            r.attrs[k] = c.get_attr<std::string>(k);
                     }
-                    ff_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
-                    al_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(c - b).count();
-                    hp.reset(new host_phase("drv.extract"));
-                    parallel_for(b1 - b0, [&](size_t i) {  // (what SINA's writer stage does per sequence)
-                        const uint32_t q = b0 + (uint32_t)i;
-                        tray &t = trays[i];
-                        result &r = p->results[q];
-                        r.log = t.log.str();
-                        r.family = t.input_sequence->get_attr<std::string>(fn::family);
-                        if (t.aligned_sequence) {
-                            const cseq &c = *t.aligned_sequence;
-                            r.qual = c.get_attr<int>(fn::qual);
-                            r.head = c.get_attr<int>(fn::head);
-                            r.tail = c.get_attr<int>(fn::tail);
-                            r.width = c.getWidth();
-                            r.ab.assign(c.packed(), c.packed() + c.size());
-                            r.status = (r.log.find("copied alignment from") != std::string::npos) ? 1 : 0;
-                            for (const auto &kv : c.get_attrs()) {
-                                const std::string &k = kv.first;
-                                if (k == search_filter::fn_nearest || k.compare(0, 4, "lca_") == 0 ||
-                                    k.compare(0, 5, "copy_") == 0)
-                                    r.attrs[k] = c.get_attr<std::string>(k);
-                            }
-                            r.idty = c.has_attr(fn::idty) ? c.get_attr<float>(fn::idty) : -1.f;
-                        }
-                        if (t.search_result) {
-                            r.searched = true;
-                            for (const auto &it : *t.search_result) {
-                                r.sr_ids.push_back(p->search_store->id_of(it.sequence));
-                                r.sr_scores.push_back(it.score);
-                            }
-                        }
-                        t.destroy();
-                    });
-                    hp.reset();
+                    r.idty = c.has_attr(fn::idty) ? c.get_attr<float>(fn::idty) : -1.f;
                 }
+                if (t.search_result) {
+                    r.searched = true;
+                    for (const auto &sr : *t.search_result) {
+                        r.sr_ids.push_back(p->search_store->id_of(sr.sequence));
+                        r.sr_scores.push_back(sr.score);
+                    }
+                }
+                t.destroy();
+            });
+        };
+        auto take = [&](item &it) -> bool {
+            it.b0 = next.fetch_add(batch);
+            if (it.b0 >= nq) return false;
+            it.b1 = std::min(nq, it.b0 + batch);
+            return true;
+        };
+        auto guarded = [&](auto &&body) {
+            try {
+                body();
             } catch (...) {
                 std::lock_guard<std::mutex> lk(err_mu);
                 if (!err) err = std::current_exception();
             }
         };
-        std::vector<std::thread> th;
-        for (uint32_t i = 1; i < inflight; i++) th.emplace_back(worker);
-        worker();
-        for (auto &t : th) t.join();
+        if (inflight == 1) {
+            // one batch at a time, stage after stage (kernel timings taken this way are undisturbed)
+            guarded([&] {
+                item it;
+                while (take(it)) {
+                    build_and_find(it);
+                    align_and_search(it);
+                    extract(it);
+                }
+            });
+        } else {
+            // The stages as nodes with their own threads and bounded hand-over queues, as SINA wires them
+            // (src/sina.cpp:452-586: source -> famfinder -> aligner -> search -> sink).  `inflight`
+            // aligner threads keep the GPU's DP slot busy (graph build of one batch beside the DP of
+            // another); the famfinder threads run ahead by at most two finished batches, so an aligner
+            // thread never waits for a k-mer search to start.
+            struct handover {
+                std::mutex mu;
+                std::condition_variable cv;
+                std::deque<item> q;
+                size_t cap = 2;
+                int producers = 0;
+                bool abort = false;
+                void push(item &&it) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return q.size() < cap || abort; });
+                    if (abort) {
+                        for (auto &t : it.trays) t.destroy();
+                        return;
+                    }
+                    q.push_back(std::move(it));
+                    cv.notify_all();
+                }
+                bool pop(item &it) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !q.empty() || producers == 0 || abort; });
+                    if (q.empty()) return false;
+                    it = std::move(q.front());
+                    q.pop_front();
+                    cv.notify_all();
+                    return true;
+                }
+                void producer_done() {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (--producers == 0) cv.notify_all();
+                }
+                void stop() {
+                    std::lock_guard<std::mutex> lk(mu);
+                    abort = true;
+                    for (auto &it : q)
+                        for (auto &t : it.trays) t.destroy();
+                    q.clear();
+                    cv.notify_all();
+                }
+            };
+            handover found, aligned;
+            const uint32_t n_find = inflight >= 3 ? 2 : 1, n_align = inflight, n_sink = 1;
+            found.producers = (int)n_find;
+            aligned.producers = (int)n_align;
+            auto on_error = [&] {
+                found.stop();
+                aligned.stop();
+                next.store(nq);
+            };
+            std::vector<std::thread> th;
+            for (uint32_t i = 0; i < n_find; i++)
+                th.emplace_back([&] {
+                    try {
+                        item it;
+                        while (take(it)) {
+                            build_and_find(it);
+                            found.push(std::move(it));
+                            it = item();
+                        }
+                    } catch (...) {
+                        { std::lock_guard<std::mutex> lk(err_mu); if (!err) err = std::current_exception(); }
+                        on_error();
+                    }
+                    found.producer_done();
+                });
+            for (uint32_t i = 0; i < n_align; i++)
+                th.emplace_back([&] {
+                    try {
+                        item it;
+                        while (found.pop(it)) {
+                            align_and_search(it);
+                            aligned.push(std::move(it));
+                            it = item();
+                        }
+                    } catch (...) {
+                        { std::lock_guard<std::mutex> lk(err_mu); if (!err) err = std::current_exception(); }
+                        on_error();
+                    }
+                    aligned.producer_done();
+                });
+            for (uint32_t i = 0; i < n_sink; i++)
+                th.emplace_back([&] {
+                    try {
+                        item it;
+                        while (aligned.pop(it)) {
+                            extract(it);
+                            it = item();
+                        }
+                    } catch (...) {
+                        { std::lock_guard<std::mutex> lk(err_mu); if (!err) err = std::current_exception(); }
+                        on_error();
+                    }
+                });
+            for (auto &t : th) t.join();
+        }
         p->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         p->ff_s = ff_ns.load() * 1e-9;
         p->al_s = al_ns.load() * 1e-9;

@@ -315,26 +315,28 @@ std::shared_ptr<reference_store> reference_store::open(const std::string &path) 
 }
 
 reference_store::~reference_store() {
-    for (auto *f : idle_forks) sina_hip_destroy(f);
+    for (auto &pool : idle_forks)
+        for (auto *f : pool) sina_hip_destroy(f);
     if (ctx) sina_hip_destroy(ctx);
 }
 
-reference_store::lease reference_store::worker_device() {
+reference_store::lease reference_store::worker_device(device_role role) {
     sina_hip_ctx *root = device();
     std::lock_guard<std::mutex> lk(gpu_mu);
     sina_hip_ctx *c = nullptr;
-    if (!idle_forks.empty()) {
-        c = idle_forks.back();
-        idle_forks.pop_back();
+    auto &pool = idle_forks[role];
+    if (!pool.empty()) {
+        c = pool.back();
+        pool.pop_back();
     } else {
         hip_check(sina_hip_fork(root, &c), "sina_hip_fork");
     }
-    return lease(this, c);
+    return lease(this, c, role);
 }
 reference_store::lease::~lease() {
     if (!c) return;
     std::lock_guard<std::mutex> lk(st->gpu_mu);
-    st->idle_forks.push_back(c);
+    st->idle_forks[role].push_back(c);
 }
 
 const cseq &reference_store::getCseq(const std::string &name) const {
@@ -507,7 +509,7 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
         const auto &b = queries[i]->getAlignedBases();
         for (size_t x = 0; x < b.size(); x++) qmask[qoff[i] + x] = b[x].getBase().mask();
     }
-    auto dev = st.worker_device();
+    auto dev = st.worker_device(reference_store::dev_search);
     sina_hip_ctx *ctx = dev.get();
     if (max <= 4096) {
         std::vector<uint32_t> ids((size_t)queries.size() * max), cnt(queries.size());
@@ -1141,7 +1143,7 @@ void aligner::operator()(std::vector<tray> &batch) {
         }
         std::vector<sina_hip_align_out> out(nq);
         std::vector<uint32_t> out_pos(qoff.back() ? qoff.back() : 1);
-        auto dev = store->worker_device();
+        auto dev = store->worker_device(reference_store::dev_align);
         sina_hip_ctx *ctx = dev.get();
         uint32_t width = 0;
 
@@ -1270,7 +1272,7 @@ void aligner::operator()(std::vector<tray> &batch) {
                     cids[coff[x] + y] = store->id_of(jobs[idx[x]].family[y]);
             }
             std::vector<sina_hip_match_counts> counts(coff.back() ? coff.back() : 1);
-            auto dev = store->worker_device();
+            auto dev = store->worker_device(reference_store::dev_compare);
             hip_check(sina_hip_compare(dev.get(), qab.data(), qoff.data(), (uint32_t)nq, cids.data(), coff.data(),
                                        SINA_CMP_IUPAC_OPTIMISTIC, 0, counts.data()),
                       "sina_hip_compare");
@@ -1599,7 +1601,7 @@ void search_filter::operator()(std::vector<tray> &batch) {
     // ---- scores: one comparison launch per slice of the batch
     {
         scoped_phase ph("sf.compare(C-ABI)");
-        auto dev = st.worker_device();
+        auto dev = st.worker_device(reference_store::dev_compare);
         const uint64_t max_pairs = 8u << 20;
         size_t x0 = 0;
         while (x0 < nq) {

@@ -147,10 +147,14 @@ public:
 
     // A forked context (own stream + scratch, shared store/index: sina_hip_fork) for the duration
     // of one GPU call, so that batches in flight on different host threads overlap on the GPU.
+    // Contexts are pooled per KIND of call: a context's scratch buffers grow to what its calls need
+    // (the aligner's trace-back plane is tens of GB), growing means hipMalloc, and hipMalloc in
+    // steady state stalls the device -- a context that only ever searches never grows aligner scratch.
+    enum device_role { dev_search = 0, dev_align = 1, dev_compare = 2, dev_roles = 3 };
     class lease {
     public:
-        lease(reference_store *s, sina_hip_ctx *c) : st(s), c(c) {}
-        lease(lease &&o) : st(o.st), c(o.c) { o.c = nullptr; }
+        lease(reference_store *s, sina_hip_ctx *c, int role) : st(s), c(c), role(role) {}
+        lease(lease &&o) : st(o.st), c(o.c), role(o.role) { o.c = nullptr; }
         lease(const lease &) = delete;
         ~lease();
         sina_hip_ctx *get() const { return c; }
@@ -158,8 +162,9 @@ public:
     private:
         reference_store *st;
         sina_hip_ctx *c;
+        int role;
     };
-    lease worker_device();
+    lease worker_device(device_role role);
 
 private:
     reference_store() = default;
@@ -169,7 +174,7 @@ private:
     std::vector<alignment_stats> vastats;
     int device_id{0};
     sina_hip_ctx *ctx{nullptr};
-    std::vector<sina_hip_ctx *> idle_forks;  // guarded by gpu_mu
+    std::vector<sina_hip_ctx *> idle_forks[dev_roles];  // guarded by gpu_mu
     int idx_k{-1};
     bool idx_nofast{false};
     std::string idx_origin;

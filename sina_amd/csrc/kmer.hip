@@ -635,6 +635,9 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
     for (uint32_t q0 = 0; q0 < nq; q0 += per) {
         const uint32_t bq = std::min(per, nq - q0);
         if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>() + q0, bq, max, max_qlen, false)) return 1;
+        // (wait for the kernels FIRST: a copy to pageable memory queued behind running kernels waits
+        // inside the runtime, under locks other threads' launches need -- see HostBuf in common.h)
+        SH_CHECK(hipStreamSynchronize(s));
         SH_CHECK(hipMemcpyAsync(out_ids + (size_t)q0 * max, c->k_out_ids.p, (size_t)bq * max * 4, hipMemcpyDeviceToHost, s));
         SH_CHECK(hipMemcpyAsync(out_scores + (size_t)q0 * max, c->k_out_scores.p, (size_t)bq * max * 4, hipMemcpyDeviceToHost, s));
         SH_CHECK(hipMemcpyAsync(out_n + q0, c->k_out_n.p, (size_t)bq * 4, hipMemcpyDeviceToHost, s));

@@ -233,6 +233,8 @@ extern "C" int sina_hip_compare(sina_hip_ctx *c, const uint32_t *q_ab, const uin
     hipLaunchKernelGGL(compare_kernel, dim3(nq), dim3(kCT), lds, s, a);
     SH_CHECK(hipGetLastError());
     SH_CHECK(hipEventRecord(c->ev[4], s));
+    // (wait for the kernel first: see HostBuf in common.h)
+    SH_CHECK(hipStreamSynchronize(s));
     SH_CHECK(hipMemcpyAsync(out, c->s_out.p, sizeof(sina_hip_match_counts) * ncand, hipMemcpyDeviceToHost, s));
     SH_CHECK(hipStreamSynchronize(s));
     float ms = 0;
