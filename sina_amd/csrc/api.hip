@@ -153,6 +153,10 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     });
     if (c->order.reserve(4 * (size_t)bq)) return 1;
     SH_CHECK(hipMemcpyAsync(c->order.p, order.data(), 4 * (size_t)bq, hipMemcpyHostToDevice, s));
+    // from here on the DP stream, behind everything queued on the context's main stream so far
+    SH_CHECK(hipEventRecord(c->ev[8], s));
+    s = c->stream_dp;
+    SH_CHECK(hipStreamWaitEvent(s, c->ev[8], 0));
     DpArgs a;
     a.qd = c->qd.as<QDesc>();
     a.order = c->order.as<uint32_t>();
@@ -217,6 +221,19 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     c->st->stats.backtrack_ms += ms;
     c->st->stats.dp_cells += cells;
     c->st->stats.dp_launches++;
+    return 0;
+}
+
+// A DP kernel holds every CU's LDS for ~20 ms, and the kernels that prepare the NEXT DP launch (DAG
+// build, k-mer search of other contexts) only get workgroup slots as DP workgroups retire: a 3 ms DAG
+// build took up to 19 ms beside a DP kernel and the next DP launch waited for it.  The DP kernel and
+// backtrack therefore run on a lowest-priority stream, everything else on a highest-priority one:
+// a retiring DP workgroup's slot goes to the preparing kernels first.
+int make_streams(sina_hip_ctx *c) {
+    int least = 0, greatest = 0;
+    SH_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    SH_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+    SH_CHECK(hipStreamCreateWithPriority(&c->stream_dp, hipStreamNonBlocking, least));
     return 0;
 }
 
@@ -352,7 +369,7 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
     c->device = device;
     c->st = new sina_hip_store();
     c->owns_store = true;
-    SH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (make_streams(c)) return 1;
     for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
     c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 40) * 1024;
     c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 48) << 30;
@@ -368,7 +385,7 @@ int sina_hip_fork(sina_hip_ctx *parent, sina_hip_ctx **ctx) {
     c->device = parent->device;
     c->st = parent->st;  // same reference store, index and counters; never freed by the fork
     c->owns_store = false;
-    SH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (make_streams(c)) return 1;
     for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
     c->lds_budget = parent->lds_budget;
     c->tb_budget_bytes = parent->tb_budget_bytes;
@@ -381,9 +398,11 @@ void sina_hip_destroy(sina_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream_dp) (void)hipStreamSynchronize(c->stream_dp);
     c->free_all();
     for (auto &e : c->ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
+    if (c->stream_dp) (void)hipStreamDestroy(c->stream_dp);
     delete c;
 }
 
@@ -391,6 +410,7 @@ int sina_hip_sync(sina_hip_ctx *c) {
     if (!c) SH_FAIL("sync: null ctx");
     SH_CHECK(hipSetDevice(c->device));
     SH_CHECK(hipStreamSynchronize(c->stream));
+    SH_CHECK(hipStreamSynchronize(c->stream_dp));
     return 0;
 }
 

@@ -26,9 +26,10 @@ struct sina_hip_store {
 
 struct sina_hip_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // everything but the DP: highest priority
+    hipStream_t stream_dp = nullptr;  // DP kernel + backtrack: lowest priority (see make_streams)
     std::mutex mu;
-    hipEvent_t ev[8];
+    hipEvent_t ev[10];
 
     sina_hip_store *st = nullptr;
     bool owns_store = false;
