@@ -13,6 +13,12 @@ struct sina_hip_store {
     uint32_t n_refs = 0, width = 0, k = 0, nofast = 0;
     uint64_t n_postings = 0, total_bases = 0;
     bool have_refs = false, have_index = false;
+    // Dense posting lists as bitmaps over the references (kmer.hip, ensure_dense): built lazily from
+    // the CSR index by the first search after the index changed
+    sina_hip::DevBuf dense_id, dense_bits;  // u32 [4^k]: bitmap number or ~0; u32 [n_dense][dense_words]
+    uint32_t n_dense = 0, dense_words = 0;
+    bool dense_ready = false;
+    std::mutex aux_mu;
     std::mutex stats_mu;
     // One DP kernel at a time per device: a DP launch fills every CU by itself, and contexts that
     // all reach their DP phase together would otherwise run in lock-step (GPU idle while all of
@@ -86,6 +92,8 @@ struct sina_hip_ctx {
             st->ref_off.release();
             st->idx_off.release();
             st->idx_ids.release();
+            st->dense_id.release();
+            st->dense_bits.release();
             delete st;
         }
         st = nullptr;

@@ -114,7 +114,37 @@ struct CountArgs {
     uint32_t n_refs, stride, kmax;
     unsigned k;
     int fast;
+    // dense posting lists as bitmaps (see ensure_dense): bitmap number per k-mer or kNoDense, words per bitmap
+    const uint32_t *dense_id;
+    const uint32_t *dense_bits;
+    uint32_t dense_words;
 };
+
+constexpr uint32_t kNoDense = 0xFFFFFFFFu;
+constexpr uint32_t kMaxDenseQ = 1023;  // dense k-mers of one query counted bit-sliced in 10 planes
+static_assert(kTileRefs / 32 == kCountThreads, "one bitmap word of the tile per thread");
+
+// ---- dense lists: which k-mers, and their bitmaps
+__global__ void mark_dense(const uint32_t *idx_off, uint32_t n_kmers, uint32_t thresh, uint32_t *dense_id,
+                           uint32_t *counter) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_kmers) return;
+    const uint32_t len = idx_off[v + 1] - idx_off[v];
+    dense_id[v] = (len > thresh) ? atomicAdd(counter, 1u) : kNoDense;
+}
+__global__ void fill_dense(const uint32_t *idx_off, const uint32_t *idx_ids, const uint32_t *dense_id,
+                           uint32_t n_kmers, uint32_t *bits, uint32_t words) {
+    // one wave per k-mer (most leave at once)
+    const uint32_t v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (v >= n_kmers) return;
+    const uint32_t d = dense_id[v];
+    if (d == kNoDense) return;
+    uint32_t *b = bits + (size_t)d * words;
+    for (uint32_t x = idx_off[v] + lane; x < idx_off[v + 1]; x += 64) {
+        const uint32_t r = idx_ids[x];
+        atomicOr(&b[r >> 5], 1u << (r & 31));
+    }
+}
 
 // One workgroup (16 waves) per query.  Every query k-mer keeps a cursor into its (ascending)
 // posting list; the reference range is processed in tiles of kTileRefs whose int16 counters
@@ -124,16 +154,20 @@ struct CountArgs {
 // cursor: there is no search, and the tile is written out once.  (64 VGPRs: two workgroups per CU.)
 __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) kmer_count_kernel(CountArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t n_kmers, next_kmer;
+    __shared__ uint32_t n_kmers, next_kmer, n_dense_q;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);                 // [kTileRefs/2]
     uint32_t *cur = hist + kTileRefs / 2;                                // [kmax]
     uint32_t *end = cur + a.kmax;                                        // [kmax]
     uint8_t *qb = reinterpret_cast<uint8_t *>(end + a.kmax);             // [kmax] query masks
+    // bitmap numbers of the query's dense k-mers: from the top of cur[] downwards (cursor slots grow
+    // from the bottom; together they are at most kmax k-mers) -- a third array would cost the second
+    // workgroup per CU
+    uint32_t *dtop = cur + a.kmax - 1;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63;
     const uint8_t *qm = a.qmask + a.qoff[q];
     const uint32_t len = (uint32_t)(a.qoff[q + 1] - a.qoff[q]);
-    if (tid == 0) n_kmers = 0;
+    if (tid == 0) n_kmers = n_dense_q = 0;
     for (uint32_t i = tid; i < len; i += kCountThreads) qb[i] = qm[i];
     __syncthreads();
     unsigned long long mine = 0;
@@ -142,15 +176,25 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
         if (kmer_at(qb, len, e, a.k, a.fast != 0, &v)) {
             const uint32_t lo = a.idx_off[v], hi = a.idx_off[v + 1];
             if (lo != hi) {
-                const uint32_t slot = atomicAdd(&n_kmers, 1u);
-                cur[slot] = lo;
-                end[slot] = hi;
+                // a k-mer of a conserved region is in a large share of the references: its list comes
+                // as a bitmap and is counted without atomics (below); everything else by cursor
+                const uint32_t did = a.dense_id ? a.dense_id[v] : kNoDense;
+                uint32_t dslot = kMaxDenseQ;
+                if (did != kNoDense) dslot = atomicAdd(&n_dense_q, 1u);
+                if (dslot < kMaxDenseQ) {
+                    *(dtop - dslot) = did;
+                } else {
+                    const uint32_t slot = atomicAdd(&n_kmers, 1u);
+                    cur[slot] = lo;
+                    end[slot] = hi;
+                }
                 mine += hi - lo;
             }
         }
     }
     __syncthreads();
     const uint32_t nk = n_kmers;
+    const uint32_t nd = min(n_dense_q, kMaxDenseQ);
     const uint32_t ntiles = (a.n_refs + kTileRefs - 1) / kTileRefs;
     int16_t *row = a.scores + (size_t)q * a.stride;
     for (uint32_t t = 0; t < ntiles; t++) {
@@ -205,6 +249,56 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
             if (lane == 0) cur[i] = c;
         }
         __syncthreads();
+        // Dense k-mers: thread t owns the 32 references of bitmap word t of this tile and counts, for
+        // each of them, in how many of the query's dense bitmaps its bit is set -- bit-sliced: the
+        // planes hold one bit of all 32 counters each; eight bitmap words go in with seven carry-save
+        // adders (ones / twos / fours) and one ripple of the resulting eights (7 operations per word,
+        // no atomics, nothing but registers).
+        if (nd) {
+            const uint32_t *bw = a.dense_bits + (size_t)(tile_lo >> 5) + tid;
+            uint32_t ones = 0, twos = 0, fours = 0, hi[7] = {0, 0, 0, 0, 0, 0, 0};  // hi[p]: weight 8 << p
+            auto csa = [](uint32_t &h, uint32_t &l, uint32_t x, uint32_t y, uint32_t z) {
+                const uint32_t u = x ^ y;
+                h = (x & y) | (u & z);
+                l = u ^ z;
+            };
+            for (uint32_t i = 0; i < nd; i += 8) {
+                uint32_t w[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) w[u] = (i + u < nd) ? bw[(size_t)*(dtop - (i + u)) * a.dense_words] : 0u;
+                uint32_t twosA, twosB, foursA, foursB, eights;
+                csa(twosA, ones, ones, w[0], w[1]);
+                csa(twosB, ones, ones, w[2], w[3]);
+                csa(foursA, twos, twos, twosA, twosB);
+                csa(twosA, ones, ones, w[4], w[5]);
+                csa(twosB, ones, ones, w[6], w[7]);
+                csa(foursB, twos, twos, twosA, twosB);
+                csa(eights, fours, fours, foursA, foursB);
+                uint32_t carry = eights;
+#pragma unroll
+                for (int p = 0; p < 7; p++) {
+                    const uint32_t t2 = hi[p] & carry;
+                    hi[p] ^= carry;
+                    carry = t2;
+                }
+            }
+            // add my 32 counts to the tile's counters: words 16 t .. 16 t + 15 are mine alone now
+            // (word j of lane l in step (j - l) mod 16: the lanes of a wave spread over the LDS banks)
+#pragma unroll 4
+            for (int jj = 0; jj < 16; jj++) {
+                const int j = (jj + lane) & 15;
+                const int b0 = 2 * j, b1 = 2 * j + 1;
+                uint32_t cl = ((ones >> b0) & 1u) | (((twos >> b0) & 1u) << 1) | (((fours >> b0) & 1u) << 2);
+                uint32_t ch = ((ones >> b1) & 1u) | (((twos >> b1) & 1u) << 1) | (((fours >> b1) & 1u) << 2);
+#pragma unroll
+                for (int p = 0; p < 7; p++) {
+                    cl |= ((hi[p] >> b0) & 1u) << (3 + p);
+                    ch |= ((hi[p] >> b1) & 1u) << (3 + p);
+                }
+                hist[16 * tid + j] += cl | (ch << 16);
+            }
+            __syncthreads();
+        }
         // tile scores out: two int16 per 32-bit store (row stride is even)
         uint32_t *dst = reinterpret_cast<uint32_t *>(row + tile_lo);
         const uint32_t words = (tile_hi - tile_lo + 1) / 2;
@@ -431,6 +525,46 @@ static int index_ready(sina_hip_ctx *c) {
     return 0;
 }
 
+// Posting lists longer than 1/32 of the references (k-mers of conserved regions: a few hundred per
+// query hold 97 % of its postings) as bitmaps over the references, zero-padded to whole tiles, for
+// the count kernel's atomic-free path.  Built from the CSR index by the first search after the
+// index changed (also when the index arrived by broadcast), under the store's mutex.
+static int ensure_dense(sina_hip_ctx *c) {
+    sina_hip_store *st = c->st;
+    std::lock_guard<std::mutex> lk(st->aux_mu);
+    if (st->dense_ready) return 0;
+    hipStream_t s = c->stream;
+    const uint32_t nk = 1u << (2 * st->k);
+    uint32_t div_ = 32;
+    if (const char *e_ = getenv("SINA_HIP_DENSE_DIV")) div_ = (uint32_t)std::max(1, atoi(e_));
+    const uint32_t thresh = std::max<uint32_t>(256u, st->n_refs / div_);
+    const uint32_t ntiles = (st->n_refs + kTileRefs - 1) / kTileRefs;
+    st->dense_words = ntiles * (uint32_t)(kTileRefs / 32);
+    sina_hip::DevBuf counter;
+    if (st->dense_id.reserve_exact(4 * (size_t)nk) || counter.reserve_exact(4)) return 1;
+    SH_CHECK(hipMemsetAsync(counter.p, 0, 4, s));
+    hipLaunchKernelGGL(mark_dense, dim3((nk + 255) / 256), dim3(256), 0, s, st->idx_off.as<uint32_t>(), nk, thresh,
+                       st->dense_id.as<uint32_t>(), counter.as<uint32_t>());
+    SH_CHECK(hipGetLastError());
+    SH_CHECK(hipStreamSynchronize(s));
+    uint32_t nd = 0;
+    SH_CHECK(hipMemcpy(&nd, counter.p, 4, hipMemcpyDeviceToHost));
+    counter.release();
+    st->n_dense = nd;
+    if (nd) {
+        const size_t bytes = 4 * (size_t)nd * st->dense_words;
+        if (st->dense_bits.reserve_exact(bytes)) return 1;
+        SH_CHECK(hipMemsetAsync(st->dense_bits.p, 0, bytes, s));
+        hipLaunchKernelGGL(fill_dense, dim3((unsigned)(((uint64_t)nk * 64 + 255) / 256)), dim3(256), 0, s,
+                           st->idx_off.as<uint32_t>(), st->idx_ids.as<uint32_t>(), st->dense_id.as<uint32_t>(), nk,
+                           st->dense_bits.as<uint32_t>(), st->dense_words);
+        SH_CHECK(hipGetLastError());
+    }
+    SH_CHECK(hipStreamSynchronize(s));  // (other contexts' streams read it next)
+    st->dense_ready = true;
+    return 0;
+}
+
 // counts + selects for nq queries whose masks are already on the device
 static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint64_t *d_qoff, uint32_t nq,
                             uint32_t max, uint32_t max_qlen, bool want_scores_only) {
@@ -452,6 +586,10 @@ static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint6
     ca.kmax = (max_qlen + 63u) & ~63u;
     ca.k = c->st->k;
     ca.fast = c->st->nofast ? 0 : 1;
+    if (ensure_dense(c)) return 1;
+    ca.dense_id = c->st->n_dense ? c->st->dense_id.as<uint32_t>() : nullptr;
+    ca.dense_bits = c->st->dense_bits.as<uint32_t>();
+    ca.dense_words = c->st->dense_words;
     const size_t clds = (size_t)kTileRefs * 2 + (size_t)ca.kmax * 9 + 64;
     SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kmer_count_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
@@ -502,6 +640,7 @@ int sina_hip_upload_index(sina_hip_ctx *c, unsigned k, int nofast, const uint32_
     c->st->nofast = nofast ? 1 : 0;
     c->st->n_postings = n_postings;
     c->st->have_index = true;
+    c->st->dense_ready = false;
     return 0;
 }
 
@@ -590,6 +729,7 @@ int sina_hip_build_index(sina_hip_ctx *c, unsigned k, int nofast) {
         c->st->nofast = nofast ? 1 : 0;
         c->st->n_postings = np;
         c->st->have_index = true;
+        c->st->dense_ready = false;
         rc = 0;
     } while (0);
     keys_in.release();
@@ -715,6 +855,7 @@ int sina_hip_store_alloc_like(sina_hip_ctx *c, sina_hip_store_view *v) {
     c->st->nofast = v->nofast;
     c->st->n_postings = v->n_postings;
     c->st->have_refs = c->st->have_index = true;
+    c->st->dense_ready = false;  // (the index arrives by broadcast after this call: built by the first search)
     c->st->ref_off_host.clear();  // re-read from the device after the broadcast filled it
     v->ref_ab = c->st->ref_ab.p;
     v->ref_ab_bytes = 4 * v->total_bases;
