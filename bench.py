@@ -114,7 +114,9 @@ def main():
 
     # ---- synthetic inputs (identical on every rank; queries differ per rank)
     refs = synth.make_refs(a.refs, length=a.length, width=a.width, seed=2)
-    n_q = a.batch * (a.steps + a.warmup + 1)  # + one untimed step for the isolated kernel timings
+    # + one untimed step for the isolated kernel timings + the set-up pass (launches of the timed size)
+    prime_n = a.sub_batch * 2 * max(1, a.inflight)
+    n_q = a.batch * (a.steps + a.warmup + 1) + prime_n
     window = (1.0 / 3.0, a.window) if a.window else None
     qs = synth.make_queries(refs, n_q, seed=3 + 1000 * rank, window=window)
 
@@ -137,13 +139,12 @@ def main():
 
     # Set-up, like the index build: one pass that lets every context of the pipeline allocate its
     # scratch (a 48 GB trace-back plane takes 1.4 s to allocate; with few warm-up steps not every
-    # aligner context would have seen a batch before the timed region).  Uses the queries of the
-    # extra, untimed step.
-    prime_n = min(a.batch, 512 * 4 * max(1, a.inflight))
-    lo_p = qs.off[(a.warmup + a.steps) * a.batch]
-    hi_p = qs.off[(a.warmup + a.steps) * a.batch + prime_n]
-    off_p = (qs.off[(a.warmup + a.steps) * a.batch:(a.warmup + a.steps) * a.batch + prime_n + 1] - lo_p).astype(np.uint64)
-    pl.run(qs.mask[lo_p:hi_p], off_p, batch=512, inflight=a.inflight)  # (512 queries: already a multi-GB plane)
+    # aligner context would have seen a batch before the timed region).  Its own queries; launches of
+    # the timed size, two per aligner context.
+    q_p = a.batch * (a.steps + a.warmup + 1)  # its own queries, behind those of the steps
+    lo_p, hi_p = qs.off[q_p], qs.off[q_p + prime_n]
+    off_p = (qs.off[q_p:q_p + prime_n + 1] - lo_p).astype(np.uint64)
+    pl.run(qs.mask[lo_p:hi_p], off_p, batch=a.sub_batch, inflight=a.inflight)
     if a.warmup:
         run_steps(0, a.warmup)
     pl.profile(reset=True)
