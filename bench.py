@@ -51,42 +51,127 @@ def parse():
     ap.add_argument("--window", type=int, default=0, help="cut queries to this many bases (V4: 250)")
     ap.add_argument("--inflight", type=int, default=3, help="batches worked on concurrently per rank")
     ap.add_argument("--sub-batch", type=int, default=2048, help="queries per GPU launch inside a step")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="queries for the CPU baseline (0 = auto)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="CPU baseline: queries per thread and thread count (0 = 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", type=int, default=8,
+                    help="queries of the timed run re-done by the oracle afterwards and compared (0 = none; "
+                         "skipped together with the CPU baseline, whose oracle index it shares)")
     ap.add_argument("--host-graph", action="store_true", help="build family DAGs on the host")
     ap.add_argument("--host-threads", type=int, default=0, help="threads of the host-side loop pool (0 = default)")
     return ap.parse_args()
 
 
-def cpu_baseline(refs, qs, n_sample, threads):
-    """Times the oracle (CPU restatement, test infrastructure) on a bounded sample of the same
-    workload.  Two thread counts are tried (all hardware threads, and half of them = one per
-    core on an SMT-2 host) and the faster one is reported; every thread first runs one untimed
-    query so that its mesh scratch is mapped (steady state, like a 100k-query run).  Reported
-    beside the GPU number; never part of it."""
-    from oracle import pyoracle as po
-    t0 = time.time()
-    cs = [po.Cseq.from_packed("ref%d" % i, refs.seq(i), refs.width) for i in range(refs.n)]
-    idx = po.Index(cs, k=10)
-    build_s = time.time() - t0
-    queries = []
-    for i in range(n_sample):
+def kernel_source_rev():
+    """Hash of the DP kernel's sources: a recorded PMC profile only describes the kernel it was taken on."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("mesh_dp.hip", "common.h"):
+        h.update(open(os.path.join(ROOT, "sina_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def physical_cores():
+    """Physical cores of this host (SMT siblings counted once)."""
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+class OracleWorld:
+    """The CPU oracle's view of the workload (test infrastructure): reference cseqs + k-mer index,
+    built once and shared by the cpu_baseline and --verify legs.  Never part of the measured path."""
+
+    def __init__(self, refs):
+        from oracle import pyoracle as po
+        self.po = po
+        t0 = time.time()
+        self.cs = [po.Cseq.from_packed("ref%d" % i, refs.seq(i), refs.width) for i in range(refs.n)]
+        self.idx = po.Index(self.cs, k=10)
+        self.build_s = time.time() - t0
+
+    def query(self, qs, i):
         m = qs.seq(i)
         ab = np.arange(len(m), dtype=np.uint32) | (m.astype(np.uint32) << 24)
-        queries.append(po.Cseq.from_packed("q%d" % i, ab, len(m)))
-    best = None
-    for th in sorted({threads, max(1, threads // 2)}, reverse=True):
-        r = po.bench_run(idx, queries, th)
-        r["threads"] = th
-        if best is None or r["aligned"] / r["seconds"] > best["aligned"] / best["seconds"]:
-            best = r
-    return dict(value=best["aligned"] / best["seconds"], unit="sequences/s", cores=best["threads"], kind="port",
-                sample="%d of the same synthetic queries vs the same %d references, oracle (plain C restatement of "
-                       "the reference algorithm, full 28-byte-cell mesh), best of %d and %d threads, %.1f s wall, "
-                       "%.1f Mcell/s, %.1f Mcell/s/thread; index build %.0f s not timed"
-                       % (n_sample, refs.n, threads, max(1, threads // 2), best["seconds"],
-                          best["cells"] / best["seconds"] / 1e6,
-                          best["cells"] / best["seconds"] / 1e6 / best["threads"], build_s))
+        return self.po.Cseq.from_packed("q%d" % i, ab, len(m))
+
+
+def cpu_baseline(world, refs, qs, per_thread):
+    """Times the oracle (CPU restatement of the reference algorithm, full 28-byte-cell mesh) on a
+    bounded sample of the same workload, as SURVEY 8d / BASELINE.md 3 ask: one thread alone, a sweep
+    over thread counts (one query per thread at a time like the reference's TBB nodes, pages
+    interleaved over the NUMA nodes, every thread warmed with one untimed query) and the per-core
+    rate x physical cores.  `value` is the FASTEST of those -- the extrapolation included, so the
+    baseline errs on the CPU's side.  Reported beside the GPU number; never part of it."""
+    po = world.po
+    hw = os.cpu_count() or 1
+    cores = physical_cores()
+    counts = sorted({t for t in (16, 32, 64, 128, cores, hw) if 1 < t <= hw})
+    n_max = per_thread * max(counts + [1])
+    queries = [world.query(qs, i) for i in range(min(qs.n, max(n_max, 8)))]
+    t_all = time.time()
+    one = po.bench_run(world.idx, queries[:6], 1)
+    one_rate = one["aligned"] / one["seconds"]
+    one_mcell = one["cells"] / one["seconds"] / 1e6
+    sweep = []
+    for th in counts:
+        r = po.bench_run(world.idx, queries[:per_thread * th], th, interleave=True)
+        sweep.append(dict(threads=th, seq_per_s=r["aligned"] / r["seconds"],
+                          mcell_per_s_per_thread=r["cells"] / r["seconds"] / 1e6 / th, interleaved=r["interleaved"]))
+    best = max(sweep, key=lambda x: x["seq_per_s"]) if sweep else dict(threads=1, seq_per_s=one_rate)
+    extrapolated = one_rate * cores
+    value = max(best["seq_per_s"], extrapolated)
+    return dict(value=value, unit="sequences/s", cores=cores, kind="port",
+                one_thread=dict(seq_per_s=one_rate, mcell_per_s=one_mcell),
+                measured_best=best, per_core_rate_x_cores=extrapolated, sweep=sweep,
+                sample="oracle (plain C restatement of the reference algorithm, full 28-byte-cell mesh) on the same "
+                       "synthetic queries vs the same %d references: 1 thread %.1f seq/s = %.1f Mcell/s; best "
+                       "measured %.0f seq/s at %d threads (%d queries per thread, NUMA-interleaved: %s); 1-thread "
+                       "rate x %d physical cores = %.0f seq/s; value = the larger; %.1f s of CPU-baseline wall, "
+                       "index build %.0f s not timed"
+                       % (refs.n, one_rate, one_mcell, best["seq_per_s"], best["threads"], per_thread,
+                          "yes" if any(x["interleaved"] for x in sweep) else "single node", cores, extrapolated,
+                          time.time() - t_all, world.build_s))
+
+
+def verify_against_oracle(world, qs, picked):
+    """Untimed: re-does the picked queries of the timed run with the oracle (k-mer search + family
+    selection + DAG + DP + backtrack + NAST at the full reference count) and compares family, aligned
+    columns and case bits, head / tail / quality.  Returns (checked, identical, first differences)."""
+    po = world.po
+    diffs = []
+    for q, got in sorted(picked.items()):
+        c = world.query(qs, q)
+        ids, sc, fflog = world.idx.famfinder(c, po.ff_opts())
+        if len(ids) == 0:
+            ok = got["status"] == 2
+            what = "status"
+        else:
+            want = po.align([world.cs[i] for i in ids], c, po.align_opts())
+            fam = "".join("ref%d.0:%.2f " % (i, x) for i, x in zip(ids, sc))
+            checks = (("family", got["family"] == fam), ("status", got["status"] == want["status"]),
+                      ("alignment", len(got["packed"]) == len(want["packed"]) and
+                       bool((got["packed"] == want["packed"]).all())),
+                      ("head/tail/qual", (got["head"], got["tail"], got["qual"]) ==
+                       (want["head"], want["tail"], want["qual"])))
+            ok = all(v for _, v in checks)
+            what = ",".join(k for k, v in checks if not v)
+        if not ok:
+            diffs.append("query %d: %s" % (q, what))
+    return len(picked), len(picked) - len(diffs), diffs[:4]
 
 
 def main():
@@ -166,6 +251,12 @@ def main():
 
     n_done = a.batch * a.steps
     n_aligned = sum(1 for q in range(n_done) if pl.result(q)["status"] in (0, 1))
+    picked = {}
+    if a.verify and not a.no_cpu_baseline and rank == 0 and world == 1:
+        rng = np.random.default_rng(12345)
+        first = a.warmup * a.batch  # (results are indexed from the first query of the timed call)
+        for q in rng.choice(n_done, size=min(a.verify, n_done), replace=False):
+            picked[first + int(q)] = pl.result(int(q))
 
     # One more step, untimed and with ONE batch in flight: kernels run alone on the GPU, so their
     # HIP-event durations are the kernels' own (in the timed region batches overlap on separate
@@ -186,12 +277,20 @@ def main():
 
     # HBM bytes per DP launch from the PMC passes of this same command (tools/prof_bench.sh ->
     # profiles/r01_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); null if not collected
-    dp_traffic = None
+    dp_traffic, traffic_note = None, "no PMC profile recorded for this kernel source + configuration"
     try:
-        tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")))
-        dp_traffic = tj["mesh_dp_kernel"]["hbm_bytes"]
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        meta = tj.get("_meta", {})
+        if (meta.get("kernel_source_rev") == kernel_source_rev() and meta.get("batch") == a.batch and
+                meta.get("sub_batch") == a.sub_batch and meta.get("refs") == a.refs and
+                meta.get("length") == a.length and meta.get("window") == a.window):
+            dp_traffic = tj["mesh_dp_kernel"]["hbm_bytes"]
+            traffic_note = ("HBM bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from the separate "
+                            "--pmc passes of this same command recorded in profiles/r02_traffic.json (same kernel "
+                            "source revision and configuration as this run; not measured by this run)")
     except Exception:
         pass
+    verify_failed = False
     if rank == 0 and os.environ.get("SINA_HOST_PROFILE"):
         print(pl.profile(), file=sys.stderr)
     if rank == 0:
@@ -212,6 +311,7 @@ def main():
                 "workload": "configs[1]: full-length 16S (~%d bp%s) vs %d-seq SILVA-NR-like aligned reference, "
                             "width %d, SINA defaults (k=10 fast, family 40, match 2/mismatch -1/gap 5/ext 2)"
                             % (a.length, (", cut to %d" % a.window) if a.window else "", a.refs, a.width),
+                "refs": a.refs, "length": a.length, "width": a.width, "window": a.window,
                 "queries_per_step_per_gpu": a.batch,
                 "queries_per_launch": a.sub_batch,
                 "inflight_batches": a.inflight,
@@ -228,7 +328,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": dp_traffic,
-                "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_traffic.json)",
+                "traffic_unit": traffic_note,
                 "algorithmic_bytes_per_launch": DP_BYTES_PER_CELL * dp_cells / dp_launches if dp_launches else 0,
                 "cells_per_launch": dp_cells / dp_launches if dp_launches else 0,
                 "ms_per_launch": dp_ms / dp_launches if dp_launches else 0,
@@ -262,9 +362,14 @@ def main():
             },
         }
         if not a.no_cpu_baseline and world == 1:
-            threads = os.cpu_count() or 1
-            n_sample = a.cpu_sample or min(n_q, max(64, 12 * threads))
-            out["cpu_baseline"] = cpu_baseline(refs, qs, n_sample, threads)
+            ow = OracleWorld(refs)
+            out["cpu_baseline"] = cpu_baseline(ow, refs, qs, a.cpu_sample or 6)
+            if picked:
+                n_chk, n_same, diffs = verify_against_oracle(ow, qs, picked)
+                out["verify"] = {"checked": n_chk, "identical": n_same, "differences": diffs,
+                                 "what": "randomly picked queries of the timed run re-done by the CPU oracle at the "
+                                         "full reference count: family, aligned columns + case bits, head/tail/quality"}
+                verify_failed = n_same != n_chk
     pl.close()
     if dist is not None:
         dist.barrier()
@@ -272,6 +377,8 @@ def main():
     if rank == 0:
         sys.stderr.flush()
         print(json.dumps(out), flush=True)  # the ONE JSON line, after RCCL has said whatever it says
+        if verify_failed:
+            raise SystemExit("bench.py --verify: results differ from the oracle: %s" % out["verify"]["differences"])
 
 
 if __name__ == "__main__":

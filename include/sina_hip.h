@@ -246,7 +246,9 @@ typedef struct sina_hip_stats {
     uint32_t dp_launches, kmer_launches;
     double compare_ms;       /* search-stage comparison kernel            */
     uint64_t compare_bases;  /* candidate bases streamed by it            */
-    uint32_t compare_launches, reserved;
+    uint32_t compare_launches;
+    uint32_t n_dense_lists;  /* gauge, not cumulative: posting lists the index currently also holds as
+                                reference bitmaps (0 until the first search after an index change) */
 } sina_hip_stats;
 int sina_hip_get_stats(sina_hip_ctx *ctx, sina_hip_stats *s);
 

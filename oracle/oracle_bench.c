@@ -9,9 +9,12 @@
 #define _GNU_SOURCE
 #include <pthread.h>
 #include <stdatomic.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/syscall.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "sina_oracle.h"
 
@@ -72,6 +75,38 @@ static void *bench_worker(void *arg) {
     free(sc);
     free(fam);
     return NULL;
+}
+
+/* Memory policy of the calling thread and the threads it starts afterwards: on != 0 interleaves new
+ * pages over all online NUMA nodes (what `numactl --interleave=all` does; the mesh scratch of many
+ * threads otherwise lands on the node of whoever touched it first), 0 restores the default.
+ * Returns 0 on success, -1 when the kernel refuses (single-node hosts: nothing to do). */
+int so_bench_mempolicy_interleave(int on) {
+#ifdef SYS_set_mempolicy
+    unsigned long mask[16] = {0};
+    if (!on) return (int)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, NULL, 0);
+    FILE *f = fopen("/sys/devices/system/node/online", "r");
+    if (!f) return -1;
+    char buf[256] = {0};
+    if (!fgets(buf, sizeof buf, f)) buf[0] = 0;
+    fclose(f);
+    int any = 0;
+    for (char *p = buf; *p;) { /* "0-3,8" */
+        char *e;
+        long a = strtol(p, &e, 10), b;
+        if (e == p) break;
+        b = a;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        for (long x = a; x <= b && x < 1024; x++) mask[x / (8 * sizeof(long))] |= 1UL << (x % (8 * sizeof(long))), any++;
+        p = (*e == ',') ? e + 1 : e;
+        if (*e != ',') break;
+    }
+    if (any < 2) return -1;
+    return (int)syscall(SYS_set_mempolicy, 3 /* MPOL_INTERLEAVE */, mask, 1024 + 1);
+#else
+    (void)on;
+    return -1;
+#endif
 }
 
 /* returns wall seconds; *cells = mesh cells filled, *aligned = queries with a result */

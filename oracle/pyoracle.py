@@ -127,6 +127,8 @@ def lib():
         L.so_index_scores.argtypes = [vp, vp, i16p]
         L.so_index_find.restype = C.c_uint32
         L.so_index_find.argtypes = [vp, vp, C.c_uint32, u32p, f32p]
+        L.so_turn_check.restype = C.c_int
+        L.so_turn_check.argtypes = [vp, vp, C.c_int, f32p]
         L.so_index_csr.restype = C.c_uint64
         L.so_index_csr.argtypes = [vp, u32p, u32p]
         L.so_ff_opts_default.argtypes = [C.POINTER(FFOpts)]
@@ -367,6 +369,14 @@ class Index:
         self.k = k
         return self
 
+    TURN_NAMES = ("none", "reversed", "complemented", "reversed and complemented")
+
+    def turn_check(self, q, all_orientations):
+        """famfinder::impl::turn_check: (orientation 0..3, the four top-1 scores)."""
+        sc = np.zeros(4, np.float32)
+        best = lib().so_turn_check(self.h, q.h, int(all_orientations), _p(sc, f32p))
+        return best, sc
+
     def famfinder(self, q, opts=None):
         opts = opts or ff_opts()
         cap = len(self.refs)
@@ -432,16 +442,24 @@ def align(fam, query, opts=None):
     return d
 
 
-def bench_run(index, queries, threads, ff=None, al=None):
-    """Times the oracle's whole path over `queries` (list of Cseq) on `threads` host threads.
-    Returns dict(seconds, cells, aligned)."""
+def bench_run(index, queries, threads, ff=None, al=None, interleave=False):
+    """Times the oracle's whole path over `queries` (list of Cseq) on `threads` host threads
+    (interleave: new pages spread over all NUMA nodes, as `numactl --interleave=all`).
+    Returns dict(seconds, cells, aligned, interleaved)."""
     ff = ff or ff_opts()
     al = al or align_opts()
     qh = handles(queries)
     cells, aligned = C.c_uint64(), C.c_uint32()
-    sec = lib().so_bench_run(index.h, index._h, qh, len(queries), C.byref(ff), C.byref(al), threads,
+    L = lib()
+    L.so_bench_mempolicy_interleave.argtypes = [C.c_int]
+    il = bool(interleave) and L.so_bench_mempolicy_interleave(1) == 0
+    try:
+        sec = L.so_bench_run(index.h, index._h, qh, len(queries), C.byref(ff), C.byref(al), threads,
                              C.byref(cells), C.byref(aligned))
-    return dict(seconds=sec, cells=cells.value, aligned=aligned.value)
+    finally:
+        if il:
+            L.so_bench_mempolicy_interleave(0)
+    return dict(seconds=sec, cells=cells.value, aligned=aligned.value, interleaved=il)
 
 
 # ---- section 8f-1: cseq_comparator + search_filter

@@ -753,6 +753,42 @@ void so_ff_opts_default(so_ff_opts *o) { /* famfinder.cpp:156-203 */
     o->fs_cover_gene = 0;
 }
 
+/* famfinder.cpp:344-378 (turn_check): top-1 k-mer score of the query as it is [0], reversed [1],
+ * complemented [2], reversed and complemented [3]; [1] and [2] are only searched with --turn=all
+ * (else 0).  The orientation with the strictly largest score wins, the first one on ties, "as it
+ * is" when every search comes back empty.  cseq::reverse() also mirrors the columns; the k-mer
+ * search only reads the base order. */
+int so_turn_check(const so_index *idx, const so_cseq *query, int all, float *scores4) {
+    double score[4];
+    uint32_t id;
+    float sc;
+    score[0] = so_index_find(idx, query, 1, &id, &sc) ? sc : 0;
+    so_cseq *turn = so_cseq_clone(query);
+    so_cseq_reverse(turn);
+    if (all) {
+        score[1] = so_index_find(idx, turn, 1, &id, &sc) ? sc : 0;
+        so_cseq *comp = so_cseq_clone(query);
+        so_cseq_complement(comp);
+        score[2] = so_index_find(idx, comp, 1, &id, &sc) ? sc : 0;
+        so_cseq_free(comp);
+    } else {
+        score[1] = score[2] = 0;
+    }
+    so_cseq_complement(turn);
+    score[3] = so_index_find(idx, turn, 1, &id, &sc) ? sc : 0;
+    so_cseq_free(turn);
+    double max = 0;
+    int best = 0;
+    for (int i = 0; i < 4; i++) {
+        if (scores4) scores4[i] = (float)score[i];
+        if (max < score[i]) {
+            max = score[i];
+            best = i;
+        }
+    }
+    return best;
+}
+
 /* famfinder.cpp:497-612 (match) then :472-491 (gap filter, fs_req).
  * remove_similar (:545-548) needs cseq_comparator and is a provable no-op for
  * fs_msc_max >= 1 (identity <= 1, cseq_comparator.cpp:280); smaller values are

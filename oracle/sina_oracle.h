@@ -138,6 +138,9 @@ typedef struct so_ff_opts {
     uint32_t fs_req, fs_req_full, fs_full_len, fs_req_gaps, fs_min_len, fs_cover_gene;
 } so_ff_opts;
 void so_ff_opts_default(so_ff_opts *o);
+/* famfinder::impl::turn_check, src/famfinder.cpp:344-378: 0 none, 1 reversed, 2 complemented,
+ * 3 reversed and complemented; scores4 (may be NULL) receives the four top-1 scores */
+int so_turn_check(const so_index *idx, const so_cseq *query, int all, float *scores4);
 /* returns number of family members (0 + log text "unable to align" if < fs_req) */
 uint32_t so_famfinder(const so_index *idx, const so_cseq *const *refs, const so_cseq *query,
                       const so_ff_opts *o, uint32_t *out_ids, float *out_scores, uint32_t cap,

@@ -67,7 +67,7 @@ class Stats(C.Structure):
                 ("kmer_count_ms", C.c_double), ("kmer_select_ms", C.c_double), ("dp_cells", C.c_uint64),
                 ("postings", C.c_uint64), ("dp_launches", C.c_uint32), ("kmer_launches", C.c_uint32),
                 ("compare_ms", C.c_double), ("compare_bases", C.c_uint64), ("compare_launches", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("n_dense_lists", C.c_uint32)]
 
 
 _lib = None
@@ -175,6 +175,14 @@ class Context:
         ids = _c(ids, np.uint32)
         self._check(self.L.sina_hip_upload_index(self.h, k, int(nofast), _ptr(offsets, u32p), _ptr(ids, u32p),
                                                  len(ids)))
+
+    def download_index(self):
+        """The device index as CSR: (offsets u32[4^k+1], ids u32[n_postings])."""
+        v = self.store_view()
+        off = np.zeros((1 << (2 * v.k)) + 1, np.uint32)
+        ids = np.zeros(max(int(v.n_postings), 1), np.uint32)
+        self._check(self.L.sina_hip_download_index(self.h, _ptr(off, u32p), _ptr(ids, u32p)))
+        return off, ids[:int(v.n_postings)]
 
     def store_view(self):
         v = StoreView()

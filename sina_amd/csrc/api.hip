@@ -438,7 +438,11 @@ int sina_hip_upload_refs(sina_hip_ctx *c, const uint32_t *ab, const uint64_t *of
     SH_CHECK(hipMemcpyAsync(c->st->ref_ab.p, ab, 4 * total, hipMemcpyHostToDevice, c->stream));
     SH_CHECK(hipMemcpyAsync(c->st->ref_off.p, off, 8 * ((uint64_t)n_refs + 1), hipMemcpyHostToDevice, c->stream));
     SH_CHECK(hipStreamSynchronize(c->stream));
-    c->st->ref_off_host.assign(off, off + n_refs + 1);
+    {
+        std::lock_guard<std::mutex> alk(c->st->aux_mu);
+        c->st->ref_off_host.assign(off, off + n_refs + 1);
+        c->st->ref_off_host_ready.store(true, std::memory_order_release);
+    }
     c->st->n_refs = n_refs;
     c->st->width = width;
     c->st->total_bases = total;
@@ -469,6 +473,7 @@ int sina_hip_get_stats(sina_hip_ctx *c, sina_hip_stats *s) {
     if (!c || !s) SH_FAIL("get_stats: null argument");
     std::lock_guard<std::mutex> slk(c->st->stats_mu);
     *s = c->st->stats;
+    s->n_dense_lists = c->st->dense_ready.load() ? c->st->n_dense : 0;
     return 0;
 }
 

@@ -1,6 +1,7 @@
 // The context object behind the opaque sina_hip_ctx handle.
 #pragma once
 
+#include <atomic>
 #include <cmath>
 
 #include "common.h"
@@ -9,7 +10,12 @@
 // sina_hip_init() made; contexts made by sina_hip_fork() point at their parent's.
 struct sina_hip_store {
     sina_hip::DevBuf ref_ab, ref_off, idx_off, idx_ids;
-    std::vector<uint64_t> ref_off_host;  // host copy of the offsets (sizing of DAG-build scratch)
+    // host copy of the offsets (sizing of DAG-build scratch).  Written once per store content, under
+    // aux_mu, BEFORE ref_off_host_ready is set (release); every reader goes through
+    // sina_hip::ensure_ref_off_host() and sees either "not ready" or the completed vector.  Forked
+    // contexts share the store and call in concurrently (per-context mutexes do not cover it).
+    std::vector<uint64_t> ref_off_host;
+    std::atomic<bool> ref_off_host_ready{false};
     uint32_t n_refs = 0, width = 0, k = 0, nofast = 0;
     uint64_t n_postings = 0, total_bases = 0;
     bool have_refs = false, have_index = false;
@@ -17,7 +23,7 @@ struct sina_hip_store {
     // the CSR index by the first search after the index changed
     sina_hip::DevBuf dense_id, dense_bits;  // u32 [4^k]: bitmap number or ~0; u32 [n_dense][dense_words]
     uint32_t n_dense = 0, dense_words = 0;
-    bool dense_ready = false;
+    std::atomic<bool> dense_ready{false};
     std::mutex aux_mu;
     std::mutex stats_mu;
     // One DP kernel at a time per device: a DP launch fills every CU by itself, and contexts that
@@ -99,6 +105,22 @@ struct sina_hip_ctx {
         st = nullptr;
     }
 };
+
+namespace sina_hip {
+// The host copy of the reference offsets, complete.  upload_refs fills it; a store that arrived by
+// broadcast (sina_hip_store_alloc_like) re-reads it from the device on first use -- exactly once,
+// under the store's mutex, whichever forked context gets here first.
+inline int ensure_ref_off_host(sina_hip_ctx *c) {
+    sina_hip_store *st = c->st;
+    if (st->ref_off_host_ready.load(std::memory_order_acquire)) return 0;
+    std::lock_guard<std::mutex> lk(st->aux_mu);
+    if (st->ref_off_host_ready.load(std::memory_order_relaxed)) return 0;
+    st->ref_off_host.assign((size_t)st->n_refs + 1, 0);
+    SH_CHECK(hipMemcpy(st->ref_off_host.data(), st->ref_off.p, 8 * ((size_t)st->n_refs + 1), hipMemcpyDeviceToHost));
+    st->ref_off_host_ready.store(true, std::memory_order_release);
+    return 0;
+}
+}  // namespace sina_hip
 
 // publishes the context's scratch capacities when an API call ends (see sina_hip_store::cap_hint)
 struct sina_hip_hint_guard {

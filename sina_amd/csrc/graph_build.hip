@@ -477,10 +477,7 @@ struct BuiltGraphs {
 int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t *fam_off, uint32_t q0,
                         uint32_t bq, float fs_weight, int W, BuiltGraphs *bg) {
     hipStream_t s = c->stream;
-    if (c->st->ref_off_host.size() != (size_t)c->st->n_refs + 1) {  // store arrived by broadcast (store_alloc_like)
-        c->st->ref_off_host.resize((size_t)c->st->n_refs + 1);
-        SH_CHECK(hipMemcpy(c->st->ref_off_host.data(), c->st->ref_off.p, 8 * ((size_t)c->st->n_refs + 1), hipMemcpyDeviceToHost));
-    }
+    if (ensure_ref_off_host(c)) return 1;  // (a store that arrived by broadcast reads it back once)
     // weight table: the reference's expression (mseq.cpp:113) evaluated on the host
     if (!(c->wtab_fs_weight == fs_weight) || !c->g_wtab.p) {
         std::vector<float> wt((size_t)(kMaxFam + 1) * (kMaxFam + 1), 0.f);

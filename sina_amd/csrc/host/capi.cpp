@@ -368,6 +368,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                 result &r = p->results[q];
                 r.log = t.log.str();
                 r.family = t.input_sequence->get_attr<std::string>(fn::family);
+                if (t.input_sequence->has_attr(fn::turn)) r.attrs[fn::turn] = t.input_sequence->get_attr<std::string>(fn::turn);
                 if (t.aligned_sequence) {
                     const cseq &c = *t.aligned_sequence;
                     r.qual = c.get_attr<int>(fn::qual);

@@ -663,7 +663,8 @@ public:
     }
     ~impl() { delete index; }
     int turn_check(const cseq &query, bool all);
-    void do_turn_check(cseq &c);
+    std::vector<int> best_orientations(const std::vector<const cseq *> &queries, bool all);
+    void orient_batch(std::vector<tray *> &batch);
     void select_astats(tray &t);
     void run(std::vector<tray *> &batch);
 };
@@ -675,45 +676,66 @@ famfinder::~famfinder() = default;
 
 int famfinder::turn_check(const cseq &query, bool all) { return pimpl->turn_check(query, all); }
 
-// src/famfinder.cpp:344-378
-int famfinder::impl::turn_check(const cseq &query, bool all) {
-    search::result_vector matches;
-    double score[4];
-    index->find(query, matches, 1);
-    score[0] = matches.empty() ? 0 : matches[0].score;
-    cseq turn(query);
-    turn.reverse();
-    if (all) {
-        index->find(turn, matches, 1);
-        score[1] = matches.empty() ? 0 : matches[0].score;
-        cseq comp(query);
-        comp.complement();
-        index->find(comp, matches, 1);
-        score[2] = matches.empty() ? 0 : matches[0].score;
-    } else {
-        score[1] = score[2] = 0;
+// --turn (behaviour of src/famfinder.cpp:312-378): a query may arrive reversed and / or
+// complemented.  Orientation o = (bit 0: reversed) | (bit 1: complemented); each candidate
+// orientation gets one top-1 k-mer search and the strictly best-scoring one wins, the lowest o on
+// ties and o = 0 when nothing scores above zero.  "revcomp" only tries o = 0 and o = 3, "all" tries
+// the four.  All orientation variants of a whole batch go to the GPU as ONE top-1 search.
+namespace {
+cseq oriented(const cseq &q, int o) {
+    cseq v(q);
+    if (o & 1) v.reverse();
+    if (o & 2) v.complement();
+    return v;
+}
+const char *const orientation_names[4] = {"none", "reversed", "complemented", "reversed and complemented"};
+}  // namespace
+
+std::vector<int> famfinder::impl::best_orientations(const std::vector<const cseq *> &queries, bool all) {
+    const int tried[4] = {0, 3, 1, 2};
+    const int n_tried = all ? 4 : 2;
+    std::vector<cseq> variants;
+    variants.reserve(queries.size() * (size_t)n_tried);
+    for (const cseq *q : queries)
+        for (int x = 0; x < n_tried; x++) variants.push_back(oriented(*q, tried[x]));
+    std::vector<const cseq *> vp;
+    for (const cseq &v : variants) vp.push_back(&v);
+    std::vector<search::result_vector> top1;
+    index->find_batch(vp, top1, 1);
+    std::vector<int> best(queries.size(), 0);
+    for (size_t i = 0; i < queries.size(); i++) {
+        float by_orientation[4] = {0, 0, 0, 0};
+        for (int x = 0; x < n_tried; x++) {
+            const search::result_vector &r = top1[i * (size_t)n_tried + x];
+            if (!r.empty()) by_orientation[tried[x]] = r[0].score;
+        }
+        float top = 0;
+        for (int o = 0; o < 4; o++)
+            if (by_orientation[o] > top) {
+                top = by_orientation[o];
+                best[i] = o;
+            }
     }
-    turn.complement();
-    index->find(turn, matches, 1);
-    score[3] = matches.empty() ? 0 : matches[0].score;
-    double max = 0;
-    int best = 0;
-    for (int i = 0; i < 4; i++)
-        if (max < score[i]) max = score[i], best = i;
     return best;
 }
 
-// src/famfinder.cpp:312-341
-void famfinder::impl::do_turn_check(cseq &c) {
-    if (ff_opts.turn_which != TURN_NONE) {
-        switch (turn_check(c, ff_opts.turn_which == TURN_ALL)) {
-        case 0: c.set_attr(fn::turn, "none"); break;
-        case 1: c.set_attr(fn::turn, "reversed"); c.reverse(); break;
-        case 2: c.set_attr(fn::turn, "complemented"); c.complement(); break;
-        case 3: c.set_attr(fn::turn, "reversed and complemented"); c.reverse(); c.complement(); break;
-        }
-    } else {
-        c.set_attr(fn::turn, "turn-check disabled");
+int famfinder::impl::turn_check(const cseq &query, bool all) {
+    return best_orientations(std::vector<const cseq *>{&query}, all)[0];
+}
+
+// turns the input sequences of a batch in place and records what was done (fn::turn)
+void famfinder::impl::orient_batch(std::vector<tray *> &batch) {
+    if (ff_opts.turn_which == TURN_NONE) {
+        for (tray *t : batch) t->input_sequence->set_attr(fn::turn, "turn-check disabled");
+        return;
+    }
+    std::vector<const cseq *> qs;
+    for (tray *t : batch) qs.push_back(t->input_sequence);
+    const std::vector<int> o = best_orientations(qs, ff_opts.turn_which == TURN_ALL);
+    for (size_t i = 0; i < batch.size(); i++) {
+        cseq &c = *batch[i]->input_sequence;
+        c.set_attr(fn::turn, orientation_names[o[i]]);
+        if (o[i]) c = oriented(c, o[i]);
     }
 }
 
@@ -773,9 +795,9 @@ bool match_pass(search::result_vector &results, const cseq &query, match_state &
 void famfinder::impl::run(std::vector<tray *> &batch) {
     const ff_options &o = ff_opts;
     std::vector<tray *> todo;
+    orient_batch(batch);
     for (tray *t : batch) {
         t->alignment_reference = new search::result_vector();
-        do_turn_check(*t->input_sequence);
         todo.push_back(t);
     }
     size_t max_results = (size_t)o.fs_max + 1;

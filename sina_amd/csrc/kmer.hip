@@ -856,7 +856,11 @@ int sina_hip_store_alloc_like(sina_hip_ctx *c, sina_hip_store_view *v) {
     c->st->n_postings = v->n_postings;
     c->st->have_refs = c->st->have_index = true;
     c->st->dense_ready = false;  // (the index arrives by broadcast after this call: built by the first search)
-    c->st->ref_off_host.clear();  // re-read from the device after the broadcast filled it
+    {   // re-read from the device, once, after the broadcast filled it (ensure_ref_off_host)
+        std::lock_guard<std::mutex> alk(c->st->aux_mu);
+        c->st->ref_off_host_ready.store(false, std::memory_order_release);
+        c->st->ref_off_host.clear();
+    }
     v->ref_ab = c->st->ref_ab.p;
     v->ref_ab_bytes = 4 * v->total_bases;
     v->ref_off = c->st->ref_off.p;

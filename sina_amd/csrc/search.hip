@@ -240,7 +240,7 @@ extern "C" int sina_hip_compare(sina_hip_ctx *c, const uint32_t *q_ab, const uin
     float ms = 0;
     SH_CHECK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
     uint64_t bases = 0;
-    if (c->st->ref_off_host.size() == (size_t)c->st->n_refs + 1)
+    if (ensure_ref_off_host(c) == 0)
         for (uint64_t i = 0; i < ncand; i++) {
             const uint32_t id = cand_ids[cand_off[0] + i];
             bases += c->st->ref_off_host[id + 1] - c->st->ref_off_host[id];

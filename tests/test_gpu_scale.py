@@ -1,0 +1,344 @@
+"""GPU parity at the sizes the benchmark configurations run at: the k-mer search above one
+reference tile (32 768 references) with the dense-bitmap lists active, the V4 and 23S query
+shapes against >= 32 768 references, the rank != 0 start-up path (a store that arrives by
+broadcast), --turn, and a 500 000-reference property test (BASELINE.json configs[3])."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from sina_amd import capi, pipeline, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wide(oracle):
+    """70 000 short references in six clades: three reference tiles, 200+ posting lists longer than
+    1/32 of the references (the dense-bitmap path), an oracle index that builds in seconds."""
+    refs = synth.make_refs(70000, length=200, width=2000, seed=5, n_clades=6)
+    cs = util.cseqs_from_refs(refs)
+    qs = synth.make_queries(refs, 12, seed=6, amb_rate=0.01)
+    return refs, cs, qs
+
+
+def _scores_and_topk_equal(ctx, idx, qs, maxes=(1, 41, 410, 4096)):
+    for qi in range(qs.n):
+        q = util.query_cseq(qs, qi)
+        assert (ctx.kmer_scores(qs.seq(qi)) == idx.scores(q)).all(), qi
+    for mx in maxes:
+        gi, gs, gn = ctx.kmer_topk(qs.mask, qs.off, mx)
+        for qi in range(qs.n):
+            oi, os_ = idx.find(util.query_cseq(qs, qi), mx)
+            assert gn[qi] == len(oi)
+            assert (gi[qi, :gn[qi]] == oi).all(), (mx, qi)
+            assert (gs[qi, :gn[qi]] == os_).all(), (mx, qi)
+
+
+@pytest.mark.parametrize("dense_div,expect_dense", [(None, "some"), ("1", "none"), ("1000000", "many")])
+def test_kmer_multi_tile_dense_equals_oracle(oracle, wide, dense_div, expect_dense):
+    """kmer_count_kernel + kmer_select_kernel on the code path every BASELINE config runs: several
+    reference tiles and posting lists counted from bitmaps (kmer_search.cpp:366-420, idset.h:315-337).
+    SINA_HIP_DENSE_DIV moves the list-length threshold (n_refs / div, at least 256): 1 switches the
+    bitmaps off, a huge value makes every list above 256 references a bitmap -- the results must not
+    depend on it."""
+    refs, cs, qs = wide
+    idx = oracle.Index(cs, k=10)
+    off, ids = idx.csr()
+    old = os.environ.get("SINA_HIP_DENSE_DIV")
+    if dense_div is None:
+        os.environ.pop("SINA_HIP_DENSE_DIV", None)
+    else:
+        os.environ["SINA_HIP_DENSE_DIV"] = dense_div
+    ctx = capi.Context(0)
+    try:
+        ctx.upload_refs(refs.ab, refs.off, refs.width)
+        ctx.upload_index(10, False, off, ids)          # (bitmaps are rebuilt by the first search after this)
+        _scores_and_topk_equal(ctx, idx, qs)
+        nd = ctx.stats()["n_dense_lists"]
+        ln = np.diff(off.astype(np.int64))
+        if expect_dense == "none":
+            assert nd == 0
+        elif expect_dense == "some":
+            assert nd == int((ln > max(256, refs.n // 32)).sum()) and nd > 100
+        else:
+            assert nd == int((ln > 256).sum()) and nd > 1000
+    finally:
+        ctx.close()
+        if old is None:
+            os.environ.pop("SINA_HIP_DENSE_DIV", None)
+        else:
+            os.environ["SINA_HIP_DENSE_DIV"] = old
+
+
+@pytest.mark.parametrize("nofast", [False, True])
+def test_device_index_multi_tile_equals_oracle_csr(oracle, wide, nofast):
+    """sina_hip_build_index at 70 000 references: the CSR index itself (offsets and ids, downloaded)
+    equals the oracle's IndexBuilder (kmer_search.cpp:152-211,245-276), and searching it gives the
+    oracle's scores -- with all k-mers (no-fast) the lists are four times as many."""
+    refs, cs, qs = wide
+    idx = oracle.Index(cs, k=10, nofast=nofast)
+    off, ids = idx.csr()
+    ctx = capi.Context(0)
+    try:
+        ctx.upload_refs(refs.ab, refs.off, refs.width)
+        ctx.build_index(10, nofast)
+        goff, gids = ctx.download_index()
+        assert (goff == off).all()
+        assert len(gids) == len(ids) and (gids == ids).all()
+        _scores_and_topk_equal(ctx, idx, qs, maxes=(41,))
+    finally:
+        ctx.close()
+
+
+def _hip_runtime():
+    L = C.CDLL("libamdhip64.so")
+    L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.hipMemcpy.restype = C.c_int
+    return L
+
+
+def test_store_alloc_like_second_context(oracle, wide):
+    """What every rank but 0 does at start-up (sina_amd/dist.py): sina_hip_store_alloc_like, the four
+    buffers filled in place (a device-to-device copy stands in for the RCCL broadcast), then searches
+    and alignments on forks of that context from several threads at once -- the bitmaps and the host
+    copy of the reference offsets are rebuilt lazily by whichever fork gets there first.  Results
+    must equal the builder context's."""
+    import threading
+    refs, cs, qs = wide
+    hip = _hip_runtime()
+    a = capi.Context(0)
+    b = capi.Context(0)
+    try:
+        a.upload_refs(refs.ab, refs.off, refs.width)
+        a.build_index(10, False)
+        va = a.store_view()
+        vb = capi.StoreView()
+        C.memmove(C.byref(vb), C.byref(va), C.sizeof(va))
+        b.store_alloc_like(vb)
+        for name in ("ref_ab", "ref_off", "idx_offsets", "idx_ids"):
+            assert getattr(vb, name) != getattr(va, name)
+            n = getattr(va, name + "_bytes")
+            assert getattr(vb, name + "_bytes") == n
+            assert hip.hipMemcpy(getattr(vb, name), getattr(va, name), n, 3) == 0   # hipMemcpyDeviceToDevice
+        want_topk = a.kmer_topk(qs.mask, qs.off, 41)
+        fams = [want_topk[0][qi, :want_topk[2][qi]] for qi in range(qs.n)]
+        foff = np.zeros(qs.n + 1, np.uint64)
+        foff[1:] = np.cumsum([len(f) for f in fams])
+        qm = qs.mask & 0x0f
+        want_al = a.align_families(np.concatenate(fams), foff, qm, qs.off)
+        forks = [b.fork() for _ in range(4)]
+        got, errs = [None] * 4, []
+
+        def work(i):
+            try:
+                # even forks align first (host copy of the offsets), odd ones search first (bitmaps)
+                if i % 2 == 0:
+                    al = forks[i].align_families(np.concatenate(fams), foff, qm, qs.off)
+                    tk = forks[i].kmer_topk(qs.mask, qs.off, 41)
+                else:
+                    tk = forks[i].kmer_topk(qs.mask, qs.off, 41)
+                    al = forks[i].align_families(np.concatenate(fams), foff, qm, qs.off)
+                got[i] = (tk, al)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for tk, al in got:
+            assert all((x == y).all() for x, y in zip(tk, want_topk))
+            assert (al[0] == want_al[0]).all() and (al[1] == want_al[1]).all()
+        assert b.stats()["n_dense_lists"] == a.stats()["n_dense_lists"] > 0
+        for f in forks:
+            f.close()
+    finally:
+        b.close()
+        a.close()
+
+
+# ---------------------------------------------------------------- query shapes of configs[2] / configs[4]
+
+def _oracle_run(oracle, cs, idx, qs, qi):
+    q = util.query_cseq(qs, qi, upper=False)
+    ids, sc, fflog = idx.famfinder(q, oracle.ff_opts())
+    if len(ids) == 0:
+        return dict(status=2, log=fflog, ids=ids, sc=sc)
+    r = oracle.align([cs[i] for i in ids], q, oracle.align_opts())
+    r["log"] = fflog + r["log"]
+    r["ids"], r["sc"] = ids, sc
+    return r
+
+
+def _pipeline_equals_oracle(oracle, refs, qs, key, min_dp):
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    st = pipeline.Store(key, refs)
+    try:
+        st.build_index(10, False)
+        pl = pipeline.Pipeline(st)
+        pl.run(qs.mask, qs.off, batch=max(1, qs.n // 2), inflight=2)
+        n_dp = 0
+        for qi in range(qs.n):
+            want = _oracle_run(oracle, cs, idx, qs, qi)
+            got = pl.result(qi)
+            assert got["status"] == want["status"], (qi, got["log"], want["log"])
+            if want["status"] == 2:
+                continue
+            fam = "".join("ref%d.0:%.2f " % (i, s) for i, s in zip(want["ids"], want["sc"]))
+            assert got["family"] == fam, qi
+            assert (got["packed"] == want["packed"]).all(), qi
+            assert (got["head"], got["tail"], got["qual"]) == (want["head"], want["tail"], want["qual"])
+            if want["status"] == 0:
+                assert got["log"] == want["log"]
+                n_dp += 1
+        assert n_dp >= min_dp
+        assert st.stats()["n_dense_lists"] > 0
+        pl.close()
+    finally:
+        st.close()
+
+
+def test_v4_amplicons_vs_40k_references(oracle):
+    """configs[2] shape: 250-base windows of full-length 16S against 40 000 full-length references
+    (two reference tiles, bitmaps active): family, alignment, head / tail / quality and log text equal
+    the oracle's."""
+    refs = synth.make_refs(40000, length=1500, width=50000, seed=31)
+    qs = synth.make_queries(refs, 8, seed=32, window=(1.0 / 3.0, 250))
+    _pipeline_equals_oracle(oracle, refs, qs, ":mem:v4-40k", min_dp=7)
+
+
+def test_23s_vs_33k_references(oracle):
+    """configs[4] shape: ~3000-base queries, alignment width 150 000, 33 000 references (two tiles):
+    the 256x12 DP geometry and the wide DAG build against the oracle."""
+    refs = synth.make_refs(33000, length=3000, width=150000, seed=41)
+    qs = synth.make_queries(refs, 2, seed=42)
+    _pipeline_equals_oracle(oracle, refs, qs, ":mem:23s-33k", min_dp=2)
+
+
+def test_turn_orientations_equal_oracle(oracle):
+    """--turn none / revcomp / all (famfinder.cpp:312-378; the shape of the reference's own
+    famfinder_test.cpp:89-116): queries handed in reversed, complemented, or both are recognised by
+    the four top-1 k-mer searches, turned back, and then align exactly like the oracle aligns the
+    sequence the oracle's turn_check picks."""
+    refs = synth.make_refs(500, length=320, width=3200, seed=51)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    base = synth.make_queries(refs, 12, seed=57)
+    comp = np.zeros(32, np.uint8)
+    for m in range(32):   # A<->T/U, G<->C, case bit kept (aligned_base.h:117-124)
+        comp[m] = ((m & 2) << 1) | ((m & 4) >> 1) | ((m & 1) << 3) | ((m & 8) >> 3) | (m & 16)
+    masks, handed = [], []
+    for qi in range(base.n):
+        m = base.seq(qi).copy()
+        o = qi % 4
+        if o & 1:
+            m = m[::-1].copy()
+        if o & 2:
+            m = comp[m]
+        masks.append(m)
+        handed.append(o)
+    qoff = np.zeros(base.n + 1, np.int64)
+    qoff[1:] = np.cumsum([len(m) for m in masks])
+    qs = synth.QuerySet(mask=np.concatenate(masks), off=qoff, src=base.src)
+    st = pipeline.Store(":mem:turn", refs)
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    try:
+        for mode, all_o in (("none", None), ("revcomp", False), ("all", True)):
+            pl = pipeline.Pipeline(st, famfinder=dict(ff, turn=mode))
+            pl.run(qs.mask, qs.off, batch=5, inflight=2)
+            n_turned = 0
+            for qi in range(qs.n):
+                q = util.query_cseq(qs, qi, upper=False)
+                got = pl.result(qi)
+                if all_o is None:
+                    assert pl.attr(qi, "turn") == "turn-check disabled"
+                    o = 0
+                else:
+                    o, sc4 = idx.turn_check(q, all_o)
+                    assert pl.attr(qi, "turn") == oracle.Index.TURN_NAMES[o], (mode, qi, sc4)
+                    if all_o:
+                        assert o == handed[qi]      # a turned 16S-like query is always recognised
+                    n_turned += o != 0
+                if o & 1:
+                    oracle.lib().so_cseq_reverse(q.h)
+                if o & 2:
+                    oracle.lib().so_cseq_complement(q.h)
+                ids, sc, fflog = idx.famfinder(q, oracle.ff_opts(fs_min_len=100, fs_full_len=250))
+                if len(ids) == 0:
+                    assert got["status"] == 2 and got["log"] == fflog
+                    continue
+                want = oracle.align([cs[i] for i in ids], q, oracle.align_opts())
+                assert got["status"] == want["status"], (mode, qi)
+                assert (got["packed"] == want["packed"]).all(), (mode, qi)
+                assert (got["head"], got["tail"], got["qual"]) == (want["head"], want["tail"], want["qual"])
+            if all_o is not None:
+                assert n_turned >= (9 if all_o else 3)
+            pl.close()
+    finally:
+        st.close()
+
+
+def test_500k_references_properties():
+    """BASELINE.json configs[3] scale for the reference side: 500 000 (short) references = 16
+    reference tiles.  No oracle at this size; size-independent properties instead: the device index
+    holds every reference's k-mers (a query that IS a reference scores its own k-mer count, and
+    nothing scores higher), results do not depend on how the queries are cut into launches, and two
+    runs are identical; through the whole pipeline such queries come back with the alignment of the
+    reference they copy."""
+    refs = synth.make_refs(500000, length=200, width=2000, seed=61, n_clades=40)
+    qs = synth.make_queries(refs, 48, seed=62, sub=0.0, dele=0.0, ins=0.0)
+    ctx = capi.Context(0)
+    try:
+        ctx.upload_refs(refs.ab, refs.off, refs.width)
+        ctx.build_index(10, False)
+        assert ctx.store_view().n_postings > 10 * refs.n
+        full = ctx.kmer_topk(qs.mask, qs.off, 41)
+        again = ctx.kmer_topk(qs.mask, qs.off, 41)
+        assert all((x == y).all() for x, y in zip(full, again))
+        half = 24
+        lo = ctx.kmer_topk(qs.mask[:qs.off[half]], qs.off[:half + 1], 41)
+        hi = ctx.kmer_topk(qs.mask[qs.off[half]:], qs.off[half:] - qs.off[half], 41)
+        for part, sl in ((lo, slice(0, half)), (hi, slice(half, qs.n))):
+            assert all((x == y[sl]).all() for x, y in zip(part, full))
+        assert ctx.stats()["n_dense_lists"] > 0
+        for qi in range(qs.n):
+            m = qs.seq(qi) & 0x0f
+            # k-mers with multiplicity: windows of 10 unambiguous bases ending before the last base
+            # whose first base is A (kmer.h:69-83,122-124,188-201)
+            nk = sum(1 for e in range(9, len(m) - 1) if m[e - 9] == 1)
+            row = ctx.kmer_scores(qs.seq(qi))
+            assert row.max() == nk == full[1][qi, 0]
+            assert row[qs.src[qi]] == nk
+            assert (np.sort(row)[::-1][:41] == full[1][qi]).all()
+            ties = np.flatnonzero(row == nk)
+            assert full[0][qi, 0] == ties.max()                  # (score desc, id desc)
+    finally:
+        ctx.close()
+    st = pipeline.Store(":mem:500k", refs)
+    try:
+        st.build_index(10, False)
+        pl = pipeline.Pipeline(st, famfinder={"fs-min-len": 100, "fs-full-len": 180})
+        pl.run(qs.mask, qs.off, batch=16, inflight=2)
+        res = [pl.result(qi) for qi in range(qs.n)]
+        pl.run(qs.mask, qs.off, batch=48, inflight=1)
+        n_copy = 0
+        for qi in range(qs.n):
+            again = pl.result(qi)
+            assert again["status"] == res[qi]["status"] and (again["packed"] == res[qi]["packed"]).all()
+            assert again["family"] == res[qi]["family"]
+            assert res[qi]["status"] in (0, 1)
+            got_bases = (res[qi]["packed"] >> 24) & 0x0f
+            assert (got_bases == (qs.seq(qi) & 0x0f)).all()       # every base placed, in order
+            if res[qi]["status"] == 1:                            # copied from a reference that contains it
+                n_copy += 1
+                assert res[qi]["qual"] == 100
+        assert n_copy >= 40
+        pl.close()
+    finally:
+        st.close()

@@ -300,3 +300,32 @@ def test_oracle_matches_live_reference_parts(oracle):
             buf = np.zeros(len(ab) + 1, np.uint32)
             n = R.ref_kmers(ab.ctypes.data_as(oracle.u32p), len(ab), k, pl, pv, u, buf.ctypes.data_as(oracle.u32p))
             assert oracle.kmers(ab, k, pl, pv, bool(u)).tolist() == buf[:n].tolist()
+
+
+def test_turn_check_orientations(oracle):
+    """so_turn_check (famfinder.cpp:344-378): a query handed in reversed / complemented / both is told
+    apart by its top-1 k-mer scores; without --turn=all only "as is" and "reversed and complemented"
+    are searched (the other two score 0); ties and all-zero fall back to the lowest orientation."""
+    import numpy as np
+    from sina_amd import synth
+    from tests import util
+    refs = synth.make_refs(200, length=300, width=3000, seed=91)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    qs = synth.make_queries(refs, 6, seed=92)
+    L = oracle.lib()
+    for qi in range(qs.n):
+        for o in range(4):
+            q = util.query_cseq(qs, qi)
+            if o & 1:
+                L.so_cseq_reverse(q.h)
+            if o & 2:
+                L.so_cseq_complement(q.h)
+            best, sc = idx.turn_check(q, True)
+            assert best == o and sc[o] == sc.max() and sc[o] > 4 * np.delete(sc, o).max()
+            best2, sc2 = idx.turn_check(q, False)
+            assert sc2[1] == 0 and sc2[2] == 0
+            assert best2 == (o if o in (0, 3) else (3 if sc2[3] > sc2[0] else 0))
+    # a query without any k-mer: every score 0 -> orientation 0
+    q = oracle.Cseq.from_packed("tiny", np.arange(5, dtype=np.uint32) | (np.uint32(1) << 24), 5)
+    assert idx.turn_check(q, True)[0] == 0

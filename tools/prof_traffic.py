@@ -47,4 +47,15 @@ for k in agg:
                              "kmer_select_kernel", "ref_kmer_keys", "mark_unique", "scatter_unique") if n in k), k[:48])
     js[name] = {"fetch_bytes_raw": f, "fetch_bytes_x2": 2 * f, "write_bytes": w, "hbm_bytes": 2 * f + w,
                 "launches": len(cnt[(k, "WRITE_SIZE")])}
+# what the profile was taken on: bench.py reports these bytes only for the same kernel source + configuration
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    line = [x for x in open(os.path.join(d, "bench_fetch.log")) if x.startswith("{")][-1]
+    cfg = json.loads(line)["config"]
+    js["_meta"] = {"kernel_source_rev": bench.kernel_source_rev(), "batch": cfg["queries_per_step_per_gpu"],
+                   "sub_batch": cfg["queries_per_launch"], "refs": cfg["refs"], "length": cfg["length"],
+                   "window": cfg["window"]}
+except Exception as e:  # noqa: BLE001
+    print("no _meta:", e)
 json.dump(js, open(os.path.join(d, "traffic.json"), "w"), indent=1)
