@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--window", type=int, default=0, help="cut queries to this many bases (V4: 250)")
     ap.add_argument("--inflight", type=int, default=3, help="batches worked on concurrently per rank")
     ap.add_argument("--sub-batch", type=int, default=2048, help="queries per GPU launch inside a step")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="CPU baseline: queries per thread and thread count (0 = 6)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="CPU baseline: queries per thread and thread count (0 = 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=8,
                     help="queries of the timed run re-done by the oracle afterwards and compared (0 = none; "
@@ -119,7 +119,7 @@ def cpu_baseline(world, refs, qs, per_thread):
     po = world.po
     hw = os.cpu_count() or 1
     cores = physical_cores()
-    counts = sorted({t for t in (16, 32, 64, 128, cores, hw) if 1 < t <= hw})
+    counts = sorted({t for t in (16, 32, 64, 128, cores) if 1 < t <= hw})
     n_max = per_thread * max(counts + [1])
     queries = [world.query(qs, i) for i in range(min(qs.n, max(n_max, 8)))]
     t_all = time.time()
@@ -363,7 +363,7 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             ow = OracleWorld(refs)
-            out["cpu_baseline"] = cpu_baseline(ow, refs, qs, a.cpu_sample or 6)
+            out["cpu_baseline"] = cpu_baseline(ow, refs, qs, a.cpu_sample or 4)
             if picked:
                 n_chk, n_same, diffs = verify_against_oracle(ow, qs, picked)
                 out["verify"] = {"checked": n_chk, "identical": n_same, "differences": diffs,
