@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsina_hip.so")
+# (SINA_HIP_LIB: the profiling build of the same library, tools only)
+LIB_PATH = os.path.abspath(os.environ["SINA_HIP_LIB"]) if os.environ.get("SINA_HIP_LIB") else os.path.join(_HERE, "libsina_hip.so")
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)

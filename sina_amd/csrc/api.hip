@@ -19,9 +19,9 @@ static size_t env_size(const char *name, size_t dflt) {
 }
 
 int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl) {
-    if (!pick_geom(maxL, &pl->geom)) SH_FAIL("align: query longer than the largest DP geometry (6144)");
+    if (!pick_geom(maxL, &pl->geom)) SH_FAIL("align: query longer than the largest DP geometry (8192)");
     const size_t slot = dp_slot_bytes(pl->geom), fixed = dp_fixed_lds_bytes(pl->geom);
-    size_t budget = c->lds_budget;
+    size_t budget = c->lds_budget ? c->lds_budget : dp_default_lds_budget(pl->geom);
     if (budget < fixed + slot) budget = fixed + slot;
     if (budget > 160 * 1024) budget = 160 * 1024;
     int W = (int)((budget - fixed) / slot);
@@ -124,8 +124,8 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
 
 // Runs DP + backtrack for bq queries whose graphs (qd, rec, pred, node_pos, succ_minpos) and
 // query masks are already in the context's device buffers; copies results back.
-int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint32_t bq, uint64_t tb_cells, uint64_t spill_rows,
-                  uint64_t cells, uint64_t nqm, const sina_hip_align_params *p, uint32_t width,
+int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint32_t bq, uint64_t n_node_entries,
+                  uint64_t tb_cells, uint64_t spill_rows, uint64_t cells, uint64_t nqm, const sina_hip_align_params *p, uint32_t width,
                   sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value) {
     hipStream_t s = c->stream;
     const int Lp = pl.geom.Lp();
@@ -141,6 +141,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         }
     }
     if (c->tb.reserve(4 * tb_cells) || c->spill.reserve(std::max<uint64_t>(spill_rows, 1) * 8 * (uint64_t)Lp) ||
+        c->edge.reserve(std::max<uint64_t>(1, (uint64_t)(pl.geom.T / 64 - 1) * n_node_entries) * sizeof(EdgeRec)) ||
         c->res.reserve(sizeof(DpResult) * bq) || c->out.reserve(sizeof(sina_hip_align_out) * bq) ||
         c->out_pos.reserve(4 * std::max<uint64_t>(nqm, 1)))
         return 1;
@@ -168,6 +169,8 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     a.tb = c->tb.as<uint32_t>();
     a.dbg_value = want_dbg_value ? c->dbg.as<float>() : nullptr;
     a.spill = c->spill.as<float>();
+    a.edge = c->edge.as<EdgeRec>();
+    a.edge_stride = n_node_entries;
     a.res = c->res.as<DpResult>();
     a.weights = weighted ? c->weights.as<float>() : nullptr;
     a.n_weights = weighted ? p->n_weights : 0;
@@ -299,7 +302,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         if (g->succ_minpos)
             SH_CHECK(hipMemcpyAsync(c->succ_minpos.p, g->succ_minpos + nbase, 4 * nn, hipMemcpyHostToDevice, s));
         SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qbase, nqm, hipMemcpyHostToDevice, s));
-        if (run_dp_device(c, pl, hp.qd.data(), bq, hp.tb_cells, hp.spill_rows, hp.cells, nqm, p, g->width, out + q0,
+        if (run_dp_device(c, pl, hp.qd.data(), bq, nn, hp.tb_cells, hp.spill_rows, hp.cells, nqm, p, g->width, out + q0,
                           out_pos + qbase, dbg_value_host != nullptr))
             return 1;
         if (dbg_vm) {  // single-query debug: unpack the planes
@@ -371,7 +374,7 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
     c->owns_store = true;
     if (make_streams(c)) return 1;
     for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
-    c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 40) * 1024;
+    c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 0) * 1024;
     c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 48) << 30;
     memset(&c->st->stats, 0, sizeof(c->st->stats));
     *ctx = c;

@@ -120,7 +120,7 @@ struct QDesc {
 //   y = node weight (float bits, mseq.cpp:113)
 //   z = #pred | iupac mask << 8 | flags << 16 | (index of the first spilled predecessor + 1) << 24
 //       flags bit0: sink = no successors; bit1: some successor is further than kFarLds rows away
-//       (its spill row must be visible to the whole workgroup before the row is published)
+//       (such a row is kept in a spill row: it would hold an LDS slot for hundreds of rows)
 //   w = where the finished row {value, gapm_val} is kept for its successors:
 //       0xFFFFFFFF nowhere (no successors), kRowSpilled | spill row index, or the LDS slot number.
 // LDS slots are handed out by liveness (a slot is reused once the last successor of its row has
@@ -134,8 +134,18 @@ constexpr uint32_t kRowNone = 0xFFFFFFFFu;
 constexpr uint32_t kRowSpilled = 0x80000000u;
 constexpr uint32_t kPredSpilled = 0x80000000u;
 constexpr uint32_t kMaxSpillRows = 32768;  // 15 bits in a predecessor entry
-constexpr int kBndHist = 256;  // rows of left-boundary value history kept in LDS per wave (power of two)
-constexpr int kFarLds = 192;   // predecessors up to this distance find their left-boundary value there
+constexpr int kFarLds = 192;   // a row with a successor further away than this never takes an LDS slot
+
+// What a strip of the DP leaves behind per row for the strip to its right (mesh_dp.hip): the value of
+// its last column (the match candidate's source for the next strip's first column) and the exit
+// state of the insertion chain there.  One record per row and strip boundary, in global memory.
+struct EdgeRec {
+    float bnd;      // value[m][last column of the strip]
+    float xv;       // chain exit state: value ...
+    uint32_t xe;    // ... "gaps_val == value" << 31 | gaps_idx
+    uint32_t gmax;  // ... gaps_max (--insertion=forbid)
+};
+static_assert(sizeof(EdgeRec) == 16, "read back with one 16-byte scalar load");
 
 // Trace-back cell (one u32 per DP cell, the only per-cell HBM traffic):
 //   bits 31..16 value_midx, bits 12..0 value_sidx, and two bits that replace carrying gapm_idx
@@ -182,6 +192,8 @@ struct DpArgs {
     uint32_t *tb;               // trace-back cells (kTb* above)
     float *dbg_value;           // optional [N*Lp] plane of the first query
     float *spill;               // spill rows: value[Lp] | gapm_val[Lp]
+    EdgeRec *edge;              // [strips - 1][edge_stride] edge records, indexed like the node arrays
+    uint64_t edge_stride;       // records per strip boundary (= node array entries of the launch)
     DpResult *res;
     const float *weights;       // posvar weights (device) or nullptr
     uint32_t n_weights;
@@ -213,7 +225,8 @@ struct DpGeom {
 bool pick_geom(uint32_t maxL, DpGeom *g);
 size_t dp_slot_bytes(const DpGeom &g);
 size_t dp_fixed_lds_bytes(const DpGeom &g);
-int dp_max_ring(const DpGeom &g);  // deepest LDS ring the wave pipeline supports
+int dp_max_ring(const DpGeom &g);  // deepest LDS ring the slot allocators support
+size_t dp_default_lds_budget(const DpGeom &g);  // LDS per workgroup that keeps the register-limited occupancy
 int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
                    size_t lds_bytes, hipStream_t s);
 int launch_backtrack(const BtArgs &a, hipStream_t s);
@@ -232,8 +245,8 @@ struct sina_hip_ctx;
 namespace sina_hip {
 int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl);
 int upload_weights(sina_hip_ctx *c, const sina_hip_align_params *p);
-int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint32_t bq, uint64_t tb_cells, uint64_t spill_rows,
-                  uint64_t cells, uint64_t nqm, const sina_hip_align_params *p, uint32_t width,
+int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint32_t bq, uint64_t n_node_entries,
+                  uint64_t tb_cells, uint64_t spill_rows, uint64_t cells, uint64_t nqm, const sina_hip_align_params *p, uint32_t width,
                   sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value);
 
 }  // namespace sina_hip

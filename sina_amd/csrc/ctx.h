@@ -47,24 +47,24 @@ struct sina_hip_ctx {
     bool owns_store = false;
 
     // per-batch scratch, grown on demand and reused
-    sina_hip::DevBuf qd, order, rec, node_pos, pred, succ_minpos, qmask, tb, spill, res, weights, out, out_pos, dbg;
+    sina_hip::DevBuf qd, order, rec, node_pos, pred, succ_minpos, qmask, tb, spill, edge, res, weights, out, out_pos, dbg;
     sina_hip::DevBuf k_qoff, k_scores, k_out_ids, k_out_scores, k_out_n, k_tmp0, k_tmp1, k_tmp2;
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes, g_wtab;
     sina_hip::DevBuf s_qab, s_qoff, s_cand, s_coff, s_out;  // search-stage comparison
     sina_hip::HostBuf h_out, h_out_pos;  // pinned staging for the DP results
     float wtab_fs_weight = NAN;  // fs_weight the device weight table was computed for
 
-    size_t lds_budget = 40 * 1024;
+    size_t lds_budget = 0;  // LDS per DP workgroup; 0 = what keeps the register-limited occupancy (dp_default_lds_budget)
     uint64_t tb_budget_bytes = (uint64_t)48 << 30;
 
-    static constexpr int kNumScratch = 34;
+    static constexpr int kNumScratch = 35;
     static_assert(kNumScratch <= 64, "sina_hip_store::cap_hint is too short");
     void scratch(sina_hip::DevBuf **all) {
         sina_hip::DevBuf *list[kNumScratch] = {&qd, &rec, &node_pos, &pred, &succ_minpos, &qmask, &tb, &spill, &res,
                                                &weights, &out, &out_pos, &k_qoff, &k_scores, &k_out_ids,
                                                &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2, &g_fam_ids,
                                                &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab, &order,
-                                               &s_qab, &s_qoff, &s_cand, &s_coff, &s_out};
+                                               &s_qab, &s_qoff, &s_cand, &s_coff, &s_out, &edge};
         for (int i = 0; i < kNumScratch; i++) all[i] = list[i];
     }
     void publish_hints() {  // after a call: remember how big my buffers had to be

@@ -632,7 +632,8 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
             if (c->qd.reserve(sizeof(QDesc) * rq) || c->qmask.reserve(std::max<uint64_t>(nqm, 1))) return 1;
             SH_CHECK(hipMemcpyAsync(c->qd.p, qd.data(), sizeof(QDesc) * rq, hipMemcpyHostToDevice, s));
             SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qbase, nqm, hipMemcpyHostToDevice, s));
-            if (run_dp_device(c, pl, qd.data(), rq, tbc, sprows, cells, nqm, p, c->st->width, out + q0 + r0, out_pos + qbase, false))
+            if (run_dp_device(c, pl, qd.data(), rq, (uint64_t)bq * bg.ncap, tbc, sprows, cells, nqm, p, c->st->width,
+                              out + q0 + r0, out_pos + qbase, false))
                 return 1;
             r0 = r1;
         }

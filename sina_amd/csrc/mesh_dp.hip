@@ -9,13 +9,13 @@
 // SSE build.
 //
 // How it maps to the hardware (no MFMA: this is a compare/select recurrence):
-//   * one workgroup per query; lane l of wave w owns B consecutive query columns
-//     (wave w owns a contiguous block of 64*B columns);
-//   * every wave sweeps the DAG rows in topological (id) order ON ITS OWN: the row
-//     record {first pred, weight, #pred|mask|flags, spill slot} and the pred list
-//     are wave-uniform and come through the scalar cache (s_load), so there is no
-//     divergence on graph structure and no vector-memory latency on the row
-//     critical path;
+//   * one WAVE per query (a 64-thread workgroup); the query's columns are cut into strips
+//     of 64*B columns, lane l owns B consecutive columns of the current strip, and the wave
+//     sweeps all DAG rows for one strip before it starts the next (left to right);
+//   * the rows are swept in topological (id) order: the row record {first pred, weight,
+//     #pred|mask|flags, spill slot} and the pred list are wave-uniform and come through
+//     the scalar cache (s_load), so there is no divergence on graph structure and no
+//     vector-memory latency on the row critical path;
 //   * finished rows {value, gapm_val} of a wave's own columns are kept for their
 //     successors in W LDS slots (8 B per column) that only that wave touches; slots
 //     are handed out by liveness when the graph is built, and a row that finds every
@@ -33,11 +33,11 @@
 //     through all B cells of a lane or dies inside it, B adds + B compares per step
 //     -- until none changes (wave vote, no barrier), and one full pass over the B
 //     cells with the converged left states finishes the row (weighted / forbid
-//     schemes: full chain passes are iterated instead).  Between waves they travel through two small LDS
-//     histories (boundary value and exit state per row) guarded by a per-wave
-//     progress counter: wave w starts row m once wave w-1 has published it.  The
-//     waves of a workgroup thus form a software pipeline skewed by one row and
-//     the main loop contains no s_barrier at all;
+//     schemes: full chain passes are iterated instead).  Between strips they travel through a
+//     per-row edge record in global memory {value of the strip's last column, exit state}: lane 63
+//     writes it, and the next strip -- the same wave, a whole sweep later -- reads it back through
+//     the scalar cache together with the row record.  There is no other wave to wait for: the
+//     kernel has no barrier, no flag and no spin loop at all;
 //   * the only per-cell HBM traffic is the write-once trace-back cell (4 bytes), row-major.
 #include <cstdio>
 #include <cstdlib>
@@ -48,8 +48,6 @@
 namespace sina_hip {
 
 namespace {
-
-constexpr int kHist = 32;  // rows of boundary/exit-state history kept per wave (power of two)
 
 struct ChainState {  // canonical exit state of cell (m, s): what cell (m, s+1) can observe
     float v;         // final value
@@ -110,7 +108,27 @@ struct Cells {
 #pragma unroll
         for (int i = 0; i < B / 4; i++) v[i] = *reinterpret_cast<const V *>(src + 4 * i);
     }
+    // LDS row slot layout: the i-th group of four cells of all 64 lanes is contiguous ([B/4][64][4]
+    // floats), so that every 16-byte access of a wave covers 1 KiB without a gap -- lane-major rows
+    // of B floats put lanes l and l + 8 on the same banks for B = 8 (2-way conflict on every access)
+    __device__ __forceinline__ void load_slot(const float *__restrict__ arr, int lane) {
+#pragma unroll
+        for (int i = 0; i < B / 4; i++) v[i] = *reinterpret_cast<const V *>(arr + (i * 64 + lane) * 4);
+    }
 };
+template <int B>
+__device__ __forceinline__ void store_slot(float *__restrict__ arr, int lane, const float (&src)[B]) {
+    using V = __attribute__((ext_vector_type(4))) float;
+#pragma unroll
+    for (int i = 0; i < B / 4; i++) {
+        V v;
+        v.x = src[4 * i];
+        v.y = src[4 * i + 1];
+        v.z = src[4 * i + 2];
+        v.w = src[4 * i + 3];
+        *reinterpret_cast<V *>(arr + (i * 64 + lane) * 4) = v;
+    }
+}
 
 // B consecutive 4-byte cells to a 16-byte aligned address (B % 4 == 0) or 8-byte aligned one
 // (B % 2 == 0): wide stores, both for LDS and for global memory
@@ -157,80 +175,71 @@ __device__ int g_dp_abl;  // ablation mask (timing experiments only, results are
 #define SH_PROF_FLUSH
 #endif
 
-__device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// 16 bytes from a wave-uniform address through the scalar cache.  The compiler cannot use s_load
+// here by itself: the edge records are written by this same kernel (one strip earlier), so it would
+// fall back to a vector load whose completion (vmcnt, in order) also waits for the trace-back stores
+// of the row.  An asm load is not tracked: sload_wait() before the first use.
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+__device__ __forceinline__ u32x4 sload16(uint64_t addr) {  // addr: provably wave-uniform (see uniform())
+    u32x4 v;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(v) : "s"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void sload_wait(u32x4 &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory"); }
+__device__ __forceinline__ uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t uniform(uint64_t x) {
+    return (uint64_t)uniform((uint32_t)x) | ((uint64_t)uniform((uint32_t)(x >> 32)) << 32);
 }
 
-template <int T, int B, bool WEIGHTED, bool FORBID, bool BELOW_INIT>
-__global__ void __launch_bounds__(T, (B <= 4 ? 4 : (B <= 8 ? 3 : 2)))
+template <int B, bool WEIGHTED, bool FORBID, bool BELOW_INIT, bool DBG>
+__global__ void __launch_bounds__(64, (B <= 4 ? 4 : (B <= 8 ? 3 : 2)))
 mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ orderv, const uint4 *__restrict__ recv, const uint32_t *__restrict__ predv,
                const uint32_t *__restrict__ node_posv, const uint32_t *__restrict__ succ_minposv,
                const uint8_t *__restrict__ qmaskv, const float *__restrict__ weights, uint32_t n_weights,
-               uint32_t *__restrict__ tbv, float *__restrict__ dbg_value, float *spillv,
-               DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe) {
-    constexpr int Lp = T * B;
-    constexpr int NW = T / 64;
-    static_assert(T % 64 == 0, "whole waves only");
+               uint32_t *__restrict__ tbv, float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev,
+               uint64_t edge_stride, uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp,
+               float gpe) {
     static_assert(B % 4 == 0, "16-byte accesses per array");
+    constexpr int kStrip = 64 * B;  // columns per strip
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int j = threadIdx.x;
-    const int lane = j & 63;
-    const int w = j >> 6;
+    const int lane = threadIdx.x;
     // workgroups are dispatched in blockIdx order: the launch lists the queries by decreasing work
     // (longest first), so that a launch of more workgroups than the GPU holds at once ends evenly
     const uint32_t qi = orderv[blockIdx.x];
     const QDesc d = qdv[qi];
-    const uint32_t N = d.N, L = d.L;
-    const uint32_t s0 = (uint32_t)j * B;
+    const uint32_t N = uniform(d.N), L = uniform(d.L);
+    const uint32_t S = n_strips;
+    const uint32_t Lp = S * (uint32_t)kStrip;  // row stride of the trace-back plane and of the spill rows
+    const uint64_t node_off = uniform(d.node_off);
 
-    // ---- LDS carve (all dynamic; every offset a multiple of 16)
-    uint32_t *progress = reinterpret_cast<uint32_t *>(smem);                    // [NW] rows done by wave
-    float *bnd_val = reinterpret_cast<float *>(smem + 64);                      // [NW][kBndHist]
-    float *xs_v = bnd_val + NW * kBndHist;                                       // [NW][kHist]
-    uint32_t *xs_e = reinterpret_cast<uint32_t *>(xs_v + NW * kHist);            // [NW][kHist]
-    uint32_t *xs_gmax = xs_e + NW * kHist;                                       // [NW][kHist]
-    uint32_t *fin = xs_gmax + NW * kHist;                                        // [NW][16] per-wave results
-    unsigned char *ring = smem + 64 + 4 * NW * kBndHist + 12 * NW * kHist + 64 * NW;
-    constexpr size_t kValBytes = (size_t)Lp * 4;
-    constexpr size_t kSlotBytes = 2 * kValBytes;  // value f32 | gapm_val f32
+    // ---- LDS: W row slots, each value[kStrip] | gapm_val[kStrip] | value of the column left of the strip
+    unsigned char *ring = smem;
+    constexpr size_t kValBytes = (size_t)kStrip * 4;
+    constexpr size_t kSlotBytes = 2 * kValBytes + 16;
 
-    const uint4 *__restrict__ rec = recv + d.node_off;
-    const uint32_t *__restrict__ pred = predv + d.edge_off;
-    const uint32_t *__restrict__ node_pos = node_posv + d.node_off;
-    const uint32_t *__restrict__ succ_minpos = succ_minposv + d.node_off;
-    uint32_t *__restrict__ tb = tbv + d.tb_off;
-    float *spill = spillv + d.spill_off * (size_t)(2 * Lp);
+    const uint4 *__restrict__ rec = recv + node_off;
+    const uint32_t *__restrict__ pred = predv + uniform(d.edge_off);
+    const uint32_t *__restrict__ node_pos = node_posv + node_off;
+    const uint32_t *__restrict__ succ_minpos = succ_minposv + node_off;
+    uint32_t *__restrict__ tb = tbv + uniform(d.tb_off);
+    float *spill = spillv + uniform(d.spill_off) * (size_t)(2 * Lp);
+    const uint64_t q_off = uniform(d.q_off);
 
-    if (j < NW) progress[j] = 0;
-    __syncthreads();
-
-    // query masks of my columns (0 beyond L: never matches, never stored)
-    uint32_t qm[B];
-#pragma unroll
-    for (int k = 0; k < B; k++) {
-        const uint32_t s = s0 + k;
-        qm[k] = (s < L) ? (uint32_t)(qmaskv[d.q_off + s] & 0xf) : 0u;
-    }
-
-    // end-cell search state (mesh.h:567-592)
-    const bool own_last = (L - 1) / B == (uint32_t)j;
+    // end-cell search (mesh.h:567-592), accumulated over the strips
+    const uint32_t strip_last = (L - 1) / (uint32_t)kStrip;         // the strip that owns column L-1
+    const int lane_last = (int)(((L - 1) / B) & 63u);               // ... and the lane
     const int k_last = (int)((L - 1) % B);
     const int kg_last = k_last >> 2, kr_last = k_last & 3;
     const uint32_t kr_is1 = kr_last == 1 ? ~0u : 0u, kr_is2 = kr_last == 2 ? ~0u : 0u,
                    kr_is3 = kr_last == 3 ? ~0u : 0u;  // select masks
-    const int w_last = (int)(((L - 1) / B) >> 6);  // the wave that owns column L-1
-    float lc_min = 0.f, lc_snk0 = 0.f;  // step 1: rows at column L-1 (lane own_last only)
+    float lc_min = 0.f, lc_snk0 = 0.f;  // step 1: rows at column L-1 (lane lane_last of strip strip_last only)
     uint32_t lc_arg = 0;
     bool lc_any = false;
-    float sk_min = __builtin_inff();  // step 2: sink rows x my wave's columns, first in scan order
-    uint32_t sk_m = 0, sk_s = 0xffffffffu, snk0 = 0;
-    bool sk_any = false;
+    float all_min = __builtin_inff();   // step 2 over the strips done so far: sink rows x columns
+    uint32_t all_m = 0, all_s = 0xffffffffu, snk0 = 0;
+    bool all_any = false;
 
-    // the wave to my right reads my exit state of its current row only (kHist slots) and my
-    // boundary values up to kFarLds rows back (kBndHist slots): I may run this far ahead of it
-    const uint32_t throttle = (uint32_t)(kHist - 2);
-    static_assert(kFarLds + kHist <= kBndHist, "boundary history too short");
     SH_PROF_DECL
     // kLazy: trace-back cells carry a type code, value_sidx is derived in backtrack (common.h);
     // kGsi: gaps_idx is read by the recurrence itself (gap costs by length, --insertion=forbid)
@@ -246,7 +255,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
 
     // Per-row scalars (wave-uniform, from the row record through the scalar cache).
     struct Row {
-        uint32_t pb, npred, first_far, mmask, keep, z, mpos, smax;
+        uint32_t pb, npred, mmask, keep, z, mpos, smax;
         float cM, cX, gd_open, gd_ext, gi_open, init_v;
     };
     auto setup_row = [&](const uint4 r, uint32_t m) {
@@ -256,7 +265,6 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         o.z = r.z;
         o.npred = r.z & 0xffu;
         o.mmask = (r.z >> 8) & 0xfu;
-        o.first_far = r.z >> 24;  // index + 1 of the first spilled predecessor, 0 = none
         o.keep = r.w;
         o.mpos = 0;
         if constexpr (WEIGHTED) {
@@ -285,26 +293,44 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         o.init_v = (o.npred == 0) ? 1.0f : 1000000.0f;  // edge rows start at 1 (mesh.h init_edge)
         return o;
     };
-    // wave pipeline hand-shake for row m (LDS flags, no barrier)
-    // (the neighbours' counters only grow: the last value read stays a valid lower bound, and LDS is
-    // asked again only when that bound no longer suffices -- most rows cost no LDS round trip here)
-    uint32_t left_done = 0, right_done = 0;
-    auto handshake = [&](uint32_t m) {
-        if (w > 0 && !SH_ABL(8) && left_done <= m) {  // the wave to my left must have published row m
-            while ((left_done = lds_load_relaxed(&progress[w - 1])) <= m) __builtin_amdgcn_s_sleep(1);
-        }
-        if (w < NW - 1 && !SH_ABL(8) && m >= right_done + throttle) {  // do not lap the history slots the
-            // wave to my right still needs
-            while (m >= (right_done = lds_load_relaxed(&progress[w + 1])) + throttle) __builtin_amdgcn_s_sleep(1);
-        }
-        // LDS is in-order per CU: everything the publishing wave wrote before its progress
-        // store is visible once the counter is; only the compiler must not hoist loads.
-        asm volatile("" ::: "memory");
-    };
 
+    for (uint32_t strip = 0; strip < S; ++strip) {
+    const uint32_t s0 = (strip * 64u + (uint32_t)lane) * B;  // my first column
+    const bool col0_mine = (strip == 0) && (lane == 0);      // my cell 0 is query column 0
+    const bool has_col_left = !col0_mine;                     // something is to the left of my cells
+    // edge records: what the strip to my left left behind per row (read), what I leave behind (written)
+    const uint64_t e_in = uniform((uint64_t)(edgev + (size_t)(strip ? strip - 1 : 0) * edge_stride + node_off));
+    EdgeRec *e_out = edgev + (size_t)strip * edge_stride + node_off;
+    const bool have_left_strip = strip > 0, have_right_strip = strip + 1 < S;
+
+    // query masks of my columns (0 beyond L: never matches, never stored)
+    uint32_t qm[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        const uint32_t s = s0 + k;
+        qm[k] = (s < L) ? (uint32_t)(qmaskv[q_off + s] & 0xf) : 0u;
+    }
+    const bool own_last = (strip == strip_last) && (lane == lane_last);
+    float sk_min = __builtin_inff();  // step 2: sink rows x this strip's columns, first in scan order
+    uint32_t sk_m = 0, sk_s = 0xffffffffu;
+    bool sk_any = false;
+
+    // Everything a row reads through the scalar cache is requested a row ahead and waited for at a
+    // point of the previous row where no LDS access is outstanding (SMEM and LDS share one counter,
+    // and SMEM returns out of order: waiting for a scalar load means waiting for everything): the row
+    // record, the first four predecessor entries, the edge record.
+    const uint64_t pred_addr = uniform((uint64_t)pred);
     uint4 cur = rec[0];
+    u32x4 cur_pe = sload16(pred_addr + (uint64_t)cur.x * 4);
+    u32x4 cur_edge = {0, 0, 0, 0};
+    if (have_left_strip) cur_edge = sload16(e_in);
+    sload_wait(cur_pe);
+    sload_wait(cur_edge);
     for (uint32_t m = 0; m < N; ++m) {
-        const uint4 nrec = rec[m + 1 < N ? m + 1 : m];  // scalar prefetch of the next row record
+        const uint32_t m_next = m + 1 < N ? m + 1 : m;
+        const uint4 nrec = rec[m_next];  // scalar prefetch of the next row record ...
+        u32x4 nedge = {0, 0, 0, 0};
+        if (have_left_strip) nedge = sload16(e_in + (uint64_t)m_next * sizeof(EdgeRec));  // ... and of its edge record
         // phase-1 results of the current row: deletion / match candidates of my B cells
         // (dvm / mtp hold value_midx already shifted into its trace-back position, dvm with kTbExt)
         float dv[B], gm[B], mt[B];
@@ -313,7 +339,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         auto init_cells = [&](const Row &r) {
 #pragma unroll
             for (int k = 0; k < B; k++) {
-                const float iv = (s0 + k == 0) ? 1.0f : r.init_v;
+                const float iv = (k == 0 && col0_mine) ? 1.0f : r.init_v;
                 dv[k] = iv;
                 gm[k] = iv;
                 mt[k] = __builtin_inff();
@@ -326,7 +352,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
 
         // ---- phase 1: deletion / match candidates of my B cells from the predecessor rows
         const Row r = setup_row(cur, m);
-        handshake(m);
+        // what is left of my strip in this row: value of the last column there, exit state of its chain
+        const float edge_val = __uint_as_float(cur_edge.x);
         SH_PROF(1)
         if (r.npred == 0) init_cells(r);  // (otherwise the first predecessor's relax initialises)
         float gdo_v, gde_v;  // gap open / extend cost of a deletion, in VGPRs
@@ -340,9 +367,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         }
         // (FIRST: the row's first predecessor meets the initial values -- constants -- instead of
         // registers that would have to be initialised first)
-        const float iv0 = (j == 0) ? 1.0f : r.init_v;  // initial value of my cell 0 (column 0 starts at 1)
-        auto relax = [&](auto first_tag, uint32_t p, bool is_last, const Cells<B> &sv, const Cells<B> &sg,
-                         float svl) {
+        const float iv0 = col0_mine ? 1.0f : r.init_v;  // initial value of my cell 0 (column 0 starts at 1)
+        auto relax = [&](auto first_tag, uint32_t p, const Cells<B> &sv, const Cells<B> &sg, float svl) {
             // first_tag: 0 = a later predecessor, 1 = the first one, 2 = the first one in a launch whose
             // values provably stay below the 1e6 initial value (below_init): every deletion candidate
             // then beats the initial value and needs no compare (column 0, initial value 1, excepted)
@@ -362,7 +388,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 gm[k] = cand;
                 oplast[k] = op;  // (every predecessor overwrites: the last one stays)
                 const float dv_old = FIRST ? (k == 0 ? iv0 : r.init_v) : dv[k];
-                if (BELOW && k > 0) {  // (cell 0 of lane 0 is column 0: its initial value is 1)
+                if (BELOW && k > 0) {  // (cell 0 of lane 0 may be column 0: its initial value is 1)
                     dv[k] = cand;
                     dvm[k] = op ? p_open : p_ext;
                     dvs[k] = s0 + k;
@@ -378,12 +404,12 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 if constexpr (FIRST) {
                     // against the initial +inf every candidate wins: values are finite (a cell never
                     // exceeds its finite deletion candidates or initial value), so mv < inf always
-                    const bool mb = (k > 0) || (j > 0);  // s > 0
+                    const bool mb = (k > 0) || has_col_left;  // s > 0
                     mt[k] = mb ? mv : __builtin_inff();
                     mtp[k] = mb ? p_match : 0u;
                 } else {
                     const float mt_old = mt[k];
-                    const bool mb = ((s0 + k) > 0) && (mv < mt_old);
+                    const bool mb = ((k > 0) || has_col_left) && (mv < mt_old);
                     mt[k] = (k == 0) ? (mb ? mv : mt_old) : min2_raw(mv, mt_old);
                     mtp[k] = mb ? p_match : mtp[k];
                 }
@@ -391,22 +417,20 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         };
         // Predecessors in ascending id order (the reference's order: the first minimum wins, the
         // last one defines gapm).  Entry = id | (LDS slot or spill row) << 16 | spilled << 31.
-        // My own columns of a spill row were written by me; the single value I need from the wave
-        // to my left (column s0-1, lane 0 only) comes from its boundary history in LDS, or -- for
-        // predecessors further back than kFarLds rows -- from the spill row itself, which such rows
-        // publish with a workgroup-scope release (kRecFence; such rows are made to spill: see below).
+        // The single value I need from left of my strip (column s0-1, lane 0 only) sits in the row's
+        // LDS slot behind the two arrays, or, for a spill row, in the spill row itself (the previous
+        // strip wrote that column).
         for (uint32_t e = 0; e < r.npred; ++e) {
-            const uint32_t pe = pred[r.pb + e];
+            const uint32_t pe = e == 0 ? cur_pe.x : (e == 1 ? cur_pe.y : (e == 2 ? cur_pe.z : (e == 3 ? cur_pe.w : pred[r.pb + e])));
             const uint32_t p = pe & 0xffffu;
-            const bool is_last = (e + 1 == r.npred);
             Cells<B> sv, sg;
-            float far_bnd = 0.f;
+            float left_of_strip = 0.f;
             if (pe & kPredSpilled) {
                 if (SH_ABL(2)) continue;
                 const float *row = spill + (size_t)((pe >> 16) & 0x7FFFu) * (2 * Lp);
                 sv.load(row + s0);
                 sg.load(row + Lp + s0);
-                if (lane == 0 && w > 0 && m - p > (uint32_t)kFarLds) far_bnd = row[s0 - 1];
+                if (lane == 0 && have_left_strip) left_of_strip = row[s0 - 1];
                 // consume the global loads HERE: the compiler then waits for them (vmcnt) inside
                 // this rare branch instead of after the merge with the LDS path, where the wait
                 // would also drain the previous row's trace-back stores on every row
@@ -415,26 +439,30 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                     asm volatile("" : "+v"(sv.v[i]));
                     asm volatile("" : "+v"(sg.v[i]));
                 }
-                asm volatile("" : "+v"(far_bnd));
+                asm volatile("" : "+v"(left_of_strip));
                 SH_PROF_CNT(9, 1)
             } else {
                 const unsigned char *slot = ring + (size_t)(pe >> 16) * kSlotBytes;
-                sv.load(reinterpret_cast<const float *>(slot) + s0);
-                sg.load(reinterpret_cast<const float *>(slot + kValBytes) + s0);
+                sv.load_slot(reinterpret_cast<const float *>(slot), lane);
+                sg.load_slot(reinterpret_cast<const float *>(slot + kValBytes), lane);
+                if (have_left_strip) left_of_strip = *reinterpret_cast<const float *>(slot + 2 * kValBytes);
             }
             float svl = lane_shr1(sv[B - 1]);  // value[p][s0-1] lives in the lane to my left
-            if (lane == 0 && w > 0) {
-                if (m - p <= (uint32_t)kFarLds) svl = bnd_val[(w - 1) * kBndHist + (p & (kBndHist - 1))];
-                else svl = far_bnd;
-            }
+            if (lane == 0) svl = left_of_strip;
             if (e == 0) {
-                relax(std::integral_constant<int, BELOW_INIT ? 2 : 1>{}, p, is_last, sv, sg, svl);
+                relax(std::integral_constant<int, BELOW_INIT ? 2 : 1>{}, p, sv, sg, svl);
             } else {
-                relax(std::integral_constant<int, 0>{}, p, is_last, sv, sg, svl);
+                relax(std::integral_constant<int, 0>{}, p, sv, sg, svl);
             }
         }
         SH_PROF(3)
         const bool is_sink = (r.z & kRecSink) != 0;
+        // (the relaxation has just waited for its last LDS read: the next row's record is here by
+        // now -- consume it, so that the compiler's wait for it sits here and not at the top of the
+        // next row behind this row's LDS stores -- and ask for that row's predecessor entries)
+        uint32_t next_pb = nrec.x;
+        asm volatile("" : "+s"(next_pb));
+        u32x4 npe = sload16(pred_addr + (uint64_t)next_pb * 4);
 
         // ---- phase 2: insertion chain along my B cells
         float fv[B];
@@ -489,7 +517,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                         vs = mtk ? s - 1 : vs;
                     }
                 } else {
-                    const bool has_left = (k > 0) || (j > 0);  // s > 0
+                    const bool has_left = (k > 0) || has_col_left;  // s > 0
                     float gi_cost = r.gi_open;  // opening gap (mesh.h:340-343)
                     uint32_t gsi_n = s - 1;
                     if (c.e) {  // extending gap (:344-349); gaps_val == value here
@@ -517,17 +545,15 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             ex = c;
         };
 
-        // lane 0 of wave > 0 knows its real left state already (published by the left wave)
-        ChainState wave_left;
-        wave_left.v = 0.f;
-        wave_left.e = wave_left.gsi = wave_left.gmax = 0;
-        if (w > 0) {
-            const int h = (w - 1) * kHist + (int)(m & (kHist - 1));
-            wave_left.v = xs_v[h];
-            const uint32_t pe_ = xs_e[h];
-            wave_left.e = pe_ >> 31;
-            wave_left.gsi = pe_ & 0x7fffffffu;
-            wave_left.gmax = FORBID ? xs_gmax[h] : 0u;
+        // lane 0 of a later strip knows its real left state already (the edge record of the row)
+        ChainState strip_left;
+        strip_left.v = 0.f;
+        strip_left.e = strip_left.gsi = strip_left.gmax = 0;
+        if (have_left_strip) {
+            strip_left.v = __uint_as_float(cur_edge.y);
+            strip_left.e = cur_edge.z >> 31;
+            strip_left.gsi = cur_edge.z & 0x7fffffffu;
+            strip_left.gmax = FORBID ? cur_edge.w : 0u;
         }
         // "no gap enters from the left": the cell to my left did not end in a gap and is so
         // expensive that opening from it can never win
@@ -556,71 +582,78 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 float loc[B];
 #pragma unroll
                 for (int k = 0; k < B; k++) loc[k] = min2_raw(dv[k], mt[k]);
-                bool enter = false;  // the gap from my left wins at least my first cell
                 SH_PROF(4)
-                for (int guard = 0; guard < (1 << 20); ++guard) {
-                    left.v = lane_shr1(ex.v);
-                    left.e = lane_shr1(ex.e);
-                    left.gsi = 0;
-                    if (lane == 0) left = wave_left;
-                    const ChainState prev = ex;
-                    float g = left.v + (left.e ? gpe : gp);
-                    enter = (j > 0) && (g <= loc[0]);
-                    bool pass = enter;
-#pragma unroll
-                    for (int k = 1; k < B; k++) {
-                        g = g + gpe;
-                        pass = pass && (g <= loc[k]);
-                    }
-                    ex.v = pass ? g : sx.v;
-                    ex.e = pass ? 1u : sx.e;
-                    if (!__any(!same_state<kGsi>(ex, prev))) break;
-                    SH_PROF_CNT(10, 1)
-#ifdef SINA_DP_PROFILE
-                    it_++;
-#endif
-                    if (guard == 0 && !SH_ABL(8)) {
-                        // A gap does enter some lane.  Stepping lane by lane costs one iteration per
-                        // lane a run crosses, so first GUESS all exit states with a log-step scan and
-                        // let the iterations above verify the guess (any start converges to the one
-                        // consistent set of states, so this only changes the number of iterations).
-                        // A stretch of lanes acts on the gap candidate x arriving at its first cell
-                        // as  x <= th ? (x + cells * gpe, extending) : C  with a constant
-                        // state C; two stretches compose to one of the same form.  th and the sums
-                        // are computed with single adds where the cells do repeated ones, which is
-                        // the same float except at rare roundings -- hence a guess, not the result.
-                        float th = loc[0];
-#pragma unroll
-                        for (int k = 1; k < B; k++) th = min2_raw(th, loc[k] - (float)k * gpe);
-                        float th1 = lane_shr1(th);               // (the step just done was offset 1:
-                        th = min2_raw(th1, th - (float)B * gpe);  //  ex = lane (i) after lane (i-1)'s sx)
-                        if (lane <= 1) th = -__builtin_inff();  // lane 0's left state is known: constant
-                        float cv = ex.v;
-                        uint32_t ce = ex.e;
-                        // (unrolled, the 8-column variants no longer fit 3 waves per SIMD)
-                        constexpr int kScanUnroll = B > 8 ? 5 : 1;
-#pragma unroll kScanUnroll
-                        for (int o = 2; o < 64; o *= 2) {
-                            const int src = (lane - o) << 2;
-                            const float pth = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(th)));
-                            const float pv = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(cv)));
-                            const bool pe = __builtin_amdgcn_ds_bpermute(src, (int)ce) != 0;
-                            const bool valid = lane >= o;
-                            const float x = pv + (pe ? gpe : gp);
-                            const bool hit = valid && (x <= th);
-                            cv = hit ? x + (float)(o * B - 1) * gpe : cv;
-                            ce = hit ? 1u : ce;
-                            th = valid ? min2_raw(pth, th - (float)(o * B) * gpe) : th;
-                        }
-                        ex.v = cv;
-                        ex.e = ce;
-                    }
-                }
-                // 3. cells the entering gap wins (a prefix of my cells: it extends while it is no
-                // worse than the local candidates) become insertion cells; behind the cell where it
-                // loses everything is as computed in 1.  (The last iteration above ran with the
-                // final left states: `enter` is current.)
+                // does a gap enter any lane at all?  (in half of the rows none does: ex = sx, done)
+                left.v = lane_shr1(sx.v);
+                left.e = lane_shr1(sx.e);
+                left.gsi = 0;
+                if (lane == 0) left = strip_left;
+                bool enter = has_col_left && (left.v + (left.e ? gpe : gp) <= loc[0]);  // the gap from my left wins at least my first cell
                 if (__any(enter)) {
+                    for (int guard = 0; guard < (1 << 20); ++guard) {
+                        if (guard > 0) {
+                            left.v = lane_shr1(ex.v);
+                            left.e = lane_shr1(ex.e);
+                            if (lane == 0) left = strip_left;
+                        }
+                        const ChainState prev = ex;
+                        float g = left.v + (left.e ? gpe : gp);
+                        enter = has_col_left && (g <= loc[0]);
+                        bool pass = enter;
+#pragma unroll
+                        for (int k = 1; k < B; k++) {
+                            g = g + gpe;
+                            pass = pass && (g <= loc[k]);
+                        }
+                        ex.v = pass ? g : sx.v;
+                        ex.e = pass ? 1u : sx.e;
+                        if (!__any(!same_state<kGsi>(ex, prev))) break;
+                        SH_PROF_CNT(10, 1)
+#ifdef SINA_DP_PROFILE
+                        it_++;
+#endif
+                        if (guard == 0 && !SH_ABL(8)) {
+                            // A gap runs through a whole lane.  Stepping lane by lane costs one iteration per
+                            // lane a run crosses, so first GUESS all exit states with a log-step scan and
+                            // let the iterations above verify the guess (any start converges to the one
+                            // consistent set of states, so this only changes the number of iterations).
+                            // A stretch of lanes acts on the gap candidate x arriving at its first cell
+                            // as  x <= th ? (x + cells * gpe, extending) : C  with a constant
+                            // state C; two stretches compose to one of the same form.  th and the sums
+                            // are computed with single adds where the cells do repeated ones, which is
+                            // the same float except at rare roundings -- hence a guess, not the result.
+                            float th = loc[0];
+#pragma unroll
+                            for (int k = 1; k < B; k++) th = min2_raw(th, loc[k] - (float)k * gpe);
+                            float th1 = lane_shr1(th);               // (the step just done was offset 1:
+                            th = min2_raw(th1, th - (float)B * gpe);  //  ex = lane (i) after lane (i-1)'s sx)
+                            if (lane <= 1) th = -__builtin_inff();  // lane 0's left state is known: constant
+                            float cv = ex.v;
+                            uint32_t ce = ex.e;
+                            // (unrolled, the 8-column variants no longer fit 3 waves per SIMD)
+                            constexpr int kScanUnroll = B > 8 ? 5 : 1;
+#pragma unroll kScanUnroll
+                            for (int o = 2; o < 64; o *= 2) {
+                                const int src = (lane - o) << 2;
+                                // (the gap candidate a lane hands to its right neighbour is computed where
+                                // the state is: two values travel instead of three)
+                                const float xout = cv + (ce ? gpe : gp);
+                                const float pth = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(th)));
+                                const float x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(xout)));
+                                const bool valid = lane >= o;
+                                const bool hit = valid && (x <= th);
+                                cv = hit ? x + (float)(o * B - 1) * gpe : cv;
+                                ce = hit ? 1u : ce;
+                                th = valid ? min2_raw(pth, th - (float)(o * B) * gpe) : th;
+                            }
+                            ex.v = cv;
+                            ex.e = ce;
+                        }
+                    }
+                    // 3. cells the entering gap wins (a prefix of my cells: it extends while it is no
+                    // worse than the local candidates) become insertion cells; behind the cell where it
+                    // loses everything is as computed in 1.  (The last iteration above ran with the
+                    // final left states: `left` and `enter` are current.)
                     float g = left.v + (left.e ? gpe : gp);
                     bool alive = enter;
 #pragma unroll
@@ -649,9 +682,9 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 left.v = lane_shr1(ex.v);
                 left.e = lane_shr1(ex.e);
                 left.gsi = lane_shr1(ex.gsi);
-                if (lane == 0) left = wave_left;
+                if (lane == 0) left = strip_left;
                 bool take0 = false;
-                if (j > 0) {
+                if (has_col_left) {
                     const float g0 = left.v + (left.e ? ext_cost(s0, left.gsi) : r.gi_open);
                     take0 = (g0 <= dv[0]) && !(mt[0] < g0);
                 }
@@ -670,8 +703,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                     left.e = lane_shr1(ex.e);
                     left.gsi = lane_shr1(ex.gsi);
                     left.gmax = FORBID ? lane_shr1(ex.gmax) : 0u;
-                    if (lane == 0) left = wave_left;
-                    if (j > 0) run_chain(left);
+                    if (lane == 0) left = strip_left;
+                    if (has_col_left) run_chain(left);
                     if (!__any(!same_state<kGsi>(ex, prev))) break;
                 }
             }
@@ -684,37 +717,31 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
 #endif
         SH_PROF(5)
 
-        // ---- publish: boundary + exit state for the wave to my right; the row itself into its
-        // LDS slot or spill row (own columns only), unless nothing will ever read it
-        if (lane == 63) {
-            const int h = w * kHist + (int)(m & (kHist - 1));
-            bnd_val[w * kBndHist + (int)(m & (kBndHist - 1))] = fv[B - 1];
-            xs_v[h] = ex.v;
-            xs_e[h] = (ex.e << 31) | (kGsi ? ex.gsi : 0u);
-            if (FORBID) xs_gmax[h] = ex.gmax;
+        // (the scalar loads for the next row: waited for here, before this row's LDS stores go out)
+        sload_wait(npe);
+        if (have_left_strip) sload_wait(nedge);
+        // ---- publish: the edge record for the strip to my right (its column s0-1 value and chain
+        // state); the row itself into its LDS slot or spill row, unless nothing will ever read it
+        if (lane == 63 && have_right_strip) {
+            EdgeRec er;
+            er.bnd = fv[B - 1];
+            er.xv = ex.v;
+            er.xe = (ex.e << 31) | (kGsi ? ex.gsi : 0u);
+            er.gmax = FORBID ? ex.gmax : 0u;
+            e_out[m] = er;
         }
         if (r.keep != kRowNone) {
             if (!(r.keep & kRowSpilled)) {
                 unsigned char *myslot = ring + (size_t)r.keep * kSlotBytes;
-                store_cells<B>(reinterpret_cast<float *>(myslot) + s0, fv);
-                store_cells<B>(reinterpret_cast<float *>(myslot + kValBytes) + s0, gm);
+                store_slot<B>(reinterpret_cast<float *>(myslot), lane, fv);
+                store_slot<B>(reinterpret_cast<float *>(myslot + kValBytes), lane, gm);
+                if (lane == 0 && have_left_strip) *reinterpret_cast<float *>(myslot + 2 * kValBytes) = edge_val;
             } else if (!SH_ABL(2)) {
                 float *row = spill + (size_t)(r.keep & ~kRowSpilled) * (2 * Lp);
                 store_cells<B>(row + s0, fv);
                 store_cells<B>(row + Lp + s0, gm);
             }
         }
-        // release: LDS writes before the progress counter.  A spill row is read back by the lane
-        // that wrote it (program order suffices) -- except by successors further than kFarLds
-        // rows away, whose left-boundary value has left the LDS history: only rows with such a
-        // successor pay for a workgroup-scope release (which also waits for older trace-back stores).
-        if ((r.z & kRecFence) && !SH_ABL(2)) {
-            SH_PROF_CNT(11, 1)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        if (lane == 0) __hip_atomic_store(&progress[w], m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         SH_PROF(6)
 
         // ---- trace-back cells: the only per-cell HBM traffic
@@ -725,10 +752,12 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 tc[k] = kLazy ? (fvm[k] | (oplast[k] ? kTbOpLast : 0u)) : (fvm[k] | fvs[k] | (oplast[k] ? kTbOpLast : 0u));
             store_cells<B>(tb + (size_t)m * Lp + s0, tc);
         }
-        if (dbg_value != nullptr && qi == 0) store_cells<B>(dbg_value + (size_t)m * Lp + s0, fv);
+        if constexpr (DBG) {  // (test hook sina_hip_debug_mesh: the value plane of the launch's first query)
+            if (qi == 0) store_cells<B>(dbg_value + (size_t)m * Lp + s0, fv);
+        }
 
-        // ---- end-cell search, step 1: rows at the last query column (one lane)
-        if (w == w_last) {
+        // ---- end-cell search, step 1: rows at the last query column (one lane of one strip)
+        if (strip == strip_last) {
             // fv[k_last], k_last wave-uniform: a scalar branch picks the group of four, three selects
             // the cell (B select masks would not fit the SGPR budget and come back from spill lanes
             // every row)
@@ -760,7 +789,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             }
             if (own_last && is_sink && !sk_any) lc_snk0 = v;  // value of sinks[0] at column L-1
         }
-        // step 2: sink rows x every column; each wave keeps the best of its own columns
+        // step 2: sink rows x every column of this strip
         if (is_sink) {
             float bv = __builtin_inff();
             uint32_t bs = 0xffffffffu;
@@ -790,62 +819,44 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         SH_PROF(7)
         SH_PROF_CNT(8, 1)
         cur = nrec;
+        cur_edge = nedge;
+        cur_pe = npe;
     }
+    // this strip's best sink cell joins the earlier strips': smaller value, then smaller sink id,
+    // then smaller column (mesh.h:579-592 scans sinks ascending, columns ascending, strict <)
+    if (sk_any && (!all_any || sk_min < all_min || (sk_min == all_min && sk_m < all_m))) {
+        all_min = sk_min;
+        all_m = sk_m;
+        all_s = sk_s;
+    }
+    all_any = all_any || sk_any;
+    // my edge records and spill rows must have left this CU before the next strip reads them back
+    // (through the scalar cache / from another lane)
+    if (have_right_strip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }  // strips
     SH_PROF_FLUSH
 
-    // ---- combine (mesh.h:567-592)
+    // ---- combine (mesh.h:567-592): the lane that owns column L-1 has step 1
+    const float v1min = __shfl(lc_min, lane_last);
+    const float v_snk0 = __shfl(lc_snk0, lane_last);
+    const uint32_t v1arg = __shfl(lc_arg, lane_last);
     if (lane == 0) {
-        uint32_t *f = fin + w * 16;
-        f[0] = __float_as_uint(sk_min);
-        f[1] = sk_m;
-        f[2] = sk_s;
-        f[3] = snk0;
-        f[4] = sk_any ? 1u : 0u;
-    }
-    if (own_last) {
-        uint32_t *f = fin + w * 16;
-        f[8] = 1u;
-        f[9] = lc_arg;
-        f[10] = __float_as_uint(lc_min);
-        f[11] = __float_as_uint(lc_snk0);
-    }
-    __syncthreads();
-    if (j == 0) {
         DpResult r;
         r.status = 0;
-        // step 2 across waves: min value, then smaller sink id, then smaller column
-        float bmin = __builtin_inff();
-        uint32_t bm = 0, bs = 0;
-        bool any = false;
-        for (int x = 0; x < NW; x++) {
-            const uint32_t *f = fin + x * 16;
-            if (!f[4]) continue;
-            const float v = __uint_as_float(f[0]);
-            if (!any || v < bmin || (v == bmin && (f[1] < bm || (f[1] == bm && f[2] < bs)))) {
-                bmin = v;
-                bm = f[1];
-                bs = f[2];
-            }
-            any = true;
-        }
-        const int wl = (int)(((L - 1) / B) >> 6);  // wave of the lane that owns column L-1
-        const uint32_t *fl = fin + wl * 16;
-        const float v1min = __uint_as_float(fl[10]);
-        const float v_snk0 = __uint_as_float(fl[11]);
         // m = sinks[0]; replaced only by a strictly smaller value, first such row wins
-        uint32_t em = fin[3], es = L - 1;
+        uint32_t em = snk0, es = L - 1;
         float ev = v_snk0;
         if (v1min < v_snk0) {
-            em = fl[9];
+            em = v1arg;
             ev = v1min;
         }
         // sinks x columns, strict <, scan order (t asc, x asc)
-        if (any && bmin < ev) {
-            em = bm;
-            es = bs;
-            ev = bmin;
+        if (all_any && all_min < ev) {
+            em = all_m;
+            es = all_s;
+            ev = all_min;
         }
-        if (!any) r.status = -2;
+        if (!all_any) r.status = -2;
         r.end_m = em;
         r.end_s = es;
         r.raw = ev;
@@ -993,16 +1004,16 @@ __global__ void backtrack_kernel(BtArgs a) {
     a.out[q] = o;
 }
 
-template <int T, int B>
-int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, size_t lds, hipStream_t s) {
+template <int B>
+int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t n_strips, size_t lds, hipStream_t s) {
 #define SH_LAUNCH(WG, FB, BL)                                                                              \
     do {                                                                                                \
-        auto kfn = mesh_dp_kernel<T, B, WG, FB, BL>;                                                        \
+        auto kfn = a.dbg_value ? mesh_dp_kernel<B, WG, FB, BL, true> : mesh_dp_kernel<B, WG, FB, BL, false>;     \
         SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                               \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-        hipLaunchKernelGGL(kfn, dim3(nq), dim3(T), lds, s, a.qd, a.order, a.rec, a.pred, a.node_pos, a.succ_minpos, \
-                           a.qmask, a.weights, a.n_weights, a.tb, a.dbg_value, a.spill, a.res, a.ms, a.mms, \
-                           a.gp, a.gpe);                                                           \
+        hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.node_pos, a.succ_minpos, \
+                           a.qmask, a.weights, a.n_weights, a.tb, a.dbg_value, a.spill, a.edge, a.edge_stride, \
+                           n_strips, a.res, a.ms, a.mms, a.gp, a.gpe);                                   \
     } while (0)
     if (!weighted && !forbid && a.below_init) SH_LAUNCH(false, false, true);
     else if (!weighted && !forbid) SH_LAUNCH(false, false, false);
@@ -1016,58 +1027,61 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, size_t l
 
 }  // namespace
 
-// Few, fat lanes win: the per-row fixed work of a wave (row record, hand-shake, chain exchange,
-// publish) is amortised over more cells -- up to the point where the registers of a lane allow
-// only one wave per SIMD.  Measured on MI355X (16S, 1024 queries, Gcell/s): 128x12 217 (2 waves/
-// SIMD), 192x8 135 (3 waves/SIMD), 64x24 159 (1 wave/SIMD, no cross-wave hand-shake at all); on an
-// earlier version 128x12 152, 256x6 133, 512x3 97.  A variant that kept the recent rows in
-// registers instead of LDS (deeper ring, but scratch spills) reached 82-90 and was dropped.
-static const DpGeom kGeoms[] = {{64, 4},  {64, 8},  {64, 12},  {128, 8}, {128, 12},
-                                {256, 8}, {256, 12}, {512, 8}, {512, 12}};
+// A geometry is (columns per lane B, strips S): one wave sweeps S strips of 64*B columns; T = 64 * S
+// is kept as the geometry's "virtual thread count" (T * B columns).  Fat lanes amortise the per-row
+// fixed work of a wave (row record, chain exchange, publish) over more cells, thin lanes need fewer
+// registers and allow more waves per SIMD.  Measured on MI355X, 16S queries, DP kernel alone on a
+// launch that fills every wave slot (tools/perf_dp_geoms.sh): B = 12 (2 waves/SIMD) 403 Gcell/s,
+// B = 8 (3 waves/SIMD) 461, B = 4 (4 waves/SIMD) 226.  The geometry for a launch is the one with
+// the smallest padded width / throughput.
+static const int kLaneCells[] = {4, 8, 12};
+static const double kLaneRate[] = {226.0, 461.0, 403.0};  // Gcell/s of the B = 4, 8, 12 kernels (above)
+constexpr int kMaxStrips = 16;
 
 bool pick_geom(uint32_t maxL, DpGeom *g) {
     // tuning override: SINA_HIP_DP_GEOM="T,B" (used if it covers the batch's longest query)
     if (const char *ov = getenv("SINA_HIP_DP_GEOM")) {
         int t = 0, b = 0;
-        if (sscanf(ov, "%d,%d", &t, &b) == 2 && (uint32_t)(t * b) >= maxL) {
-            for (const DpGeom &c : kGeoms) {
-                if (c.T == t && c.B == b) {
-                    *g = c;
-                    return true;
-                }
-            }
-        }
-    }
-    for (const DpGeom &c : kGeoms) {
-        if ((uint32_t)c.Lp() >= maxL) {
-            *g = c;
+        if (sscanf(ov, "%d,%d", &t, &b) == 2 && (uint32_t)(t * b) >= maxL && t % 64 == 0 && t >= 64 &&
+            t <= 64 * kMaxStrips && (b == 4 || b == 8 || b == 12)) {
+            g->T = t;
+            g->B = b;
             return true;
         }
     }
-    return false;
+    double best = 0;
+    bool found = false;
+    for (int i = 0; i < 3; i++) {
+        const int b = kLaneCells[i];
+        const uint32_t strips = (maxL + 64u * b - 1) / (64u * b);
+        if (strips > (uint32_t)kMaxStrips || strips * 64u * b > 8192u) continue;  // (13-bit value_sidx, common.h)
+        const double cost = (double)(strips * 64u * b) / kLaneRate[i];
+        if (!found || cost < best) {
+            best = cost;
+            g->T = (int)strips * 64;
+            g->B = b;
+            found = true;
+        }
+    }
+    return found;
 }
 
-size_t dp_slot_bytes(const DpGeom &g) { return (size_t)g.Lp() * 8; }
-size_t dp_fixed_lds_bytes(const DpGeom &g) {
-    const size_t nw = (size_t)g.T / 64;
-    return 64 + 4 * nw * kBndHist + 12 * nw * kHist + 64 * nw;
-}
+// one LDS row slot: value | gapm_val of the strip's columns + the value left of the strip
+size_t dp_slot_bytes(const DpGeom &g) { return (size_t)64 * g.B * 8 + 16; }
+size_t dp_fixed_lds_bytes(const DpGeom &) { return 0; }
 int dp_max_ring(const DpGeom &) { return 8; }  // the slot allocators keep 8 slot states; deeper rings gain nothing
+// LDS per workgroup (= per wave) that still lets the kernel's register budget decide the occupancy
+size_t dp_default_lds_budget(const DpGeom &g) {
+    const int waves_per_simd = g.B <= 4 ? 4 : (g.B <= 8 ? 3 : 2);
+    return (size_t)160 * 1024 / (4 * waves_per_simd) - 64;
+}
 
 int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
                    size_t lds, hipStream_t s) {
-#define SH_GEOM(TT, BB) \
-    if (g.T == TT && g.B == BB) return launch_tb<TT, BB>(weighted, forbid, a, nq, lds, s)
-    SH_GEOM(64, 4);
-    SH_GEOM(64, 8);
-    SH_GEOM(64, 12);
-    SH_GEOM(128, 8);
-    SH_GEOM(128, 12);
-    SH_GEOM(256, 8);
-    SH_GEOM(256, 12);
-    SH_GEOM(512, 8);
-    SH_GEOM(512, 12);
-#undef SH_GEOM
+    const uint32_t n_strips = (uint32_t)g.T / 64;
+    if (g.B == 4) return launch_tb<4>(weighted, forbid, a, nq, n_strips, lds, s);
+    if (g.B == 8) return launch_tb<8>(weighted, forbid, a, nq, n_strips, lds, s);
+    if (g.B == 12) return launch_tb<12>(weighted, forbid, a, nq, n_strips, lds, s);
     SH_FAIL("mesh_dp: unsupported geometry");
 }
 

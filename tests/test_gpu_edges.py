@@ -89,9 +89,9 @@ def test_error_returns(oracle, gpu_ctx):
     refs = synth.make_refs(140, length=100, width=700, seed=331)
     cs = util.cseqs_from_refs(refs)
     g = util.graph_dict([cs[0], cs[1]])
-    too_long = np.ones(6145, np.uint8)
+    too_long = np.ones(8193, np.uint8)
     with pytest.raises(capi.SinaHipError):
-        gpu_ctx.align_graphs(gpu_ctx.graph_batch([g], refs.width), too_long, np.array([0, 6145], np.uint64),
+        gpu_ctx.align_graphs(gpu_ctx.graph_batch([g], refs.width), too_long, np.array([0, 8193], np.uint64),
                              gpu_ctx.params())
     with pytest.raises(capi.SinaHipError):   # empty query
         gpu_ctx.align_graphs(gpu_ctx.graph_batch([g], refs.width), np.ones(1, np.uint8), np.array([0, 0], np.uint64),

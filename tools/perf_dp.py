@@ -39,7 +39,7 @@ for mask in masks:
 if prof:
     a = (ctypes.c_ulonglong * 32)()
     lib.sina_hip_debug_dp_profile(a, 1)
-    names = ["setup", "handshake", "far preds", "near preds", "chain+verify", "rerun", "publish", "tb+end"]
+    names = ["-", "row setup", "-", "preds", "chain first pass", "propagate+scan+overwrite", "publish", "tb+end"]
     tot = float(sum(a[:8]))
     rows = a[8]
     for i, n in enumerate(names):
