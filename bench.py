@@ -44,13 +44,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096, help="queries per step and rank")
+    ap.add_argument("--batch", type=int, default=6144, help="queries per step and rank")
     ap.add_argument("--refs", type=int, default=100000)
     ap.add_argument("--length", type=int, default=1500)
     ap.add_argument("--width", type=int, default=50000)
     ap.add_argument("--window", type=int, default=0, help="cut queries to this many bases (V4: 250)")
-    ap.add_argument("--inflight", type=int, default=3, help="batches worked on concurrently per rank")
-    ap.add_argument("--sub-batch", type=int, default=2048, help="queries per GPU launch inside a step")
+    ap.add_argument("--inflight", type=int, default=4, help="batches worked on concurrently per rank")
+    ap.add_argument("--sub-batch", type=int, default=3072,
+                    help="queries per GPU launch inside a step (one DP wave per query: 3072 = every wave slot of "
+                         "an MI355X at three waves per SIMD)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="CPU baseline: queries per thread and thread count (0 = 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=8,

@@ -154,10 +154,6 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     });
     if (c->order.reserve(4 * (size_t)bq)) return 1;
     SH_CHECK(hipMemcpyAsync(c->order.p, order.data(), 4 * (size_t)bq, hipMemcpyHostToDevice, s));
-    // from here on the DP stream, behind everything queued on the context's main stream so far
-    SH_CHECK(hipEventRecord(c->ev[8], s));
-    s = c->stream_dp;
-    SH_CHECK(hipStreamWaitEvent(s, c->ev[8], 0));
     DpArgs a;
     a.qd = c->qd.as<QDesc>();
     a.order = c->order.as<uint32_t>();
@@ -185,11 +181,19 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     }
 
     {
-        std::lock_guard<std::mutex> token(c->st->dp_token);
-        SH_CHECK(hipEventRecord(c->ev[0], s));
-        if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, s)) return 1;
-        SH_CHECK(hipEventRecord(c->ev[1], s));
-        SH_CHECK(hipEventSynchronize(c->ev[1]));
+        // the DP kernel: on the store's heavy stream, behind the uploads queued on c->stream; the
+        // backtrack walk and the result copies then follow it on the context's low-priority stream
+        std::unique_lock<std::mutex> token(c->st->dp_token, std::defer_lock);
+        if (!serialize_kernels()) token.lock();  // (then: one DP kernel at a time by this token)
+        SH_CHECK(hipEventRecord(c->ev[8], s));
+        s = c->stream_dp;
+        SH_CHECK(hipStreamWaitEvent(s, c->ev[8], 0));
+        heavy_launch hl(c, s);
+        SH_CHECK(hipEventRecord(c->ev[0], hl.stream()));
+        if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, hl.stream())) return 1;
+        SH_CHECK(hipEventRecord(c->ev[1], hl.stream()));
+        if (hl.done(s)) return 1;
+        if (token.owns_lock()) SH_CHECK(hipEventSynchronize(c->ev[1]));
     }
     BtArgs b;
     b.qd = a.qd;
@@ -373,9 +377,10 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
     c->st = new sina_hip_store();
     c->owns_store = true;
     if (make_streams(c)) return 1;
+    SH_CHECK(hipStreamCreateWithFlags(&c->st->heavy, hipStreamNonBlocking));
     for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
     c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 0) * 1024;
-    c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 48) << 30;
+    c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 56) << 30;
     memset(&c->st->stats, 0, sizeof(c->st->stats));
     *ctx = c;
     return 0;
@@ -414,6 +419,7 @@ int sina_hip_sync(sina_hip_ctx *c) {
     SH_CHECK(hipSetDevice(c->device));
     SH_CHECK(hipStreamSynchronize(c->stream));
     SH_CHECK(hipStreamSynchronize(c->stream_dp));
+    if (c->st->heavy) SH_CHECK(hipStreamSynchronize(c->st->heavy));
     return 0;
 }
 

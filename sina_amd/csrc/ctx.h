@@ -30,6 +30,10 @@ struct sina_hip_store {
     // all reach their DP phase together would otherwise run in lock-step (GPU idle while all of
     // them are in their host phases).  Holding this while the DP kernel runs staggers them.
     std::mutex dp_token;
+    // The device-filling kernels of all contexts (k-mer count/select, DAG build, DP) go through ONE
+    // stream, in the order the host threads reach them: see sina_hip::heavy_launch below.
+    hipStream_t heavy = nullptr;
+    std::mutex heavy_mu;
     // largest capacity any context has needed for each scratch buffer so far: a new fork reserves
     // these at once (hipMalloc / hipFree synchronise the device; never in steady state)
     size_t cap_hint[64] = {};  // (indexed like sina_hip_ctx::scratch(): kNumScratch entries)
@@ -41,7 +45,7 @@ struct sina_hip_ctx {
     hipStream_t stream = nullptr;     // everything but the DP: highest priority
     hipStream_t stream_dp = nullptr;  // DP kernel + backtrack: lowest priority (see make_streams)
     std::mutex mu;
-    hipEvent_t ev[10];
+    hipEvent_t ev[12];  // [10], [11]: hand-over to / from the store's heavy stream
 
     sina_hip_store *st = nullptr;
     bool owns_store = false;
@@ -55,7 +59,7 @@ struct sina_hip_ctx {
     float wtab_fs_weight = NAN;  // fs_weight the device weight table was computed for
 
     size_t lds_budget = 0;  // LDS per DP workgroup; 0 = what keeps the register-limited occupancy (dp_default_lds_budget)
-    uint64_t tb_budget_bytes = (uint64_t)48 << 30;
+    uint64_t tb_budget_bytes = (uint64_t)56 << 30;
 
     static constexpr int kNumScratch = 35;
     static_assert(kNumScratch <= 64, "sina_hip_store::cap_hint is too short");
@@ -94,6 +98,7 @@ struct sina_hip_ctx {
         h_out.release();
         h_out_pos.release();
         if (owns_store && st) {
+            if (st->heavy) (void)hipStreamDestroy(st->heavy);
             st->ref_ab.release();
             st->ref_off.release();
             st->idx_off.release();
@@ -120,6 +125,50 @@ inline int ensure_ref_off_host(sina_hip_ctx *c) {
     st->ref_off_host_ready.store(true, std::memory_order_release);
     return 0;
 }
+}  // namespace sina_hip
+
+namespace sina_hip {
+// The kernels of this library each fill the device by themselves.  Beside a resident DP kernel (all
+// VGPRs of every SIMD taken) the others only get the slots of retiring DP waves and run several
+// times longer than alone, while the DP kernel loses those slots for as long: one device-filling
+// kernel at a time is faster for both (measured: DP 24 instead of 33 ms per launch inside the
+// pipeline).  So every such kernel is queued on the store's one "heavy" stream -- a FIFO the GPU
+// works off without the host in between: the kernel waits (event) for what its context queued before
+// it, and the context's own stream waits (event) for the kernel.  Thin, latency-bound work (copies,
+// the backtrack walk) stays on the contexts' streams and runs beside whatever is resident.
+// SINA_HIP_SERIALIZE=0 (experiments): every kernel on its own context's stream again, DP launches
+// taking turns through a host-side token.
+inline bool serialize_kernels() {
+    static const bool on = [] {
+        const char *v = getenv("SINA_HIP_SERIALIZE");
+        return !(v && *v == '0');
+    }();
+    return on;
+}
+struct heavy_launch {
+    sina_hip_ctx *c;
+    hipStream_t own, hs;
+    std::unique_lock<std::mutex> lk;
+    bool failed = false;
+    // `own`: the context stream whose queued work (uploads) the kernel depends on
+    heavy_launch(sina_hip_ctx *c_, hipStream_t own_) : c(c_), own(own_), hs(own_) {
+        if (!serialize_kernels() || !c->st->heavy) return;
+        hs = c->st->heavy;
+        failed = hipEventRecord(c->ev[10], own) != hipSuccess;
+        lk = std::unique_lock<std::mutex>(c->st->heavy_mu);
+        failed = failed || hipStreamWaitEvent(hs, c->ev[10], 0) != hipSuccess;
+    }
+    hipStream_t stream() const { return hs; }
+    // after the launches: `next` (a stream of the context) continues behind them
+    int done(hipStream_t next) {
+        if (hs == next) return failed ? 1 : 0;
+        failed = failed || hipEventRecord(c->ev[11], hs) != hipSuccess;
+        if (lk.owns_lock()) lk.unlock();
+        failed = failed || hipStreamWaitEvent(next, c->ev[11], 0) != hipSuccess;
+        if (failed) set_error("heavy_launch: event hand-over failed");
+        return failed ? 1 : 0;
+    }
+};
 }  // namespace sina_hip
 
 // publishes the context's scratch capacities when an API call ends (see sina_hip_store::cap_hint)

@@ -539,11 +539,15 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         ga.W = W;
         SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(family_graph_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-        SH_CHECK(hipEventRecord(c->ev[6], s));
-        hipLaunchKernelGGL(family_graph_kernel, dim3(bq), dim3(kGT), glds, s, ga);
-        SH_CHECK(hipGetLastError());
-        SH_CHECK(hipEventRecord(c->ev[7], s));
         bg->sizes.resize(4 * (size_t)bq);
+        {
+            heavy_launch hl(c, s);  // (a device-filling kernel: ctx.h)
+            SH_CHECK(hipEventRecord(c->ev[6], hl.stream()));
+            hipLaunchKernelGGL(family_graph_kernel, dim3(bq), dim3(kGT), glds, hl.stream(), ga);
+            SH_CHECK(hipGetLastError());
+            SH_CHECK(hipEventRecord(c->ev[7], hl.stream()));
+            if (hl.done(s)) return 1;
+        }
         // (wait for the kernels FIRST: a copy to pageable memory queued behind running kernels waits
         // inside the runtime, under locks other threads' launches need -- see HostBuf in common.h)
         SH_CHECK(hipStreamSynchronize(s));
@@ -597,7 +601,10 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
     if (upload_weights(c, p)) return 1;
 
     const uint64_t tb_budget_cells = c->tb_budget_bytes / 4;
-    const uint32_t chunk_q = 2048;
+    // queries per DAG-build + DP launch: one DP wave per query, so a launch should be able to fill
+    // every wave slot of the device (256 CUs x 4 SIMDs x up to 4 waves); the trace-back budget cuts
+    // it further below
+    const uint32_t chunk_q = 4096;
     BuiltGraphs bg;
     for (uint32_t q0 = 0; q0 < nq; q0 += chunk_q) {
         const uint32_t bq = std::min(chunk_q, nq - q0);

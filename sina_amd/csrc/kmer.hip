@@ -593,10 +593,12 @@ static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint6
     const size_t clds = (size_t)kTileRefs * 2 + (size_t)ca.kmax * 9 + 64;
     SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kmer_count_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
-    SH_CHECK(hipEventRecord(c->ev[3], s));
-    hipLaunchKernelGGL(kmer_count_kernel, dim3(nq), dim3(kCountThreads), clds, s, ca);
+    heavy_launch hl(c, s);  // (count + select: device-filling kernels, ctx.h)
+    const hipStream_t hs = hl.stream();
+    SH_CHECK(hipEventRecord(c->ev[3], hs));
+    hipLaunchKernelGGL(kmer_count_kernel, dim3(nq), dim3(kCountThreads), clds, hs, ca);
     SH_CHECK(hipGetLastError());
-    SH_CHECK(hipEventRecord(c->ev[4], s));
+    SH_CHECK(hipEventRecord(c->ev[4], hs));
     if (!want_scores_only) {
         if (c->k_out_ids.reserve((size_t)nq * max * 4) || c->k_out_scores.reserve((size_t)nq * max * 4) ||
             c->k_out_n.reserve((size_t)nq * 4))
@@ -610,11 +612,11 @@ static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint6
         sa.out_n = c->k_out_n.as<uint32_t>();
         sa.n_refs = c->st->n_refs;
         sa.max = max;
-        hipLaunchKernelGGL(kmer_select_kernel, dim3(nq), dim3(kSelThreads), 0, s, sa);
+        hipLaunchKernelGGL(kmer_select_kernel, dim3(nq), dim3(kSelThreads), 0, hs, sa);
         SH_CHECK(hipGetLastError());
     }
-    SH_CHECK(hipEventRecord(c->ev[5], s));
-    return 0;
+    SH_CHECK(hipEventRecord(c->ev[5], hs));
+    return hl.done(s);
 }
 
 }  // namespace sina_hip

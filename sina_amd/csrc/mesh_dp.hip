@@ -159,14 +159,23 @@ __device__ __forceinline__ void store_cells(T *__restrict__ dst, const T (&src)[
 }
 
 #ifdef SINA_DP_PROFILE
-// Profiling build only (make PROFILE=1): per-phase s_memtime totals summed over all waves.
+// Profiling builds only (make PROFILE=1: per-phase s_memtime totals summed over all waves + ablation
+// switches; make PROFILE=2: the ablation switches alone, without the timers' own cost).
 __device__ unsigned long long g_dp_prof[32];
 __device__ int g_dp_abl;  // ablation mask (timing experiments only, results are WRONG when set)
 #define SH_ABL(bit) (abl_ & (bit))
+#if SINA_DP_PROFILE == 1
 #define SH_PROF_DECL unsigned long long pa_[32] = {}; unsigned long long pt_ = __builtin_amdgcn_s_memtime();
 #define SH_PROF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pa_[i] += t_ - pt_; pt_ = t_; }
 #define SH_PROF_CNT(i, n) pa_[i] += (n);
 #define SH_PROF_FLUSH if (lane == 0) { for (int i_ = 0; i_ < 32; i_++) atomicAdd(&g_dp_prof[i_], pa_[i_]); }
+#define SH_PROF_TIMERS 1
+#else
+#define SH_PROF_DECL
+#define SH_PROF(i)
+#define SH_PROF_CNT(i, n)
+#define SH_PROF_FLUSH
+#endif
 #else
 #define SH_ABL(bit) false
 #define SH_PROF_DECL
@@ -175,10 +184,6 @@ __device__ int g_dp_abl;  // ablation mask (timing experiments only, results are
 #define SH_PROF_FLUSH
 #endif
 
-// 16 bytes from a wave-uniform address through the scalar cache.  The compiler cannot use s_load
-// here by itself: the edge records are written by this same kernel (one strip earlier), so it would
-// fall back to a vector load whose completion (vmcnt, in order) also waits for the trace-back stores
-// of the row.  An asm load is not tracked: sload_wait() before the first use.
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 __device__ __forceinline__ u32x4 sload16(uint64_t addr) {  // addr: provably wave-uniform (see uniform())
     u32x4 v;
@@ -421,6 +426,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         // LDS slot behind the two arrays, or, for a spill row, in the spill row itself (the previous
         // strip wrote that column).
         for (uint32_t e = 0; e < r.npred; ++e) {
+            if (SH_ABL(16) && e > 0) break;
             const uint32_t pe = e == 0 ? cur_pe.x : (e == 1 ? cur_pe.y : (e == 2 ? cur_pe.z : (e == 3 ? cur_pe.w : pred[r.pb + e])));
             const uint32_t p = pe & 0xffffu;
             Cells<B> sv, sg;
@@ -561,7 +567,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         none.v = __builtin_inff();
         none.e = none.gsi = none.gmax = 0;
         ChainState left = none;
-#ifdef SINA_DP_PROFILE
+#ifdef SH_PROF_TIMERS
         int it_ = 0;
 #endif
         bool done = false;
@@ -609,7 +615,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                         ex.e = pass ? 1u : sx.e;
                         if (!__any(!same_state<kGsi>(ex, prev))) break;
                         SH_PROF_CNT(10, 1)
-#ifdef SINA_DP_PROFILE
+#ifdef SH_PROF_TIMERS
                         it_++;
 #endif
                         if (guard == 0 && !SH_ABL(8)) {
@@ -695,7 +701,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             if (rerun) {
                 for (int guard = 0; guard < (1 << 20); ++guard) {
                     SH_PROF_CNT(10, 1)
-#ifdef SINA_DP_PROFILE
+#ifdef SH_PROF_TIMERS
                     it_++;
 #endif
                     const ChainState prev = ex;
@@ -709,7 +715,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                 }
             }
         }
-#ifdef SINA_DP_PROFILE
+#ifdef SH_PROF_TIMERS
         {   // histogram of rerun iterations per row: 0,1,2,3,4,5-8,9-16,17-32,33+
             const int b_ = it_ <= 4 ? it_ : (it_ <= 8 ? 5 : (it_ <= 16 ? 6 : (it_ <= 32 ? 7 : 8)));
             pa_[16 + b_] += 1;
@@ -730,7 +736,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             er.gmax = FORBID ? ex.gmax : 0u;
             e_out[m] = er;
         }
-        if (r.keep != kRowNone) {
+        if (r.keep != kRowNone && !SH_ABL(32)) {
             if (!(r.keep & kRowSpilled)) {
                 unsigned char *myslot = ring + (size_t)r.keep * kSlotBytes;
                 store_slot<B>(reinterpret_cast<float *>(myslot), lane, fv);
@@ -757,7 +763,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         }
 
         // ---- end-cell search, step 1: rows at the last query column (one lane of one strip)
-        if (strip == strip_last) {
+        if (strip == strip_last && !SH_ABL(64)) {
             // fv[k_last], k_last wave-uniform: a scalar branch picks the group of four, three selects
             // the cell (B select masks would not fit the SGPR budget and come back from spill lanes
             // every row)
@@ -790,7 +796,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             if (own_last && is_sink && !sk_any) lc_snk0 = v;  // value of sinks[0] at column L-1
         }
         // step 2: sink rows x every column of this strip
-        if (is_sink) {
+        if (is_sink && !SH_ABL(64)) {
             float bv = __builtin_inff();
             uint32_t bs = 0xffffffffu;
 #pragma unroll
