@@ -134,13 +134,14 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     // The trace-back plane is the one buffer whose size follows the batch (tens of GB for 16S): a
     // context that needs a big one gets the whole budget at once instead of growing again and again
     // -- a reallocation of that size stalls every stream of the device for milliseconds.
-    if (4 * tb_cells > c->tb.cap && 4 * tb_cells > ((uint64_t)4 << 30) && c->tb_budget_bytes >= 4 * tb_cells) {
+    const uint64_t tb_bytes = tb_cell_bytes(forbid) * tb_cells;
+    if (tb_bytes > c->tb.cap && tb_bytes > ((uint64_t)4 << 30) && c->tb_budget_bytes >= tb_bytes) {
         if (c->tb.reserve_exact(c->tb_budget_bytes)) {  // (not enough memory for the whole budget: grow as usual)
             (void)hipGetLastError();
             set_error("");
         }
     }
-    if (c->tb.reserve(4 * tb_cells) || c->spill.reserve(std::max<uint64_t>(spill_rows, 1) * 8 * (uint64_t)Lp) ||
+    if (c->tb.reserve(tb_bytes) || c->spill.reserve(std::max<uint64_t>(spill_rows, 1) * 8 * (uint64_t)Lp) ||
         c->edge.reserve(std::max<uint64_t>(1, (uint64_t)(pl.geom.T / 64 - 1) * n_node_entries) * sizeof(EdgeRec)) ||
         c->res.reserve(sizeof(DpResult) * bq) || c->out.reserve(sizeof(sina_hip_align_out) * bq) ||
         c->out_pos.reserve(4 * std::max<uint64_t>(nqm, 1)))
@@ -162,7 +163,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     a.node_pos = c->node_pos.as<uint32_t>();
     a.succ_minpos = c->succ_minpos.as<uint32_t>();
     a.qmask = c->qmask.as<uint8_t>();
-    a.tb = c->tb.as<uint32_t>();
+    a.tb = c->tb.p;
     a.dbg_value = want_dbg_value ? c->dbg.as<float>() : nullptr;
     a.spill = c->spill.as<float>();
     a.edge = c->edge.as<EdgeRec>();
@@ -275,7 +276,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
     const int Lp = pl.geom.Lp();
     if (upload_weights(c, p)) return 1;
 
-    const uint64_t tb_budget_cells = c->tb_budget_bytes / 4;
+    const uint64_t tb_budget_cells = c->tb_budget_bytes / tb_cell_bytes(forbid);
     HostPrep hp;
     uint32_t q0 = 0;
     while (q0 < nq) {
@@ -312,33 +313,41 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         if (dbg_vm) {  // single-query debug: unpack the planes
             const QDesc &d = hp.qd[0];
             std::vector<uint32_t> tbh((size_t)d.N * Lp);
-            SH_CHECK(hipMemcpy(tbh.data(), c->tb.p, 4 * tbh.size(), hipMemcpyDeviceToHost));
+            if (forbid) {
+                SH_CHECK(hipMemcpy(tbh.data(), c->tb.p, 4 * tbh.size(), hipMemcpyDeviceToHost));
+            } else {  // 16-bit cells (common.h)
+                std::vector<uint16_t> t16(tbh.size());
+                SH_CHECK(hipMemcpy(t16.data(), c->tb.p, 2 * t16.size(), hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < tbh.size(); i++) tbh[i] = t16[i];
+            }
             std::vector<float> vh;
             if (dbg_value_host) {
                 vh.resize(tbh.size());
                 SH_CHECK(hipMemcpy(vh.data(), c->dbg.p, 4 * vh.size(), hipMemcpyDeviceToHost));
             }
-            // value_midx of a gap-extending deletion is the predecessor's gapm_idx (common.h, kTbExt)
+            // value_midx of a gap-extending deletion is the predecessor's gapm_idx (common.h, Ext / OpLast)
             const uint4 *rec = hp.rec.data() + d.node_off;
             const uint32_t *pr = hp.pred.data() + d.edge_off;
+            const uint32_t ext_bit = forbid ? kTbExt : kTb16Ext, oplast_bit = forbid ? kTbOpLast : kTb16OpLast;
             auto gapm_idx = [&](uint32_t x, uint32_t col) -> uint32_t {
                 for (;;) {
                     const uint32_t np = rec[x].z & 0xffu;
                     if (np == 0) return 0;
                     const uint32_t lastp = pr[rec[x].x + np - 1] & 0xffffu;
-                    if (tbh[(size_t)x * Lp + col] & kTbOpLast) return lastp;
+                    if (tbh[(size_t)x * Lp + col] & oplast_bit) return lastp;
                     x = lastp;
                 }
             };
             for (uint32_t m = 0; m < d.N; m++)
                 for (uint32_t x = 0; x < d.L; x++) {
                     const uint32_t cell = tbh[(size_t)m * Lp + x];
-                    uint32_t vm = cell >> 16;
-                    if (cell & kTbExt) vm = gapm_idx(vm, x);
-                    dbg_vm[(size_t)m * d.L + x] = vm;
-                    uint32_t vs = cell & kTbSMask;
-                    if (!forbid) {  // type code instead of value_sidx (common.h, kTbTypeMask)
+                    uint32_t vm, vs;
+                    if (forbid) {
+                        vm = cell >> 16;
+                        vs = cell & kTbSMask;
+                    } else {  // type code + predecessor ordinal instead of the indices
                         const uint32_t t = cell & kTbTypeMask;
+                        vm = t == kTbIns ? m : (t == kTbNone ? 0u : (pr[rec[m].x + (cell >> kTb16OrdShift)] & 0xffffu));
                         if (t == kTbNone) vs = 0;
                         else if (t == kTbMatch) vs = x - 1;
                         else if (t == kTbDel) vs = x;
@@ -348,6 +357,8 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
                             vs = k;
                         }
                     }
+                    if (cell & ext_bit) vm = gapm_idx(vm, x);
+                    dbg_vm[(size_t)m * d.L + x] = vm;
                     dbg_vs[(size_t)m * d.L + x] = vs;
                     if (dbg_value_host) dbg_value_host[(size_t)m * d.L + x] = vh[(size_t)m * Lp + x];
                 }

@@ -147,24 +147,36 @@ struct EdgeRec {
 };
 static_assert(sizeof(EdgeRec) == 16, "read back with one 16-byte scalar load");
 
-// Trace-back cell (one u32 per DP cell, the only per-cell HBM traffic):
-//   bits 31..16 value_midx, bits 12..0 value_sidx, and two bits that replace carrying gapm_idx
-//   through the recurrence (it is only ever needed for cells ON the final path):
-//   kTbExt:    the cell took a deletion that EXTENDS the gap of its predecessor `value_midx`; the
-//              reference's value_midx is that row's gapm_idx at this column (mesh.h:318-330)
-//   kTbOpLast: this row's own gapm at this column was OPENED from its last predecessor, i.e.
-//              gapm_idx = last predecessor; otherwise gapm_idx = the last predecessor's gapm_idx.
-// backtrack resolves kTbExt by walking last predecessors until a kTbOpLast cell (resolve_gapm_idx).
-// All scoring schemes except --insertion=forbid store a TYPE CODE in place of value_sidx (it follows
-// from the type: a match came from column s-1, a deletion from s, an untouched cell keeps 0, and an
-// insertion from the column where the run of insertion cells to its left ends -- a cell's
-// gaps_val == value, the reference's "extend" condition, holds exactly for insertion cells), so the
-// recurrence carries no column indices at all; backtrack walks the few insertion runs on the path.
+// Trace-back cell: what backtrack() needs of a DP cell -- the only per-cell HBM traffic.  Two formats:
+//
+// * 16 bits (every scheme except --insertion=forbid): bits 1..0 type, bit 2 kTb16Ext, bit 3
+//   kTb16OpLast, bits 11..4 the ORDINAL of the winning predecessor in the row's predecessor list.
+//   value_midx is that predecessor (a deletion / match cell), the row itself (an insertion cell) or 0
+//   (an untouched cell); value_sidx follows from the type: a match came from column s-1, a deletion
+//   from s, an untouched cell keeps 0, and an insertion from the column where the run of insertion
+//   cells to its left ends (a cell's gaps_val == value, the reference's "extend" condition, holds
+//   exactly for insertion cells).  So the recurrence carries neither row nor column indices, and
+//   backtrack looks the few of them on the final path up.
+// * 32 bits (--insertion=forbid, where a cell that may not take a gap keeps its initial gaps_val and
+//   the insertion-run rule above does not hold): bits 31..16 value_midx, bits 12..0 value_sidx,
+//   kTbExt, kTbOpLast.
+//
+// Two bits replace carrying gapm_idx through the recurrence (it is only ever needed on the final path):
+//   Ext:    the cell took a deletion that EXTENDS the gap of its predecessor `value_midx`; the
+//           reference's value_midx is that row's gapm_idx at this column (mesh.h:318-330)
+//   OpLast: this row's own gapm at this column was OPENED from its last predecessor, i.e.
+//           gapm_idx = last predecessor; otherwise gapm_idx = the last predecessor's gapm_idx.
+// backtrack resolves Ext by walking last predecessors until an OpLast cell.
 constexpr uint32_t kTbSMask = 0x1FFFu;
 constexpr uint32_t kTbExt = 1u << 13;
 constexpr uint32_t kTbOpLast = 1u << 14;
-constexpr uint32_t kTbTypeMask = 3u;  // lazy format only
+constexpr uint32_t kTbTypeMask = 3u;
 constexpr uint32_t kTbDel = 0u, kTbMatch = 1u, kTbIns = 2u, kTbNone = 3u;
+constexpr uint32_t kTb16Ext = 1u << 2;
+constexpr uint32_t kTb16OpLast = 1u << 3;
+constexpr int kTb16OrdShift = 4;  // 8 bits: a row has at most 255 predecessors (rec.z & 0xff)
+// bytes per trace-back cell of a launch
+inline size_t tb_cell_bytes(bool forbid) { return forbid ? 4 : 2; }
 
 struct DpResult {
     uint32_t end_m, end_s;
@@ -189,7 +201,7 @@ struct DpArgs {
     const uint32_t *succ_minpos;
     const uint8_t *qmask;
     int below_init;             // see dp_below_init()
-    uint32_t *tb;               // trace-back cells (kTb* above)
+    void *tb;                   // trace-back cells: u16 or u32 (kTb* above); QDesc::tb_off counts cells
     float *dbg_value;           // optional [N*Lp] plane of the first query
     float *spill;               // spill rows: value[Lp] | gapm_val[Lp]
     EdgeRec *edge;              // [strips - 1][edge_stride] edge records, indexed like the node arrays
@@ -205,7 +217,7 @@ struct BtArgs {
     const uint4 *rec;
     const uint32_t *pred;
     const uint32_t *node_pos;
-    const uint32_t *tb;
+    const void *tb;  // u16 cells if lazy_sidx, else u32
     const DpResult *res;
     const float *weights;
     uint32_t n_weights;

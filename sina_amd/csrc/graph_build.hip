@@ -600,7 +600,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
     const int Lp = pl.geom.Lp();
     if (upload_weights(c, p)) return 1;
 
-    const uint64_t tb_budget_cells = c->tb_budget_bytes / 4;
+    const uint64_t tb_budget_cells = c->tb_budget_bytes / tb_cell_bytes(p->insertion == SINA_INSERTION_FORBID);
     // queries per DAG-build + DP launch: one DP wave per query, so a launch should be able to fill
     // every wave slot of the device (256 CUs x 4 SIMDs x up to 4 waves); the trace-back budget cuts
     // it further below

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(64, (B <= 4 ? 4 : (B <= 8 ? 3 : 2)))
 mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ orderv, const uint4 *__restrict__ recv, const uint32_t *__restrict__ predv,
                const uint32_t *__restrict__ node_posv, const uint32_t *__restrict__ succ_minposv,
                const uint8_t *__restrict__ qmaskv, const float *__restrict__ weights, uint32_t n_weights,
-               uint32_t *__restrict__ tbv, float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev,
+               void *__restrict__ tbv, float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev,
                uint64_t edge_stride, uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp,
                float gpe) {
     static_assert(B % 4 == 0, "16-byte accesses per array");
@@ -227,7 +227,9 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     const uint32_t *__restrict__ pred = predv + uniform(d.edge_off);
     const uint32_t *__restrict__ node_pos = node_posv + node_off;
     const uint32_t *__restrict__ succ_minpos = succ_minposv + node_off;
-    uint32_t *__restrict__ tb = tbv + uniform(d.tb_off);
+    // (16-bit trace-back cells except with --insertion=forbid: common.h)
+    using TbCell = std::conditional_t<FORBID, uint32_t, uint16_t>;
+    TbCell *__restrict__ tb = reinterpret_cast<TbCell *>(tbv) + uniform(d.tb_off);
     float *spill = spillv + uniform(d.spill_off) * (size_t)(2 * Lp);
     const uint64_t q_off = uniform(d.q_off);
 
@@ -251,6 +253,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     constexpr bool kLazy = !FORBID;
     constexpr bool kGsi = WEIGHTED || FORBID;
     constexpr uint32_t kTagNone = kLazy ? kTbNone : 0u;
+    constexpr uint32_t kTagOpLast = kLazy ? kTb16OpLast : kTbOpLast;
     // BELOW_INIT (chosen by the host per launch, dp_below_init()): no value of this launch can reach
     // the 1e6 initial value of rows with predecessors, so their first deletion candidate always
     // replaces it and needs no compare.
@@ -379,7 +382,10 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             // then beats the initial value and needs no compare (column 0, initial value 1, excepted)
             constexpr bool FIRST = decltype(first_tag)::value != 0;
             constexpr bool BELOW = decltype(first_tag)::value == 2;
-            const uint32_t p_open = p << 16, p_ext = (p << 16) | kTbExt;  // (type code kTbDel == 0)
+            // trace-back tags of this predecessor: its ordinal in the row's list (16-bit cells) or its
+            // row id (32-bit cells), plus type / Ext bits (type code kTbDel == 0)
+            const uint32_t p_open = kLazy ? (p << kTb16OrdShift) : (p << 16);
+            const uint32_t p_ext = p_open | (kLazy ? kTb16Ext : kTbExt);
             const uint32_t p_match = kLazy ? (p_open | kTbMatch) : p_open;
 #pragma unroll
             for (int k = 0; k < B; k++) {
@@ -455,10 +461,11 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             }
             float svl = lane_shr1(sv[B - 1]);  // value[p][s0-1] lives in the lane to my left
             if (lane == 0) svl = left_of_strip;
+            const uint32_t p_tag = kLazy ? e : p;
             if (e == 0) {
-                relax(std::integral_constant<int, BELOW_INIT ? 2 : 1>{}, p, sv, sg, svl);
+                relax(std::integral_constant<int, BELOW_INIT ? 2 : 1>{}, p_tag, sv, sg, svl);
             } else {
-                relax(std::integral_constant<int, 0>{}, p, sv, sg, svl);
+                relax(std::integral_constant<int, 0>{}, p_tag, sv, sg, svl);
             }
         }
         SH_PROF(3)
@@ -489,7 +496,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         // that keeps the cell-to-cell dependency at add -> min3 -> compare -> select instead of
         // seven dependent operations.  (No NaN and no -0 can occur among these values: they are
         // sums that start at 1 or 1e6.)
-        const uint32_t m_ins = (m << 16) | (kLazy ? kTbIns : 0u);  // tag of an insertion cell
+        const uint32_t m_ins = kLazy ? kTbIns : (m << 16);  // tag of an insertion cell (value_midx = this row)
         auto run_chain = [&](const ChainState &left) {
             ChainState c = left;
 #pragma unroll
@@ -755,8 +762,15 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             uint32_t tc[B];
 #pragma unroll
             for (int k = 0; k < B; k++)
-                tc[k] = kLazy ? (fvm[k] | (oplast[k] ? kTbOpLast : 0u)) : (fvm[k] | fvs[k] | (oplast[k] ? kTbOpLast : 0u));
-            store_cells<B>(tb + (size_t)m * Lp + s0, tc);
+                tc[k] = kLazy ? (fvm[k] | (oplast[k] ? kTagOpLast : 0u)) : (fvm[k] | fvs[k] | (oplast[k] ? kTagOpLast : 0u));
+            if constexpr (kLazy) {
+                uint32_t tp[B / 2];  // two 16-bit cells per word
+#pragma unroll
+                for (int k = 0; k < B / 2; k++) tp[k] = tc[2 * k] | (tc[2 * k + 1] << 16);
+                store_cells<B / 2>(reinterpret_cast<uint32_t *>(tb + (size_t)m * Lp + s0), tp);
+            } else {
+                store_cells<B>(tb + (size_t)m * Lp + s0, tc);
+            }
         }
         if constexpr (DBG) {  // (test hook sina_hip_debug_mesh: the value plane of the launch's first query)
             if (qi == 0) store_cells<B>(dbg_value + (size_t)m * Lp + s0, fv);
@@ -878,7 +892,14 @@ __global__ void backtrack_kernel(BtArgs a) {
     const QDesc d = a.qd[q];
     const uint32_t L = d.L;
     const uint32_t Lp = a.Lp;
-    const uint32_t *tb = a.tb + d.tb_off;
+    // 16-bit cells (type code + predecessor ordinal) or 32-bit cells (explicit indices): common.h
+    const bool lazy = a.lazy_sidx != 0;
+    const uint16_t *tb16 = reinterpret_cast<const uint16_t *>(a.tb) + d.tb_off;
+    const uint32_t *tb32 = reinterpret_cast<const uint32_t *>(a.tb) + d.tb_off;
+    auto cell_at = [&](uint32_t row, uint32_t col) -> uint32_t {
+        const size_t i = (size_t)row * Lp + col;
+        return lazy ? (uint32_t)tb16[i] : tb32[i];
+    };
     const uint4 *rec = a.rec + d.node_off;
     const uint32_t *node_pos = a.node_pos + d.node_off;
     uint32_t *out = a.out_pos + d.q_off;
@@ -928,24 +949,33 @@ __global__ void backtrack_kernel(BtArgs a) {
     sum_weight = sum_weight + mscore(m);
 
     // value_midx of a cell whose deletion extends the gap of predecessor x: gapm_idx[x][col]
-    // (common.h, kTbExt / kTbOpLast) -- follow last predecessors to the row that opened the gap
+    // (common.h, Ext / OpLast) -- follow last predecessors to the row that opened the gap
     const uint32_t *pred = a.pred + d.edge_off;
+    const uint32_t ext_bit = lazy ? kTb16Ext : kTbExt, oplast_bit = lazy ? kTb16OpLast : kTbOpLast;
     auto gapm_idx = [&](uint32_t x, uint32_t col) -> uint32_t {
         for (uint32_t guard = 0; guard < 65536u; ++guard) {
             const uint4 rx = rec[x];
             const uint32_t np = rx.z & 0xffu;
             if (np == 0) return 0u;  // an edge row keeps its initial gapm_idx
             const uint32_t lastp = pred[rx.x + np - 1] & 0xffffu;
-            if (tb[(size_t)x * Lp + col] & kTbOpLast) return lastp;
+            if (cell_at(x, col) & oplast_bit) return lastp;
             x = lastp;
         }
         return 0u;
+    };
+    // the row a cell of row `row` points at, before Ext is resolved: stored (32-bit cells), or the
+    // row itself / 0 / the predecessor with the stored ordinal (16-bit cells)
+    auto midx_raw = [&](uint32_t c, uint32_t row, uint32_t pb) -> uint32_t {
+        if (!lazy) return c >> 16;
+        const uint32_t t = c & kTbTypeMask;
+        if (t == kTbIns) return row;
+        if (t == kTbNone) return 0u;
+        return pred[pb + (c >> kTb16OrdShift)] & 0xffffu;
     };
     // :642-685 (a source node has no predecessors).  Dependent loads dominate: per step the two
     // trace-back cells are inherently serial; the row record / column of the node just reached and
     // its NEXT cell are requested together.
     // value_sidx of cell c = (row, col): stored, or (type-code cells, common.h) what the type implies
-    const bool lazy = a.lazy_sidx != 0;
     auto sidx_of = [&](uint32_t c, uint32_t row, uint32_t col) -> uint32_t {
         if (!lazy) return c & kTbSMask;
         const uint32_t t = c & kTbTypeMask;
@@ -953,24 +983,29 @@ __global__ void backtrack_kernel(BtArgs a) {
         if (t == kTbMatch) return col - 1;
         if (t == kTbDel) return col;
         uint32_t k = col - 1;  // insertion: the gap began where the run of insertion cells to the left ends
-        while (k > 0 && (tb[(size_t)row * Lp + k] & kTbTypeMask) == kTbIns) --k;
+        while (k > 0 && (cell_at(row, k) & kTbTypeMask) == kTbIns) --k;
         return k;
     };
     auto is_deletion_at = [&](uint32_t c, uint32_t col) -> bool {  // value_sidx == own column
         return lazy ? (c & kTbTypeMask) == kTbDel : (c & kTbSMask) == col;
     };
-    uint32_t c = tb[(size_t)m * Lp + s];
-    uint32_t npred_m = rec[m].z & 0xffu;
+    uint32_t c = cell_at(m, s);
+    uint4 rm = rec[m];
+    uint32_t npred_m = rm.z & 0xffu;
     while (s != 0 && npred_m != 0) {
         const uint32_t snew = sidx_of(c, m, s);
-        m = (c & kTbExt) ? gapm_idx(c >> 16, s) : (c >> 16);
+        const uint32_t vm = midx_raw(c, m, rm.x);
+        m = (c & ext_bit) ? gapm_idx(vm, s) : vm;
         if (snew != 0) {
-            const uint32_t c2 = tb[(size_t)m * Lp + snew];
-            if (is_deletion_at(c2, snew)) m = (c2 & kTbExt) ? gapm_idx(c2 >> 16, snew) : (c2 >> 16);
+            const uint32_t c2 = cell_at(m, snew);
+            if (is_deletion_at(c2, snew)) {
+                const uint32_t vm2 = midx_raw(c2, m, rec[m].x);
+                m = (c2 & ext_bit) ? gapm_idx(vm2, snew) : vm2;
+            }
         }
         // everything below depends on m only: one round trip
-        c = tb[(size_t)m * Lp + snew];
-        const uint4 rm = rec[m];
+        c = cell_at(m, snew);
+        rm = rec[m];
         const uint32_t np_pos = node_pos[m];
         npred_m = rm.z & 0xffu;
         pos = width - 1 - np_pos;
