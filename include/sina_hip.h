@@ -167,7 +167,9 @@ typedef struct sina_hip_align_params {
 void sina_hip_align_params_default(sina_hip_align_params *p);
 
 /* A batch of family DAGs in CSR form (node id == topological rank == mesh row).
- * All arrays are concatenated over the nq queries of the batch. */
+ * All arrays are concatenated over the nq queries of the batch.  Limits (the call fails, nothing is
+ * truncated): at most 65535 nodes per DAG, at most 255 predecessors per node, every predecessor id
+ * smaller than its node's id, queries of 1..8191 bases. */
 typedef struct sina_hip_graph_batch {
     uint32_t nq;
     const uint64_t *node_off;  /* [nq+1] into the node arrays                      */

@@ -65,6 +65,11 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
         const uint32_t *po = g->pred_off + no + q;  // N+1 entries, relative to eo
         uint4 *rec = hp->rec.data() + d.node_off;
         for (uint32_t m = 0; m < N; m++) {
+            // (what the row record and the kernel's topological sweep can represent: fail, do not truncate)
+            if (po[m + 1] < po[m] || po[m + 1] - po[m] > 255u)
+                SH_FAIL("align_graphs: a node has more than 255 predecessors (or pred_off is not ascending)");
+            for (uint32_t e = po[m]; e < po[m + 1]; e++)
+                if (g->pred[eo + e] >= m) SH_FAIL("align_graphs: predecessor ids must be smaller than the node's id");
             uint32_t wbits;
             memcpy(&wbits, &g->node_weight[no + m], 4);
             rec[m].x = po[m];
@@ -83,14 +88,18 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
                 if (m - p > (uint32_t)kFarLds) rec[p].z |= kRecFence;
             }
         }
-        // LDS slots by liveness, first free slot wins; a row that finds none is spilled
+        // LDS slots by liveness, first free slot wins; a row that finds none is spilled.  Rows are
+        // allocated in independent segments (dp_slot_segment, common.h), like the device DAG build does.
         uint32_t nsp = 0;
         uint32_t free_at[64];
-        for (int x = 0; x < W; x++) free_at[x] = 0;
+        const uint32_t seg_len = dp_slot_segment(N);
         for (uint32_t m = 0; m < N; m++) {
+            if (m % seg_len == 0)
+                for (int x = 0; x < W; x++) free_at[x] = 0;
             if (rec[m].z & kRecSink) continue;  // w stays kRowNone
             int slot = -1;
-            if (!(rec[m].z & kRecFence))  // (a row with a successor beyond kFarLds must be a spill row)
+            const uint32_t seg_end = std::min<uint32_t>(N, (m / seg_len + 1) * seg_len);
+            if (!(rec[m].z & kRecFence) && last[m] < seg_end)  // (else: always a spill row)
                 for (int x = 0; x < W; x++)
                     if (free_at[x] <= m) {
                         slot = x;
@@ -391,7 +400,7 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
     SH_CHECK(hipStreamCreateWithFlags(&c->st->heavy, hipStreamNonBlocking));
     for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
     c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 0) * 1024;
-    c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 56) << 30;
+    c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 32) << 30;
     memset(&c->st->stats, 0, sizeof(c->st->stats));
     *ctx = c;
     return 0;

@@ -135,6 +135,12 @@ constexpr uint32_t kRowSpilled = 0x80000000u;
 constexpr uint32_t kPredSpilled = 0x80000000u;
 constexpr uint32_t kMaxSpillRows = 32768;  // 15 bits in a predecessor entry
 constexpr int kFarLds = 192;   // a row with a successor further away than this never takes an LDS slot
+// The slot allocators cut the rows into independent segments of this many rows (at most 16 of them):
+// a row whose last successor lies in a later segment is kept in a spill row (graph_build.hip, step 7).
+__host__ __device__ inline uint32_t dp_slot_segment(uint32_t n_rows) {
+    const uint32_t s = (n_rows + 15u) / 16u;
+    return s < 256u ? 256u : s;
+}
 
 // What a strip of the DP leaves behind per row for the strip to its right (mesh_dp.hip): the value of
 // its last column (the match candidate's source for the next strip's first column) and the exit

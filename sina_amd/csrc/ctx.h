@@ -59,7 +59,7 @@ struct sina_hip_ctx {
     float wtab_fs_weight = NAN;  // fs_weight the device weight table was computed for
 
     size_t lds_budget = 0;  // LDS per DP workgroup; 0 = what keeps the register-limited occupancy (dp_default_lds_budget)
-    uint64_t tb_budget_bytes = (uint64_t)56 << 30;
+    uint64_t tb_budget_bytes = (uint64_t)32 << 30;
 
     static constexpr int kNumScratch = 35;
     static_assert(kNumScratch <= 64, "sina_hip_store::cap_hint is too short");

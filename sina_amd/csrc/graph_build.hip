@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
     // tabm[c][j]: mask (8) | local node index (5) << 8 | first base of the member << 13 ; 0 = absent
     uint16_t *tabm = reinterpret_cast<uint16_t *>(rc + kTC);                // [kTC][FS]
     uint16_t *tabp = tabm + (size_t)kTC * FS;                               // [kTC][FS] previous node, 0xFFFF none
+    uint8_t *ncolT = reinterpret_cast<uint8_t *>(tabp + (size_t)kTC * FS);  // [kTC * 32] tile column of every node of the tile
 
     uint32_t *sz = a.sizes + 4 * (size_t)q;
     for (uint32_t j = tid; j < F; j += kGT) {
@@ -264,6 +265,8 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         GP(4)
         const uint32_t tn = block_exscan(nn, nbaseT, tc, s_tmp);
         const uint32_t te = block_exscan(rc, ebaseT, tc, s_tmp);
+        for (uint32_t c = tid; c < tc; c += kGT)
+            for (uint32_t k = 0; k < nn[c]; k++) ncolT[nbaseT[c] + k] = (uint8_t)c;
         GP(5)
         // 4. node of every base's predecessor base
         for (uint32_t idx = tid; idx < F * (uint32_t)kTC; idx += kGT) {
@@ -287,79 +290,87 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         }
         __syncthreads();
         GP(6)
-        // 5. node records + sorted unique predecessor lists
-        for (uint32_t c = tid; c < tc; c += kGT) {
+        // 5. node records + sorted unique predecessor lists: one thread per NODE of the tile (a column
+        // has 1.7 nodes on average and up to five or so: threads per column would wait for the widest
+        // column of their wave).  One pass over the column's F members gives the node its member
+        // count, mask, the raw edge entries of the column's earlier nodes (= where its CSR segment
+        // starts) and its predecessors.
+        for (uint32_t ln = tid; ln < tn; ln += kGT) {
+            const uint32_t c = ncolT[ln];
+            const uint32_t k = ln - nbaseT[c];
             const uint16_t *rowm = tabm + c * FS;
             const uint16_t *rowp = tabp + c * FS;
-            const uint32_t knodes = nn[c];
             const uint32_t pos = cposT[c];
-            uint32_t seg = E + ebaseT[c];
-            for (uint32_t k = 0; k < knodes; k++) {
-                const uint32_t node = N + nbaseT[c] + k;
-                uint32_t cnt = 0, np = 0, rawk = 0, mask = 0;
-                // sorted unique predecessor ids, first in registers (8 cover all but freak
-                // columns): no read-modify-write round trips to the CSR segment in HBM
-                uint32_t pl[8];
+            const uint32_t node = N + ln;
+            uint32_t cnt = 0, np = 0, rawk = 0, raw_before = 0, mask = 0;
+            // sorted unique predecessor ids, first in registers (8 cover all but freak
+            // columns): no read-modify-write round trips to the CSR segment in HBM
+            uint32_t pl[8];
 #pragma unroll
-                for (int t8 = 0; t8 < 8; t8++) pl[t8] = 0xFFFFFFFFu;
-                bool overflow = false;
-                for (uint32_t j = 0; j < F; j++) {
-                    const uint32_t t = rowm[j];
-                    if ((t & 0xFFu) == 0 || ((t >> 8) & 31u) != k) continue;
-                    mask = t & 0xFFu;
-                    cnt++;
-                    if (t & (1u << 13)) continue;
-                    rawk++;
-                    uint32_t x = rowp[j];
+            for (int t8 = 0; t8 < 8; t8++) pl[t8] = 0xFFFFFFFFu;
+            bool overflow = false;
+            uint32_t recent = 0xFFFFFFFFu;  // (most members of a node come from the same previous node)
+            for (uint32_t j = 0; j < F; j++) {
+                const uint32_t t = rowm[j];
+                if ((t & 0xFFu) == 0) continue;
+                const uint32_t lj = (t >> 8) & 31u;
+                const bool has_prev = !(t & (1u << 13));
+                if (lj < k) raw_before += has_prev ? 1u : 0u;
+                if (lj != k) continue;
+                mask = t & 0xFFu;
+                cnt++;
+                if (!has_prev) continue;
+                rawk++;
+                uint32_t x = rowp[j];
+                if (x == recent) continue;
+                recent = x;
 #pragma unroll
-                    for (int t8 = 0; t8 < 8; t8++) {  // bubble x into place; a duplicate turns into the pad value
-                        const uint32_t y = pl[t8];
-                        if (x == y) x = 0xFFFFFFFFu;
-                        const bool sw = x < y;
-                        pl[t8] = sw ? x : y;
-                        x = sw ? y : x;
-                    }
-                    overflow = overflow || (x != 0xFFFFFFFFu);
+                for (int t8 = 0; t8 < 8; t8++) {  // bubble x into place; a duplicate turns into the pad value
+                    const uint32_t y = pl[t8];
+                    if (x == y) x = 0xFFFFFFFFu;
+                    const bool sw = x < y;
+                    pl[t8] = sw ? x : y;
+                    x = sw ? y : x;
                 }
-                if (node < a.ncap) {
-                    if (!overflow) {
+                overflow = overflow || (x != 0xFFFFFFFFu);
+            }
+            const uint32_t seg = E + ebaseT[c] + raw_before;
+            if (node < a.ncap) {
+                if (!overflow) {
 #pragma unroll
-                        for (int t8 = 0; t8 < 8; t8++) {
-                            const uint32_t pa = pl[t8];
-                            if (pa != 0xFFFFFFFFu) {
-                                pred[seg + np] = pa;
-                                np++;
-                                atomicMin(&smin[pa], pos);
-                                atomicMax(&last[pa], node);
-                            }
-                        }
-                    } else {  // more than 8 distinct predecessors: insertion sort in the segment itself
-                        for (uint32_t j = 0; j < F; j++) {
-                            const uint32_t t = rowm[j];
-                            if ((t & 0xFFu) == 0 || ((t >> 8) & 31u) != k || (t & (1u << 13))) continue;
-                            const uint32_t pa = rowp[j];
-                            uint32_t x = 0;
-                            while (x < np && pred[seg + x] < pa) x++;
-                            if (x < np && pred[seg + x] == pa) continue;
-                            for (uint32_t y = np; y > x; y--) pred[seg + y] = pred[seg + y - 1];
-                            pred[seg + x] = pa;
+                    for (int t8 = 0; t8 < 8; t8++) {
+                        const uint32_t pa = pl[t8];
+                        if (pa != 0xFFFFFFFFu) {
+                            pred[seg + np] = pa;
                             np++;
                             atomicMin(&smin[pa], pos);
                             atomicMax(&last[pa], node);
                         }
                     }
+                } else {  // more than 8 distinct predecessors: insertion sort in the segment itself
+                    for (uint32_t j = 0; j < F; j++) {
+                        const uint32_t t = rowm[j];
+                        if ((t & 0xFFu) == 0 || ((t >> 8) & 31u) != k || (t & (1u << 13))) continue;
+                        const uint32_t pa = rowp[j];
+                        uint32_t x = 0;
+                        while (x < np && pred[seg + x] < pa) x++;
+                        if (x < np && pred[seg + x] == pa) continue;
+                        for (uint32_t y = np; y > x; y--) pred[seg + y] = pred[seg + y - 1];
+                        pred[seg + x] = pa;
+                        np++;
+                        atomicMin(&smin[pa], pos);
+                        atomicMax(&last[pa], node);
+                    }
                 }
-                if (node < a.ncap) {
-                    uint4 r;
-                    r.x = seg;
-                    r.y = __float_as_uint(wt[cnt]);
-                    r.z = (np & 0xFFu) | (mask << 8);
-                    r.w = kRowNone;
-                    rec[node] = r;
-                    node_pos[node] = pos;
-                }
-                seg += rawk;
+                uint4 r;
+                r.x = seg;
+                r.y = __float_as_uint(wt[cnt]);
+                r.z = (np & 0xFFu) | (mask << 8);
+                r.w = kRowNone;
+                rec[node] = r;
+                node_pos[node] = pos;
             }
+            (void)rawk;
         }
         __syncthreads();
         for (uint32_t j = tid; j < F; j += kGT) {
@@ -393,44 +404,53 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
     __syncthreads();
     GP(9)
     // 7. where every finished DP row is kept for its successors: LDS slots by liveness (first slot
-    // whose row has seen its last successor), otherwise a spill row.  Inherently sequential over
-    // the rows; one wave walks them 64 at a time (coalesced loads, wave-uniform bookkeeping).
-    if (tid < 64) {
-        // lane x < W holds free_at[x] = the last successor of the row in slot x (0: empty);
-        // "first free slot" is then one vector compare + find-first-set on the ballot
-        uint32_t fa = ((int)tid < a.W) ? 0u : 0xFFFFFFFFu;
+    // whose row has seen its last successor), otherwise a spill row.  The greedy is sequential over
+    // the rows, so the rows are cut into up to 16 segments that are allocated independently, one LANE
+    // per segment: a row whose last successor lies in a later segment is kept in a spill row (three
+    // or so per boundary), every segment starts with all slots free.  Spill rows are numbered in row
+    // order (per-segment counts, prefix sum).  tests/util.py row_store_model states the same rule.
+    const uint32_t seg_len = dp_slot_segment(N);
+    const uint32_t n_seg = (N + seg_len - 1) / seg_len;
+    if (tid < n_seg) {
+        uint32_t fa[8];  // last successor of the row in slot x (0: empty)
+#pragma unroll
+        for (int x = 0; x < 8; x++) fa[x] = (x < a.W) ? 0u : 0xFFFFFFFFu;
         uint32_t nsp = 0;
-        for (uint32_t m0 = 0; m0 < N; m0 += 64) {
-            const uint32_t mi = m0 + tid;
-            const uint32_t l_c = (mi < N) ? last[mi] : 0u;
-            const uint32_t z_c = (mi < N) ? rec[mi].z : kRecSink;
-            const uint32_t s_c = (z_c & kRecSink) ? 1u : ((z_c & kRecFence) ? 2u : 0u);
-            uint32_t myw = kRowNone;
-            const uint32_t cnt = min(64u, N - m0);
-            for (uint32_t i = 0; i < cnt; i++) {
-                // wave-uniform copies (v_readlane): the bookkeeping below runs on the scalar unit
-                const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)l_c, (int)i);
-                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)s_c, (int)i);
-                if (sk == 1) continue;
-                const uint32_t m = m0 + i;
-                const unsigned long long free_mask = __ballot(fa <= m);
-                uint32_t wv;
-                if (sk == 0 && free_mask != 0ull) {  // (a row with a successor beyond kFarLds must be a spill row)
-                    const uint32_t slot = (uint32_t)__ffsll((long long)free_mask) - 1u;
-                    fa = (tid == slot) ? li : fa;
-                    wv = slot;
-                } else {
-                    wv = kRowSpilled | nsp++;
-                }
-                if (tid == i) myw = wv;
+        const uint32_t b = tid * seg_len, e = min(N, b + seg_len);
+        for (uint32_t m = b; m < e; m++) {
+            const uint32_t z = rec[m].z, l = last[m];
+            uint32_t wv = kRowNone;
+            if (!(z & kRecSink)) {
+                // (a row with a successor beyond kFarLds, or in a later segment, is always a spill row)
+                const bool may_slot = !(z & kRecFence) && l < e;
+                uint32_t slot = 8;
+#pragma unroll
+                for (int x = 7; x >= 0; x--) slot = (may_slot && fa[x] <= m) ? (uint32_t)x : slot;
+#pragma unroll
+                for (int x = 0; x < 8; x++) fa[x] = (slot == (uint32_t)x) ? l : fa[x];
+                wv = slot < 8 ? slot : (kRowSpilled | nsp++);
             }
-            if (mi < N) rec[mi].w = myw;
+            rec[m].w = wv;
+        }
+        s_ids[tid] = nsp;  // (s_ids is free by now: spill rows of my segment)
+    }
+    __syncthreads();
+    {   // spill rows get their final numbers: segment base + number within the segment
+        uint32_t tot = 0;
+        for (uint32_t g = 0; g < n_seg; g++) tot += s_ids[g];
+        for (uint32_t i = tid; i < N; i += kGT) {
+            const uint32_t w = rec[i].w;
+            if (w != kRowNone && (w & kRowSpilled)) {
+                uint32_t base = 0;
+                for (uint32_t g = 0; g < i / seg_len; g++) base += s_ids[g];
+                rec[i].w = w + base;
+            }
         }
         if (tid == 0) {
             sz[0] = N;
             sz[1] = E;
-            sz[2] = nsp;
-            sz[3] = (nsp > kMaxSpillRows) ? 4u : 0u;
+            sz[2] = tot;
+            sz[3] = (tot > kMaxSpillRows) ? 4u : 0u;
         }
     }
     __syncthreads();
@@ -456,7 +476,8 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
 size_t graph_lds_bytes(uint32_t width, uint32_t max_family) {
     const size_t nwords = (width + 31) / 32;
     const size_t fs = (max_family + 1) | 1u;
-    return ((6 * nwords + 15) & ~(size_t)15) + (size_t)kTC * (4 + 4 + 4 + 1 + 1) + 2 * 2 * (size_t)kTC * fs + 64;
+    return ((6 * nwords + 15) & ~(size_t)15) + (size_t)kTC * (4 + 4 + 4 + 1 + 1) + 2 * 2 * (size_t)kTC * fs +
+           (size_t)kTC * 32 + 64;
 }
 
 }  // namespace

@@ -465,7 +465,11 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                 }
             };
             handover found, aligned;
-            const uint32_t n_find = inflight >= 3 ? 2 : 1, n_align = inflight, n_sink = 1;
+            // (SINA_HOST_FINDERS: famfinder threads; they run ahead by `found.cap` finished batches)
+            const char *nf_env = getenv("SINA_HOST_FINDERS");
+            const uint32_t n_find = nf_env ? (uint32_t)std::max(1, atoi(nf_env)) : (inflight >= 4 ? 3 : (inflight >= 3 ? 2 : 1));
+            const uint32_t n_align = inflight, n_sink = 1;
+            found.cap = n_find;
             found.producers = (int)n_find;
             aligned.producers = (int)n_align;
             auto on_error = [&] {

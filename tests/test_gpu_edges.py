@@ -202,3 +202,30 @@ def test_scoring_parameter_sets_planes(oracle, gpu_ctx, scores):
         q, qm = _cseq("ins%d" % length, qmask)
         _planes_equal(oracle, gpu_ctx, fam, q, qm, refs.width, match_score=ms, mismatch_score=mms,
                       gap_penalty=gp, gap_ext_penalty=gpe)
+
+
+def test_malformed_graphs_are_rejected(oracle, gpu_ctx):
+    """sina_hip_align_graphs validates host-supplied DAGs instead of truncating them: a predecessor
+    that is not an earlier node, or more than 255 predecessors of one node, is an error."""
+    refs = synth.make_refs(40, length=100, width=700, seed=332)
+    cs = util.cseqs_from_refs(refs)
+    g = util.graph_dict([cs[0], cs[1], cs[2]])
+    q = np.ones(30, np.uint8)
+    qoff = np.array([0, 30], np.uint64)
+    bad = dict(g)
+    bad["pred"] = g["pred"].copy()
+    m = int(np.flatnonzero(np.diff(g["pred_off"]) > 0)[0])
+    bad["pred"][g["pred_off"][m]] = m            # a node as its own predecessor
+    with pytest.raises(capi.SinaHipError):
+        gpu_ctx.align_graphs(gpu_ctx.graph_batch([bad], refs.width), q, qoff, gpu_ctx.params())
+    n = 300                                       # node 299 with 256 predecessors
+    poff = np.zeros(n + 1, np.uint32)
+    poff[1:299] = np.arange(0, 298)               # a chain: node i <- i-1
+    npred_last = 256
+    pred = list(range(0, 297)) + list(range(0, npred_last))
+    poff[299] = 297
+    poff[300] = 297 + npred_last
+    wide = dict(n=n, pos=np.arange(n, dtype=np.uint32), mask=np.ones(n, np.uint8), weight=np.ones(n, np.float32),
+                pred_off=poff, pred=np.array(pred, np.uint32), succ_minpos=np.arange(1, n + 1, dtype=np.uint32))
+    with pytest.raises(capi.SinaHipError):
+        gpu_ctx.align_graphs(gpu_ctx.graph_batch([wide], 400), q, qoff, gpu_ctx.params())

@@ -79,20 +79,26 @@ def f32_bits(a):
 def row_store_model(pred_off, pred, n_slots, far_lds=192):
     """Where mesh_dp_kernel keeps each finished DP row for its successors (sina_amd/csrc/common.h):
     0xFFFFFFFF nowhere (no successors), an LDS slot number (first slot whose occupant has seen its
-    last successor), or 0x80000000 | spill row index when no slot is free or some successor is more
-    than far_lds rows away."""
+    last successor), or 0x80000000 | spill row index when no slot is free, some successor is more
+    than far_lds rows away, or the last successor lies in a later allocation segment (the rows are
+    allocated in independent segments of max(256, ceil(n / 16)) rows, every segment starting with all
+    slots free: graph_build.hip step 7)."""
     n = len(pred_off) - 1
     last = np.zeros(n, np.int64)
     node = np.repeat(np.arange(n), np.diff(pred_off))
     np.maximum.at(last, np.asarray(pred, np.int64), node)
     out = np.full(n, 0xFFFFFFFF, np.uint32)
+    seg_len = max(256, (n + 15) // 16)
     free_at = [0] * n_slots
     nsp = 0
     for m in range(n):
+        if m % seg_len == 0:
+            free_at = [0] * n_slots
         if last[m] == 0:
             continue
         slot = -1
-        if last[m] - m <= far_lds:
+        seg_end = min(n, (m // seg_len + 1) * seg_len)
+        if last[m] - m <= far_lds and last[m] < seg_end:
             for x in range(n_slots):
                 if free_at[x] <= m:
                     slot = x
