@@ -202,7 +202,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         SH_CHECK(hipEventRecord(c->ev[0], hl.stream()));
         if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, hl.stream())) return 1;
         SH_CHECK(hipEventRecord(c->ev[1], hl.stream()));
-        if (hl.done(s)) return 1;
+        if (hl.done()) return 1;
         if (token.owns_lock()) SH_CHECK(hipEventSynchronize(c->ev[1]));
     }
     BtArgs b;

@@ -134,7 +134,7 @@ namespace sina_hip {
 // kernel at a time is faster for both (measured: DP 24 instead of 33 ms per launch inside the
 // pipeline).  So every such kernel is queued on the store's one "heavy" stream -- a FIFO the GPU
 // works off without the host in between: the kernel waits (event) for what its context queued before
-// it, and the context's own stream waits (event) for the kernel.  Thin, latency-bound work (copies,
+// it; the host thread that queued it waits for its end.  Thin, latency-bound work (copies,
 // the backtrack walk) stays on the contexts' streams and runs beside whatever is resident.
 // SINA_HIP_SERIALIZE=0 (experiments): every kernel on its own context's stream again, DP launches
 // taking turns through a host-side token.
@@ -159,12 +159,16 @@ struct heavy_launch {
         failed = failed || hipStreamWaitEvent(hs, c->ev[10], 0) != hipSuccess;
     }
     hipStream_t stream() const { return hs; }
-    // after the launches: `next` (a stream of the context) continues behind them
-    int done(hipStream_t next) {
-        if (hs == next) return failed ? 1 : 0;
+    // After the launches: the HOST waits for them.  (Never let a context stream wait for the heavy
+    // stream on the GPU side: streams share hardware queues once there are more streams than queues,
+    // a queue blocked on the heavy stream would hold up another context's uploads that an EARLIER
+    // heavy kernel is waiting for -- a deadlock, seen with five batches in flight.  The heavy stream
+    // waits for context streams, context streams wait for nothing but themselves.)
+    int done() {
+        if (hs == own) return failed ? 1 : 0;
         failed = failed || hipEventRecord(c->ev[11], hs) != hipSuccess;
         if (lk.owns_lock()) lk.unlock();
-        failed = failed || hipStreamWaitEvent(next, c->ev[11], 0) != hipSuccess;
+        failed = failed || hipEventSynchronize(c->ev[11]) != hipSuccess;
         if (failed) set_error("heavy_launch: event hand-over failed");
         return failed ? 1 : 0;
     }

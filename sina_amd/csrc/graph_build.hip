@@ -567,7 +567,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
             hipLaunchKernelGGL(family_graph_kernel, dim3(bq), dim3(kGT), glds, hl.stream(), ga);
             SH_CHECK(hipGetLastError());
             SH_CHECK(hipEventRecord(c->ev[7], hl.stream()));
-            if (hl.done(s)) return 1;
+            if (hl.done()) return 1;
         }
         // (wait for the kernels FIRST: a copy to pageable memory queued behind running kernels waits
         // inside the runtime, under locks other threads' launches need -- see HostBuf in common.h)

@@ -616,7 +616,7 @@ static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint6
         SH_CHECK(hipGetLastError());
     }
     SH_CHECK(hipEventRecord(c->ev[5], hs));
-    return hl.done(s);
+    return hl.done();
 }
 
 }  // namespace sina_hip
