@@ -256,13 +256,26 @@ struct rcell {
     uint32_t gaps_max;
 };
 
-void ref_mesh_compute_simple(void *r, const uint32_t *qab, uint32_t L, float ms, float mms, float gp,
-                             float gpe, rcell *cells) {
-    rdag &G = ((rgraph *)r)->g;
-    std::vector<aligned_base> q = unpack(qab, L);
-    scoring_scheme_simple s(ms, mms, gp, gpe);
+} /* extern "C" (the cell loop below is a template over the REAL scoring scheme classes) */
+
+/* The cell loop of compute_node_simple::calc over transition_simple / transition_aspace_aware
+ * (src/mesh.h:307-374,403-437,455-502) on the REAL dag, calling the REAL scoring scheme for every
+ * operation.  The loop itself is harness code (mesh.h needs Boost / TBB headers the image lacks);
+ * what it pins is the arithmetic, the order of candidates and the DAG it runs on.
+ * forbid != 0: transition_aspace_aware (--insertion=forbid): an insertion run may be at most
+ * max_insert = min over successors of (pos(succ)) - pos(m) - 1 columns long (:480-489). */
+template <typename SCHEME>
+static void mesh_cells(rdag &G, const std::vector<aligned_base> &q, SCHEME &s, int forbid, rcell *cells) {
+    const uint32_t L = (uint32_t)q.size();
     for (rdag::iterator m = G.begin(); m != G.end(); ++m) {
         const uint32_t midx = get_node_id(G, m);
+        uint32_t max_insert = 0;
+        if (forbid) {
+            unsigned int min_mpos = 1000000;
+            for (rdag::pn_iterator n = m.next_begin(); n != m.next_end(); ++n)
+                min_mpos = std::min<unsigned int>(min_mpos, n->getPosition());
+            max_insert = (uint32_t)(int)(min_mpos - m->getPosition() - 1);
+        }
         for (uint32_t sidx = 0; sidx < L; sidx++) {
             rcell d;
             const bool edge = (prev_begin(G, m) == prev_end(G, m)) || sidx == 0;
@@ -292,14 +305,29 @@ void ref_mesh_compute_simple(void *r, const uint32_t *qab, uint32_t L, float ms,
             if (sidx > 0) {
                 const uint32_t si = sidx - 1;
                 const rcell &src = cells[(size_t)midx * L + si];
-                if (src.gaps_val != src.value) {
+                bool inserted = true;
+                if (!forbid) {
+                    if (src.gaps_val != src.value) {
+                        d.gaps_val = s.insertion(src.value, *m, q[sidx]);
+                        d.gaps_idx = si;
+                    } else {
+                        d.gaps_val = s.insertion_ext(src.gaps_val, *m, q[sidx], si - src.gaps_idx);
+                        d.gaps_idx = src.gaps_idx;
+                    }
+                } else if (max_insert < 1) {
+                    inserted = false;
+                } else if (src.gaps_val != src.value) {
                     d.gaps_val = s.insertion(src.value, *m, q[sidx]);
                     d.gaps_idx = si;
-                } else {
+                    d.gaps_max = max_insert - 1;
+                } else if (src.gaps_max > 0) {
                     d.gaps_val = s.insertion_ext(src.gaps_val, *m, q[sidx], si - src.gaps_idx);
                     d.gaps_idx = src.gaps_idx;
+                    d.gaps_max = src.gaps_max - 1;
+                } else {
+                    inserted = false;
                 }
-                if (d.gaps_val <= d.value) {
+                if (inserted && d.gaps_val <= d.value) {
                     d.value = d.gaps_val;
                     d.value_sidx = d.gaps_idx;
                     d.value_midx = midx;
@@ -317,6 +345,28 @@ void ref_mesh_compute_simple(void *r, const uint32_t *qab, uint32_t L, float ms,
             cells[(size_t)midx * L + sidx] = d;
         }
     }
+}
+
+extern "C" {
+
+/* weights == NULL: scoring_scheme_simple, else scoring_scheme_weighted over those column weights */
+void ref_mesh_compute(void *r, const uint32_t *qab, uint32_t L, float ms, float mms, float gp, float gpe,
+                      const float *weights, uint32_t nw, int forbid, rcell *cells) {
+    rdag &G = ((rgraph *)r)->g;
+    std::vector<aligned_base> q = unpack(qab, L);
+    if (!weights) {
+        scoring_scheme_simple s(ms, mms, gp, gpe);
+        mesh_cells(G, q, s, forbid, cells);
+    } else {
+        std::vector<float> w(weights, weights + nw);
+        scoring_scheme_weighted s(ms, mms, gp, gpe, w);
+        mesh_cells(G, q, s, forbid, cells);
+    }
+}
+
+void ref_mesh_compute_simple(void *r, const uint32_t *qab, uint32_t L, float ms, float mms, float gp,
+                             float gpe, rcell *cells) {
+    ref_mesh_compute(r, qab, L, ms, mms, gp, gpe, NULL, 0, 0, cells);
 }
 
 } /* extern "C" */

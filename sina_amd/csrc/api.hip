@@ -227,7 +227,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     if (c->h_out.reserve(sizeof(sina_hip_align_out) * bq) || c->h_out_pos.reserve(4 * std::max<uint64_t>(nqm, 1))) return 1;
     SH_CHECK(hipMemcpyAsync(c->h_out.p, c->out.p, sizeof(sina_hip_align_out) * bq, hipMemcpyDeviceToHost, s));
     SH_CHECK(hipMemcpyAsync(c->h_out_pos.p, c->out_pos.p, 4 * nqm, hipMemcpyDeviceToHost, s));
-    SH_CHECK(hipStreamSynchronize(s));
+    SH_CHECK(wait_stream(c, s));
     memcpy(out, c->h_out.p, sizeof(sina_hip_align_out) * bq);
     memcpy(out_pos, c->h_out_pos.p, 4 * nqm);
     float ms = 0;

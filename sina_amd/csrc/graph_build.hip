@@ -571,9 +571,9 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         }
         // (wait for the kernels FIRST: a copy to pageable memory queued behind running kernels waits
         // inside the runtime, under locks other threads' launches need -- see HostBuf in common.h)
-        SH_CHECK(hipStreamSynchronize(s));
+        SH_CHECK(wait_stream(c, s));
         SH_CHECK(hipMemcpyAsync(bg->sizes.data(), c->g_sizes.p, 16 * (uint64_t)bq, hipMemcpyDeviceToHost, s));
-        SH_CHECK(hipStreamSynchronize(s));
+        SH_CHECK(wait_stream(c, s));
         float gms = 0;
         SH_CHECK(hipEventElapsedTime(&gms, c->ev[6], c->ev[7]));
         {

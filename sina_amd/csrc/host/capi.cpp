@@ -335,10 +335,12 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                     t.seqno = q;
                     const std::string name = "query" + std::to_string(q);
                     t.input_sequence = new cseq(name.c_str());
-                    for (uint64_t x = qoff[q]; x < qoff[q + 1]; x++)
-                        t.input_sequence->append(
-                            aligned_base((uint32_t)(x - qoff[q]), base_iupac::from_mask(qmask[x])));
-                    t.input_sequence->setWidth((uint32_t)(qoff[q + 1] - qoff[q]));
+                    // (an unaligned query: base i in column i -- built in one piece, not by per-base appends)
+                    std::vector<aligned_base> ab((size_t)(qoff[q + 1] - qoff[q]));
+                    for (size_t x = 0; x < ab.size(); x++)
+                        ab[x] = aligned_base::from_raw((uint32_t)x | ((uint32_t)qmask[qoff[q] + x] << 24));
+                    t.input_sequence->setAlignedBases(ab);
+                    t.input_sequence->setWidth((uint32_t)ab.size());
                 });
             }
             const auto a = std::chrono::steady_clock::now();

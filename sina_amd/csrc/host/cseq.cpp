@@ -1,6 +1,7 @@
-// Host-side cseq container: behaviour of src/cseq.cpp / src/aligned_base.cpp,
-// implemented from the specs in SURVEY.md (A.4 "container rule", A.5 NAST
-// fix-up).  Index-based, flat; no code shared with the reference.
+// Host-side cseq container: behaviour of src/cseq.cpp / src/aligned_base.cpp, written from the specs
+// in SURVEY.md (A.4 "container rule", A.5 NAST fix-up) as flat, index-based code.  The log and
+// exception texts are the reference's own (they are part of the result: align_log_slv); the
+// structure is not.
 #include "cseq.h"
 
 #include <algorithm>
@@ -166,85 +167,83 @@ std::ostream &operator<<(std::ostream &out, const cseq_base &c) { return out << 
 // range is too small, the run swallows neighbouring bases, always towards the
 // nearer free column, until it fits.
 void cseq_base::fix_duplicate_positions(std::ostream &log, bool lowercase, bool remove) {
-    idx_type total_inserts = 0, longest_insert = 0, orig_inserts = 0;
     if (remove) log << "insertion=remove not implemented, using shift; ";
-
     const long n = (long)bases.size();
     auto col = [&](long i) { return bases[(size_t)i].getPosition(); };
-    long anchor = 0;
-    for (long cur = 0; cur < n; ++cur) {
-        if (col(anchor) == col(cur)) {
-            if (cur + 1 != n) continue;  // still inside a run
-            ++cur;                       // run reaches the end of the sequence
-        }
-        idx_type run = (idx_type)(cur - anchor - 1);
-        if (run == 0) {
-            anchor = cur;
+    // A placement problem: the bases [first, last] must go into the free columns [lo, hi).
+    struct span {
+        long first, last;
+        idx_type lo, hi;
+        idx_type need() const { return (idx_type)(last - first + 1); }
+        idx_type room() const { return hi - lo; }
+    };
+    // Nearest free column left of the span, and the base from which everything up to the span
+    // would have to move along with it: bases that sit column to column with their right neighbour
+    // are walked over.  -1: the alignment's left edge is reached without finding one.
+    auto free_left = [&](const span &s, long *from) -> int {
+        *from = s.first;
+        if (s.first == 0) return s.lo > 0 ? (int)(s.lo - 1) : -1;
+        if (col(s.first - 1) + 1 < s.lo) return (int)(s.lo - 1);
+        long l = s.first - 1;
+        while (l != 0 && col(l - 1) + 1 >= col(l)) --l;
+        *from = l;
+        return (int)(col(l) - 1u);
+    };
+    // ... and the same to the right (-1: the alignment's right edge)
+    auto free_right = [&](const span &s, long *upto) -> int {
+        *upto = s.last;
+        if (s.last + 1 == n) return s.hi < alignment_width ? (int)s.hi : -1;
+        if (col(s.last + 1) > s.hi) return (int)s.hi;
+        long r = s.last + 1;
+        while (r + 1 != n && col(r) + 1 >= col(r + 1)) ++r;
+        *upto = r;
+        return (int)(col(r) + 1);
+    };
+
+    idx_type placed_total = 0, placed_longest = 0, last_run_before_shifting = 0;
+    for (long anchor = 0; anchor < n;) {
+        // the bases after `anchor` that share its column are an insertion
+        long after = anchor + 1;
+        while (after < n && col(after) == col(anchor)) ++after;
+        if (after == anchor + 1) {
+            anchor = after;
             continue;
         }
-        idx_type free_begin = col(anchor) + 1;                          // first free column
-        idx_type free_end = (cur == n) ? alignment_width : col(cur);    // first taken column
-        long first = anchor + 1, last = cur - 1;                        // the run [first, last]
-        orig_inserts = run;
-        if (free_end - free_begin < run) {
-            log << "shifting bases to fit in " << run << " bases at pos " << free_begin << " to " << free_end
-                << ";";
-            while (free_end - free_begin < run) {
-                // nearest free column to the left of the range (-1: none)
-                int left_gap;
-                long l = first;
-                if (l == 0) {
-                    left_gap = free_begin > 0 ? (int)(free_begin - 1) : -1;
-                } else if (col(l - 1) + 1 < free_begin) {
-                    left_gap = (int)(free_begin - 1);
+        span s{anchor + 1, after - 1, col(anchor) + 1, after == n ? alignment_width : col(after)};
+        last_run_before_shifting = s.need();
+        if (s.room() >= s.need()) {
+            s.lo = s.hi - s.need();  // enough room: right-aligned in the free range
+        } else {
+            log << "shifting bases to fit in " << s.need() << " bases at pos " << s.lo << " to " << s.hi << ";";
+            while (s.room() < s.need()) {  // grow towards the nearer free column, taking the bases in between along
+                long from, upto;
+                const int lgap = free_left(s, &from), rgap = free_right(s, &upto);
+                const bool to_left = rgap == -1 || (lgap != -1 && (idx_type)(s.lo - (idx_type)lgap) <=
+                                                                      (idx_type)((idx_type)rgap - (s.hi - 1)));
+                if (to_left && lgap == -1)
+                    throw std::runtime_error("ERROR: no space to left and right?? sequence longe than alignment?!");
+                if (to_left) {
+                    s.first = from;
+                    s.lo = (idx_type)lgap;
                 } else {
-                    --l;
-                    while (l != 0 && col(l - 1) + 1 >= col(l)) --l;
-                    left_gap = (int)(col(l) - 1u);
-                }
-                // nearest free column to the right of the range (-1: none)
-                int right_gap;
-                long r = last;
-                if (r + 1 == n) {
-                    right_gap = free_end < alignment_width ? (int)free_end : -1;
-                } else if (col(r + 1) > free_end) {
-                    right_gap = (int)free_end;
-                } else {
-                    ++r;
-                    while (r + 1 != n && col(r) + 1 >= col(r + 1)) ++r;
-                    right_gap = (int)(col(r) + 1);
-                }
-                const bool go_left = right_gap == -1 ||
-                                     (left_gap != -1 && (idx_type)(free_begin - (idx_type)left_gap) <=
-                                                            (idx_type)((idx_type)right_gap - (free_end - 1)));
-                if (go_left) {
-                    if (left_gap == -1)
-                        throw std::runtime_error("ERROR: no space to left and right?? sequence longe than alignment?!");
-                    run += (idx_type)(first - l);
-                    free_begin = (idx_type)left_gap;
-                    first = l;
-                } else {
-                    run += (idx_type)(r - last);
-                    free_end = (idx_type)right_gap + 1;
-                    last = r;
+                    s.last = upto;
+                    s.hi = (idx_type)rgap + 1;
                 }
             }
-        } else {
-            free_begin = free_end - run;  // right-align inside the free range
         }
-        for (long i = first; i <= last; ++i) {
-            bases[(size_t)i].setPosition(free_begin++);
+        idx_type c = s.lo;
+        for (long i = s.first; i <= s.last; ++i) {
+            bases[(size_t)i].setPosition(c++);
             if (lowercase) bases[(size_t)i].setLowerCase();
         }
-        total_inserts += run;
-        longest_insert = std::max(longest_insert, run);
-        cur = last + 1;
-        anchor = cur;
+        placed_total += s.need();
+        placed_longest = std::max(placed_longest, s.need());
+        anchor = s.last + 1;
     }
-    if (total_inserts > 0) {
-        log << "total inserted bases=" << total_inserts << ";"
-            << "longest insertion=" << longest_insert << ";"
-            << "total inserted bases before shifting=" << orig_inserts << ";";
+    if (placed_total > 0) {
+        log << "total inserted bases=" << placed_total << ";"
+            << "longest insertion=" << placed_longest << ";"
+            << "total inserted bases before shifting=" << last_run_before_shifting << ";";
     }
 }
 

@@ -285,39 +285,47 @@ log_printer::log_printer(const log_printer &) = default;
 log_printer &log_printer::operator=(const log_printer &) = default;
 log_printer::~log_printer() = default;
 
-// src/log.cpp:279-325 (without a comparison database: orig = the input sequence as it was read)
+// --show-dist (behaviour of src/log.cpp:279-325, without a comparison database: "orig" is the input
+// sequence as it was read, which for an aligned input file is the alignment to compare with).
+// Three identities, each the match fraction over the first sequence's bases:
+//   orig_idty          exact-IUPAC identity of the input alignment with the new one (the SP score),
+//   orig_closest_idty  identity of the input alignment with its closest relative,
+//   closest_idty       identity of the new alignment with that same relative,
+// and cpm, the loss against the closest relative: orig_closest_idty - closest_idty.
 void log_printer::priv_data::show(cseq &orig, cseq &aligned, search::result_vector &ref, std::ostream &log) {
-    char buf[96];
+    auto report = [&](const char *what, float v) {
+        char line[96];
+        snprintf(line, sizeof line, "%s: %.6f\n", what, (double)v);
+        log << line;
+    };
+    auto identity = [](const cseq &a, const cseq &b, CMP_IUPAC_TYPE rule) {
+        return cseq_comparator(rule, CMP_DIST_NONE, CMP_COVER_QUERY, false)(a, b);
+    };
     if (orig.getWidth() != aligned.getWidth()) {
         log << "Cannot show dist - " << orig.getName() << " and " << aligned.getName() << " have lengths "
             << orig.getWidth() << " and " << aligned.getWidth() << "\n";
         return;
     }
-    const cseq_comparator cmp_exact(CMP_IUPAC_EXACT, CMP_DIST_NONE, CMP_COVER_QUERY, false);
-    const float sps = cmp_exact(orig, aligned);
-    snprintf(buf, sizeof buf, "orig_idty: %.6f\n", (double)sps);
-    log << buf;
+    const float sps = identity(orig, aligned, CMP_IUPAC_EXACT);
+    report("orig_idty", sps);
     total_sps += sps;
     if (ref.empty()) {
         log << "reference / search result empty?\n";
         return;
     }
-    const cseq_comparator cmp_optimistic(CMP_IUPAC_OPTIMISTIC, CMP_DIST_NONE, CMP_COVER_QUERY, false);
-    auto scored = ref;  // copy
-    for (auto &item : scored) item.score = cmp_optimistic(orig, *item.sequence);
-    std::sort(scored.begin(), scored.end());
-    auto &closest = *scored.rbegin();
-    const float orig_idty = closest.score;
-    total_idty += orig_idty;
-    snprintf(buf, sizeof buf, "orig_closest_idty: %.6f\n", (double)orig_idty);
-    log << buf;
-    const float aligned_idty = cmp_optimistic(aligned, *closest.sequence);
-    snprintf(buf, sizeof buf, "closest_idty: %.6f\n", (double)aligned_idty);
-    log << buf;
-    const float cpm = orig_idty - aligned_idty;
-    snprintf(buf, sizeof buf, "cpm: %.6f\n", (double)cpm);
-    log << buf;
-    total_cpm += cpm;
+    // the closest relative of the input alignment: the last of the relatives sorted by identity
+    // (std::sort on a copy, as the reference does: which of several equally close ones that is, is
+    // the sort's business)
+    search::result_vector by_identity(ref);
+    for (search::result_item &r : by_identity) r.score = identity(orig, *r.sequence, CMP_IUPAC_OPTIMISTIC);
+    std::sort(by_identity.begin(), by_identity.end());
+    const search::result_item &closest = by_identity.back();
+    const float before = closest.score, after = identity(aligned, *closest.sequence, CMP_IUPAC_OPTIMISTIC);
+    total_idty += before;
+    report("orig_closest_idty", before);
+    report("closest_idty", after);
+    report("cpm", before - after);
+    total_cpm += before - after;
 }
 
 tray log_printer::operator()(tray t, std::ostream &log) {  // src/log.cpp:364-430

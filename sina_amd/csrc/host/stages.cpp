@@ -505,10 +505,10 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
     std::vector<uint64_t> qoff(queries.size() + 1, 0);
     for (size_t i = 0; i < queries.size(); i++) qoff[i + 1] = qoff[i] + queries[i]->size();
     std::vector<uint8_t> qmask(qoff.back() ? qoff.back() : 1);
-    for (size_t i = 0; i < queries.size(); i++) {
+    parallel_for(queries.size(), [&](size_t i) {
         const auto &b = queries[i]->getAlignedBases();
-        for (size_t x = 0; x < b.size(); x++) qmask[qoff[i] + x] = b[x].getBase().mask();
-    }
+        for (size_t x = 0; x < b.size(); x++) qmask[qoff[i] + x] = (uint8_t)(b[x].raw >> 24);
+    });
     auto dev = st.worker_device(reference_store::dev_search);
     sina_hip_ctx *ctx = dev.get();
     if (max <= 4096) {
@@ -1056,6 +1056,21 @@ void aligner::operator()(std::vector<tray> &batch) {
             if (prep_store && !batch.empty() && prep_store->size() > 0) prep_store->upper_bases(0);  // (fills the cache outside the loop)
         }
     }
+    // (the scores of alignment_reference are k-mer counts when famfinder's internal engine made them)
+    const bool search_scores_are_kmer_counts = ff_opts.engine == ENGINE_SINA_KMER && !ff_opts.database.empty();
+    auto query_kmer_count = [](const cseq &c) -> unsigned {
+        // |K(q)|: windows of k unambiguous bases ending before the last base, first base A in "fast"
+        // mode (src/kmer.h:69-83,122-124,188-201)
+        const unsigned k = ff_opts.fs_kmer_len;
+        const auto &b = c.getAlignedBases();
+        unsigned run = 0, n = 0;
+        for (size_t e = 0; e + 1 < b.size(); e++) {
+            const unsigned m = (b[e].raw >> 24) & 0xfu;
+            run = (__builtin_popcount(m) == 1) ? run + 1 : 0;
+            if (run >= k && (ff_opts.fs_no_fast || ((b[e + 1 - k].raw >> 24) & 0xfu) == 1u)) n++;
+        }
+        return n;
+    };
     parallel_for(batch.size(), [&](size_t i) {
         tray &t = batch[i];
         if (t.input_sequence == nullptr || t.alignment_reference == nullptr || t.astats == nullptr) return;  // :310-318
@@ -1071,7 +1086,12 @@ void aligner::operator()(std::vector<tray> &batch) {
             tmp = upper_copy(r->getBases());
             return tmp;
         };
+        // A family member can only contain the query's bases if it has every one of the query's
+        // k-mers, i.e. if its k-mer score (what famfinder ranked it by) is the query's k-mer count --
+        // which spares the string search for all but exact relatives.
+        const float all_kmers = search_scores_are_kmer_counts ? (float)query_kmer_count(c) : -1.f;
         auto not_contains_query = [&](search::result_item &item) {
+            if (item.score < all_kmers) return true;
             std::string tmp;
             return ref_ubases(item.sequence, tmp).find(ubases) == std::string::npos;
         };
@@ -1159,10 +1179,10 @@ void aligner::operator()(std::vector<tray> &batch) {
         std::vector<uint64_t> qoff(nq + 1, 0);
         for (size_t x = 0; x < nq; x++) qoff[x + 1] = qoff[x] + jobs[idx[x]].c->size();
         std::vector<uint8_t> qmask(qoff.back() ? qoff.back() : 1);
-        for (size_t x = 0; x < nq; x++) {
+        parallel_for(nq, [&](size_t x) {
             const auto &b = jobs[idx[x]].c->getAlignedBases();
-            for (size_t y = 0; y < b.size(); y++) qmask[qoff[x] + y] = b[y].getBase().mask();
-        }
+            for (size_t y = 0; y < b.size(); y++) qmask[qoff[x] + y] = (uint8_t)(b[y].raw >> 24);
+        });
         std::vector<sina_hip_align_out> out(nq);
         std::vector<uint32_t> out_pos(qoff.back() ? qoff.back() : 1);
         auto dev = store->worker_device(reference_store::dev_align);
@@ -1310,92 +1330,73 @@ void aligner::operator()(std::vector<tray> &batch) {
 
 // ================================================================ cseq_comparator (src/cseq_comparator.cpp)
 
-// traverse() + match_counter::counter, src/cseq_comparator.cpp:56-111,165-206 (host restatement for
-// single pairs and for the CPU-side tests; batches go through sina_hip_compare)
+// The six counters cseq_comparator derives its score from (behaviour of src/cseq_comparator.cpp:
+// 56-111,165-206), stated by column membership like compare_kernel (search.hip) states them: a
+// filtered (lower-case, with filter_lowercase) base is as good as absent; a base outside the column
+// range of the other sequence's remaining bases is "overhang"; inside it, it has a partner in the
+// same column (match / mismatch by the IUPAC rule) or it has none.  A side without any remaining
+// base gives all-zero counters.  Host version for single pairs and the CPU-side tests; batches go
+// through sina_hip_compare.
 void cseq_comparator::counts(const cseq &A, const cseq &B, CMP_IUPAC_TYPE iupac, bool filter_lc,
                              sina_hip_match_counts *m) {
     memset(m, 0, sizeof(*m));
-    const auto &av = A.getAlignedBases();
-    const auto &bv = B.getAlignedBases();
-    auto filtered = [&](const aligned_base &x) { return filter_lc && x.getBase().isLowerCase(); };
-    auto cmp = [&](const aligned_base &x, const aligned_base &y) {
-        switch (iupac) {
-        case CMP_IUPAC_OPTIMISTIC: return x.getBase().comp(y.getBase());
-        case CMP_IUPAC_PESSIMISTIC: return x.getBase().comp_pessimistic(y.getBase());
-        default: return x.getBase().comp_exact(y.getBase());
-        }
+    auto remaining = [&](const cseq &s) {
+        std::vector<aligned_base> v;
+        v.reserve(s.size());
+        for (const aligned_base &x : s.getAlignedBases())
+            if (!(filter_lc && x.getBase().isLowerCase())) v.push_back(x);
+        return v;
     };
-    auto a = av.begin(), a_end = av.end();
-    auto b = bv.begin(), b_end = bv.end();
-    while (a != a_end && filtered(*a)) ++a;
-    while (b != b_end && filtered(*b)) ++b;
-    while (a != a_end && filtered(*(a_end - 1))) --a_end;
-    while (b != b_end && filtered(*(b_end - 1))) --b_end;
-    if (a == a_end || b == b_end) return;  // (the reference dereferences end() here)
-    if (a->getPosition() < b->getPosition()) {
-        while (a != a_end && a->getPosition() < b->getPosition()) {
-            if (!filtered(*a)) m->only_a_overhang++;
-            ++a;
-        }
-    } else {
-        while (b != b_end && a->getPosition() > b->getPosition()) {
-            if (!filtered(*b)) m->only_b_overhang++;
-            ++b;
-        }
-    }
-    while (a != a_end && b != b_end) {
-        const int diff = (int)a->getPosition() - (int)b->getPosition();
-        if (diff > 0) {
-            if (!filtered(*b)) m->only_b++;
-            ++b;
-        } else if (diff < 0) {
-            if (!filtered(*a)) m->only_a++;
-            ++a;
+    const std::vector<aligned_base> a = remaining(A), b = remaining(B);
+    if (a.empty() || b.empty()) return;
+    auto same = [&](const aligned_base &x, const aligned_base &y) {
+        const base_iupac p = x.getBase(), q = y.getBase();
+        return iupac == CMP_IUPAC_OPTIMISTIC ? p.comp(q) : (iupac == CMP_IUPAC_PESSIMISTIC ? p.comp_pessimistic(q) : p.comp_exact(q));
+    };
+    const uint32_t a_lo = a.front().getPosition(), a_hi = a.back().getPosition();
+    const uint32_t b_lo = b.front().getPosition(), b_hi = b.back().getPosition();
+    size_t i = 0, j = 0;  // columns ascend on both sides: one merge
+    while (i < a.size() || j < b.size()) {
+        const uint32_t pa = i < a.size() ? a[i].getPosition() : 0xFFFFFFFFu;
+        const uint32_t pb = j < b.size() ? b[j].getPosition() : 0xFFFFFFFFu;
+        if (pa == pb) {
+            if (same(a[i], b[j])) m->match++;
+            else m->mismatch++;
+            i++;
+            j++;
+        } else if (pa < pb) {
+            if (pa < b_lo || pa > b_hi) m->only_a_overhang++;
+            else m->only_a++;
+            i++;
         } else {
-            if (!filtered(*a) && !filtered(*b)) {
-                if (cmp(*a, *b)) m->match++;
-                else m->mismatch++;
-            } else if (!filtered(*a)) {
-                m->only_a++;
-            } else if (!filtered(*b)) {
-                m->only_b++;
-            }
-            ++a;
-            ++b;
+            if (pb < a_lo || pb > a_hi) m->only_b_overhang++;
+            else m->only_b++;
+            j++;
         }
     }
-    for (; a != a_end; ++a)
-        if (!filtered(*a)) m->only_a_overhang++;
-    for (; b != b_end; ++b)
-        if (!filtered(*b)) m->only_b_overhang++;
 }
 
-// src/cseq_comparator.cpp:240-296
+// match fraction over the cover rule's denominator, optionally Jukes-Cantor corrected (behaviour of
+// src/cseq_comparator.cpp:240-296, :42-44)
 float cseq_comparator::score(const sina_hip_match_counts &m) const {
-    int base;
+    const int paired = m.match + m.mismatch;
+    const int a_alone = m.only_a + m.only_a_overhang, b_alone = m.only_b + m.only_b_overhang;
+    int denom = 0;
     switch (cover_rule) {
-    case CMP_COVER_ABS: base = 1; break;
-    case CMP_COVER_QUERY: base = m.match + m.mismatch + m.only_a + m.only_a_overhang; break;
-    case CMP_COVER_TARGET: base = m.match + m.mismatch + m.only_b + m.only_b_overhang; break;
-    case CMP_COVER_OVERLAP: base = m.match + m.mismatch + m.only_a + m.only_b; break;
-    case CMP_COVER_ALL:
-        base = m.match + m.mismatch + m.only_a + m.only_b + m.only_a_overhang + m.only_b_overhang;
-        break;
-    case CMP_COVER_AVERAGE:
-        base = m.match + m.mismatch + (m.only_a + m.only_b + m.only_a_overhang + m.only_b_overhang) / 2;
-        break;
-    case CMP_COVER_MIN:
-        base = m.match + m.mismatch + std::min(m.only_a + m.only_a_overhang, m.only_b + m.only_b_overhang);
-        break;
-    case CMP_COVER_MAX:
-        base = m.match + m.mismatch + std::max(m.only_a + m.only_a_overhang, m.only_b + m.only_b_overhang);
-        break;
-    case CMP_COVER_NOGAP: base = m.match + m.mismatch; break;
+    case CMP_COVER_ABS: denom = 1; break;
+    case CMP_COVER_QUERY: denom = paired + a_alone; break;
+    case CMP_COVER_TARGET: denom = paired + b_alone; break;
+    case CMP_COVER_OVERLAP: denom = paired + m.only_a + m.only_b; break;
+    case CMP_COVER_ALL: denom = paired + m.only_a + m.only_b + m.only_a_overhang + m.only_b_overhang; break;
+    case CMP_COVER_AVERAGE: denom = paired + (m.only_a + m.only_b + m.only_a_overhang + m.only_b_overhang) / 2; break;
+    case CMP_COVER_MIN: denom = paired + std::min(a_alone, b_alone); break;
+    case CMP_COVER_MAX: denom = paired + std::max(a_alone, b_alone); break;
+    case CMP_COVER_NOGAP: denom = paired; break;
     default: throw std::logic_error("unknown cover rule");
     }
-    float dist = (float)m.match / base;
-    if (dist_rule == CMP_DIST_JC) dist = (float)(-3.0 / 4 * log(1.0 - 4.0 / 3 * dist));  // jukes_cantor :42-44
-    return dist;
+    const float identity = (float)m.match / denom;
+    if (dist_rule != CMP_DIST_JC) return identity;
+    return (float)(-3.0 / 4 * log(1.0 - 4.0 / 3 * identity));
 }
 float cseq_comparator::operator()(const cseq &query, const cseq &target) const {
     sina_hip_match_counts m;
@@ -1548,34 +1549,39 @@ bool contains_query(const cseq &ref, const cseq &q) {
     return false;
 }
 
-// the LCA vote of search_filter.cpp:374-409 over the taxonomy paths of the results
-std::string lca_vote(std::vector<std::vector<std::string>> group_names, size_t n_results, float quorum) {
-    std::stringstream result;
-    for (auto &vs : group_names) std::reverse(vs.begin(), vs.end());
-    int outliers = n_results * (1 - quorum) + .5;
-    while (outliers >= 0 && !group_names.empty()) {
-        auto it = group_names.begin();
-        if (it->empty()) {
-            group_names.erase(it);
-            outliers--;
-            continue;
+// LCA classification (behaviour of src/search_filter.cpp:374-409): the taxonomy paths of the search
+// results, in result order, vote level by level.  The first path still in the vote names the group
+// of the current level; the first path that cannot follow it (it has ended, or names another group)
+// is dropped from the vote -- as is the leading path itself once it has ended -- and every drop
+// uses up one of the `n_results * (1 - quorum)` allowed outliers.  The vote ends when the outliers
+// are used up or no path is left; what all remaining paths agreed on so far is the classification.
+std::string lca_vote(const std::vector<std::vector<std::string>> &paths, size_t n_results, float quorum) {
+    int outliers_left = n_results * (1 - quorum) + .5;
+    std::vector<size_t> voting(paths.size());
+    for (size_t i = 0; i < voting.size(); i++) voting[i] = i;
+    std::string agreed;
+    for (size_t level = 0; outliers_left >= 0 && !voting.empty();) {
+        const std::vector<std::string> &lead = paths[voting[0]];
+        size_t dissenter = voting.size();
+        if (level >= lead.size()) {
+            dissenter = 0;
+        } else {
+            for (size_t k = 1; k < voting.size() && dissenter == voting.size(); k++) {
+                const std::vector<std::string> &p = paths[voting[k]];
+                if (level >= p.size() || p[level] != lead[level]) dissenter = k;
+            }
         }
-        std::string name = it->back();
-        ++it;
-        for (; it != group_names.end(); ++it)
-            if (it->empty() || it->back() != name) break;
-        if (it != group_names.end()) {
-            group_names.erase(it);
-            outliers--;
-            continue;
+        if (dissenter < voting.size()) {
+            voting.erase(voting.begin() + (std::ptrdiff_t)dissenter);
+            outliers_left--;
+        } else {
+            agreed += lead[level] + ";";
+            level++;
         }
-        for (auto &vs : group_names) vs.pop_back();
-        result << name << ";";
     }
-    std::string res = result.str();
-    if (res.size() > 1 && res.substr(res.size() - 2) == ";;") res = res.substr(res.size() - 1);
-    if (res.empty() || res == ";") res = "Unclassified;";
-    return res;
+    const bool nothing = agreed.empty() || agreed == ";" ||
+                         (agreed.size() > 1 && agreed.compare(agreed.size() - 2, 2, ";;") == 0);
+    return nothing ? "Unclassified;" : agreed;
 }
 }  // namespace
 
@@ -1677,24 +1683,28 @@ void search_filter::operator()(std::vector<tray> &batch) {
         tray &t = batch[idx[x]];
         cseq *c = t.aligned_sequence;
         auto &vc = *t.search_result;
-        if (o.search_all) {  // :271-296
-            search::result_vector &result = cand[x];
-            auto it = result.begin();
-            auto middle = it + std::min<size_t>((size_t)o.max_result, result.size());
-            auto end = result.end();
-            do {
-                std::partial_sort(it, middle, end, std::greater<search::result_item>());
+        if (o.search_all) {
+            // every reference was compared: the `max_result` best that are not super-strings of the
+            // query (--search-ignore-super), if above --search-min-sim (behaviour of src/
+            // search_filter.cpp:271-296).  The sequence of libstdc++ calls is the contract here:
+            // the window is re-sorted from the first kept candidate to the PREVIOUS window end, then
+            // widened again, so std::partition also sees entries std::partial_sort left unordered.
+            search::result_vector &all = cand[x];
+            const auto stop = all.end();
+            auto first_kept = all.begin();
+            auto window_end = first_kept + (std::ptrdiff_t)std::min<size_t>((size_t)o.max_result, all.size());
+            for (;;) {
+                std::partial_sort(first_kept, window_end, stop, std::greater<search::result_item>());
                 if (o.ignore_super) {
-                    middle = it + std::min<size_t>((size_t)o.max_result, (size_t)(end - it));
-                    it = std::partition(it, middle, [&](search::result_item &item) {
+                    window_end = first_kept + (std::ptrdiff_t)std::min<size_t>((size_t)o.max_result, (size_t)(stop - first_kept));
+                    first_kept = std::partition(first_kept, window_end, [&](search::result_item &item) {
                         return contains_query(*item.sequence, *c);
                     });
                 }
-            } while (middle != end && it + o.max_result > middle);
-            while (it != middle && it->score > o.min_sim) {
-                vc.push_back(*it);
-                ++it;
+                const bool window_full = first_kept + o.max_result <= window_end;
+                if (window_end == stop || window_full) break;
             }
+            for (auto it = first_kept; it != window_end && it->score > o.min_sim; ++it) vc.push_back(*it);
         } else {  // :297-331
             vc.swap(cand[x]);
             auto it = vc.begin();

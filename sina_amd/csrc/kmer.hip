@@ -779,13 +779,13 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
         if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>() + q0, bq, max, max_qlen, false)) return 1;
         // (wait for the kernels FIRST: a copy to pageable memory queued behind running kernels waits
         // inside the runtime, under locks other threads' launches need -- see HostBuf in common.h)
-        SH_CHECK(hipStreamSynchronize(s));
+        SH_CHECK(wait_stream(c, s));
         SH_CHECK(hipMemcpyAsync(out_ids + (size_t)q0 * max, c->k_out_ids.p, (size_t)bq * max * 4, hipMemcpyDeviceToHost, s));
         SH_CHECK(hipMemcpyAsync(out_scores + (size_t)q0 * max, c->k_out_scores.p, (size_t)bq * max * 4, hipMemcpyDeviceToHost, s));
         SH_CHECK(hipMemcpyAsync(out_n + q0, c->k_out_n.p, (size_t)bq * 4, hipMemcpyDeviceToHost, s));
         unsigned long long visited = 0;
         SH_CHECK(hipMemcpyAsync(&visited, c->k_tmp2.p, 8, hipMemcpyDeviceToHost, s));
-        SH_CHECK(hipStreamSynchronize(s));
+        SH_CHECK(wait_stream(c, s));
         float ms = 0;
         SH_CHECK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
         std::lock_guard<std::mutex> slk(c->st->stats_mu);

@@ -103,6 +103,32 @@ for wi, fsw in enumerate([1.0, 0.0, 2.5]):
                 out["mesh%d_%s" % (qi, f)] = cells[f].view(np.uint32)
     R.ref_dag_free(rd)
 
+# ---- cell planes of many families, all scheme / transition combinations, as plane hashes
+# (the cell loop of oracle/ref_parts.cpp on the real dag<T> with the real scoring_scheme_simple /
+# scoring_scheme_weighted; --insertion=forbid through the aspace-aware transition).  Inputs are
+# regenerated by the tests from the same synth seeds: tests/util.py mesh_case_inputs().
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from tests import util  # noqa: E402
+R.ref_mesh_compute.argtypes = [C.c_void_p, po.u32p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float,
+                               po.f32p, C.c_uint32, C.c_int, C.c_void_p]
+case_rows, case_hashes = [], []
+for case in util.MESH_CASES:
+    fam, qa, width, w, sch = util.mesh_case_inputs(case)
+    arrs = [np.ascontiguousarray(a) for a in fam]
+    ptrs = (po.u32p * len(arrs))(*[a.ctypes.data_as(po.u32p) for a in arrs])
+    ns = np.array([len(a) for a in arrs], np.uint32)
+    rd = R.ref_dag_build(ptrs, ns.ctypes.data_as(po.u32p), len(arrs), width, sch["fs_weight"])
+    N = R.ref_dag_size(rd)
+    cells = np.zeros((N, len(qa)), po.CELL_DTYPE)
+    R.ref_mesh_compute(rd, qa.ctypes.data_as(po.u32p), len(qa), -sch["match"], -sch["mismatch"], sch["gap"],
+                       sch["gapext"], w.ctypes.data_as(po.f32p) if w is not None else None,
+                       len(w) if w is not None else 0, int(sch["forbid"]), cells.ctypes.data_as(C.c_void_p))
+    R.ref_dag_free(rd)
+    case_rows.append((N, len(qa)))
+    case_hashes.append([util.plane_hash(cells[f]) for f in util.MESH_PLANES])
+out["mesh_case_shape"] = np.array(case_rows, np.int64)
+out["mesh_case_hash"] = np.array(case_hashes, np.uint64)
+
 # ---- scoring scheme single-op probes (real scoring_schemes.h arithmetic)
 rs = np.random.default_rng(9)
 wts = rs.uniform(0.1, 2.0, 64).astype(np.float32)

@@ -248,3 +248,27 @@ def test_align_families_equals_align_graphs(oracle, gpu_ctx, small):
         o1, p1 = gpu_ctx.align_graphs(gpu_ctx.graph_batch(graphs, refs.width), np.concatenate(qms), qoff, p)
         o2, p2 = gpu_ctx.align_families(np.concatenate(fams), foff, np.concatenate(qms), qoff, p)
         assert (o1 == o2).all() and (p1 == p2).all()
+
+
+def test_mesh_planes_equal_reference_parts_hashes(oracle, gpu_ctx):
+    """The DP kernel against planes the REFERENCE's scoring schemes and dag<T> produced (oracle/_ref cell
+    loop, tests/golden/make_ref_vectors.py): value / value_midx / value_sidx of 25 families -- 1..41
+    members, fs-weight 0 / 1 / 2.5, simple and weighted scheme, --insertion=forbid, gap-open ==
+    gap-extend, one full-length 16S family -- compared by plane hash."""
+    import os
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_vectors.npz"))
+    hashes = ref["mesh_case_hash"]
+    col = {f: i for i, f in enumerate(util.MESH_PLANES)}
+    for ci, case in enumerate(util.MESH_CASES):
+        fam, qa, width, w, sch = util.mesh_case_inputs(case)
+        cs = [oracle.Cseq.from_packed("f%d" % i, a, width) for i, a in enumerate(fam)]
+        g = util.graph_dict(cs, sch["fs_weight"])
+        gb = gpu_ctx.graph_batch([g], width)
+        p = gpu_ctx.params(weights=w, match_score=sch["match"], mismatch_score=sch["mismatch"],
+                           gap_penalty=sch["gap"], gap_ext_penalty=sch["gapext"], fs_weight=sch["fs_weight"],
+                           insertion=1 if sch["forbid"] else 0)
+        vm, vs, val = gpu_ctx.debug_mesh(gb, (qa >> 24).astype(np.uint8), p)
+        assert val.shape == tuple(ref["mesh_case_shape"][ci])
+        assert util.plane_hash(val) == hashes[ci][col["value"]], (ci, case["scheme"])
+        assert util.plane_hash(vm) == hashes[ci][col["value_midx"]], (ci, case["scheme"])
+        assert util.plane_hash(vs) == hashes[ci][col["value_sidx"]], (ci, case["scheme"])

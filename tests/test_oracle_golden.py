@@ -329,3 +329,32 @@ def test_turn_check_orientations(oracle):
     # a query without any k-mer: every score 0 -> orientation 0
     q = oracle.Cseq.from_packed("tiny", np.arange(5, dtype=np.uint32) | (np.uint32(1) << 24), 5)
     assert idx.turn_check(q, True)[0] == 0
+
+
+def _mesh_case_oracle_inputs(oracle, case):
+    from tests import util
+    fam, qa, width, w, sch = util.mesh_case_inputs(case)
+    cs = [oracle.Cseq.from_packed("f%d" % i, a, width) for i, a in enumerate(fam)]
+    q = oracle.Cseq.from_packed("q", qa, len(qa))
+    opts = oracle.align_opts(weights=w, match_score=sch["match"], mismatch_score=sch["mismatch"],
+                             gap_penalty=sch["gap"], gap_ext_penalty=sch["gapext"], fs_weight=sch["fs_weight"],
+                             insertion=1 if sch["forbid"] else 0)
+    return cs, q, opts
+
+
+def test_mesh_planes_equal_reference_parts_hashes(oracle):
+    """All seven cell planes of 25 families (1..41 members, fs-weight 0 / 1 / 2.5, simple and weighted
+    scheme, --insertion=forbid, gap-open == gap-extend, one full-length 16S family) equal what the
+    reference's own scoring schemes and dag<T> produce in the oracle/_ref cell loop -- compared by
+    plane hash (tests/golden/make_ref_vectors.py; inputs regenerated from the synth seeds)."""
+    import numpy as np
+    from tests import util
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_vectors.npz"))
+    shapes, hashes = ref["mesh_case_shape"], ref["mesh_case_hash"]
+    assert len(shapes) == len(util.MESH_CASES) >= 25
+    for ci, case in enumerate(util.MESH_CASES):
+        cs, q, opts = _mesh_case_oracle_inputs(oracle, case)
+        cells = oracle.mesh_compute(cs, q, opts)
+        assert cells.shape == tuple(shapes[ci]), ci
+        got = [util.plane_hash(cells[f]) for f in util.MESH_PLANES]
+        assert got == list(hashes[ci]), (ci, case["scheme"])

@@ -110,3 +110,62 @@ def row_store_model(pred_off, pred, n_slots, far_lds=192):
             out[m] = 0x80000000 | nsp
             nsp += 1
     return out
+
+
+# ---------------------------------------------------------------- reference-parts mesh cases
+# (tests/golden/make_ref_vectors.py computes the planes of these cases with the reference's own
+# scoring schemes and DAG and stores one hash per plane; the oracle and the GPU are checked against
+# the hashes.  A case: synth seed, references generated, their length / width, family size, scheme.)
+MESH_PLANES = ("value", "gapm_val", "gaps_val", "value_midx", "value_sidx", "gapm_idx", "gaps_idx")
+
+
+def _mesh_cases():
+    schemes = [
+        dict(match=2.0, mismatch=-1.0, gap=5.0, gapext=2.0, weighted=False, forbid=False),
+        dict(match=3.0, mismatch=-2.0, gap=4.0, gapext=1.5, weighted=False, forbid=False),
+        dict(match=2.0, mismatch=-1.0, gap=5.0, gapext=2.0, weighted=True, forbid=False),
+        dict(match=2.0, mismatch=-1.0, gap=5.0, gapext=2.0, weighted=False, forbid=True),
+        dict(match=2.0, mismatch=-1.0, gap=5.0, gapext=2.0, weighted=True, forbid=True),
+        dict(match=1.0, mismatch=-1.0, gap=2.0, gapext=2.0, weighted=False, forbid=False),
+    ]
+    cases = []
+    fam_sizes = [1, 2, 3, 5, 7, 12, 15, 23, 40, 41, 40, 40]
+    for i in range(24):
+        sch = dict(schemes[i % len(schemes)])
+        sch["fs_weight"] = (1.0, 0.0, 2.5)[i % 3]
+        cases.append(dict(seed=300 + i, n_refs=64, length=140 + 10 * (i % 5), width=900 + 50 * (i % 4),
+                          F=fam_sizes[i % len(fam_sizes)], scheme=sch))
+    # one full-length 16S family of 40 (2800 rows x 1500 columns), default scheme
+    cases.append(dict(seed=777, n_refs=48, length=1500, width=50000, F=40,
+                      scheme=dict(schemes[0], fs_weight=1.0)))
+    return cases
+
+
+MESH_CASES = _mesh_cases()
+
+
+def mesh_case_inputs(case):
+    """(family as packed aligned sequences, packed upper-cased query, width, column weights or None, scheme)."""
+    small = case["length"] < 1000
+    refs = synth.make_refs(case["n_refs"], length=case["length"], width=case["width"], seed=case["seed"], n_clades=3,
+                           amb_rate=0.03 if small else 0.0, lower_rate=0.05 if small else 0.0,
+                           long_del_prob=0.4 if small else 0.1, del_rate=0.03 if small else 0.01,
+                           ins_rate=0.02 if small else 0.005)
+    qs = synth.make_queries(refs, 1, seed=case["seed"] + 5000, amb_rate=0.02 if small else 0.0)
+    rng = np.random.default_rng(case["seed"] + 9000)
+    ids = rng.choice(refs.n, size=case["F"], replace=False)
+    fam = [refs.seq(int(i)).copy() for i in ids]
+    qm = qs.seq(0) & 0x0f   # the aligner upper-cases its working copy (align.cpp:324-326)
+    qa = np.arange(len(qm), dtype=np.uint32) | (qm.astype(np.uint32) << 24)
+    w = None
+    if case["scheme"]["weighted"]:   # long enough that pos + 1 + offset never runs past the end
+        w = rng.uniform(0.2, 2.0, size=refs.width + len(qm) + 8).astype(np.float32)
+    return fam, qa, refs.width, w, case["scheme"]
+
+
+def plane_hash(a):
+    """64-bit hash of a plane's 32-bit patterns (floats by their bits)."""
+    import hashlib
+    b = np.ascontiguousarray(a)
+    b = b.view(np.uint32) if b.dtype == np.float32 else b.astype(np.uint32)
+    return np.frombuffer(hashlib.sha1(b.tobytes()).digest()[:8], np.uint64)[0]
