@@ -249,6 +249,7 @@ def main():
     elapsed = time.time() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     host_cores = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / elapsed
+    host_cores_sys = (ru1.ru_stime - ru0.ru_stime) / elapsed
     s1 = store.stats()
 
     n_done = a.batch * a.steps
@@ -353,6 +354,7 @@ def main():
                 "backtrack_kernel": iso["backtrack_ms"],
             },
             "host_cores_busy": host_cores,  # CPU seconds per wall second of this rank in the timed region
+            "host_cores_busy_kernel_mode": host_cores_sys,
             "stages_ms_per_step": {
                 "famfinder_host_wall": 1e3 * timing["famfinder_s"] / a.steps,
                 "aligner_host_wall": 1e3 * timing["aligner_s"] / a.steps,

@@ -163,7 +163,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         return (uint64_t)qd_host[x].N * qd_host[x].L > (uint64_t)qd_host[y].N * qd_host[y].L;
     });
     if (c->order.reserve(4 * (size_t)bq)) return 1;
-    SH_CHECK(hipMemcpyAsync(c->order.p, order.data(), 4 * (size_t)bq, hipMemcpyHostToDevice, s));
+    if (upload(c, 0, c->order.p, order.data(), 4 * (size_t)bq, s)) return 1;
     DpArgs a;
     a.qd = c->qd.as<QDesc>();
     a.order = c->order.as<uint32_t>();
@@ -203,7 +203,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, hl.stream())) return 1;
         SH_CHECK(hipEventRecord(c->ev[1], hl.stream()));
         if (hl.done()) return 1;
-        if (token.owns_lock()) SH_CHECK(hipEventSynchronize(c->ev[1]));
+        if (token.owns_lock()) SH_CHECK(wait_event(c->ev[1]));
     }
     BtArgs b;
     b.qd = a.qd;

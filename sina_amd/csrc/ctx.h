@@ -3,6 +3,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstring>
 
 #include "common.h"
 
@@ -56,6 +57,7 @@ struct sina_hip_ctx {
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes, g_wtab;
     sina_hip::DevBuf s_qab, s_qoff, s_cand, s_coff, s_out;  // search-stage comparison
     sina_hip::HostBuf h_out, h_out_pos;  // pinned staging for the DP results
+    sina_hip::HostBuf h_stage[12];       // pinned staging of the per-batch uploads / downloads (sina_hip::upload)
     float wtab_fs_weight = NAN;  // fs_weight the device weight table was computed for
 
     size_t lds_budget = 0;  // LDS per DP workgroup; 0 = what keeps the register-limited occupancy (dp_default_lds_budget)
@@ -97,6 +99,7 @@ struct sina_hip_ctx {
         dbg.release();
         h_out.release();
         h_out_pos.release();
+        for (auto &h : h_stage) h.release();
         if (owns_store && st) {
             if (st->heavy) (void)hipStreamDestroy(st->heavy);
             st->ref_ab.release();
@@ -145,10 +148,42 @@ inline bool serialize_kernels() {
     }();
     return on;
 }
-// Waits for everything queued on a stream of the context.  (Tried: events created with
-// hipEventBlockingSync and hipEventSynchronize instead -- the host threads' CPU time did not change,
-// the wake-up latency cost 10 % throughput at four batches in flight.)
-inline hipError_t wait_stream(sina_hip_ctx *, hipStream_t s) { return hipStreamSynchronize(s); }
+// Waits for an event / for everything queued on a stream of the context WITHOUT burning a core: the
+// runtime's hipStreamSynchronize and hipEventSynchronize (hipEventBlockingSync or not) busy-poll, and
+// so does its hipLaunchHostFunc helper thread (tools/ubench/wait_cpu.hip: 50 ms of CPU per 50 ms
+// waited) -- with seven host threads of a pipeline waiting for the GPU most of the time that was a
+// third of the process's CPU time.  Poll-and-sleep instead: the wake-up is at most ~100 us late,
+// which only matters if nothing else is queued behind on the heavy stream.
+inline hipError_t wait_event(hipEvent_t ev) {
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        timespec ts{0, 100000};
+        nanosleep(&ts, nullptr);
+    }
+}
+inline hipError_t wait_stream(sina_hip_ctx *c, hipStream_t s) {
+    const hipError_t e = hipEventRecord(c->ev[9], s);
+    return e != hipSuccess ? e : wait_event(c->ev[9]);
+}
+// Host <-> device copies of the per-batch arrays go through pinned staging buffers of the context:
+// a copy from / to pageable memory makes the runtime pin and unpin the pages (ioctls, TLB shoot-downs
+// -- a quarter of a pipeline's CPU time was kernel mode) and wait inside the call.  `slot`: one
+// staging buffer per copy of a call (the copies of a call are in flight together).
+inline int upload(sina_hip_ctx *c, int slot, void *dst, const void *src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return 0;
+    if (c->h_stage[slot].reserve(bytes)) return 1;
+    memcpy(c->h_stage[slot].p, src, bytes);
+    SH_CHECK(hipMemcpyAsync(dst, c->h_stage[slot].p, bytes, hipMemcpyHostToDevice, s));
+    return 0;
+}
+// device -> pinned staging; the caller waits for the stream and then copies out of staged(slot)
+inline int download(sina_hip_ctx *c, int slot, const void *src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return 0;
+    if (c->h_stage[slot].reserve(bytes)) return 1;
+    SH_CHECK(hipMemcpyAsync(c->h_stage[slot].p, src, bytes, hipMemcpyDeviceToHost, s));
+    return 0;
+}
 struct heavy_launch {
     sina_hip_ctx *c;
     hipStream_t own, hs;
@@ -172,7 +207,7 @@ struct heavy_launch {
         if (hs == own) return failed ? 1 : 0;
         failed = failed || hipEventRecord(c->ev[11], hs) != hipSuccess;
         if (lk.owns_lock()) lk.unlock();
-        failed = failed || hipEventSynchronize(c->ev[11]) != hipSuccess;
+        failed = failed || wait_event(c->ev[11]) != hipSuccess;
         if (failed) set_error("heavy_launch: event hand-over failed");
         return failed ? 1 : 0;
     }

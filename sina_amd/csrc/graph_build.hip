@@ -539,9 +539,10 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
             c->succ_minpos.reserve(4 * (uint64_t)bq * ncap) || c->g_tmp3.reserve(4 * (uint64_t)bq * ncap) ||
             c->pred.reserve(4 * pred_total) || c->g_sizes.reserve(16 * (uint64_t)bq))
             return 1;
-        SH_CHECK(hipMemcpyAsync(c->g_fam_ids.p, fam_ids + fam_off[q0], 4 * foff[bq], hipMemcpyHostToDevice, s));
-        SH_CHECK(hipMemcpyAsync(c->g_fam_off.p, foff.data(), 8 * ((uint64_t)bq + 1), hipMemcpyHostToDevice, s));
-        SH_CHECK(hipMemcpyAsync(c->g_tmp1.p, bg->pred_off.data(), 8 * (uint64_t)bq, hipMemcpyHostToDevice, s));
+        if (upload(c, 1, c->g_fam_ids.p, fam_ids + fam_off[q0], 4 * foff[bq], s) ||
+            upload(c, 2, c->g_fam_off.p, foff.data(), 8 * ((uint64_t)bq + 1), s) ||
+            upload(c, 3, c->g_tmp1.p, bg->pred_off.data(), 8 * (uint64_t)bq, s))
+            return 1;
         GraphArgs ga;
         ga.ref_ab = c->st->ref_ab.as<uint32_t>();
         ga.ref_off = c->st->ref_off.as<uint64_t>();
@@ -569,11 +570,9 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
             SH_CHECK(hipEventRecord(c->ev[7], hl.stream()));
             if (hl.done()) return 1;
         }
-        // (wait for the kernels FIRST: a copy to pageable memory queued behind running kernels waits
-        // inside the runtime, under locks other threads' launches need -- see HostBuf in common.h)
+        if (download(c, 4, c->g_sizes.p, 16 * (uint64_t)bq, s)) return 1;
         SH_CHECK(wait_stream(c, s));
-        SH_CHECK(hipMemcpyAsync(bg->sizes.data(), c->g_sizes.p, 16 * (uint64_t)bq, hipMemcpyDeviceToHost, s));
-        SH_CHECK(wait_stream(c, s));
+        memcpy(bg->sizes.data(), c->h_stage[4].p, 16 * (uint64_t)bq);
         float gms = 0;
         SH_CHECK(hipEventElapsedTime(&gms, c->ev[6], c->ev[7]));
         {
@@ -658,8 +657,8 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
             const uint32_t rq = r1 - r0;
             const uint64_t qbase = qoff[q0 + r0], nqm = qoff[q0 + r1] - qbase;
             if (c->qd.reserve(sizeof(QDesc) * rq) || c->qmask.reserve(std::max<uint64_t>(nqm, 1))) return 1;
-            SH_CHECK(hipMemcpyAsync(c->qd.p, qd.data(), sizeof(QDesc) * rq, hipMemcpyHostToDevice, s));
-            SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qbase, nqm, hipMemcpyHostToDevice, s));
+            if (upload(c, 5, c->qd.p, qd.data(), sizeof(QDesc) * rq, s) || upload(c, 6, c->qmask.p, qmask + qbase, nqm, s))
+                return 1;
             if (run_dp_device(c, pl, qd.data(), rq, (uint64_t)bq * bg.ncap, tbc, sprows, cells, nqm, p, c->st->width,
                               out + q0 + r0, out_pos + qbase, false))
                 return 1;

@@ -2,6 +2,7 @@
 // Not part of the drop-in boundary (that is include/sina_hip.h below the stages
 // and the famfinder/aligner classes above it); this only lets Python feed trays
 // through the stages and read the results back.
+#include <malloc.h>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -278,8 +279,24 @@ int sina_host_set_option(const char *stage, const char *name, const char *value)
     }
 }
 
+// The driver allocates and frees tens of MB of trays per batch: keep what the allocator got from the
+// kernel (no trimming, no per-vector mmap) so that steady-state batches do not page-fault their
+// memory in again.  Process-wide; SINA_HOST_MALLOPT=0 leaves the allocator alone.
+static void tune_allocator() {
+    static const bool once = [] {
+        const char *v = getenv("SINA_HOST_MALLOPT");
+        if (v && *v == '0') return false;
+        mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        mallopt(M_TOP_PAD, 64 << 20);
+        mallopt(M_MMAP_THRESHOLD, 256 << 20);
+        return true;
+    }();
+    (void)once;
+}
+
 void *sina_host_pipeline_create(void) {
     try {
+        tune_allocator();
         famfinder::validate_options();
         aligner::validate_options();
         return new pipeline();
@@ -291,6 +308,7 @@ void *sina_host_pipeline_create(void) {
 // the same with the search stage behind the aligner (sina --search)
 void *sina_host_pipeline_create_search(void) {
     try {
+        tune_allocator();
         famfinder::validate_options();
         aligner::validate_options();
         search_filter::validate_options();
@@ -368,6 +386,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                 const uint32_t q = b0 + (uint32_t)i;
                 tray &t = trays[i];
                 result &r = p->results[q];
+                const double c_a = host_thread_cpu_seconds();
                 r.log = t.log.str();
                 r.family = t.input_sequence->get_attr<std::string>(fn::family);
                 if (t.input_sequence->has_attr(fn::turn)) r.attrs[fn::turn] = t.input_sequence->get_attr<std::string>(fn::turn);
@@ -394,7 +413,11 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                         r.sr_scores.push_back(sr.score);
                     }
                 }
+                const double c_b = host_thread_cpu_seconds();
                 t.destroy();
+                const double c_c = host_thread_cpu_seconds();
+                host_profile_add_cpu("drv.extract: copy out", c_b - c_a);
+                host_profile_add_cpu("drv.extract: tray.destroy", c_c - c_b);
             });
         };
         auto take = [&](item &it) -> bool {

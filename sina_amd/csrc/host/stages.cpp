@@ -44,12 +44,32 @@ prof_state &prof() {
     static prof_state p;
     return p;
 }
+thread_local const char *tl_phase = "(no phase)";  // innermost phase of this thread: names its pool jobs
+double thread_cpu_s() {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+void add_cpu(const char *phase, double s) {  // CPU seconds spent under a phase, by whichever thread
+    prof_state &p = prof();
+    if (!p.on) return;
+    std::lock_guard<std::mutex> lk(p.mu);
+    auto &e = p.acc[std::string(phase) + " [cpu]"];
+    e.first += s;
+    e.second++;
+}
 struct scoped_phase {
     const char *name;
+    const char *outer;
+    double cpu0;
     std::chrono::steady_clock::time_point t0;
-    explicit scoped_phase(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    explicit scoped_phase(const char *n) : name(n), outer(tl_phase), cpu0(thread_cpu_s()), t0(std::chrono::steady_clock::now()) {
+        tl_phase = n;
+    }
     ~scoped_phase() {
+        tl_phase = outer;
         prof_state &p = prof();
+        if (p.on) add_cpu(name, thread_cpu_s() - cpu0);
         if (!p.on && !p.trace_path) return;
         const auto t1 = std::chrono::steady_clock::now();
         const double s = std::chrono::duration<double>(t1 - t0).count();
@@ -66,6 +86,8 @@ struct scoped_phase {
 };
 }  // namespace
 
+void host_profile_add_cpu(const char *what, double seconds) { add_cpu(what, seconds); }
+double host_thread_cpu_seconds() { return thread_cpu_s(); }
 host_phase::host_phase(const char *n) : impl(new scoped_phase(n)) {}
 host_phase::~host_phase() { delete static_cast<scoped_phase *>(impl); }
 
@@ -99,6 +121,7 @@ namespace {
 class pool {
     struct job {
         const std::function<void(size_t)> *fn;
+        const char *phase;
         size_t n;
         std::atomic<size_t> next{0}, done{0};
         std::mutex err_mu;
@@ -123,6 +146,7 @@ public:
         }
         auto j = std::make_shared<job>();
         j->fn = &fn;
+        j->phase = tl_phase;
         j->n = n;
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -158,6 +182,16 @@ private:
         workers.clear();
     }
     void work_on(job &j) {
+        const bool helper = tl_phase != j.phase;  // (the posting thread's own time is in its scoped_phase)
+        const double c0 = (helper && prof().on) ? thread_cpu_s() : 0;
+        struct at_exit {
+            bool on;
+            const char *ph;
+            double c0;
+            ~at_exit() {
+                if (on) add_cpu(ph, thread_cpu_s() - c0);
+            }
+        } acc{helper && prof().on, j.phase, c0};
         for (;;) {
             const size_t i = j.next.fetch_add(1);
             if (i >= j.n) break;

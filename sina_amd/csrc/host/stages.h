@@ -459,6 +459,8 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn);
 void set_host_threads(unsigned n);
 unsigned host_threads();
 std::string host_profile_dump(bool reset);  // per-phase wall time when SINA_HOST_PROFILE is set
+void host_profile_add_cpu(const char *what, double seconds);  // (no-op unless SINA_HOST_PROFILE is set)
+double host_thread_cpu_seconds();
 class host_phase {                           // a named phase of the calling thread (profile / SINA_HOST_TRACE)
 public:
     explicit host_phase(const char *name);

@@ -772,20 +772,22 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
     if (c->qmask.reserve(std::max<uint64_t>(nqm, 1)) || c->k_qoff.reserve(8 * ((uint64_t)nq + 1))) return 1;
     std::vector<uint64_t> rel(nq + 1);
     for (uint32_t q = 0; q <= nq; q++) rel[q] = qoff[q] - qoff[0];
-    SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qoff[0], nqm, hipMemcpyHostToDevice, s));
-    SH_CHECK(hipMemcpyAsync(c->k_qoff.p, rel.data(), 8 * ((uint64_t)nq + 1), hipMemcpyHostToDevice, s));
+    if (upload(c, 7, c->qmask.p, qmask + qoff[0], nqm, s) || upload(c, 8, c->k_qoff.p, rel.data(), 8 * ((uint64_t)nq + 1), s))
+        return 1;
     for (uint32_t q0 = 0; q0 < nq; q0 += per) {
         const uint32_t bq = std::min(per, nq - q0);
         if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>() + q0, bq, max, max_qlen, false)) return 1;
-        // (wait for the kernels FIRST: a copy to pageable memory queued behind running kernels waits
-        // inside the runtime, under locks other threads' launches need -- see HostBuf in common.h)
+        // (the kernels have finished: kmer_topk_device waits for the heavy stream; results come back
+        // through pinned staging -- see HostBuf in common.h)
+        if (download(c, 9, c->k_out_ids.p, (size_t)bq * max * 4, s) || download(c, 10, c->k_out_scores.p, (size_t)bq * max * 4, s) ||
+            download(c, 11, c->k_out_n.p, (size_t)bq * 4, s) || download(c, 0, c->k_tmp2.p, 8, s))
+            return 1;
         SH_CHECK(wait_stream(c, s));
-        SH_CHECK(hipMemcpyAsync(out_ids + (size_t)q0 * max, c->k_out_ids.p, (size_t)bq * max * 4, hipMemcpyDeviceToHost, s));
-        SH_CHECK(hipMemcpyAsync(out_scores + (size_t)q0 * max, c->k_out_scores.p, (size_t)bq * max * 4, hipMemcpyDeviceToHost, s));
-        SH_CHECK(hipMemcpyAsync(out_n + q0, c->k_out_n.p, (size_t)bq * 4, hipMemcpyDeviceToHost, s));
+        memcpy(out_ids + (size_t)q0 * max, c->h_stage[9].p, (size_t)bq * max * 4);
+        memcpy(out_scores + (size_t)q0 * max, c->h_stage[10].p, (size_t)bq * max * 4);
+        memcpy(out_n + q0, c->h_stage[11].p, (size_t)bq * 4);
         unsigned long long visited = 0;
-        SH_CHECK(hipMemcpyAsync(&visited, c->k_tmp2.p, 8, hipMemcpyDeviceToHost, s));
-        SH_CHECK(wait_stream(c, s));
+        memcpy(&visited, c->h_stage[0].p, 8);
         float ms = 0;
         SH_CHECK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
         std::lock_guard<std::mutex> slk(c->st->stats_mu);

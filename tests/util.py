@@ -133,7 +133,7 @@ def _mesh_cases():
     for i in range(24):
         sch = dict(schemes[i % len(schemes)])
         sch["fs_weight"] = (1.0, 0.0, 2.5)[i % 3]
-        cases.append(dict(seed=300 + i, n_refs=64, length=140 + 10 * (i % 5), width=900 + 50 * (i % 4),
+        cases.append(dict(seed=300 + i, n_refs=96, length=260 + 20 * (i % 5), width=1700 + 100 * (i % 4),
                           F=fam_sizes[i % len(fam_sizes)], scheme=sch))
     # one full-length 16S family of 40 (2800 rows x 1500 columns), default scheme
     cases.append(dict(seed=777, n_refs=48, length=1500, width=50000, F=40,
@@ -149,13 +149,16 @@ def mesh_case_inputs(case):
     small = case["length"] < 1000
     refs = synth.make_refs(case["n_refs"], length=case["length"], width=case["width"], seed=case["seed"], n_clades=3,
                            amb_rate=0.03 if small else 0.0, lower_rate=0.05 if small else 0.0,
-                           long_del_prob=0.4 if small else 0.1, del_rate=0.03 if small else 0.01,
+                           long_del_prob=0.3 if small else 0.1, del_rate=0.03 if small else 0.01,
                            ins_rate=0.02 if small else 0.005)
-    qs = synth.make_queries(refs, 1, seed=case["seed"] + 5000, amb_rate=0.02 if small else 0.0)
+    qs = synth.make_queries(refs, 16, seed=case["seed"] + 5000, amb_rate=0.02 if small else 0.0)
     rng = np.random.default_rng(case["seed"] + 9000)
-    ids = rng.choice(refs.n, size=case["F"], replace=False)
+    sizes = np.diff(refs.off)
+    usable = np.flatnonzero(sizes >= case["length"] // 3)   # (a long deletion can take most of a short reference)
+    ids = rng.choice(usable, size=case["F"], replace=False)
     fam = [refs.seq(int(i)).copy() for i in ids]
-    qm = qs.seq(0) & 0x0f   # the aligner upper-cases its working copy (align.cpp:324-326)
+    qi = next(i for i in range(qs.n) if len(qs.seq(i)) >= case["length"] // 3)
+    qm = qs.seq(qi) & 0x0f   # the aligner upper-cases its working copy (align.cpp:324-326)
     qa = np.arange(len(qm), dtype=np.uint32) | (qm.astype(np.uint32) << 24)
     w = None
     if case["scheme"]["weighted"]:   # long enough that pos + 1 + offset never runs past the end
