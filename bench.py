@@ -311,9 +311,13 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: full-length 16S (~%d bp%s) vs %d-seq SILVA-NR-like aligned reference, "
+                "workload": "%s (~%d bp%s) vs %d-seq SILVA-NR-like aligned reference, "
                             "width %d, SINA defaults (k=10 fast, family 40, match 2/mismatch -1/gap 5/ext 2)"
-                            % (a.length, (", cut to %d" % a.window) if a.window else "", a.refs, a.width),
+                            % ("configs[2] shape: V4 amplicons cut from full-length 16S" if a.window else
+                               ("configs[4] shape: full-length 23S" if a.length >= 2500 else
+                                ("configs[3] shape: full-length 16S, large reference" if a.refs >= 400000 else
+                                 "configs[1]: full-length 16S")),
+                               a.length, (", cut to %d" % a.window) if a.window else "", a.refs, a.width),
                 "refs": a.refs, "length": a.length, "width": a.width, "window": a.window,
                 "queries_per_step_per_gpu": a.batch,
                 "queries_per_launch": a.sub_batch,

@@ -1090,9 +1090,18 @@ bool pick_geom(uint32_t maxL, DpGeom *g) {
             return true;
         }
     }
+    // one strip covers the query: the thinnest lanes that do (a wider lane would only idle -- V4
+    // amplicons, 250 bases: B = 4 487 Gcell/s, B = 8 with half the lanes unused 260)
+    for (int i = 0; i < 3; i++)
+        if (maxL <= 64u * (uint32_t)kLaneCells[i]) {
+            g->T = 64;
+            g->B = kLaneCells[i];
+            return true;
+        }
+    // several strips: B = 8 or 12 by padded width / throughput
     double best = 0;
     bool found = false;
-    for (int i = 0; i < 3; i++) {
+    for (int i = 1; i < 3; i++) {
         const int b = kLaneCells[i];
         const uint32_t strips = (maxL + 64u * b - 1) / (64u * b);
         if (strips > (uint32_t)kMaxStrips || strips * 64u * b > 8192u) continue;  // (13-bit value_sidx, common.h)
