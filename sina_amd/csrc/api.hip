@@ -97,6 +97,7 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
             if (m % seg_len == 0)
                 for (int x = 0; x < W; x++) free_at[x] = 0;
             if (rec[m].z & kRecSink) continue;  // w stays kRowNone
+            if (last[m] == m + 1) continue;      // only the next row reads it: handed over in registers
             int slot = -1;
             const uint32_t seg_end = std::min<uint32_t>(N, (m / seg_len + 1) * seg_len);
             if (!(rec[m].z & kRecFence) && last[m] < seg_end)  // (else: always a spill row)
@@ -116,9 +117,10 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
             uint32_t first_far = 0;
             for (uint32_t e = po[m]; e < po[m + 1]; e++) {
                 const uint32_t p = g->pred[eo + e];
-                const bool sp = (rec[p].w & kRowSpilled) != 0;
+                const uint32_t pw = rec[p].w == kRowNone ? 0u : rec[p].w;  // (kRowNone: in registers for this row)
+                const bool sp = (pw & kRowSpilled) != 0;
                 if (sp && first_far == 0) first_far = e - po[m] + 1;
-                hp->pred[d.edge_off + e] = p | ((rec[p].w & 0x7FFFu) << 16) | (sp ? kPredSpilled : 0u);
+                hp->pred[d.edge_off + e] = p | ((pw & 0x7FFFu) << 16) | (sp ? kPredSpilled : 0u);
             }
             rec[m].z |= first_far << 24;
         }

@@ -122,7 +122,9 @@ struct QDesc {
 //       flags bit0: sink = no successors; bit1: some successor is further than kFarLds rows away
 //       (such a row is kept in a spill row: it would hold an LDS slot for hundreds of rows)
 //   w = where the finished row {value, gapm_val} is kept for its successors:
-//       0xFFFFFFFF nowhere (no successors), kRowSpilled | spill row index, or the LDS slot number.
+//       0xFFFFFFFF nowhere (no successors, or the next row is the only one: the DP kernel hands the
+//       row just finished to the next one in registers), kRowSpilled | spill row index, or the LDS
+//       slot number.
 // LDS slots are handed out by liveness (a slot is reused once the last successor of its row has
 // been computed); a row that finds every slot busy, or that has a successor more than kFarLds
 // rows away (kRecFence), goes to a spill row in HBM instead.

@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         for (uint32_t m = b; m < e; m++) {
             const uint32_t z = rec[m].z, l = last[m];
             uint32_t wv = kRowNone;
-            if (!(z & kRecSink)) {
+            if (!(z & kRecSink) && l != m + 1) {  // (a row only the next row reads is handed over in registers)
                 // (a row with a successor beyond kFarLds, or in a later segment, is always a spill row)
                 const bool may_slot = !(z & kRecFence) && l < e;
                 uint32_t slot = 8;
@@ -462,7 +462,8 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         uint32_t first_far = 0;
         for (uint32_t x = 0; x < np; x++) {
             const uint32_t pa = pred[r.x + x];
-            const uint32_t pw = rec[pa].w;
+            uint32_t pw = rec[pa].w;
+            if (pw == kRowNone) pw = 0;  // (kept in registers for this row: the entry's slot is not read)
             const bool sp = (pw & kRowSpilled) != 0;
             if (sp && first_far == 0) first_far = x + 1;
             pred[r.x + x] = pa | ((pw & 0x7FFFu) << 16) | (sp ? kPredSpilled : 0u);

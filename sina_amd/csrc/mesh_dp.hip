@@ -334,6 +334,12 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     if (have_left_strip) cur_edge = sload16(e_in);
     sload_wait(cur_pe);
     sload_wait(cur_edge);
+    // The row just finished stays in registers: it is the last predecessor of more than half of the
+    // rows, and a row whose ONLY successor is the next row is kept nowhere else (common.h).
+    Cells<B> prev_v, prev_g;
+    float prev_edge_val = 0.f;
+#pragma unroll
+    for (int i = 0; i < B / 4; i++) prev_v.v[i] = prev_g.v[i] = typename Cells<B>::V{0.f, 0.f, 0.f, 0.f};
     for (uint32_t m = 0; m < N; ++m) {
         const uint32_t m_next = m + 1 < N ? m + 1 : m;
         const uint4 nrec = rec[m_next];  // scalar prefetch of the next row record ...
@@ -437,7 +443,11 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             const uint32_t p = pe & 0xffffu;
             Cells<B> sv, sg;
             float left_of_strip = 0.f;
-            if (pe & kPredSpilled) {
+            if (p + 1 == m) {  // the previous row: still in registers
+                sv = prev_v;
+                sg = prev_g;
+                left_of_strip = prev_edge_val;
+            } else if (pe & kPredSpilled) {
                 if (SH_ABL(2)) continue;
                 const float *row = spill + (size_t)((pe >> 16) & 0x7FFFu) * (2 * Lp);
                 sv.load(row + s0);
@@ -841,6 +851,12 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         cur = nrec;
         cur_edge = nedge;
         cur_pe = npe;
+#pragma unroll
+        for (int i = 0; i < B / 4; i++) {
+            prev_v.v[i] = typename Cells<B>::V{fv[4 * i], fv[4 * i + 1], fv[4 * i + 2], fv[4 * i + 3]};
+            prev_g.v[i] = typename Cells<B>::V{gm[4 * i], gm[4 * i + 1], gm[4 * i + 2], gm[4 * i + 3]};
+        }
+        prev_edge_val = edge_val;
     }
     // this strip's best sink cell joins the earlier strips': smaller value, then smaller sink id,
     // then smaller column (mesh.h:579-592 scans sinks ascending, columns ascending, strict <)

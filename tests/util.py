@@ -78,7 +78,7 @@ def f32_bits(a):
 
 def row_store_model(pred_off, pred, n_slots, far_lds=192):
     """Where mesh_dp_kernel keeps each finished DP row for its successors (sina_amd/csrc/common.h):
-    0xFFFFFFFF nowhere (no successors), an LDS slot number (first slot whose occupant has seen its
+    0xFFFFFFFF nowhere (no successors, or only the next row: the kernel hands that over in registers), an LDS slot number (first slot whose occupant has seen its
     last successor), or 0x80000000 | spill row index when no slot is free, some successor is more
     than far_lds rows away, or the last successor lies in a later allocation segment (the rows are
     allocated in independent segments of max(256, ceil(n / 16)) rows, every segment starting with all
@@ -94,7 +94,7 @@ def row_store_model(pred_off, pred, n_slots, far_lds=192):
     for m in range(n):
         if m % seg_len == 0:
             free_at = [0] * n_slots
-        if last[m] == 0:
+        if last[m] == 0 or last[m] == m + 1:   # no successor / only the next row: handed over in registers
             continue
         slot = -1
         seg_end = min(n, (m // seg_len + 1) * seg_len)
