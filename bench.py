@@ -241,12 +241,16 @@ def main():
     torch.cuda.synchronize(device)
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    if os.environ.get("SINA_HIP_TRACE_ALLOC"):
+        print("[bench] %.3f timed region starts" % (time.clock_gettime(time.CLOCK_MONOTONIC) % 1000), file=sys.stderr)
     t0 = time.time()
     timing = run_steps(a.warmup, a.steps)
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
     elapsed = time.time() - t0
+    if os.environ.get("SINA_HIP_TRACE_ALLOC"):
+        print("[bench] %.3f timed region ends" % (time.clock_gettime(time.CLOCK_MONOTONIC) % 1000), file=sys.stderr)
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     host_cores = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / elapsed
     host_cores_sys = (ru1.ru_stime - ru0.ru_stime) / elapsed

@@ -388,6 +388,23 @@ extern "C" {
 int sina_hip_abi_version(void) { return SINA_HIP_ABI_VERSION; }
 const char *sina_hip_last_error(void) { return g_last_error.c_str(); }
 
+// a partly built context is taken apart again when init / fork fails half-way
+static void discard_ctx(sina_hip_ctx *c) {
+    if (!c) return;
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream_dp) (void)hipStreamDestroy(c->stream_dp);
+    c->free_all();
+    delete c;
+}
+static int finish_ctx(sina_hip_ctx *c) {  // streams + events of a new context
+    for (auto &e : c->ev) e = nullptr;
+    if (make_streams(c)) return 1;
+    for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
+    return 0;
+}
+
 int sina_hip_init(int device, sina_hip_ctx **ctx) {
     if (!ctx) SH_FAIL("init: null ctx pointer");
     int ndev = 0;
@@ -398,12 +415,15 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
     c->device = device;
     c->st = new sina_hip_store();
     c->owns_store = true;
-    if (make_streams(c)) return 1;
-    SH_CHECK(hipStreamCreateWithFlags(&c->st->heavy, hipStreamNonBlocking));
-    for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
+    memset(&c->st->stats, 0, sizeof(c->st->stats));
+    if (finish_ctx(c) || hipStreamCreateWithFlags(&c->st->heavy, hipStreamNonBlocking) != hipSuccess) {
+        const std::string why = sina_hip_last_error();
+        discard_ctx(c);
+        set_error(why.empty() ? "init: could not create the context's streams" : why);
+        return 1;
+    }
     c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 0) * 1024;
     c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 32) << 30;
-    memset(&c->st->stats, 0, sizeof(c->st->stats));
     *ctx = c;
     return 0;
 }
@@ -415,11 +435,14 @@ int sina_hip_fork(sina_hip_ctx *parent, sina_hip_ctx **ctx) {
     c->device = parent->device;
     c->st = parent->st;  // same reference store, index and counters; never freed by the fork
     c->owns_store = false;
-    if (make_streams(c)) return 1;
-    for (auto &e : c->ev) SH_CHECK(hipEventCreate(&e));
     c->lds_budget = parent->lds_budget;
     c->tb_budget_bytes = parent->tb_budget_bytes;
-    if (c->adopt_hints()) return 1;
+    if (finish_ctx(c) || c->adopt_hints()) {
+        const std::string why = sina_hip_last_error();
+        discard_ctx(c);
+        set_error(why);
+        return 1;
+    }
     *ctx = c;
     return 0;
 }

@@ -90,6 +90,11 @@ struct HostBuf {
         p = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 4 + 4096;
+        if (getenv("SINA_HIP_TRACE_ALLOC")) {
+            timespec ts;
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            fprintf(stderr, "[sina_hip] %.3f hipHostMalloc %.1f MB\n", ts.tv_sec % 1000 + ts.tv_nsec * 1e-9, want / 1048576.0);
+        }
         SH_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
         cap = want;
         return 0;

@@ -829,8 +829,19 @@ bool match_pass(search::result_vector &results, const cseq &query, match_state &
 void famfinder::impl::run(std::vector<tray *> &batch) {
     const ff_options &o = ff_opts;
     std::vector<tray *> todo;
-    orient_batch(batch);
+    // (the device searches queries of up to 8192 bases; a longer one fails alone, softly, like a
+    // sequence without relatives -- not the whole batch)
+    std::vector<tray *> searchable;
     for (tray *t : batch) {
+        if (t->input_sequence->size() > 8192u) {
+            t->log << "unable to align: sequence longer than 8192 bases;";
+            t->input_sequence->set_attr(fn::turn, "turn-check disabled");
+        } else {
+            searchable.push_back(t);
+        }
+    }
+    orient_batch(searchable);
+    for (tray *t : searchable) {
         t->alignment_reference = new search::result_vector();
         todo.push_back(t);
     }
@@ -866,6 +877,10 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
     scoped_phase ph_post("ff.post");
     parallel_for(batch.size(), [&](size_t i) {
         tray &t = *batch[i];
+        if (t.alignment_reference == nullptr) {  // (not searched, see above)
+            select_astats(t);
+            return;
+        }
         auto &vc = *t.alignment_reference;
         cseq &c = *t.input_sequence;
         std::string fam;
@@ -1108,6 +1123,10 @@ void aligner::operator()(std::vector<tray> &batch) {
     parallel_for(batch.size(), [&](size_t i) {
         tray &t = batch[i];
         if (t.input_sequence == nullptr || t.alignment_reference == nullptr || t.astats == nullptr) return;  // :310-318
+        if (t.input_sequence->size() > 8191u) {  // (device limit: soft failure of this tray)
+            t.log << "unable to align: sequence of " << t.input_sequence->size() << " bases (device limit 8191);";
+            return;
+        }
         cseq &c = *(new cseq(*t.input_sequence));
         search::result_vector &vc = *t.alignment_reference;
         const std::string bases = c.getBases();

@@ -190,3 +190,30 @@ def test_baseline_config_shapes(oracle, shape):
         pl.close()
     finally:
         st.close()
+
+
+def test_overlong_query_fails_alone(oracle, world):
+    """A sequence beyond the device limits (8192 bases for the k-mer search, 8191 for the DP) is a soft
+    failure of THAT tray -- reason in the log, no aligned sequence -- and the rest of its batch is
+    aligned as usual (the reference aligns any length; this engine does not abort the run)."""
+    refs, cs, idx, st = world
+    qs = synth.make_queries(refs, 6, seed=61)
+    rng = np.random.default_rng(62)
+    long_q = synth.CODE_TO_MASK[rng.integers(0, 4, size=9000)]
+    masks = [qs.seq(i) for i in range(3)] + [long_q] + [qs.seq(i) for i in range(3, 6)]
+    off = np.zeros(len(masks) + 1, np.int64)
+    off[1:] = np.cumsum([len(m) for m in masks])
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    pl = pipeline.Pipeline(st, famfinder=ff)
+    pl.run(np.concatenate(masks), off, batch=7, inflight=1)
+    got = [pl.result(i) for i in range(7)]
+    assert got[3]["status"] == 2 and "longer than 8192 bases" in got[3]["log"]
+    sub = synth.QuerySet(mask=qs.mask, off=qs.off, src=qs.src)
+    for k, qi in enumerate([0, 1, 2, None, 3, 4, 5]):
+        if qi is None:
+            continue
+        want = _oracle_run(oracle, cs, idx, sub, qi, dict(fs_min_len=100, fs_full_len=250))
+        assert got[k]["status"] == want["status"]
+        if want["status"] != 2:
+            assert (got[k]["packed"] == want["packed"]).all()
+    pl.close()

@@ -332,7 +332,7 @@ def test_500k_references_properties():
             again = pl.result(qi)
             assert again["status"] == res[qi]["status"] and (again["packed"] == res[qi]["packed"]).all()
             assert again["family"] == res[qi]["family"]
-            assert res[qi]["status"] in (0, 1)
+            assert res[qi]["status"] in (0, 1), (qi, res[qi]["log"], len(qs.seq(qi)))
             got_bases = (res[qi]["packed"] >> 24) & 0x0f
             assert (got_bases == (qs.seq(qi) & 0x0f)).all()       # every base placed, in order
             if res[qi]["status"] == 1:                            # copied from a reference that contains it
