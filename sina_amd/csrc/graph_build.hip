@@ -38,7 +38,13 @@
 namespace sina_hip {
 namespace {
 
-constexpr int kGT = 256;          // threads per workgroup
+#ifndef SINA_GRAPH_THREADS
+#define SINA_GRAPH_THREADS 512
+#endif
+#ifndef SINA_GRAPH_MINWAVES
+#define SINA_GRAPH_MINWAVES 6  // (3 workgroups of 8 waves per CU: <= 80 VGPRs)
+#endif
+constexpr int kGT = SINA_GRAPH_THREADS;  // threads per workgroup (the phases are latency-bound: more loads in flight per LDS byte)
 constexpr uint32_t kNoPrev = 0xFFFFu;
 constexpr int kMaxFam = 128;
 constexpr int kTC = 128;          // occupied columns per LDS tile
@@ -69,6 +75,7 @@ struct GraphArgs {
     uint32_t *pred;            // per query area of total-family-bases entries
     uint32_t *sizes;           // [nq][4]: N, raw edge entries, n_spill, status (0 ok, 2 N cap, 4 spill rows)
     uint32_t width, ncap;
+    uint32_t tile_bytes;       // LDS bytes of the tile tables (reused by the slot allocation)
     int W;                     // DP ring depth: edges longer than this need a spill row
 };
 
@@ -106,14 +113,14 @@ __device__ uint32_t block_exscan(const In *in, Out *out, uint32_t n, uint32_t *t
     return total;
 }
 
-__global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
+__global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t s_ids[kMaxFam];
     __shared__ uint32_t s_len[kMaxFam];
     __shared__ uint64_t s_beg[kMaxFam];
     __shared__ uint32_t s_cur[kMaxFam], s_curn[kMaxFam];      // first base of member j at/after the tile
     __shared__ uint32_t s_carry[kMaxFam], s_carryn[kMaxFam];  // node of member j's last base before the tile
-    __shared__ uint32_t s_tmp[8];
+    __shared__ uint32_t s_tmp[kGT / 64 + 8];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t nwords = (a.width + 31) / 32;
     const uint64_t f0 = a.fam_off[q];
@@ -132,6 +139,9 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
     uint16_t *tabm = reinterpret_cast<uint16_t *>(rc + kTC);                // [kTC][FS]
     uint16_t *tabp = tabm + (size_t)kTC * FS;                               // [kTC][FS] previous node, 0xFFFF none
     uint8_t *ncolT = reinterpret_cast<uint8_t *>(tabp + (size_t)kTC * FS);  // [kTC * 32] tile column of every node of the tile
+    // [F][kTC] tile column of member j's (s_cur[j] + slot)-th base, 255: not in the tile -- the same
+    // LDS as ncolT: cl8 is read for the last time in step 4, ncolT is filled after it
+    uint8_t *cl8 = ncolT;
 
     uint32_t *sz = a.sizes + 4 * (size_t)q;
     for (uint32_t j = tid; j < F; j += kGT) {
@@ -147,11 +157,21 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
     GP_DECL
 
     // 1. occupied columns
-    for (uint32_t j = 0; j < F; j++) {
-        const uint32_t *b = a.ref_ab + s_beg[j];
-        for (uint32_t i = tid; i < s_len[j]; i += kGT) {
-            const uint32_t pos = b[i] & 0xFFFFFFu;
-            atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+    // (latency-bound: four members' loads are in flight per thread before the first is used)
+    for (uint32_t j0 = 0; j0 < F; j0 += 4) {
+        const uint32_t maxlen = max(max(s_len[j0], j0 + 1 < F ? s_len[j0 + 1] : 0u),
+                                    max(j0 + 2 < F ? s_len[j0 + 2] : 0u, j0 + 3 < F ? s_len[j0 + 3] : 0u));
+        for (uint32_t i = tid; i < maxlen; i += kGT) {
+            uint32_t ab[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                ab[u] = (j0 + u < F && i < s_len[j0 + u]) ? a.ref_ab[s_beg[j0 + u] + i] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (ab[u] != 0xFFFFFFFFu) {
+                    const uint32_t pos = ab[u] & 0xFFFFFFu;
+                    atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+                }
         }
     }
     __syncthreads();
@@ -181,10 +201,10 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
             wrank[i] = (uint16_t)run;
             run += __popc(bitmap[i]);
         }
-        if (tid == 0) s_tmp[4] = total;
+        if (tid == 0) s_tmp[kGT / 64] = total;
     }
     __syncthreads();
-    const uint32_t NC = s_tmp[4];
+    const uint32_t NC = s_tmp[kGT / 64];
     if (NC > 65535u) {  // (cannot be a valid DAG for the DP kernel anyway: more columns than row ids)
         if (tid == 0) {
             sz[0] = NC;
@@ -217,19 +237,46 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         }
         __syncthreads();
         GP(2)
-        // 3a. masks of this tile: member j's bases cur[j].. as long as their column is in the tile
+        // 3a. masks of this tile: member j's bases cur[j].. as long as their column is in the tile (a
+        // contiguous stretch of at most kTC bases); the tile column of every such base is kept in
+        // cl8 so that nothing below has to rank a position again
+        for (uint32_t idx0 = tid; idx0 < F * (uint32_t)kTC; idx0 += 4 * kGT) {
+            // (latency-bound: four loads in flight per thread)
+            uint32_t abv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t idx = idx0 + (uint32_t)u * kGT;
+                abv[u] = 0xFFFFFFFFu;  // (no packed base looks like this: the mask byte has five bits)
+                if (idx < F * (uint32_t)kTC) {
+                    const uint32_t j = idx / kTC, i = s_cur[j] + idx % kTC;
+                    if (i < s_len[j]) abv[u] = a.ref_ab[s_beg[j] + i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t idx = idx0 + (uint32_t)u * kGT;
+                if (idx >= F * (uint32_t)kTC) continue;
+                const uint32_t j = idx / kTC, slot = idx % kTC, i = s_cur[j] + slot;
+                uint32_t cl = 255;
+                if (abv[u] != 0xFFFFFFFFu) {
+                    const uint32_t ab = abv[u];
+                    const uint32_t pos = ab & 0xFFFFFFu;
+                    const uint32_t c = rank(pos) - c0;
+                    if (c < tc) {
+                        cl = c;
+                        tabm[c * FS + j] = (uint16_t)(((ab >> 24) & 0xFFu) | (i == 0 ? (1u << 13) : 0u));
+                        cposT[c] = pos;
+                    }
+                }
+                cl8[j * kTC + slot] = (uint8_t)cl;
+            }
+        }
+        __syncthreads();
+        // the member's last base in this tile moves its cursor
         for (uint32_t idx = tid; idx < F * (uint32_t)kTC; idx += kGT) {
-            const uint32_t j = idx / kTC, i = s_cur[j] + idx % kTC;
-            if (i >= s_len[j]) continue;
-            const uint32_t *b = a.ref_ab + s_beg[j];
-            const uint32_t ab = b[i];
-            const uint32_t pos = ab & 0xFFFFFFu;
-            const uint32_t cl = rank(pos) - c0;
-            if (cl >= tc) continue;
-            tabm[cl * FS + j] = (uint16_t)(((ab >> 24) & 0xFFu) | (i == 0 ? (1u << 13) : 0u));
-            cposT[cl] = pos;
-            // the member's last base in this tile moves its cursor
-            if (i + 1 >= s_len[j] || rank(b[i + 1] & 0xFFFFFFu) - c0 >= tc) s_curn[j] = i + 1;
+            const uint32_t j = idx / kTC, slot = idx % kTC;
+            if (cl8[j * kTC + slot] != 255 && (slot + 1 == (uint32_t)kTC || cl8[j * kTC + slot + 1] == 255))
+                s_curn[j] = s_cur[j] + slot + 1;
         }
         __syncthreads();
         GP(3)
@@ -265,29 +312,28 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         GP(4)
         const uint32_t tn = block_exscan(nn, nbaseT, tc, s_tmp);
         const uint32_t te = block_exscan(rc, ebaseT, tc, s_tmp);
-        for (uint32_t c = tid; c < tc; c += kGT)
-            for (uint32_t k = 0; k < nn[c]; k++) ncolT[nbaseT[c] + k] = (uint8_t)c;
         GP(5)
-        // 4. node of every base's predecessor base
+        // 4. node of every base's predecessor base (the member's previous base: one slot to the left,
+        // or -- for its first base in the tile -- what the previous tiles carried over)
         for (uint32_t idx = tid; idx < F * (uint32_t)kTC; idx += kGT) {
-            const uint32_t j = idx / kTC, i = s_cur[j] + idx % kTC;
-            if (i >= s_len[j]) continue;
-            const uint32_t *b = a.ref_ab + s_beg[j];
-            const uint32_t cl = rank(b[i] & 0xFFFFFFu) - c0;
-            if (cl >= tc) continue;
+            const uint32_t j = idx / kTC, slot = idx % kTC;
+            const uint32_t cl = cl8[j * kTC + slot];
+            if (cl == 255) continue;
+            const uint32_t i = s_cur[j] + slot;
             const uint32_t node = N + nbaseT[cl] + ((tabm[cl * FS + j] >> 8) & 31u);
             uint32_t pn = kNoPrev;
-            if (i > 0) {
-                if (i > s_cur[j]) {
-                    const uint32_t pl = rank(b[i - 1] & 0xFFFFFFu) - c0;
-                    pn = N + nbaseT[pl] + ((tabm[pl * FS + j] >> 8) & 31u);
-                } else {
-                    pn = s_carry[j];
-                }
+            if (slot > 0) {
+                const uint32_t pl = cl8[j * kTC + slot - 1];
+                pn = N + nbaseT[pl] + ((tabm[pl * FS + j] >> 8) & 31u);
+            } else if (i > 0) {
+                pn = s_carry[j];
             }
             tabp[cl * FS + j] = (uint16_t)pn;
             if (i + 1 == s_curn[j]) s_carryn[j] = node;
         }
+        __syncthreads();
+        for (uint32_t c = tid; c < tc; c += kGT)  // (cl8 is dead: its LDS becomes the node -> column map)
+            for (uint32_t k = 0; k < nn[c]; k++) ncolT[nbaseT[c] + k] = (uint8_t)c;
         __syncthreads();
         GP(6)
         // 5. node records + sorted unique predecessor lists: one thread per NODE of the tile (a column
@@ -411,6 +457,17 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
     // order (per-segment counts, prefix sum).  tests/util.py row_store_model states the same rule.
     const uint32_t seg_len = dp_slot_segment(N);
     const uint32_t n_seg = (N + seg_len - 1) / seg_len;
+    // (the lanes walk their segments row by row: from LDS when the rows fit the tile tables' space --
+    // a dependent global load per row was most of this step's time)
+    uint32_t *codeL = reinterpret_cast<uint32_t *>(tile);
+    const bool in_lds = (size_t)N * 4 <= a.tile_bytes;
+    if (in_lds) {
+        for (uint32_t i = tid; i < N; i += kGT) {
+            const uint32_t z = rec[i].z;
+            codeL[i] = last[i] | ((z & kRecSink) ? (1u << 30) : 0u) | ((z & kRecFence) ? (1u << 31) : 0u);
+        }
+        __syncthreads();
+    }
     if (tid < n_seg) {
         uint32_t fa[8];  // last successor of the row in slot x (0: empty)
 #pragma unroll
@@ -418,11 +475,22 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         uint32_t nsp = 0;
         const uint32_t b = tid * seg_len, e = min(N, b + seg_len);
         for (uint32_t m = b; m < e; m++) {
-            const uint32_t z = rec[m].z, l = last[m];
+            uint32_t l, sink, fence;
+            if (in_lds) {
+                const uint32_t cd = codeL[m];
+                l = cd & 0xFFFFu;
+                sink = cd & (1u << 30);
+                fence = cd & (1u << 31);
+            } else {
+                const uint32_t z = rec[m].z;
+                l = last[m];
+                sink = z & kRecSink;
+                fence = z & kRecFence;
+            }
             uint32_t wv = kRowNone;
-            if (!(z & kRecSink) && l != m + 1) {  // (a row only the next row reads is handed over in registers)
+            if (!sink && l != m + 1) {  // (a row only the next row reads is handed over in registers)
                 // (a row with a successor beyond kFarLds, or in a later segment, is always a spill row)
-                const bool may_slot = !(z & kRecFence) && l < e;
+                const bool may_slot = !fence && l < e;
                 uint32_t slot = 8;
 #pragma unroll
                 for (int x = 7; x >= 0; x--) slot = (may_slot && fa[x] <= m) ? (uint32_t)x : slot;
@@ -430,7 +498,8 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
                 for (int x = 0; x < 8; x++) fa[x] = (slot == (uint32_t)x) ? l : fa[x];
                 wv = slot < 8 ? slot : (kRowSpilled | nsp++);
             }
-            rec[m].w = wv;
+            if (in_lds) codeL[m] = wv;
+            else rec[m].w = wv;
         }
         s_ids[tid] = nsp;  // (s_ids is free by now: spill rows of my segment)
     }
@@ -439,12 +508,14 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         uint32_t tot = 0;
         for (uint32_t g = 0; g < n_seg; g++) tot += s_ids[g];
         for (uint32_t i = tid; i < N; i += kGT) {
-            const uint32_t w = rec[i].w;
+            uint32_t w = in_lds ? codeL[i] : rec[i].w;
             if (w != kRowNone && (w & kRowSpilled)) {
                 uint32_t base = 0;
                 for (uint32_t g = 0; g < i / seg_len; g++) base += s_ids[g];
-                rec[i].w = w + base;
+                w += base;
             }
+            rec[i].w = w;
+            if (in_lds) codeL[i] = w;  // (read again by step 8)
         }
         if (tid == 0) {
             sz[0] = N;
@@ -462,7 +533,7 @@ __global__ void __launch_bounds__(kGT) family_graph_kernel(GraphArgs a) {
         uint32_t first_far = 0;
         for (uint32_t x = 0; x < np; x++) {
             const uint32_t pa = pred[r.x + x];
-            uint32_t pw = rec[pa].w;
+            uint32_t pw = in_lds ? codeL[pa] : rec[pa].w;
             if (pw == kRowNone) pw = 0;  // (kept in registers for this row: the entry's slot is not read)
             const bool sp = (pw & kRowSpilled) != 0;
             if (sp && first_far == 0) first_far = x + 1;
@@ -478,7 +549,7 @@ size_t graph_lds_bytes(uint32_t width, uint32_t max_family) {
     const size_t nwords = (width + 31) / 32;
     const size_t fs = (max_family + 1) | 1u;
     return ((6 * nwords + 15) & ~(size_t)15) + (size_t)kTC * (4 + 4 + 4 + 1 + 1) + 2 * 2 * (size_t)kTC * fs +
-           (size_t)kTC * 32 + 64;
+           (size_t)kTC * std::max<size_t>(32, fs) + 64;
 }
 
 }  // namespace
@@ -559,6 +630,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         ga.sizes = c->g_sizes.as<uint32_t>();
         ga.width = c->st->width;
         ga.ncap = ncap;
+        ga.tile_bytes = (uint32_t)(glds - ((6 * (size_t)((c->st->width + 31) / 32) + 15) & ~(size_t)15) - 64);
         ga.W = W;
         SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(family_graph_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));

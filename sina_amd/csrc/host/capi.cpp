@@ -357,8 +357,9 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                     std::vector<aligned_base> ab((size_t)(qoff[q + 1] - qoff[q]));
                     for (size_t x = 0; x < ab.size(); x++)
                         ab[x] = aligned_base::from_raw((uint32_t)x | ((uint32_t)qmask[qoff[q] + x] << 24));
-                    t.input_sequence->setAlignedBases(ab);
-                    t.input_sequence->setWidth((uint32_t)ab.size());
+                    const uint32_t n_bases = (uint32_t)ab.size();
+                    t.input_sequence->setAlignedBases(std::move(ab));
+                    t.input_sequence->setWidth(n_bases);
                 });
             }
             const auto a = std::chrono::steady_clock::now();

@@ -106,6 +106,8 @@ public:
     vidx_type size() const { return (vidx_type)bases.size(); }
     const std::vector<aligned_base> &getAlignedBases() const { return bases; }
     void setAlignedBases(const std::vector<aligned_base> &vab) { bases = vab; }
+    void setAlignedBases(std::vector<aligned_base> &&vab) { bases = std::move(vab); }
+    std::vector<aligned_base> takeAlignedBases() { return std::move(bases); }  // leaves the sequence empty
     vidx_type getWidth() const { return alignment_width; }
     void setWidth(vidx_type newWidth);
     void fix_duplicate_positions(std::ostream &log, bool lowercase, bool remove);

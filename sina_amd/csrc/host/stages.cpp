@@ -389,6 +389,21 @@ const std::string &reference_store::upper_bases(unsigned int id) {
     });
     return ubases[id];
 }
+const std::string &reference_store::family_label(unsigned int id) {
+    if (!labels_ready.load(std::memory_order_acquire)) {  // (set_attr resets it: stores are not modified while pipelines run)
+        std::lock_guard<std::mutex> lk(labels_mu);
+        if (!labels_ready.load(std::memory_order_relaxed)) {
+            labels.assign(seqs.size(), std::string());
+            for (size_t i = 0; i < seqs.size(); i++) {
+                loadKey(seqs[i], fn::acc);
+                loadKey(seqs[i], fn::start);
+                labels[i] = seqs[i].get_attr<std::string>(fn::acc) + "." + seqs[i].get_attr<std::string>(fn::start, "0");
+            }
+            labels_ready.store(true, std::memory_order_release);
+        }
+    }
+    return labels[id];
+}
 std::vector<std::string> reference_store::getSequenceNames() const {
     std::vector<std::string> v;
     v.reserve(seqs.size());
@@ -885,12 +900,17 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
         cseq &c = *t.input_sequence;
         std::string fam;
         char buf[64];
-        for (auto &r : vc) {
-            arb->loadKey(*r.sequence, fn::acc);
-            arb->loadKey(*r.sequence, fn::start);
+        fam.reserve(vc.size() * 24);
+        for (auto &r : vc) {  // "<acc>.<start>:<score> " per relative (famfinder.cpp:462-470)
             snprintf(buf, sizeof(buf), ":%.2f ", (double)r.score);
-            fam += r.sequence->get_attr<std::string>(fn::acc) + "." +
-                   r.sequence->get_attr<std::string>(fn::start, "0") + buf;
+            if (arb->owns(r.sequence)) {
+                fam += arb->family_label(arb->id_of(r.sequence));  // (the "<acc>.<start>" part, cached per reference)
+            } else {
+                arb->loadKey(*r.sequence, fn::acc);
+                arb->loadKey(*r.sequence, fn::start);
+                fam += r.sequence->get_attr<std::string>(fn::acc) + "." + r.sequence->get_attr<std::string>(fn::start, "0");
+            }
+            fam += buf;
         }
         c.set_attr(fn::family, fam);
         if (o.fs_req_gaps != 0) {  // :472-480
@@ -1055,14 +1075,19 @@ aligner::~aligner() = default;
 aligner::aligner(const aligner &) = default;
 aligner &aligner::operator=(const aligner &) = default;
 
-static std::string make_datetime() {  // src/align.cpp:287-299
-    time_t t;
-    struct tm tmv;
-    char buf[50];
-    time(&t);
-    gmtime_r(&t, &tmv);
-    strftime(buf, 50, "%F %T", &tmv);
-    return std::string(buf);
+static std::string make_datetime() {  // src/align.cpp:287-299 (formatted once per second and thread)
+    thread_local time_t last = (time_t)-1;
+    thread_local std::string text;
+    const time_t t = time(nullptr);
+    if (t != last) {
+        struct tm tmv;
+        char buf[50];
+        gmtime_r(&t, &tmv);
+        strftime(buf, 50, "%F %T", &tmv);
+        text = buf;
+        last = t;
+    }
+    return text;
 }
 
 namespace {
@@ -1129,8 +1154,8 @@ void aligner::operator()(std::vector<tray> &batch) {
         }
         cseq &c = *(new cseq(*t.input_sequence));
         search::result_vector &vc = *t.alignment_reference;
-        const std::string bases = c.getBases();
-        const std::string ubases = upper_copy(bases);
+        const std::string ubases = upper_copy(c.getBases());
+        const size_t n_bases = ubases.size();
         if (o.lowercase != LOWERCASE_ORIGINAL) c.upperCaseAll();
 
         // upper-case bases of a family member: cached per store (40 members x every query)
@@ -1176,7 +1201,7 @@ void aligner::operator()(std::vector<tray> &batch) {
                     const auto &refal = begin_containing->sequence->getAlignedBases();
                     std::string tmp;
                     const size_t at = ref_ubases(begin_containing->sequence, tmp).find(ubases);
-                    std::vector<aligned_base> sub(refal.begin() + at, refal.begin() + at + bases.size());
+                    std::vector<aligned_base> sub(refal.begin() + at, refal.begin() + at + n_bases);
                     c.setAlignedBases(sub);
                     t.log << "copied alignment from (longer) template sequence "
                           << begin_containing->sequence->get_attr<std::string>(fn::acc) << ":"
@@ -1302,7 +1327,7 @@ void aligner::operator()(std::vector<tray> &batch) {
             cseq &c = *jb.c;
             const sina_hip_align_out &r = out[x];
             if (r.status != 0) throw std::runtime_error("device alignment failed for " + c.getName());
-            const std::vector<aligned_base> q = c.getAlignedBases();  // query bases (maybe upper-cased)
+            const std::vector<aligned_base> q = c.takeAlignedBases();  // query bases (maybe upper-cased); c is empty now
             const uint32_t L = (uint32_t)q.size();
             const uint32_t *pos = out_pos.data() + qoff[x];
             c.clearSequence();

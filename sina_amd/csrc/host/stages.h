@@ -17,6 +17,7 @@
 #pragma once
 
 #include <condition_variable>
+#include <atomic>
 #include <functional>
 #include <future>
 #include <memory>
@@ -125,12 +126,20 @@ public:
     // getBases() of a reference in upper case, computed once for the whole store (the aligner asks
     // for it for every family member of every query: icontains(), src/align.cpp:329-333)
     const std::string &upper_bases(unsigned int id);
+    // "<acc>.<start>" of reference `id` as famfinder's family attribute lists it (computed once; a
+    // later set_attr of acc / start on a reference is not picked up)
+    const std::string &family_label(unsigned int id);
     std::vector<std::string> getSequenceNames() const;
     void loadKey(const cseq &c, const std::string &key) const;  // acc := name, start := "0" if absent
     std::vector<alignment_stats> &getAlignmentStats() { return vastats; }
     // field of a reference sequence (what loadKey would fetch from the ARB database: version, start,
     // stop, taxonomy paths ...); set before the stages run
-    void set_attr(unsigned int id, const std::string &key, const std::string &value) { seqs.at(id).set_attr(key, value); }
+    // (database fields of a reference; not while a pipeline is running)
+    void set_attr(unsigned int id, const std::string &key, const std::string &value) {
+        seqs.at(id).set_attr(key, value);
+        std::lock_guard<std::mutex> lk(labels_mu);
+        labels_ready.store(false, std::memory_order_release);  // (rebuilt by the next family_label)
+    }
 
     // device side
     void set_device(int device) { device_id = device; }
@@ -180,6 +189,9 @@ private:
     std::string idx_origin;
     std::vector<std::string> ubases;
     std::once_flag ubases_once;
+    std::vector<std::string> labels;
+    std::mutex labels_mu;
+    std::atomic<bool> labels_ready{false};
     std::mutex gpu_mu;
 };
 

@@ -26,4 +26,5 @@ if hasattr(lib, "sina_hip_debug_graph_profile"):
              "(after tiles)", "sinks/fence", "slot alloc", "pred encode"]
     tot = float(sum(a[:12]))
     for i, nme in enumerate(names):
-        print("%-14s %5.1f%%" % (nme, 100 * a[i] / tot))
+        print("%-14s %5.1f%%  %9.0f ticks per family" % (nme, 100 * a[i] / tot, a[i] / (3.0 * nq)))
+    print("total %.0f ticks per family (thread 0 of each workgroup, 3 launches)" % (tot / (3.0 * nq)))
