@@ -254,6 +254,8 @@ def main():
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     host_cores = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / elapsed
     host_cores_sys = (ru1.ru_stime - ru0.ru_stime) / elapsed
+    host_minor_faults = (ru1.ru_minflt - ru0.ru_minflt) / elapsed
+    host_ctx_switches = ((ru1.ru_nvcsw - ru0.ru_nvcsw) + (ru1.ru_nivcsw - ru0.ru_nivcsw)) / elapsed
     s1 = store.stats()
 
     n_done = a.batch * a.steps
@@ -363,6 +365,8 @@ def main():
             },
             "host_cores_busy": host_cores,  # CPU seconds per wall second of this rank in the timed region
             "host_cores_busy_kernel_mode": host_cores_sys,
+            "host_minor_faults_per_s": host_minor_faults,
+            "host_context_switches_per_s": host_ctx_switches,
             "stages_ms_per_step": {
                 "famfinder_host_wall": 1e3 * timing["famfinder_s"] / a.steps,
                 "aligner_host_wall": 1e3 * timing["aligner_s"] / a.steps,
@@ -388,6 +392,11 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         sys.stderr.flush()
+        try:  # (what native libraries -- RCCL's "Librccl path" -- left in the C stdio buffer comes out BEFORE the line)
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)  # the ONE JSON line, after RCCL has said whatever it says
         if verify_failed:
             raise SystemExit("bench.py --verify: results differ from the oracle: %s" % out["verify"]["differences"])
