@@ -155,11 +155,13 @@ inline bool serialize_kernels() {
 // third of the process's CPU time.  Poll-and-sleep instead: the wake-up is at most ~100 us late,
 // which only matters if nothing else is queued behind on the heavy stream.
 inline hipError_t wait_event(hipEvent_t ev) {
+    long ns = 50000;  // 50 us, growing to 400: short waits are answered fast, a 20 ms DP kernel costs ~60 wake-ups
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
-        timespec ts{0, 100000};
+        timespec ts{0, ns};
         nanosleep(&ts, nullptr);
+        if (ns < 400000) ns += ns / 2;
     }
 }
 inline hipError_t wait_stream(sina_hip_ctx *c, hipStream_t s) {

@@ -166,7 +166,9 @@ public:
 private:
     pool() {
         unsigned hw = std::thread::hardware_concurrency();
-        start(hw > 1 ? std::min(hw, 32u) : 1);  // (measured on a 256-thread host: 16: 39k, 32: 43k, 64: 40k, 128: 31k seq/s)
+        // (measured on a 256-thread host, round 2: 6 threads 104 k seq/s at 8.3 busy cores, 8: 111 k / 8.9,
+        // 10: 112 k / 8.7, 16: 113 k / 10.7, 32: 111 k / 15 -- more threads only fight over the allocator)
+        start(hw > 1 ? std::min(hw, 10u) : 1);
     }
     void start(unsigned n) {
         stop = false;
