@@ -300,6 +300,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
             cells += N * Lp;
             q1++;
         }
+        q1 = dp_round_range(q0, q1, nq, dp_wave_slots(c, pl.geom.B));
         if (dbg_vm) q1 = q0 + 1;
         if (prep_range(g, qoff, q0, q1, Lp, pl.W, &hp)) return 1;
         const uint32_t bq = q1 - q0;
@@ -424,6 +425,10 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
     }
     c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 0) * 1024;
     c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 32) << 30;
+    if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 1) {
+        (void)hipGetLastError();
+        c->n_cu = 256;
+    }
     *ctx = c;
     return 0;
 }
@@ -437,6 +442,7 @@ int sina_hip_fork(sina_hip_ctx *parent, sina_hip_ctx **ctx) {
     c->owns_store = false;
     c->lds_budget = parent->lds_budget;
     c->tb_budget_bytes = parent->tb_budget_bytes;
+    c->n_cu = parent->n_cu;
     if (finish_ctx(c) || c->adopt_hints()) {
         const std::string why = sina_hip_last_error();
         discard_ctx(c);

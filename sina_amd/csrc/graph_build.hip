@@ -694,10 +694,10 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
     if (upload_weights(c, p)) return 1;
 
     const uint64_t tb_budget_cells = c->tb_budget_bytes / tb_cell_bytes(p->insertion == SINA_INSERTION_FORBID);
-    // queries per DAG-build + DP launch: one DP wave per query, so a launch should be able to fill
-    // every wave slot of the device (256 CUs x 4 SIMDs x up to 4 waves); the trace-back budget cuts
-    // it further below
-    const uint32_t chunk_q = 4096;
+    // queries per DAG build: two rounds of DP wave slots (one DP wave per query); the DP launches
+    // below are whole rounds of them where the trace-back budget cuts a chunk
+    const uint32_t slots = dp_wave_slots(c, pl.geom.B);
+    const uint32_t chunk_q = 2 * slots;
     BuiltGraphs bg;
     for (uint32_t q0 = 0; q0 < nq; q0 += chunk_q) {
         const uint32_t bq = std::min(chunk_q, nq - q0);
@@ -726,6 +726,16 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
                 sprows += d.n_spill;
                 cells += (uint64_t)N * d.L;
                 r1++;
+            }
+            {
+                const uint32_t r1r = dp_round_range(r0, r1, bq, slots);
+                for (uint32_t r = r1r; r < r1; r++) {  // (the queries handed back to the next launch)
+                    tbc -= (uint64_t)qd[r - r0].N * Lp;
+                    sprows -= qd[r - r0].n_spill;
+                    cells -= (uint64_t)qd[r - r0].N * qd[r - r0].L;
+                }
+                qd.resize(r1r - r0);
+                r1 = r1r;
             }
             const uint32_t rq = r1 - r0;
             const uint64_t qbase = qoff[q0 + r0], nqm = qoff[q0 + r1] - qbase;
