@@ -93,6 +93,15 @@ def physical_cores():
     return max(1, (os.cpu_count() or 2) // 2)
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max), or None if unlimited / unknown."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
 class OracleWorld:
     """The CPU oracle's view of the workload (test infrastructure): reference cseqs + k-mer index,
     built once and shared by the cpu_baseline and --verify legs.  Never part of the measured path."""
@@ -136,17 +145,20 @@ def cpu_baseline(world, refs, qs, per_thread):
     best = max(sweep, key=lambda x: x["seq_per_s"]) if sweep else dict(threads=1, seq_per_s=one_rate)
     extrapolated = one_rate * cores
     value = max(best["seq_per_s"], extrapolated)
-    return dict(value=value, unit="sequences/s", cores=cores, kind="port",
+    quota = cpu_quota()
+    return dict(value=value, unit="sequences/s", cores=cores, kind="port", container_cpu_quota=quota,
                 one_thread=dict(seq_per_s=one_rate, mcell_per_s=one_mcell),
                 measured_best=best, per_core_rate_x_cores=extrapolated, sweep=sweep,
                 sample="oracle (plain C restatement of the reference algorithm, full 28-byte-cell mesh) on the same "
                        "synthetic queries vs the same %d references: 1 thread %.1f seq/s = %.1f Mcell/s; best "
                        "measured %.0f seq/s at %d threads (%d queries per thread, NUMA-interleaved: %s); 1-thread "
                        "rate x %d physical cores = %.0f seq/s; value = the larger; %.1f s of CPU-baseline wall, "
-                       "index build %.0f s not timed"
+                       "index build %.0f s not timed%s"
                        % (refs.n, one_rate, one_mcell, best["seq_per_s"], best["threads"], per_thread,
                           "yes" if any(x["interleaved"] for x in sweep) else "single node", cores, extrapolated,
-                          time.time() - t_all, world.build_s))
+                          time.time() - t_all, world.build_s,
+                          ("; this container's cgroup grants %.0f CPUs of time, which is what bounds the measured "
+                           "sweep -- the extrapolation is not bounded by it" % quota) if quota else ""))
 
 
 def verify_against_oracle(world, qs, picked):
@@ -198,6 +210,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # host threads of this rank on a block of cores of the GPU's NUMA node (sina_amd/affinity.py);
+    # before the host library creates its threads
+    from sina_amd import affinity
+    full_mask = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    pinned = affinity.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     # ---- synthetic inputs (identical on every rank; queries differ per rank)
     refs = synth.make_refs(a.refs, length=a.length, width=a.width, seed=2)
@@ -364,6 +381,7 @@ def main():
                 "backtrack_kernel": iso["backtrack_ms"],
             },
             "host_cores_busy": host_cores,  # CPU seconds per wall second of this rank in the timed region
+            "host_cpus_pinned": pinned,     # logical CPUs this rank's host threads are confined to (None: not pinned)
             "host_cores_busy_kernel_mode": host_cores_sys,
             "host_minor_faults_per_s": host_minor_faults,
             "host_context_switches_per_s": host_ctx_switches,
@@ -378,6 +396,8 @@ def main():
             },
         }
         if not a.no_cpu_baseline and world == 1:
+            if pinned and full_mask:
+                os.sched_setaffinity(0, full_mask)  # the CPU baseline gets the whole machine
             ow = OracleWorld(refs)
             out["cpu_baseline"] = cpu_baseline(ow, refs, qs, a.cpu_sample or 4)
             if picked:

@@ -46,6 +46,7 @@ prof_state &prof() {
 }
 thread_local const char *tl_phase = "(no phase)";  // innermost phase of this thread: names its pool jobs
 double thread_cpu_s() {
+    if (!prof().on) return 0.0;  // (a system call: only worth it when somebody reads the numbers)
     timespec ts;
     clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
@@ -167,8 +168,10 @@ private:
     pool() {
         unsigned hw = std::thread::hardware_concurrency();
         // (measured on a 256-thread host, round 2: 6 threads 104 k seq/s at 8.3 busy cores, 8: 111 k / 8.9,
-        // 10: 112 k / 8.7, 16: 113 k / 10.7, 32: 111 k / 15 -- more threads only fight over the allocator)
-        start(hw > 1 ? std::min(hw, 10u) : 1);
+        // 10: 112 k / 8.7, 16: 113 k / 10.7, 32: 111 k / 15 -- more threads only fight over the allocator;
+        // with the rank's threads pinned to 16 neighbouring cores (sina_amd/affinity.py) 16S is the same
+        // at 10 and 12 (112.7 k / 7.3 and 7.6 cores) and the host-bound V4 amplicons gain: 273 k -> 292 k)
+        start(hw > 1 ? std::min(hw, 12u) : 1);
     }
     void start(unsigned n) {
         stop = false;

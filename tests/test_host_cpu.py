@@ -129,3 +129,21 @@ def test_option_names_and_validation():
     H.sina_host_reset_options()
     assert not H.sina_host_pipeline_create()          # no --db: "Must have reference database"
     assert b"reference database" in H.sina_host_last_error()
+
+
+def test_affinity_plan_blocks():
+    """sina_amd/affinity.py: ranks sharing a NUMA node split its cores into disjoint compact blocks."""
+    from sina_amd import affinity
+    node_cpus = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    allowed = set(range(256))
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    blocks = [affinity.plan(r, nodes, node_cpus, allowed) for r in range(8)]
+    assert blocks[0] == list(range(0, 16)) and blocks[3] == list(range(48, 64)) and blocks[4] == list(range(64, 80))
+    assert len(set(c for b in blocks for c in b)) == 8 * 16  # disjoint
+    # one rank: the first sixteen cores of its node; a restricted mask is honoured
+    assert affinity.plan(0, [1], node_cpus, allowed) == list(range(64, 80))
+    assert affinity.plan(0, [0], node_cpus, set(range(8, 40))) == list(range(8, 24))
+    # unknown node, or too few cores to be worth it: leave the affinity alone
+    assert affinity.plan(0, [None], node_cpus, allowed) is None
+    assert affinity.plan(0, [0, 0, 0, 0], {0: list(range(8))}, allowed) is None
+    assert affinity._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
