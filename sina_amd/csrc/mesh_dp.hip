@@ -900,24 +900,31 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     }
 }
 
-// One thread per query: the cell walk of backtrack() (mesh.h:594-721).  Latency
-// bound (dependent 4-byte loads); runs on few CUs and overlaps the next DP batch.
-__global__ void backtrack_kernel(BtArgs a) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per query: the cell walk of backtrack() (mesh.h:594-721).  The walk is one logical thread
+// (every lane computes the same thing) -- a chain of dependent look-ups, two per step when they go
+// to HBM.  It only ever moves to smaller rows and smaller columns, so the wave keeps a WINDOW of the
+// trace-back plane in LDS: the 64 rows x 32 columns whose upper right corner is the cell that missed,
+// one row per lane, together with those rows' records, columns and first four predecessors.  A step
+// inside the window costs LDS latency; a refill (two round trips, every ~30 steps) is paid by 64
+// lanes at once.  LAZY: 16-bit cells (type code + predecessor ordinal) instead of 32-bit ones.
+constexpr int kBtRows = 64, kBtCols = 32;
+template <bool LAZY>
+__global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
+    using cell_t = typename std::conditional<LAZY, uint16_t, uint32_t>::type;
+    constexpr uint32_t kAlign = 16 / sizeof(cell_t);  // cells per 16-byte load
+    __shared__ __attribute__((aligned(16))) cell_t w_cell[kBtRows][kBtCols];
+    __shared__ uint4 w_rec[kBtRows];   // row records, .w replaced by the node's column
+    __shared__ uint4 w_pred[kBtRows];  // first four predecessor entries of the row
+    const uint32_t q = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
     if (q >= a.nq) return;
     const QDesc d = a.qd[q];
-    const uint32_t L = d.L;
+    const uint32_t L = d.L, N = d.N;
     const uint32_t Lp = a.Lp;
-    // 16-bit cells (type code + predecessor ordinal) or 32-bit cells (explicit indices): common.h
-    const bool lazy = a.lazy_sidx != 0;
-    const uint16_t *tb16 = reinterpret_cast<const uint16_t *>(a.tb) + d.tb_off;
-    const uint32_t *tb32 = reinterpret_cast<const uint32_t *>(a.tb) + d.tb_off;
-    auto cell_at = [&](uint32_t row, uint32_t col) -> uint32_t {
-        const size_t i = (size_t)row * Lp + col;
-        return lazy ? (uint32_t)tb16[i] : tb32[i];
-    };
+    const cell_t *tb = reinterpret_cast<const cell_t *>(a.tb) + d.tb_off;
     const uint4 *rec = a.rec + d.node_off;
     const uint32_t *node_pos = a.node_pos + d.node_off;
+    const uint32_t *pred = a.pred + d.edge_off;
     uint32_t *out = a.out_pos + d.q_off;
     const DpResult r = a.res[q];
     sina_hip_align_out o;
@@ -930,71 +937,118 @@ __global__ void backtrack_kernel(BtArgs a) {
     o.cutoff_head = o.cutoff_tail = 0;
     o.n_out = 0;
     if (r.status != 0) {
-        a.out[q] = o;
+        if (lane == 0) a.out[q] = o;
         return;
     }
+    // ---- the window: rows [wr0, wr0 + 64), columns [wc0, wc0 + 32); empty until the first miss
+    uint32_t wr0 = 0x80000000u, wc0 = 0;  // (no row is within 64 of that)
+    auto refill = [&](uint32_t row, uint32_t col) {
+        __syncthreads();  // (one wave: orders the LDS reads before against the writes below)
+        wr0 = row + 1 >= (uint32_t)kBtRows ? row + 1 - kBtRows : 0u;
+        const uint32_t ctop = (col & ~(kAlign - 1)) + kAlign;  // first column right of the window
+        wc0 = ctop >= (uint32_t)kBtCols ? ctop - kBtCols : 0u;
+        const uint32_t x = wr0 + lane;
+        if (x < N) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(tb + (size_t)x * Lp + wc0);
+            uint4 *dst = reinterpret_cast<uint4 *>(&w_cell[lane][0]);
+#pragma unroll
+            for (uint32_t i = 0; i < kBtCols / kAlign; i++) dst[i] = src[i];
+            uint4 rx = rec[x];
+            rx.w = node_pos[x];
+            w_rec[lane] = rx;
+            const uint32_t np = rx.z & 0xffu;
+            uint4 pe = {0u, 0u, 0u, 0u};
+            if (np > 0) pe.x = pred[rx.x];
+            if (np > 1) pe.y = pred[rx.x + 1];
+            if (np > 2) pe.z = pred[rx.x + 2];
+            if (np > 3) pe.w = pred[rx.x + 3];
+            w_pred[lane] = pe;
+        }
+        __syncthreads();
+    };
+    auto in_rows = [&](uint32_t row) -> bool { return row - wr0 < (uint32_t)kBtRows; };
+    auto cell_at = [&](uint32_t row, uint32_t col) -> uint32_t {
+        if (!(in_rows(row) && col - wc0 < (uint32_t)kBtCols)) refill(row, col);
+        return (uint32_t)w_cell[row - wr0][col - wc0];
+    };
+    // row record / column / predecessor entry e of a row (through the window if the row is in it)
+    auto rec_at = [&](uint32_t row) -> uint4 {  // (.w = the node's column)
+        if (in_rows(row)) return w_rec[row - wr0];
+        uint4 rx = rec[row];
+        rx.w = node_pos[row];
+        return rx;
+    };
+    auto pred_at = [&](uint32_t row, uint32_t pb, uint32_t e) -> uint32_t {
+        if (e < 4 && in_rows(row)) {
+            const uint4 pe = w_pred[row - wr0];
+            return (e == 0 ? pe.x : (e == 1 ? pe.y : (e == 2 ? pe.z : pe.w))) & 0xffffu;
+        }
+        return pred[pb + e] & 0xffffu;
+    };
     const uint32_t width = a.width;
     uint32_t m = r.end_m, s = r.end_s;
     uint32_t n = 0;
     const uint32_t send = L - 1;
+    auto emit = [&](uint32_t p) {  // (lane 0 writes; the walk itself is wave-uniform)
+        if (lane == 0) out[n] = p;
+        n++;
+    };
 
     // right hand overhang (:594-615)
     const int tail = (int)(send - s);
     o.cutoff_tail = tail;
+    uint32_t c = cell_at(m, s);  // (fills the window around the end cell)
     if (tail && a.overhang != SINA_OVERHANG_REMOVE) {
-        int pos = (a.overhang == SINA_OVERHANG_ATTACH) ? (int)(width - 1 - node_pos[m] - (uint32_t)tail) : 0;
+        int pos = (a.overhang == SINA_OVERHANG_ATTACH) ? (int)(width - 1 - rec_at(m).w - (uint32_t)tail) : 0;
         for (int i = 0; i < tail; i++) {
             const int p = pos++;
-            out[n++] = (uint32_t)(p > 0 ? p : 0);
+            emit((uint32_t)(p > 0 ? p : 0));
         }
     }
-    auto mscore = [&](uint32_t node) -> float {  // tr.s.match(sum, ab2, ab1) with comp()==true
-        const float wgt = __uint_as_float(rec[node].y);
+    auto mscore = [&](const uint4 &rx) -> float {  // tr.s.match(sum, ab2, ab1) with comp()==true
+        const float wgt = __uint_as_float(rx.y);
         if (a.weights != nullptr) {
             const uint32_t nw1 = a.n_weights - 1;
-            const uint32_t np = node_pos[node];
-            return a.ms * a.weights[np < nw1 ? np : nw1] * wgt;
+            return a.ms * a.weights[rx.w < nw1 ? rx.w : nw1] * wgt;
         }
         return a.ms * wgt;
     };
-    unsigned int pos = width - 1 - node_pos[m];
+    uint4 rm = rec_at(m);
+    unsigned int pos = width - 1 - rm.w;
     float sum_weight = 0.f;
     int aligned = 0;
-    out[n++] = pos;
+    emit(pos);
     aligned++;
-    sum_weight = sum_weight + mscore(m);
+    sum_weight = sum_weight + mscore(rm);
 
     // value_midx of a cell whose deletion extends the gap of predecessor x: gapm_idx[x][col]
     // (common.h, Ext / OpLast) -- follow last predecessors to the row that opened the gap
-    const uint32_t *pred = a.pred + d.edge_off;
-    const uint32_t ext_bit = lazy ? kTb16Ext : kTbExt, oplast_bit = lazy ? kTb16OpLast : kTbOpLast;
+    constexpr uint32_t ext_bit = LAZY ? kTb16Ext : kTbExt, oplast_bit = LAZY ? kTb16OpLast : kTbOpLast;
     auto gapm_idx = [&](uint32_t x, uint32_t col) -> uint32_t {
         for (uint32_t guard = 0; guard < 65536u; ++guard) {
-            const uint4 rx = rec[x];
+            const uint32_t cx = cell_at(x, col);  // (first: a refill brings the row's record along)
+            const uint4 rx = rec_at(x);
             const uint32_t np = rx.z & 0xffu;
             if (np == 0) return 0u;  // an edge row keeps its initial gapm_idx
-            const uint32_t lastp = pred[rx.x + np - 1] & 0xffffu;
-            if (cell_at(x, col) & oplast_bit) return lastp;
+            const uint32_t lastp = pred_at(x, rx.x, np - 1);
+            if (cx & oplast_bit) return lastp;
             x = lastp;
         }
         return 0u;
     };
     // the row a cell of row `row` points at, before Ext is resolved: stored (32-bit cells), or the
     // row itself / 0 / the predecessor with the stored ordinal (16-bit cells)
-    auto midx_raw = [&](uint32_t c, uint32_t row, uint32_t pb) -> uint32_t {
-        if (!lazy) return c >> 16;
-        const uint32_t t = c & kTbTypeMask;
+    auto midx_raw = [&](uint32_t cc, uint32_t row, uint32_t pb) -> uint32_t {
+        if (!LAZY) return cc >> 16;
+        const uint32_t t = cc & kTbTypeMask;
         if (t == kTbIns) return row;
         if (t == kTbNone) return 0u;
-        return pred[pb + (c >> kTb16OrdShift)] & 0xffffu;
+        return pred_at(row, pb, cc >> kTb16OrdShift);
     };
-    // :642-685 (a source node has no predecessors).  Dependent loads dominate: per step the two
-    // trace-back cells are inherently serial; the row record / column of the node just reached and
-    // its NEXT cell are requested together.
-    // value_sidx of cell c = (row, col): stored, or (type-code cells, common.h) what the type implies
-    auto sidx_of = [&](uint32_t c, uint32_t row, uint32_t col) -> uint32_t {
-        if (!lazy) return c & kTbSMask;
-        const uint32_t t = c & kTbTypeMask;
+    // value_sidx of cell cc = (row, col): stored, or (type-code cells, common.h) what the type implies
+    auto sidx_of = [&](uint32_t cc, uint32_t row, uint32_t col) -> uint32_t {
+        if (!LAZY) return cc & kTbSMask;
+        const uint32_t t = cc & kTbTypeMask;
         if (t == kTbNone) return 0u;
         if (t == kTbMatch) return col - 1;
         if (t == kTbDel) return col;
@@ -1002,42 +1056,28 @@ __global__ void backtrack_kernel(BtArgs a) {
         while (k > 0 && (cell_at(row, k) & kTbTypeMask) == kTbIns) --k;
         return k;
     };
-    auto is_deletion_at = [&](uint32_t c, uint32_t col) -> bool {  // value_sidx == own column
-        return lazy ? (c & kTbTypeMask) == kTbDel : (c & kTbSMask) == col;
+    auto is_deletion_at = [&](uint32_t cc, uint32_t col) -> bool {  // value_sidx == own column
+        return LAZY ? (cc & kTbTypeMask) == kTbDel : (cc & kTbSMask) == col;
     };
-    uint32_t c = cell_at(m, s);
-    uint4 rm = rec[m];
+    // :642-685 (a source node has no predecessors)
     uint32_t npred_m = rm.z & 0xffu;
     while (s != 0 && npred_m != 0) {
         const uint32_t snew = sidx_of(c, m, s);
         const uint32_t vm = midx_raw(c, m, rm.x);
         m = (c & ext_bit) ? gapm_idx(vm, s) : vm;
-        if (snew != 0) {
-            const uint32_t c2 = cell_at(m, snew);
-            if (is_deletion_at(c2, snew)) {
-                const uint32_t vm2 = midx_raw(c2, m, rec[m].x);
-                m = (c2 & ext_bit) ? gapm_idx(vm2, snew) : vm2;
-            }
-        }
-        // everything below depends on m only: one round trip
         c = cell_at(m, snew);
-        rm = rec[m];
-        const uint32_t np_pos = node_pos[m];
-        npred_m = rm.z & 0xffu;
-        pos = width - 1 - np_pos;
-        float ms_w;
-        {
-            const float wgt = __uint_as_float(rm.y);
-            if (a.weights != nullptr) {
-                const uint32_t nw1 = a.n_weights - 1;
-                ms_w = a.ms * a.weights[np_pos < nw1 ? np_pos : nw1] * wgt;
-            } else {
-                ms_w = a.ms * wgt;
-            }
+        if (snew != 0 && is_deletion_at(c, snew)) {  // the one-step deletion skip (:653-655)
+            const uint32_t vm2 = midx_raw(c, m, rec_at(m).x);
+            m = (c & ext_bit) ? gapm_idx(vm2, snew) : vm2;
+            c = cell_at(m, snew);
         }
+        rm = rec_at(m);
+        npred_m = rm.z & 0xffu;
+        pos = width - 1 - rm.w;
+        const float ms_w = mscore(rm);
         while (s != snew) {
             --s;
-            out[n++] = pos;
+            emit(pos);
             aligned++;
             sum_weight = sum_weight + ms_w;
         }
@@ -1048,17 +1088,17 @@ __global__ void backtrack_kernel(BtArgs a) {
         if (a.overhang == SINA_OVERHANG_ATTACH) {
             while (s-- != 0) {
                 ++pos;
-                out[n++] = (width - 1 < pos) ? width - 1 : pos;
+                emit((width - 1 < pos) ? width - 1 : pos);
             }
         } else if (a.overhang == SINA_OVERHANG_EDGE) {
             int k = (int)s;
-            while (k--) out[n++] = width - (uint32_t)k - 1;
+            while (k--) emit(width - (uint32_t)k - 1);
         }
     }
     o.sum_weight = sum_weight;
     o.aligned_bases = aligned;
     o.n_out = n;
-    a.out[q] = o;
+    if (lane == 0) a.out[q] = o;
 }
 
 template <int B>
@@ -1167,8 +1207,8 @@ extern "C" int sina_hip_debug_dp_profile(unsigned long long *out32, int reset) {
 #endif
 
 int launch_backtrack(const BtArgs &a, hipStream_t s) {
-    const int threads = 64;
-    hipLaunchKernelGGL(backtrack_kernel, dim3((a.nq + threads - 1) / threads), dim3(threads), 0, s, a);
+    if (a.lazy_sidx) hipLaunchKernelGGL(backtrack_kernel<true>, dim3(a.nq), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(backtrack_kernel<false>, dim3(a.nq), dim3(64), 0, s, a);
     SH_CHECK(hipGetLastError());
     return 0;
 }
