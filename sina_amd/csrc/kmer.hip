@@ -10,15 +10,17 @@
 //   score   = sum over K(query) WITH multiplicity of [r in postings(v)], int16.
 //   top-k   : (score desc, id desc), i.e. std::greater<pair<int16,int>>.
 //
-// How it maps to the hardware: both kernels are HBM-bound integer work.
-//   count : grid (ref tile, query).  A workgroup keeps the tile's int16 score
-//           histogram in LDS (two counters per 32-bit word), finds each query
-//           k-mer's posting sub-range for the tile by binary search (lists are
-//           ascending) and streams the u32 postings with coalesced loads into
-//           LDS atomics; the tile is written out once.
-//   select: one workgroup per query: LDS histogram over score values -> cut
-//           score -> ordered compaction (ties keep the LARGEST ids) -> bitonic
-//           sort of the <= 4096 survivors.
+// How it maps to the hardware: integer work on data that sits in L2 / Infinity Cache.
+//   count : one 1024-thread workgroup per query.  Every query k-mer keeps a cursor into its
+//           ascending posting list; the references are processed in tiles of 32768 whose int16
+//           counters live in LDS (two per 32-bit word); a wave streams a list from its cursor with
+//           2 x 1 KiB loads in flight into LDS atomics -- no search -- and the tile is written out
+//           once.  Lists longer than 1/32 of the references are kept a second time as bitmaps and
+//           counted bit-sliced in registers (carry-save adders, no atomics).
+//   select: one workgroup per query: the cut score by an 8-way search on "how many scores are >= t"
+//           (reductions over 16-byte loads; an LDS histogram serialises on the few low bins every
+//           lane hits) -> ordered compaction (ties keep the LARGEST ids) -> bitonic sort of the
+//           <= 4096 survivors.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
