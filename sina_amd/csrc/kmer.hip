@@ -399,6 +399,79 @@ __global__ void __launch_bounds__(kSelThreads) kmer_select_kernel(SelectArgs a) 
     constexpr int kWays = 8;
     int lo = 0, hi = top + 1;
     uint32_t c_hi = 0;
+    uint32_t n_ge_cut = 0;  // how many scores reach the cut, if the short cut below found it (else 0)
+    // Long rows first try a short cut: a histogram of every 16th vector places a threshold T0 that
+    // about 2 M + 128 scores of the whole row should reach -- few enough that a histogram of the
+    // scores >= T0 over the WHOLE row has no hot bins (the bulk of a row is small scores, which is
+    // what rules a plain LDS histogram out).  If at least M scores turn out to reach T0, the cut and
+    // the number of scores above it come out of that histogram: two passes instead of four or five;
+    // otherwise the search below starts from [0, T0).  The histogram borrows cand[] (unused so far).
+    constexpr uint32_t kSample = 16;
+    if (nvec >= 2048) {
+        uint32_t *hist = reinterpret_cast<uint32_t *>(cand);  // bins 0..top (top < 8192: kMaxQueryLen)
+        __shared__ int f_t;
+        __shared__ uint32_t f_above, f_at;
+        const uint32_t nb = (uint32_t)top + 1;
+        // largest bin t whose suffix count (bins >= t) reaches `target`: f_t (-1: there is none),
+        // f_above = count in the bins above t, f_at = count in bin t
+        auto suffix_find = [&](uint32_t target) {
+            const uint32_t chunk = (nb + kSelThreads - 1) / kSelThreads;
+            const uint32_t rb = min(nb, (uint32_t)tid * chunk), re = min(nb, rb + chunk);  // reversed bin index
+            uint32_t sum = 0;
+            for (uint32_t r = rb; r < re; r++) sum += hist[nb - 1 - r];
+            if (tid == 0) f_t = -1;
+            uint32_t total;
+            const uint32_t excl = block_excl_scan(sum, wsum, &total);  // (synchronises)
+            if (excl < target && excl + sum >= target) {
+                uint32_t run = excl;
+                for (uint32_t r = rb; r < re; r++) {
+                    const uint32_t h = hist[nb - 1 - r];
+                    if (run + h >= target) {
+                        f_t = (int)(nb - 1 - r);
+                        f_above = run;
+                        f_at = h;
+                        break;
+                    }
+                    run += h;
+                }
+            }
+            __syncthreads();
+        };
+        for (uint32_t i = tid; i < nb; i += kSelThreads) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = (uint32_t)tid * kSample; i < nvec; i += kSelThreads * kSample)
+            for8(i, [&](int v, uint32_t) {
+                if (v > 0) atomicAdd(&hist[min(v, top)], 1u);
+            });
+        __syncthreads();
+        const uint32_t target_s = 2 * M / kSample + 8;
+        suffix_find(target_s);
+        const int T0 = f_t;
+        const bool usable = T0 >= 1 && f_above + f_at <= 8 * target_s;  // (not one giant group of equal scores)
+        __syncthreads();
+        if (usable) {
+            for (uint32_t i = tid; i < nb; i += kSelThreads) hist[i] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < nvec; i += kSelThreads)
+                for8(i, [&](int v, uint32_t) {
+                    if (v >= T0) atomicAdd(&hist[min(v, top)], 1u);
+                });
+            __syncthreads();
+            suffix_find(M);
+            if (f_t >= 0) {  // at least M scores reach T0: the cut is among them
+                lo = f_t;
+                hi = f_t + 1;
+                c_hi = f_above;
+                n_ge_cut = f_above + f_at;
+            } else {  // fewer: count(>= T0) < M, the cut is below T0
+                uint32_t part = 0;
+                for (uint32_t i = tid; i < nb; i += kSelThreads) part += hist[i];
+                hi = T0;
+                c_hi = block_sum(part);
+            }
+            __syncthreads();
+        }
+    }
     for (int guard = 0; guard < 20 && hi - lo > 1; ++guard) {
         int th[kWays - 1];
         uint32_t c[kWays - 1];
@@ -438,6 +511,22 @@ __global__ void __launch_bounds__(kSelThreads) kmer_select_kernel(SelectArgs a) 
     const int cut = lo;
     const uint32_t acc = c_hi;  // scores > cut: all taken
 
+    // Few enough scores at or above the cut to sort them all: take every one of them -- the sort below
+    // orders by (score, id) descending, so the first M are the ones above the cut plus the ties with
+    // the LARGEST ids -- in one unordered pass.
+    const bool take_all = n_ge_cut != 0 && n_ge_cut <= (uint32_t)kSelMax;
+    if (take_all) {
+        __syncthreads();
+        if (tid == 0) sh_slot = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < nvec; i += kSelThreads)
+            for8(i, [&](int v, uint32_t id) {
+                if (v >= cut) {
+                    const uint32_t slot = atomicAdd(&sh_slot, 1u);
+                    cand[slot] = ((unsigned long long)(uint32_t)(v + 32768) << 32) | id;
+                }
+            });
+    } else {
     // Ordered pass: which ties (score == cut) to take -- those with the largest ids.  A wave owns
     // a contiguous range of vectors and reads it 64 vectors (1 KiB, coalesced) at a time; the rank
     // of a tie in id order is (ties in earlier waves) + (earlier iterations) + (lower lanes).
@@ -484,6 +573,7 @@ __global__ void __launch_bounds__(kSelThreads) kmer_select_kernel(SelectArgs a) 
                     if (slot < kSelMax) cand[slot] = ((unsigned long long)(uint32_t)(v + 32768) << 32) | id;
                 }
             });
+    }
     }
     __syncthreads();
     const uint32_t out_base = sh_slot;

@@ -73,6 +73,35 @@ def test_kmer_multi_tile_dense_equals_oracle(oracle, wide, dense_div, expect_den
             os.environ["SINA_HIP_DENSE_DIV"] = old
 
 
+@pytest.mark.parametrize("regime", ["spread", "identical", "two_groups", "unrelated"])
+def test_kmer_select_regimes_equal_oracle(oracle, regime):
+    """kmer_select_kernel's ways to the cut score on rows long enough for its histogram short cut
+    (>= 16384 references), against the oracle's partial_sort on (score, id) (kmer_search.cpp:405-418):
+    spread-out scores (sampled threshold, every score at or above the cut sorted), one giant group of
+    equal scores (the short cut refuses, 8-way search, ties with the largest ids), two groups, and
+    queries that share next to nothing with the references (fewer positive scores than asked for)."""
+    kw = dict(length=400, width=3000, long_del_prob=0.0)
+    if regime == "spread":
+        refs = synth.make_refs(24000, seed=31, n_clades=50, sub_lo=0.01, sub_hi=0.2, **kw)
+    elif regime == "identical":
+        refs = synth.make_refs(20000, seed=32, n_clades=1, sub_lo=0.0, sub_hi=0.0, del_rate=0.0, ins_rate=0.0, **kw)
+    elif regime == "two_groups":
+        refs = synth.make_refs(20000, seed=33, n_clades=2, sub_lo=0.0, sub_hi=0.0, del_rate=0.0, ins_rate=0.0, **kw)
+    else:
+        refs = synth.make_refs(20000, seed=34, n_clades=8, **kw)
+    src = synth.make_refs(64, seed=35, n_clades=4, **kw) if regime == "unrelated" else refs
+    qs = synth.make_queries(src, 6, seed=36)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    ctx = capi.Context(0)
+    try:
+        ctx.upload_refs(refs.ab, refs.off, refs.width)
+        ctx.build_index(10, False)
+        _scores_and_topk_equal(ctx, idx, qs, maxes=(1, 7, 41, 410, 4096))
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("nofast", [False, True])
 def test_device_index_multi_tile_equals_oracle_csr(oracle, wide, nofast):
     """sina_hip_build_index at 70 000 references: the CSR index itself (offsets and ids, downloaded)
