@@ -47,7 +47,10 @@ namespace {
 constexpr int kGT = SINA_GRAPH_THREADS;  // threads per workgroup (the phases are latency-bound: more loads in flight per LDS byte)
 constexpr uint32_t kNoPrev = 0xFFFFu;
 constexpr int kMaxFam = 128;
-constexpr int kTC = 128;          // occupied columns per LDS tile
+#ifndef SINA_GRAPH_KTC
+#define SINA_GRAPH_KTC 160  // (measured, 3072 families of 40: 96 -> 3.05 ms, 128 -> 2.54, 160 -> 2.40, 192 -> 3.12: a third workgroup per CU no longer fits)
+#endif
+constexpr int kTC = SINA_GRAPH_KTC;  // occupied columns per LDS tile (< 255: tile columns are bytes, 255 = none)
 
 #ifdef SINA_DP_PROFILE
 // profiling build (make PROFILE=1): per-phase s_memtime totals of thread 0, tools/perf_graph.py
@@ -286,24 +289,30 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
             uint64_t idx0 = 0, idx1 = 0, idx2 = 0;  // local node index of mask m, 5 bits each (12/12/8 masks)
             uint32_t k = 0, raw = 0;
             uint16_t *row = tabm + c * FS;
-            for (uint32_t j = 0; j < F; j++) {
-                const uint32_t t = row[j];
-                const uint32_t m = t & 0x1Fu;
-                if ((t & 0xFFu) == 0) continue;
-                uint32_t li;
-                if (!((seen >> m) & 1u)) {
-                    seen |= 1u << m;
-                    li = k++;
-                    if (m < 12) idx0 |= (uint64_t)li << (5 * m);
-                    else if (m < 24) idx1 |= (uint64_t)li << (5 * (m - 12));
-                    else idx2 |= (uint64_t)li << (5 * (m - 24));
-                } else {
-                    li = (m < 12) ? (uint32_t)(idx0 >> (5 * m)) & 31u
-                         : (m < 24) ? (uint32_t)(idx1 >> (5 * (m - 12))) & 31u
-                                    : (uint32_t)(idx2 >> (5 * (m - 24))) & 31u;
+            for (uint32_t j0 = 0; j0 < F; j0 += 8) {  // (eight LDS reads in flight, as in step 5)
+                uint32_t tv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) tv[u] = (j0 + u < F) ? (uint32_t)row[j0 + u] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t t = tv[u];
+                    const uint32_t m = t & 0x1Fu;
+                    if ((t & 0xFFu) == 0) continue;
+                    uint32_t li;
+                    if (!((seen >> m) & 1u)) {
+                        seen |= 1u << m;
+                        li = k++;
+                        if (m < 12) idx0 |= (uint64_t)li << (5 * m);
+                        else if (m < 24) idx1 |= (uint64_t)li << (5 * (m - 12));
+                        else idx2 |= (uint64_t)li << (5 * (m - 24));
+                    } else {
+                        li = (m < 12) ? (uint32_t)(idx0 >> (5 * m)) & 31u
+                             : (m < 24) ? (uint32_t)(idx1 >> (5 * (m - 12))) & 31u
+                                        : (uint32_t)(idx2 >> (5 * (m - 24))) & 31u;
+                    }
+                    row[j0 + u] = (uint16_t)(t | (li << 8));
+                    if (!(t & (1u << 13))) raw++;
                 }
-                row[j] = (uint16_t)(t | (li << 8));
-                if (!(t & (1u << 13))) raw++;
             }
             nn[c] = (uint8_t)k;
             rc[c] = (uint8_t)raw;
@@ -356,29 +365,41 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
             for (int t8 = 0; t8 < 8; t8++) pl[t8] = 0xFFFFFFFFu;
             bool overflow = false;
             uint32_t recent = 0xFFFFFFFFu;  // (most members of a node come from the same previous node)
-            for (uint32_t j = 0; j < F; j++) {
-                const uint32_t t = rowm[j];
-                if ((t & 0xFFu) == 0) continue;
-                const uint32_t lj = (t >> 8) & 31u;
-                const bool has_prev = !(t & (1u << 13));
-                if (lj < k) raw_before += has_prev ? 1u : 0u;
-                if (lj != k) continue;
-                mask = t & 0xFFu;
-                cnt++;
-                if (!has_prev) continue;
-                rawk++;
-                uint32_t x = rowp[j];
-                if (x == recent) continue;
-                recent = x;
+            // (the column's entries eight at a time: the LDS reads of a batch are in flight together
+            // instead of one round trip per family member)
+            for (uint32_t j0 = 0; j0 < F; j0 += 8) {
+                uint32_t tv[8], pv[8];
 #pragma unroll
-                for (int t8 = 0; t8 < 8; t8++) {  // bubble x into place; a duplicate turns into the pad value
-                    const uint32_t y = pl[t8];
-                    if (x == y) x = 0xFFFFFFFFu;
-                    const bool sw = x < y;
-                    pl[t8] = sw ? x : y;
-                    x = sw ? y : x;
+                for (int u = 0; u < 8; u++) {
+                    const bool in = j0 + u < F;
+                    tv[u] = in ? (uint32_t)rowm[j0 + u] : 0u;
+                    pv[u] = in ? (uint32_t)rowp[j0 + u] : 0u;
                 }
-                overflow = overflow || (x != 0xFFFFFFFFu);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t t = tv[u];
+                    if ((t & 0xFFu) == 0) continue;
+                    const uint32_t lj = (t >> 8) & 31u;
+                    const bool has_prev = !(t & (1u << 13));
+                    if (lj < k) raw_before += has_prev ? 1u : 0u;
+                    if (lj != k) continue;
+                    mask = t & 0xFFu;
+                    cnt++;
+                    if (!has_prev) continue;
+                    rawk++;
+                    uint32_t x = pv[u];
+                    if (x == recent) continue;
+                    recent = x;
+#pragma unroll
+                    for (int t8 = 0; t8 < 8; t8++) {  // bubble x into place; a duplicate turns into the pad value
+                        const uint32_t y = pl[t8];
+                        if (x == y) x = 0xFFFFFFFFu;
+                        const bool sw = x < y;
+                        pl[t8] = sw ? x : y;
+                        x = sw ? y : x;
+                    }
+                    overflow = overflow || (x != 0xFFFFFFFFu);
+                }
             }
             const uint32_t seg = E + ebaseT[c] + raw_before;
             if (node < a.ncap) {
