@@ -4,6 +4,8 @@
 // structure is not.
 #include "cseq.h"
 
+#include <cstring>
+
 #include <algorithm>
 
 namespace sina {
@@ -81,10 +83,17 @@ void cseq_base::clearSequence() {
 }
 
 cseq_base &cseq_base::append(const char *str) {
-    for (; *str; ++str) {
+    // (an aligned line is 97 % gap characters: runs of them are skipped with strspn, which the C
+    // library vectorises, instead of a branch per character)
+    for (;;) {
+        const size_t gaps = strspn(str, "-.");
+        alignment_width += (vidx_type)gaps;
+        str += gaps;
         const char c = *str;
+        if (c == 0) break;
+        ++str;
         if (c == ' ' || c == '\t' || c == '\n' || c == '\r') continue;
-        if (c != '-' && c != '.') bases.emplace_back(alignment_width, (unsigned char)c);
+        bases.emplace_back(alignment_width, (unsigned char)c);
         alignment_width++;
     }
     return *this;

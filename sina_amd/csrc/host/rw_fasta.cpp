@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <vector>
 #include <sstream>
 #include <stdexcept>
 #include <unordered_set>
@@ -54,7 +55,12 @@ void rw_fasta::set_option(const std::string &name, const std::string &value) {
 
 // ---------------------------------------------------------------- reader
 
+// (aligned FASTA is 50 KB a sequence: with the streams' default 8 KB buffers every sequence costs
+// half a dozen system calls each way)
+static constexpr size_t kStreamBuffer = 4u << 20;
+
 struct rw_fasta::reader::priv_data {
+    std::vector<char> buf = std::vector<char>(kStreamBuffer);
     std::ifstream in;
     std::string filename;
     int lineno = 0, seqno = 0, skipped = 0;
@@ -62,6 +68,7 @@ struct rw_fasta::reader::priv_data {
 
 rw_fasta::reader::reader(const std::string &infile) : data(new priv_data) {
     data->filename = infile;
+    data->in.rdbuf()->pubsetbuf(data->buf.data(), (std::streamsize)data->buf.size());  // (before open)
     data->in.open(infile, std::ios_base::binary);
     if (!data->in.is_open()) throw std::runtime_error("Unable to open file \"" + infile + "\" for reading.");
     if (fa_opts().fasta_block > 0) data->in.seekg(fa_opts().fasta_block * fa_opts().fasta_idx);
@@ -161,6 +168,7 @@ static std::string escape_string(const std::string &in) {  // :378-392
 }
 
 struct rw_fasta::writer::priv_data {
+    std::vector<char> buf = std::vector<char>(kStreamBuffer);
     std::ofstream out, out_csv;
     int count = 0, excluded = 0;
     std::unordered_set<std::string> relatives_written;
@@ -170,6 +178,7 @@ struct rw_fasta::writer::priv_data {
 
 rw_fasta::writer::writer(const std::string &outfile, unsigned int copy_relatives) : data(new priv_data) {
     data->copy_relatives = copy_relatives;
+    data->out.rdbuf()->pubsetbuf(data->buf.data(), (std::streamsize)data->buf.size());  // (before open)
     data->out.open(outfile, std::ios_base::binary);
     if (!data->out.is_open()) throw std::runtime_error("Unable to open file \"" + outfile + "\" for writing.");
     if (fa_opts().fastameta == FASTA_META_CSV) {
@@ -264,9 +273,13 @@ void rw_fasta::writer::priv_data::write(const cseq &c) {  // :437-541
     const std::string seq = c.getAligned(!o.out_dots, o.out_dna);
     const int len = (int)seq.size();
     if (o.line_length > 0) {
-        for (int i = 0; i < len; i += o.line_length) out << seq.substr(i, o.line_length) << "\n";
+        for (int i = 0; i < len; i += o.line_length) {
+            out.write(seq.data() + i, std::min(o.line_length, len - i));
+            out.put('\n');
+        }
     } else {
-        out << seq << "\n";
+        out.write(seq.data(), len);
+        out.put('\n');
     }
     count++;
 }
