@@ -57,9 +57,13 @@ def plan(local_rank, nodes, node_cpus, allowed, cores_per_rank=CORES_PER_RANK):
     Returns a sorted list, or None to leave the affinity alone."""
     node = nodes[local_rank]
     if node is None or node not in node_cpus:
-        return None
+        # no NUMA information for this device (containers often hide it): compactness is most of the
+        # gain -- the ranks without a node split all allowed cores, in order
+        if None not in node_cpus:
+            return None
+        node = None
     cores = [c for c in node_cpus[node] if c in allowed]
-    sharers = [j for j, n in enumerate(nodes) if n == node]
+    sharers = [j for j, n in enumerate(nodes) if (n if n in node_cpus else None) == node]
     k, n = sharers.index(local_rank), len(sharers)
     per = len(cores) // n
     if per < 4:  # not enough cores on the node to be worth confining anything
@@ -78,7 +82,13 @@ def pin_rank(local_rank, local_world):
         allowed = os.sched_getaffinity(0)
         node_cpus = {}
         for n in set(x for x in nodes if x is not None):
-            node_cpus[n] = _physical_cores(_parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % n).read()))
+            try:
+                node_cpus[n] = _physical_cores(_parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % n).read()))
+            except OSError:
+                pass
+        if any(x not in node_cpus for x in nodes):  # one unknown: nobody uses NUMA nodes (blocks must not overlap)
+            nodes = [None] * len(nodes)
+            node_cpus = {None: _physical_cores(sorted(allowed))}
         cpus = plan(local_rank, nodes, node_cpus, allowed)
         if not cpus:
             return None

@@ -147,3 +147,12 @@ def test_affinity_plan_blocks():
     assert affinity.plan(0, [None], node_cpus, allowed) is None
     assert affinity.plan(0, [0, 0, 0, 0], {0: list(range(8))}, allowed) is None
     assert affinity._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_affinity_plan_without_numa_information():
+    """No NUMA node known for the devices: the ranks split all allowed cores in order."""
+    from sina_amd import affinity
+    allowed = set(range(64))
+    node_cpus = {None: list(range(64))}
+    blocks = [affinity.plan(r, [None] * 4, node_cpus, allowed) for r in range(4)]
+    assert blocks == [list(range(16 * r, 16 * r + 16)) for r in range(4)]
