@@ -371,3 +371,46 @@ def test_500k_references_properties():
         pl.close()
     finally:
         st.close()
+
+
+def test_launch_ranges_cut_by_traceback_budget(oracle):
+    """A batch whose trace-back planes exceed the budget is aligned in several DP launches, each a
+    whole number of rounds of wave slots (ctx.h dp_round_range): the alignments must not depend on
+    where the batch is cut -- same results with a 3 GB and with the default budget -- and a sample is
+    compared with the oracle.  7000 queries of ~300 bases (one strip of B = 8: 3072 wave slots)."""
+    refs = synth.make_refs(600, length=300, width=1500, seed=71, n_clades=6, long_del_prob=0.0)
+    qs = synth.make_queries(refs, 7000, seed=72)
+    cs = util.cseqs_from_refs(refs)
+    runs = []
+    for gb in ("3", None):  # (3 GB: about 5000 of these queries -> cut back to one round of 3072)
+        old = os.environ.get("SINA_HIP_TB_GB")
+        if gb is None:
+            os.environ.pop("SINA_HIP_TB_GB", None)
+        else:
+            os.environ["SINA_HIP_TB_GB"] = gb
+        st = pipeline.Store(":mem:tbcut%s" % gb, refs)
+        try:
+            st.build_index(10, False)
+            pl = pipeline.Pipeline(st)
+            pl.run(qs.mask, qs.off, batch=7000, inflight=1)
+            runs.append([pl.result(qi) for qi in range(qs.n)])
+            pl.close()
+        finally:
+            st.close()
+            if old is None:
+                os.environ.pop("SINA_HIP_TB_GB", None)
+            else:
+                os.environ["SINA_HIP_TB_GB"] = old
+    small, big = runs
+    for qi in range(qs.n):
+        assert small[qi]["status"] == big[qi]["status"] and (small[qi]["packed"] == big[qi]["packed"]).all(), qi
+        assert (small[qi]["head"], small[qi]["tail"], small[qi]["qual"]) == (big[qi]["head"], big[qi]["tail"], big[qi]["qual"])
+    assert sum(1 for r in small if r["status"] == 0) > 6000
+    idx = oracle.Index(cs, k=10)
+    for qi in (0, 1, 2, 3071, 3072, 3073, 3500, 6143, 6144, 6145, 6998, 6999):  # (around the launch cuts)
+        want = _oracle_run(oracle, cs, idx, qs, qi)
+        got = small[qi]
+        assert got["status"] == want["status"], (qi, got["log"], want["log"])
+        if want["status"] != 2:
+            assert (got["packed"] == want["packed"]).all(), qi
+            assert (got["head"], got["tail"], got["qual"]) == (want["head"], want["tail"], want["qual"])
