@@ -1258,7 +1258,7 @@ void aligner::operator()(std::vector<tray> &batch) {
         p.weights = weights.empty() ? nullptr : weights.data();
         p.n_weights = (uint32_t)weights.size();
 
-        ph.reset(new scoped_phase("al.pack_queries"));
+        ph.reset(), ph.reset(new scoped_phase("al.pack_queries"));  // (the old phase ends first: the new one names the pool jobs)
         std::vector<uint64_t> qoff(nq + 1, 0);
         for (size_t x = 0; x < nq; x++) qoff[x + 1] = qoff[x] + jobs[idx[x]].c->size();
         std::vector<uint8_t> qmask(qoff.back() ? qoff.back() : 1);
@@ -1280,15 +1280,15 @@ void aligner::operator()(std::vector<tray> &batch) {
                 for (size_t y = 0; y < jobs[idx[x]].family.size(); y++)
                     fids[foff[x] + y] = store->id_of(jobs[idx[x]].family[y]);
             width = store->getAlignmentWidth();
-            ph.reset(new scoped_phase("al.align_families(C-ABI)"));
+            ph.reset(), ph.reset(new scoped_phase("al.align_families(C-ABI)"));  // (the old phase ends first: the new one names the pool jobs)
             hip_check(sina_hip_align_families(ctx, fids.data(), foff.data(), (uint32_t)nq, qmask.data(), qoff.data(),
                                               &p, out.data(), out_pos.data()),
                       "align_families");
         } else {
             std::vector<host_graph> gs(nq);
-            ph.reset(new scoped_phase("al.host_graph_build"));
+            ph.reset(), ph.reset(new scoped_phase("al.host_graph_build"));  // (the old phase ends first: the new one names the pool jobs)
             parallel_for(nq, [&](size_t x) { build_family_graph(jobs[idx[x]].family, o.fs_weight, &gs[x]); });
-            ph.reset(new scoped_phase("al.host_graph_concat"));
+            ph.reset(), ph.reset(new scoped_phase("al.host_graph_concat"));  // (the old phase ends first: the new one names the pool jobs)
             sina_hip_graph_batch gb;
             std::vector<uint64_t> node_off(nq + 1, 0), edge_off(nq + 1, 0);
             for (size_t x = 0; x < nq; x++) {
@@ -1319,13 +1319,13 @@ void aligner::operator()(std::vector<tray> &batch) {
             gb.pred = pred.data();
             gb.succ_minpos = smin.data();
             gb.width = width;
-            ph.reset(new scoped_phase("al.align_graphs(C-ABI)"));
+            ph.reset(), ph.reset(new scoped_phase("al.align_graphs(C-ABI)"));  // (the old phase ends first: the new one names the pool jobs)
             hip_check(sina_hip_align_graphs(ctx, &gb, qmask.data(), qoff.data(), &p, out.data(), out_pos.data()),
                       "align_graphs");
         }
 
         // cseq container steps of backtrack() (src/mesh.h:603-736) + do_align attrs (:507-509)
-        ph.reset(new scoped_phase("al.finish(NAST,log)"));
+        ph.reset(), ph.reset(new scoped_phase("al.finish(NAST,log)"));  // (the old phase ends first: the new one names the pool jobs)
         parallel_for(nq, [&](size_t x) {
             dp_job &jb = jobs[idx[x]];
             tray &t = *jb.t;
