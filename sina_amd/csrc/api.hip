@@ -205,6 +205,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, hl.stream())) return 1;
         SH_CHECK(hipEventRecord(c->ev[1], hl.stream()));
         if (hl.done()) return 1;
+        if (getenv("SINA_HIP_DEBUG_SYNC")) fprintf(stderr, "[sina_hip] DP kernel done: %u queries, geometry %dx%d, weighted %d forbid %d\n", bq, pl.geom.T, pl.geom.B, (int)weighted, (int)forbid);
         if (token.owns_lock()) SH_CHECK(wait_event(c->ev[1]));
     }
     BtArgs b;
@@ -225,6 +226,10 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     b.overhang = p->overhang;
     b.lazy_sidx = forbid ? 0 : 1;
     if (launch_backtrack(b, s)) return 1;
+    if (getenv("SINA_HIP_DEBUG_SYNC")) {
+        SH_CHECK(hipStreamSynchronize(s));
+        fprintf(stderr, "[sina_hip] backtrack kernel done\n");
+    }
     SH_CHECK(hipEventRecord(c->ev[2], s));
     if (c->h_out.reserve(sizeof(sina_hip_align_out) * bq) || c->h_out_pos.reserve(4 * std::max<uint64_t>(nqm, 1))) return 1;
     SH_CHECK(hipMemcpyAsync(c->h_out.p, c->out.p, sizeof(sina_hip_align_out) * bq, hipMemcpyDeviceToHost, s));

@@ -663,6 +663,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
             SH_CHECK(hipGetLastError());
             SH_CHECK(hipEventRecord(c->ev[7], hl.stream()));
             if (hl.done()) return 1;
+            if (getenv("SINA_HIP_DEBUG_SYNC")) fprintf(stderr, "[sina_hip] DAG build kernel done: %u families, ncap %u\n", bq, ncap);
         }
         if (download(c, 4, c->g_sizes.p, 16 * (uint64_t)bq, s)) return 1;
         SH_CHECK(wait_stream(c, s));

@@ -185,12 +185,21 @@ __device__ int g_dp_abl;  // ablation mask (timing experiments only, results are
 #endif
 
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
-__device__ __forceinline__ u32x4 sload16(uint64_t addr) {  // addr: provably wave-uniform (see uniform())
-    u32x4 v;
-    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(v) : "s"(addr) : "memory");
-    return v;
+// 16 bytes through the scalar cache from a wave-uniform address (see uniform()).  A load from the
+// CONSTANT address space, so that the compiler emits s_load_dwordx4 and keeps track of it being in
+// flight: it waits (lgkmcnt) before the first use -- including a register spill.  (An inline-asm
+// s_load looks finished to the compiler when the asm statement ends: the B = 12 --insertion=forbid
+// kernels, short of SGPRs, spilled the destination registers right behind it and restored garbage;
+// tools/check_inflight_spills.py looks for that pattern.)  The memory is not constant -- edge
+// records are written earlier by this very wave -- but the wave has waited for its stores
+// (vmcnt(0) at the end of a strip) and nothing else writes them.
+__device__ __forceinline__ u32x4 sload16(uint64_t addr) {
+    typedef const __attribute__((address_space(4))) u32x4 *cptr;
+    return *reinterpret_cast<cptr>(addr);
 }
-__device__ __forceinline__ void sload_wait(u32x4 &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory"); }
+// the point where the loaded value must have arrived (an empty asm that reads it: the compiler puts
+// its s_waitcnt here and not behind LDS traffic further down)
+__device__ __forceinline__ void sload_wait(u32x4 &v) { asm volatile("" : "+s"(v) : : "memory"); }
 __device__ __forceinline__ uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint64_t uniform(uint64_t x) {
     return (uint64_t)uniform((uint32_t)x) | ((uint64_t)uniform((uint32_t)(x >> 32)) << 32);

@@ -82,6 +82,25 @@ def test_pipeline_aligner_options(oracle, world, al, oal):
     pl.close()
 
 
+@pytest.mark.parametrize("geom", ["128,12", "256,12", "128,8", "384,4"])
+@pytest.mark.parametrize("insertion", ["forbid", "shift"])
+def test_pipeline_forced_multi_strip_geometries(oracle, world, monkeypatch, geom, insertion):
+    """The same 24 queries under DP geometries forced with SINA_HIP_DP_GEOM -- several strips of 12, 8
+    and 4 columns per lane, with and without --insertion=forbid (32-bit trace-back cells).  The
+    12-column forbid kernels once restored garbage for a scalar load that was spilled while in flight
+    (mesh_dp.hip, sload16): 17 or more queries in a launch crashed the GPU."""
+    refs, cs, idx, st = world
+    monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+    qs = synth.make_queries(refs, 24, seed=53, window=(0.3, 120), ins=0.02, dele=0.02, lower_rate=0.05)
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    pl = pipeline.Pipeline(st, famfinder=ff, aligner={"insertion": insertion})
+    pl.run(qs.mask, qs.off, batch=24, inflight=1)
+    n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250),
+                     al=dict(insertion=1 if insertion == "forbid" else 0))
+    assert n_dp >= 20
+    pl.close()
+
+
 def test_pipeline_calc_idty(oracle, world):
     """--calc-idty (align.cpp:380-382,443-453): align_ident_slv = 100 x the best overlap identity of the
     aligned query with a member of its family (one comparison launch per batch); 100 for copied

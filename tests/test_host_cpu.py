@@ -5,6 +5,7 @@ import ctypes as C
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -156,3 +157,25 @@ def test_affinity_plan_without_numa_information():
     node_cpus = {None: list(range(64))}
     blocks = [affinity.plan(r, [None] * 4, node_cpus, allowed) for r in range(4)]
     assert blocks == [list(range(16 * r, 16 * r + 16)) for r in range(4)]
+
+
+def test_dp_kernels_have_no_inflight_scalar_load_reads(tmp_path):
+    """Guard for a bug this repository had: a hand-placed asynchronous scalar load whose destination
+    SGPRs the compiler spilled before the load had landed (B = 12 --insertion=forbid kernels: wild
+    addresses on the GPU).  Compiles mesh_dp.hip to ISA exactly as the Makefile does and lets
+    tools/check_inflight_spills.py look for reads of an in-flight inline-asm s_load destination."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "sina_amd", "csrc")
+    out = str(tmp_path / "mesh_dp.s")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
+                    "-I" + os.path.join(root, "include"), "-I" + src, "-S", "--cuda-device-only",
+                    os.path.join(src, "mesh_dp.hip"), "-o", out], check=True, capture_output=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_inflight_spills.py"), out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "Li8ELb0ELb0ELb1ELb0E" in r.stdout  # (the production kernel was among those looked at)
