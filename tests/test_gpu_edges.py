@@ -74,13 +74,16 @@ def test_ragged_batch_mixed_lengths(oracle, gpu_ctx):
         assert aligned == want["aligned"]
 
 
-def test_largest_geometry(oracle, gpu_ctx):
-    """A 5800-base query (the 512x12 geometry, 6144 columns) against a 3-member family of
-    6000-base references: ~70 M cells, planes bit-exact."""
-    refs = synth.make_refs(6, length=6000, width=40000, seed=321, n_clades=2)
+@pytest.mark.parametrize("ref_len,lo,hi", [(6000, 100, 5900), (8400, 60, 8251)])
+def test_largest_geometry(oracle, gpu_ctx, ref_len, lo, hi):
+    """A 5800-base query (768x8: 12 strips) and one of 8191 bases -- the longest the DP kernel takes,
+    16 strips of 512 columns -- against a 3-member family of references that long: 70 - 140 M cells,
+    planes bit-exact."""
+    refs = synth.make_refs(6, length=ref_len, width=8 * ref_len, seed=321, n_clades=2)
     cs = util.cseqs_from_refs(refs)
     src = (refs.seq(2) >> 24) & 0x0f
-    q, qm = _cseq("long", src[100:5900])
+    assert hi <= len(src)
+    q, qm = _cseq("long", src[lo:hi])
     _planes_equal(oracle, gpu_ctx, [cs[0], cs[2], cs[5]], q, qm, refs.width)
 
 
