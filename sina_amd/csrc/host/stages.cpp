@@ -907,7 +907,25 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
         char buf[64];
         fam.reserve(vc.size() * 24);
         for (auto &r : vc) {  // "<acc>.<start>:<score> " per relative (famfinder.cpp:462-470)
-            snprintf(buf, sizeof(buf), ":%.2f ", (double)r.score);
+            // (":%.2f " -- the scores are k-mer counts, whole numbers: digits + ".00" without printf)
+            const float sc = r.score;
+            if (sc >= 0.f && sc < 16777216.f && sc == (float)(uint32_t)sc) {
+                char *w = buf + sizeof(buf);
+                *--w = 0;
+                *--w = ' ';
+                *--w = '0';
+                *--w = '0';
+                *--w = '.';
+                uint32_t v = (uint32_t)sc;
+                do {
+                    *--w = (char)('0' + v % 10);
+                    v /= 10;
+                } while (v);
+                *--w = ':';
+                memmove(buf, w, (size_t)(buf + sizeof(buf) - w));
+            } else {
+                snprintf(buf, sizeof(buf), ":%.2f ", (double)sc);
+            }
             if (arb->owns(r.sequence)) {
                 fam += arb->family_label(arb->id_of(r.sequence));  // (the "<acc>.<start>" part, cached per reference)
             } else {
@@ -1159,8 +1177,18 @@ void aligner::operator()(std::vector<tray> &batch) {
         }
         cseq &c = *(new cseq(*t.input_sequence));
         search::result_vector &vc = *t.alignment_reference;
-        const std::string ubases = upper_copy(c.getBases());
-        const size_t n_bases = ubases.size();
+        // (the query's upper-case base string: only built if a family member passes the k-mer-count
+        // test below and has to be searched for it -- exact relatives only)
+        std::string ubases_store;
+        bool have_ubases = false;
+        const size_t n_bases = c.size();
+        auto ubases_of_query = [&]() -> const std::string & {
+            if (!have_ubases) {
+                ubases_store = upper_copy(t.input_sequence->getBases());
+                have_ubases = true;
+            }
+            return ubases_store;
+        };
         if (o.lowercase != LOWERCASE_ORIGINAL) c.upperCaseAll();
 
         // upper-case bases of a family member: cached per store (40 members x every query)
@@ -1176,7 +1204,7 @@ void aligner::operator()(std::vector<tray> &batch) {
         auto not_contains_query = [&](search::result_item &item) {
             if (item.score < all_kmers) return true;
             std::string tmp;
-            return ref_ubases(item.sequence, tmp).find(ubases) == std::string::npos;
+            return ref_ubases(item.sequence, tmp).find(ubases_of_query()) == std::string::npos;
         };
         auto begin_containing = std::partition(vc.begin(), vc.end(), not_contains_query);
         if (begin_containing != vc.end()) {
@@ -1194,7 +1222,7 @@ void aligner::operator()(std::vector<tray> &batch) {
             } else {  // :349-388 steal the alignment
                 auto same_as_query = [&](search::result_item &item) {
                     std::string tmp;
-                    return ref_ubases(item.sequence, tmp) == ubases;
+                    return ref_ubases(item.sequence, tmp) == ubases_of_query();
                 };
                 auto exact = std::find_if(begin_containing, vc.end(), same_as_query);
                 if (exact != vc.end()) {
@@ -1205,7 +1233,7 @@ void aligner::operator()(std::vector<tray> &batch) {
                 } else {
                     const auto &refal = begin_containing->sequence->getAlignedBases();
                     std::string tmp;
-                    const size_t at = ref_ubases(begin_containing->sequence, tmp).find(ubases);
+                    const size_t at = ref_ubases(begin_containing->sequence, tmp).find(ubases_of_query());
                     std::vector<aligned_base> sub(refal.begin() + at, refal.begin() + at + n_bases);
                     c.setAlignedBases(sub);
                     t.log << "copied alignment from (longer) template sequence "
