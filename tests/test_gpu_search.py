@@ -106,10 +106,25 @@ def test_pipeline_with_search_stage(oracle, sopts, oopts):
     """tray -> famfinder -> aligner -> search_filter through the C++ stage mirror (k-mer search, DP and the
     1000-candidate comparison on the GPU) vs the oracle run query by query: result ids, score bits,
     nearest_slv and the LCA classification."""
-    refs = synth.make_refs(420, length=300, width=3000, seed=451, amb_rate=0.01, lower_rate=0.03)
+    _search_stage_case(oracle, 420, sopts, oopts)
+
+
+@pytest.mark.parametrize("sopts,oopts", [
+    ({}, {}),
+    ({"search-all": True, "search-max-result": 12}, dict(search_all=1, max_result=12)),
+])
+def test_search_stage_at_20k_references(oracle, sopts, oopts):
+    """The same at a reference count where the stage works as in production: the 1000 candidates are a
+    real selection (top 1000 of 20 000 by k-mer score: the select kernel's histogram path with M =
+    1000), and --search-all compares every query with all 20 000 references."""
+    _search_stage_case(oracle, 20000, sopts, oopts, n_queries=6)
+
+
+def _search_stage_case(oracle, n_refs, sopts, oopts, n_queries=24):
+    refs = synth.make_refs(n_refs, length=300, width=3000, seed=451, amb_rate=0.01, lower_rate=0.03)
     cs = util.cseqs_from_refs(refs)
     idx = oracle.Index(cs, k=10)
-    st = pipeline.Store(":mem:gpu-search", refs)
+    st = pipeline.Store(":mem:gpu-search-%d" % n_refs, refs)
     acc = ["ref%d" % i for i in range(refs.n)]
     ver = [str(1 + i % 3) for i in range(refs.n)]
     start = [str(i % 7) for i in range(refs.n)]
@@ -119,7 +134,7 @@ def test_pipeline_with_search_stage(oracle, sopts, oopts):
         st.set_attr(i, "start", start[i])
         st.set_attr(i, "stop", stop[i])
         st.set_attr(i, "tax_slv", _taxonomy(i))
-    qs = synth.make_queries(refs, 24, seed=452, amb_rate=0.01, lower_rate=0.05)
+    qs = synth.make_queries(refs, n_queries, seed=452, amb_rate=0.01, lower_rate=0.05)
     # three more queries that are exact pieces of references (contained: --search-ignore-super matters)
     extra = [((refs.seq(i) >> 24) & 0xff).astype(np.uint8)[a:b] for i, a, b in ((5, 10, 250), (77, 0, 200), (300, 40, 290))]
     masks = [qs.seq(i) for i in range(qs.n)] + extra
