@@ -162,18 +162,25 @@ def test_pipeline_family_escalation_and_rejects(oracle, world):
     pl.close()
 
 
-def test_pipeline_weighted_scheme(oracle, world):
+@pytest.mark.parametrize("geom,insertion", [(None, "shift"), ("128,12", "shift"), ("128,12", "forbid"),
+                                            ("128,8", "forbid"), ("384,4", "shift")])
+def test_pipeline_weighted_scheme(oracle, world, monkeypatch, geom, insertion):
+    """scoring_scheme_weighted (positional-variability weights, align.cpp:410-414) through the pipeline,
+    also under forced multi-strip geometries and combined with --insertion=forbid: 32 queries, enough
+    to fill more than one round of the 12-column kernels' scalar-register-starved variants."""
     refs, cs, idx, st = world
+    if geom:
+        monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
     rng = np.random.default_rng(8)
     w = rng.uniform(0.3, 1.4, size=refs.width).astype(np.float32)
     st.add_filter("posvar", w)
-    qs = synth.make_queries(refs, 12, seed=56)
+    qs = synth.make_queries(refs, 32, seed=56)
     ff = {"fs-min-len": 100, "fs-full-len": 250, "filter": "posvar"}
-    pl = pipeline.Pipeline(st, famfinder=ff)
+    pl = pipeline.Pipeline(st, famfinder=ff, aligner={"insertion": insertion})
     pl.run(qs.mask, qs.off)
     n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250),
-                     al=dict(weights=w))
-    assert n_dp >= 10
+                     al=dict(weights=w, insertion=1 if insertion == "forbid" else 0))
+    assert n_dp >= 28
     pl.close()
 
 
