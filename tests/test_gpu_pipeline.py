@@ -184,6 +184,21 @@ def test_pipeline_weighted_scheme(oracle, world, monkeypatch, geom, insertion):
     pl.close()
 
 
+@pytest.mark.parametrize("fs_min,fs_max", [(100, 128), (5, 5), (1, 1)])
+def test_pipeline_family_sizes(oracle, world, fs_min, fs_max):
+    """Families of 128 members (the device DAG build's limit: wide LDS tables, long predecessor
+    lists), of five and of a single reference -- a DAG that is a chain."""
+    refs, cs, idx, st = world
+    qs = synth.make_queries(refs, 16, seed=58, ins=0.01, dele=0.01)
+    ff = {"fs-min-len": 100, "fs-full-len": 250, "fs-min": fs_min, "fs-max": fs_max}
+    pl = pipeline.Pipeline(st, famfinder=ff)
+    pl.run(qs.mask, qs.off)
+    n_dp, _ = _check(oracle, refs, qs, pl, cs, idx,
+                     ff=dict(fs_min_len=100, fs_full_len=250, fs_min=fs_min, fs_max=fs_max))
+    assert n_dp >= 12
+    pl.close()
+
+
 def test_single_tray_batching_shim(oracle, world):
     """batch=1: every tray goes through the stages alone, as SINA's TBB nodes would call them."""
     refs, cs, idx, st = world
