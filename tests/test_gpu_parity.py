@@ -191,15 +191,22 @@ def test_kmer_scores_and_topk(oracle, gpu_ctx, small):
             assert (gs[qi, :gn[qi]] == os_).all()
 
 
-def test_device_index_build_equals_oracle_csr(oracle, gpu_ctx, small):
+@pytest.mark.parametrize("k", [4, 8, 12])
+def test_device_index_build_equals_oracle_csr(oracle, gpu_ctx, small, k):
+    """Index built on the device for k = 4 (256 long lists: all of them dense), 8 and 12 (the largest
+    the C ABI takes: 16.8 M list slots), fast and no-fast: scores and top-41 equal the oracle's."""
     refs, qs, cs, idx = small
     gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
     for nofast in (False, True):
-        oidx = oracle.Index(cs, k=8, nofast=nofast)
-        gpu_ctx.build_index(8, nofast)
+        oidx = oracle.Index(cs, k=k, nofast=nofast)
+        gpu_ctx.build_index(k, nofast)
         for qi in range(qs.n):
             q = util.query_cseq(qs, qi)
             assert (gpu_ctx.kmer_scores(qs.seq(qi)) == oidx.scores(q)).all()
+        gi, gs, gn = gpu_ctx.kmer_topk(qs.mask, qs.off, 41)
+        for qi in range(qs.n):
+            oi, os_ = oidx.find(util.query_cseq(qs, qi), 41)
+            assert gn[qi] == len(oi) and (gi[qi, :gn[qi]] == oi).all() and (gs[qi, :gn[qi]] == os_).all()
 
 
 def test_device_family_graph_equals_oracle(oracle, gpu_ctx):
