@@ -351,6 +351,10 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                     const uint32_t q = it.b0 + (uint32_t)i;
                     tray &t = it.trays[i];
                     t.seqno = q;
+                    // (the item's trays are reused from batch to batch: a fresh log -- destroy() frees the
+                    // sequences but leaves the text, and the previous occupant's would lead this one's)
+                    t.log.str(std::string());
+                    t.log.clear();
                     const std::string name = "query" + std::to_string(q);
                     t.input_sequence = new cseq(name.c_str());
                     // (an unaligned query: base i in column i -- built in one piece, not by per-base appends)

@@ -1,5 +1,7 @@
 """GPU end-to-end: tray -> famfinder -> aligner through the C++ stage mirror (k-mer
 search and mesh DP on the GPU) vs the CPU oracle run query by query."""
+import os
+
 import numpy as np
 import pytest
 
@@ -196,6 +198,56 @@ def test_pipeline_family_sizes(oracle, world, fs_min, fs_max):
     n_dp, _ = _check(oracle, refs, qs, pl, cs, idx,
                      ff=dict(fs_min_len=100, fs_full_len=250, fs_min=fs_min, fs_max=fs_max))
     assert n_dp >= 12
+    pl.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SINA_FUZZ_SEEDS", "12"))))
+def test_pipeline_option_fuzz(oracle, world, monkeypatch, seed):
+    """Seeded random combinations of the aligner's options, the scoring parameters (incl. gap extension
+    above gap opening: the general chain path of the kernel), the weighted scheme, the host / device DAG
+    build, the DP geometry and the query shape -- every case against the oracle, everything compared."""
+    refs, cs, idx, st = world
+    rng = np.random.default_rng(1000 + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]  # noqa: E731
+    geom = pick([None, None, "64,8", "128,8", "128,12", "192,4", "256,4"])
+    if geom:
+        monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+    overhang, lowercase, insertion = pick(["attach", "remove", "edge"]), pick(["none", "original", "unaligned"]), pick(["shift", "forbid"])
+    ms, mms = float(pick([2, 3, 1.5])), float(pick([-1, -2, -0.5]))
+    gp, gpe = pick([(5, 2), (4, 1.5), (2, 3), (3, 3), (6, 0.5)])
+    fsw = float(pick([1.0, 0.0, 0.5, 2.5]))
+    weighted = bool(rng.integers(0, 2))
+    al = {"overhang": overhang, "lowercase": lowercase, "insertion": insertion, "match-score": ms, "mismatch-score": mms,
+          "pen-gap": gp, "pen-gapext": gpe, "fs-weight": fsw, "device-graph": bool(rng.integers(0, 2))}
+    oal = dict(overhang={"attach": 0, "remove": 1, "edge": 2}[overhang], lowercase={"none": 0, "original": 1, "unaligned": 2}[lowercase],
+               insertion=1 if insertion == "forbid" else 0, match_score=ms, mismatch_score=mms, gap_penalty=gp,
+               gap_ext_penalty=gpe, fs_weight=fsw)
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    if weighted:
+        w = rng.uniform(0.3, 1.4, size=refs.width).astype(np.float32)
+        st.add_filter("fuzzvar", w)
+        ff["filter"] = "fuzzvar"
+        oal["weights"] = w
+    window = pick([None, (0.3, 120), (0.1, 200)])
+    qs = synth.make_queries(refs, 20, seed=2000 + seed, window=window, ins=float(pick([0.003, 0.02])),
+                            dele=float(pick([0.005, 0.02])), lower_rate=0.05, amb_rate=0.01)
+    pl = pipeline.Pipeline(st, famfinder=ff, aligner=al)
+    pl.run(qs.mask, qs.off, batch=int(pick([20, 7])), inflight=int(pick([1, 2])))
+    n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250), al=oal)
+    assert n_dp >= 15, (geom, al)
+    pl.close()
+
+
+def test_driver_worker_handles_many_batches(oracle, world):
+    """One worker of the host driver taking batch after batch (20 queries in batches of 3, one in
+    flight): every result -- log text and status included -- is that query's alone.  (The driver reuses
+    its tray objects; their logs once carried over from the previous batch.)"""
+    refs, cs, idx, st = world
+    qs = synth.make_queries(refs, 20, seed=61, ins=0.02, dele=0.01)
+    pl = pipeline.Pipeline(st, famfinder={"fs-min-len": 100, "fs-full-len": 250})
+    pl.run(qs.mask, qs.off, batch=3, inflight=1)
+    n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250))
+    assert n_dp >= 16
     pl.close()
 
 
