@@ -238,6 +238,29 @@ def test_pipeline_option_fuzz(oracle, world, monkeypatch, seed):
     pl.close()
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SINA_FUZZ_SEEDS", "12"))))
+def test_famfinder_option_fuzz(oracle, world, seed):
+    """Seeded random famfinder options (famfinder.cpp:497-612: family size bounds, score and identity
+    cut-offs, full-length / gap / coverage requirements, leave-query-out) with whole or partial queries,
+    exact copies of references among them: family, alignment and log against the oracle."""
+    refs, cs, idx, st = world
+    rng = np.random.default_rng(5000 + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]  # noqa: E731
+    fs_min = int(pick([40, 10, 3, 60]))
+    o = dict(fs_min=fs_min, fs_max=int(pick([fs_min, fs_min + 5, 2 * fs_min])), fs_msc=float(pick([0.7, 0.2, 50.0, 150.0])),
+             fs_msc_max=float(pick([2.0, 2.0, 0.98, 0.9])), fs_leave_query_out=int(pick([0, 0, 1])),
+             fs_req=int(pick([1, 1, 5, 30])), fs_req_full=int(pick([1, 0, 3])), fs_full_len=int(pick([250, 290, 310])),
+             fs_req_gaps=int(pick([10, 0, 400])), fs_min_len=int(pick([100, 150, 280])), fs_cover_gene=int(pick([0, 0, 2])))
+    ff = {k.replace("_", "-"): v for k, v in o.items()}
+    window = pick([None, None, (0.2, 150)])
+    qs = synth.make_queries(refs, 16, seed=6000 + seed, window=window, sub=float(pick([0.03, 0.0, 0.1])),
+                            dele=float(pick([0.005, 0.0])), ins=float(pick([0.003, 0.0])))
+    pl = pipeline.Pipeline(st, famfinder=ff)
+    pl.run(qs.mask, qs.off, batch=int(pick([16, 5])), inflight=int(pick([1, 2])))
+    _check(oracle, refs, qs, pl, cs, idx, ff=o)
+    pl.close()
+
+
 def test_driver_worker_handles_many_batches(oracle, world):
     """One worker of the host driver taking batch after batch (20 queries in batches of 3, one in
     flight): every result -- log text and status included -- is that query's alone.  (The driver reuses
