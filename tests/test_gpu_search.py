@@ -1,5 +1,7 @@
 """GPU parity for the search stage: the comparison kernel's counters against the
 oracle's literal traverse(), for every iupac rule, with and without the lower-case filter."""
+import os
+
 import numpy as np
 import pytest
 
@@ -118,6 +120,25 @@ def test_search_stage_at_20k_references(oracle, sopts, oopts):
     real selection (top 1000 of 20 000 by k-mer score: the select kernel's histogram path with M =
     1000), and --search-all compares every query with all 20 000 references."""
     _search_stage_case(oracle, 20000, sopts, oopts, n_queries=6)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SINA_FUZZ_SEEDS", "10"))))
+def test_search_stage_option_fuzz(oracle, seed):
+    """Seeded random search-stage options (search_filter.cpp:244-345, cseq_comparator.cpp:240-290: all
+    nine coverage rules, three IUPAC rules, lower-case filter, candidate counts below and above the
+    reference count, --search-all, --search-ignore-super, quorum) against the oracle."""
+    rng = np.random.default_rng(8000 + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]  # noqa: E731
+    iupac = pick(["optimistic", "pessimistic", "exact"])
+    cover = pick(["abs", "query", "target", "overlap", "all", "average", "min", "max", "nogap"])
+    o = dict(min_sim=float(pick([0.7, 0.5, 0.0, -1.0, 0.9])), max_result=int(pick([10, 1, 7, 50])), iupac=iupac, cover=cover,
+             lca_quorum=float(pick([0.7, 0.5, 1.0])), kmer_candidates=int(pick([1000, 40, 300, 5])),
+             filter_lc=int(pick([0, 1])), search_all=int(pick([0, 0, 1])), ignore_super=int(pick([0, 1])))
+    names = dict(min_sim="search-min-sim", max_result="search-max-result", iupac="search-iupac", cover="search-cover",
+                 lca_quorum="lca-quorum", kmer_candidates="search-kmer-candidates", filter_lc="search-filter-lowercase",
+                 search_all="search-all", ignore_super="search-ignore-super")
+    sopts = {names[k]: (bool(v) if k in ("filter_lc", "search_all", "ignore_super") else v) for k, v in o.items()}
+    _search_stage_case(oracle, 420, sopts, o, n_queries=10)
 
 
 def _search_stage_case(oracle, n_refs, sopts, oopts, n_queries=24):
