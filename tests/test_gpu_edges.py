@@ -1,5 +1,7 @@
 """GPU parity at the edges of the path: degenerate sizes, the largest DP geometry, error returns of
 the C ABI, and size-independent properties at full-length scale (self-alignment, determinism)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -22,6 +24,55 @@ def _planes_equal(oracle, gpu_ctx, fam, q, qm, width, **opts):
     vm, vs, val = gpu_ctx.debug_mesh(gb, qm, gpu_ctx.params(**opts) if opts else None)
     assert (util.f32_bits(val) == util.f32_bits(cells["value"])).all()
     assert (vm == cells["value_midx"]).all() and (vs == cells["value_sidx"]).all()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SINA_FUZZ_SEEDS", "10"))))
+def test_mesh_plane_fuzz(oracle, gpu_ctx, monkeypatch, seed):
+    """Seeded random families (1 - 60 members, heavy to no divergence, long deletions that make
+    far-away predecessors, ambiguity codes, lower case), scoring parameters, insertion rule, node-weight
+    scale and DP geometry (incl. a single LDS row slot): value / value_midx / value_sidx planes of the
+    production kernel bit-exact against the oracle's mesh."""
+    rng = np.random.default_rng(9000 + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]  # noqa: E731
+    length = int(pick([60, 150, 320, 700]))
+    refs = synth.make_refs(int(pick([8, 40, 90])), length=length, width=int(length * pick([3, 8])), seed=9100 + seed,
+                           n_clades=int(pick([1, 3, 8])), clade_div=float(pick([0.05, 0.2, 0.4])),
+                           sub_hi=float(pick([0.02, 0.1, 0.3])), del_rate=float(pick([0.0, 0.01, 0.08])),
+                           ins_rate=float(pick([0.0, 0.005, 0.05])), long_del_prob=float(pick([0.0, 0.3, 1.0])),
+                           amb_rate=float(pick([0.0, 0.03])), lower_rate=float(pick([0.0, 0.1])))
+    cs = util.cseqs_from_refs(refs)
+    usable = [i for i in range(refs.n) if cs[i].size >= 20]
+    if not usable:
+        pytest.skip("degenerate family")
+    nfam = int(pick([1, 2, 7, 40, 60]))
+    fam = [cs[i] for i in list(rng.permutation(usable)[:nfam])]
+    src = (refs.seq(usable[int(rng.integers(0, len(usable)))]) >> 24) & 0x0f
+    lo = int(rng.integers(0, max(1, len(src) // 3)))
+    hi = int(rng.integers(min(len(src), lo + 5), len(src) + 1))
+    qm = src[lo:hi].copy()
+    mut = rng.random(len(qm)) < float(pick([0.0, 0.05, 0.3]))
+    qm[mut] = rng.choice([1, 2, 4, 8, 15, 3], size=int(mut.sum()))
+    q, qm = _cseq("fuzz%d" % seed, qm)
+    geom = pick([None, None, "64,4", "128,4", "64,8", "128,8", "64,12", "128,12"])
+    if geom and len(qm) <= int(geom.split(",")[0]) * int(geom.split(",")[1]):
+        monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+    if rng.integers(0, 3) == 0:
+        monkeypatch.setenv("SINA_HIP_DP_LDS_KB", str(pick([5, 9])))
+    gp, gpe = pick([(5, 2), (4, 1.5), (2, 3), (3, 3), (6, 0.5), (0.3, 0.1)])
+    opts = dict(match_score=float(pick([2, 3, 0.7])), mismatch_score=float(pick([-1, -2, -0.1])), gap_penalty=float(gp),
+                gap_ext_penalty=float(gpe), insertion=int(pick([0, 0, 1])), fs_weight=float(pick([1.0, 0.0, 2.5])))
+    if rng.integers(0, 3) == 0:
+        opts["weights"] = rng.uniform(0.2, 1.6, size=refs.width).astype(np.float32)
+    ctx = capi.Context(0)   # (a context of its own: the LDS budget is read when it is created)
+    try:
+        cells = oracle.mesh_compute(fam, q, oracle.align_opts(**opts), weight=opts["fs_weight"])
+        gb = ctx.graph_batch([util.graph_dict(fam, weight=opts["fs_weight"])], refs.width)
+        popts = {k: v for k, v in opts.items() if k != "fs_weight"}
+        vm, vs, val = ctx.debug_mesh(gb, qm, ctx.params(**popts))
+        assert (util.f32_bits(val) == util.f32_bits(cells["value"])).all()
+        assert (vm == cells["value_midx"]).all() and (vs == cells["value_sidx"]).all()
+    finally:
+        ctx.close()
 
 
 def test_tiny_queries_and_tiny_families(oracle, gpu_ctx):
