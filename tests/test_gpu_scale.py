@@ -102,6 +102,40 @@ def test_kmer_select_regimes_equal_oracle(oracle, regime):
         ctx.close()
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SINA_FUZZ_SEEDS", "8"))))
+def test_kmer_search_fuzz(oracle, monkeypatch, seed):
+    """Seeded random k-mer searches: reference counts on both sides of one tile (32 768) and of the
+    select kernel's short cut (16 384), k, fast / no-fast, clade structure, the dense-list threshold,
+    index built on the device or uploaded, requested counts: full score vectors and top-M against the
+    oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]  # noqa: E731
+    n_refs = int(pick([300, 5000, 17000, 33000, 40000]))
+    length = int(pick([150, 300]))
+    refs = synth.make_refs(n_refs, length=length, width=8 * length, seed=7100 + seed, n_clades=int(pick([1, 4, 30])),
+                           clade_div=float(pick([0.05, 0.2])), sub_lo=0.0, sub_hi=float(pick([0.0, 0.05, 0.2])),
+                           long_del_prob=0.0, amb_rate=float(pick([0.0, 0.02])))
+    k, nofast = int(pick([6, 8, 10, 10])), bool(rng.integers(0, 2))
+    dd = pick([None, None, "1", "8", "1000000"])
+    if dd:
+        monkeypatch.setenv("SINA_HIP_DENSE_DIV", dd)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=k, nofast=nofast)
+    qs = synth.make_queries(refs, 5, seed=7200 + seed, sub=float(pick([0.0, 0.03, 0.2])), amb_rate=float(pick([0.0, 0.02])))
+    ctx = capi.Context(0)
+    try:
+        ctx.upload_refs(refs.ab, refs.off, refs.width)
+        if rng.integers(0, 2):
+            ctx.build_index(k, nofast)
+        else:
+            off, ids = idx.csr()
+            ctx.upload_index(k, nofast, off, ids)
+        maxes = tuple(sorted(set(int(x) for x in rng.choice([1, 2, 40, 41, 400, 1000, 4096], size=3))))
+        _scores_and_topk_equal(ctx, idx, qs, maxes=maxes)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("nofast", [False, True])
 def test_device_index_multi_tile_equals_oracle_csr(oracle, wide, nofast):
     """sina_hip_build_index at 70 000 references: the CSR index itself (offsets and ids, downloaded)
