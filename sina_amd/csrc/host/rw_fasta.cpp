@@ -6,9 +6,12 @@
 // alphabet, --fasta-idx/--fasta-block slicing; on output the three text meta formats and the csv
 // side file, dots vs dashes, DNA vs RNA, line wrapping, the --min-idty filter, --add-relatives.
 // gzip in/out (boost::iostreams filters in the reference) is not provided.
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <vector>
 #include <sstream>
 #include <stdexcept>
@@ -59,19 +62,106 @@ void rw_fasta::set_option(const std::string &name, const std::string &value) {
 // half a dozen system calls each way)
 static constexpr size_t kStreamBuffer = 4u << 20;
 
+// gzip'ed files (reference: boost::iostreams gzip filters when the extension is ".gz",
+// src/rw_fasta.cpp:200-202,358-360).  zlib is looked up at run time -- libz.so.1 is part of every
+// base image, its development link is not, and nothing else of the library needs it.
+namespace {
+struct zlib_api {
+    void *(*open)(const char *, const char *) = nullptr;
+    int (*read)(void *, void *, unsigned) = nullptr;
+    int (*write)(void *, const void *, unsigned) = nullptr;
+    int (*close)(void *) = nullptr;
+    int (*buffer)(void *, unsigned) = nullptr;
+    static const zlib_api &get() {
+        static const zlib_api api = [] {
+            zlib_api a;
+            void *h = dlopen("libz.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("libz.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) throw std::runtime_error("gzip'ed FASTA needs zlib (libz.so.1 not found)");
+            a.open = reinterpret_cast<void *(*)(const char *, const char *)>(dlsym(h, "gzopen"));
+            a.read = reinterpret_cast<int (*)(void *, void *, unsigned)>(dlsym(h, "gzread"));
+            a.write = reinterpret_cast<int (*)(void *, const void *, unsigned)>(dlsym(h, "gzwrite"));
+            a.close = reinterpret_cast<int (*)(void *)>(dlsym(h, "gzclose"));
+            a.buffer = reinterpret_cast<int (*)(void *, unsigned)>(dlsym(h, "gzbuffer"));
+            if (!a.open || !a.read || !a.write || !a.close) throw std::runtime_error("zlib without the gz* functions");
+            return a;
+        }();
+        return api;
+    }
+};
+class gz_streambuf : public std::streambuf {
+public:
+    gz_streambuf(const std::string &path, bool writing) : z(zlib_api::get()), wr(writing), buf(kStreamBuffer) {
+        f = z.open(path.c_str(), writing ? "wb" : "rb");
+        if (f && z.buffer) z.buffer(f, 1u << 20);
+        if (writing) setp(buf.data(), buf.data() + buf.size());
+    }
+    ~gz_streambuf() override {
+        if (f) {
+            if (wr) sync();
+            z.close(f);
+        }
+    }
+    bool is_open() const { return f != nullptr; }
+
+protected:
+    int_type underflow() override {
+        if (wr || !f) return traits_type::eof();
+        const int n = z.read(f, buf.data(), (unsigned)buf.size());
+        if (n <= 0) return traits_type::eof();
+        setg(buf.data(), buf.data(), buf.data() + n);
+        return traits_type::to_int_type(*gptr());
+    }
+    int_type overflow(int_type ch) override {
+        if (!wr || !f || sync() != 0) return traits_type::eof();
+        if (!traits_type::eq_int_type(ch, traits_type::eof())) {
+            *pptr() = traits_type::to_char_type(ch);
+            pbump(1);
+        }
+        return traits_type::not_eof(ch);
+    }
+    int sync() override {
+        if (!wr || !f) return 0;
+        const std::ptrdiff_t n = pptr() - pbase();
+        if (n > 0 && z.write(f, pbase(), (unsigned)n) != (int)n) return -1;
+        setp(buf.data(), buf.data() + buf.size());
+        return 0;
+    }
+
+private:
+    const zlib_api &z;
+    void *f = nullptr;
+    bool wr;
+    std::vector<char> buf;
+};
+bool has_gz_extension(const std::string &path) { return path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0; }
+}  // namespace
+
 struct rw_fasta::reader::priv_data {
     std::vector<char> buf = std::vector<char>(kStreamBuffer);
-    std::ifstream in;
+    std::ifstream file;
+    std::unique_ptr<gz_streambuf> gz;
+    std::unique_ptr<std::istream> gz_in;
+    std::istream *inp = nullptr;  // the plain file, or the gzip filter over it
     std::string filename;
     int lineno = 0, seqno = 0, skipped = 0;
 };
 
 rw_fasta::reader::reader(const std::string &infile) : data(new priv_data) {
     data->filename = infile;
-    data->in.rdbuf()->pubsetbuf(data->buf.data(), (std::streamsize)data->buf.size());  // (before open)
-    data->in.open(infile, std::ios_base::binary);
-    if (!data->in.is_open()) throw std::runtime_error("Unable to open file \"" + infile + "\" for reading.");
-    if (fa_opts().fasta_block > 0) data->in.seekg(fa_opts().fasta_block * fa_opts().fasta_idx);
+    if (has_gz_extension(infile)) {
+        if (fa_opts().fasta_block > 0) throw std::logic_error("Cannot use --fasta-idx with gzip'ed input");
+        data->gz.reset(new gz_streambuf(infile, false));
+        if (!data->gz->is_open()) throw std::runtime_error("Unable to open file \"" + infile + "\" for reading.");
+        data->gz_in.reset(new std::istream(data->gz.get()));
+        data->inp = data->gz_in.get();
+        return;
+    }
+    data->file.rdbuf()->pubsetbuf(data->buf.data(), (std::streamsize)data->buf.size());  // (before open)
+    data->file.open(infile, std::ios_base::binary);
+    if (!data->file.is_open()) throw std::runtime_error("Unable to open file \"" + infile + "\" for reading.");
+    data->inp = &data->file;
+    if (fa_opts().fasta_block > 0) data->file.seekg(fa_opts().fasta_block * fa_opts().fasta_idx);
 }
 rw_fasta::reader::reader(const reader &) = default;
 rw_fasta::reader &rw_fasta::reader::operator=(const reader &) = default;
@@ -87,6 +177,7 @@ static std::string trim(const std::string &s) {  // boost::trim
 
 bool rw_fasta::reader::operator()(tray &t) {  // :229-315
     const options &o = fa_opts();
+    std::istream &in = *data->inp;
     for (;;) {
         t.seqno = ++data->seqno;
         t.input_sequence = new cseq();
@@ -96,17 +187,17 @@ bool rw_fasta::reader::operator()(tray &t) {  // :229-315
             t.input_sequence = nullptr;
             return false;
         };
-        if (data->in.fail()) return give_up();
+        if (in.fail()) return give_up();
         // if fasta blocking enabled, check if we've passed block boundary in last sequence
-        if (o.fasta_block > 0 && data->in.tellg() > o.fasta_block * (o.fasta_idx + 1)) return give_up();
+        if (o.fasta_block > 0 && in.tellg() > o.fasta_block * (o.fasta_idx + 1)) return give_up();
 
         std::string line;
         // skip lines not beginning with '>'
-        while (data->in.peek() != '>' && std::getline(data->in, line).good()) data->lineno++;
+        while (in.peek() != '>' && std::getline(in, line).good()) data->lineno++;
 
         // parse title
         data->lineno++;
-        if (std::getline(data->in, line).good()) {
+        if (std::getline(in, line).good()) {
             if (!line.empty() && line[line.size() - 1] == '\r') line.resize(line.size() - 1);
             // set name to text between first '>' and first ' '
             unsigned int blank = (unsigned int)line.find_first_of(" \t");
@@ -118,7 +209,7 @@ bool rw_fasta::reader::operator()(tray &t) {  // :229-315
         }
 
         // handle comments: "; key = value" becomes an attribute, others are ignored
-        while (data->in.peek() == ';' && std::getline(data->in, line).good()) {
+        while (in.peek() == ';' && std::getline(in, line).good()) {
             data->lineno++;
             const size_t equalsign = line.find_first_of('=');
             if (equalsign != std::string::npos)
@@ -127,14 +218,14 @@ bool rw_fasta::reader::operator()(tray &t) {  // :229-315
 
         try {
             // all lines until eof or next /^>/ are data
-            while (data->in.peek() != '>' && data->in.good()) {
-                std::getline(data->in, line);
+            while (in.peek() != '>' && in.good()) {
+                std::getline(in, line);
                 data->lineno++;
                 c.append(line);
             }
         } catch (base_iupac::bad_character_exception &) {
             // "Skipping sequence N (>name) at file:line (contains character 'x')"
-            while (data->in.peek() != '>' && std::getline(data->in, line).good()) data->lineno++;
+            while (in.peek() != '>' && std::getline(in, line).good()) data->lineno++;
             delete t.input_sequence;
             t.input_sequence = nullptr;
             data->skipped++;
@@ -169,7 +260,10 @@ static std::string escape_string(const std::string &in) {  // :378-392
 
 struct rw_fasta::writer::priv_data {
     std::vector<char> buf = std::vector<char>(kStreamBuffer);
-    std::ofstream out, out_csv;
+    std::ofstream file, out_csv;
+    std::unique_ptr<gz_streambuf> gz;
+    std::unique_ptr<std::ostream> gz_out;
+    std::ostream *outp = nullptr;  // the plain file, or the gzip filter over it
     int count = 0, excluded = 0;
     std::unordered_set<std::string> relatives_written;
     unsigned long copy_relatives = 0;
@@ -178,9 +272,17 @@ struct rw_fasta::writer::priv_data {
 
 rw_fasta::writer::writer(const std::string &outfile, unsigned int copy_relatives) : data(new priv_data) {
     data->copy_relatives = copy_relatives;
-    data->out.rdbuf()->pubsetbuf(data->buf.data(), (std::streamsize)data->buf.size());  // (before open)
-    data->out.open(outfile, std::ios_base::binary);
-    if (!data->out.is_open()) throw std::runtime_error("Unable to open file \"" + outfile + "\" for writing.");
+    if (has_gz_extension(outfile)) {
+        data->gz.reset(new gz_streambuf(outfile, true));
+        if (!data->gz->is_open()) throw std::runtime_error("Unable to open file \"" + outfile + "\" for writing.");
+        data->gz_out.reset(new std::ostream(data->gz.get()));
+        data->outp = data->gz_out.get();
+    } else {
+        data->file.rdbuf()->pubsetbuf(data->buf.data(), (std::streamsize)data->buf.size());  // (before open)
+        data->file.open(outfile, std::ios_base::binary);
+        if (!data->file.is_open()) throw std::runtime_error("Unable to open file \"" + outfile + "\" for writing.");
+        data->outp = &data->file;
+    }
     if (fa_opts().fastameta == FASTA_META_CSV) {
         const size_t dot = outfile.find_last_of('.'), slash = outfile.find_last_of('/');
         const std::string stem =
@@ -195,7 +297,7 @@ rw_fasta::writer::~writer() = default;
 int rw_fasta::writer::written() const { return data->count; }
 int rw_fasta::writer::excluded() const { return data->excluded; }
 void rw_fasta::writer::flush() {
-    data->out.flush();
+    data->outp->flush();
     if (data->out_csv.is_open()) data->out_csv.flush();
 }
 
@@ -229,6 +331,7 @@ tray rw_fasta::writer::operator()(tray t) {  // :394-435
 void rw_fasta::writer::priv_data::write(const cseq &c) {  // :437-541
     const options &o = fa_opts();
     const auto &attrs = c.get_attrs();
+    std::ostream &out = *outp;
     out << ">" << c.getName();
     const std::string fname = c.get_attr<std::string>(fn::fullname, "");
     if (!fname.empty()) out << " " << fname;

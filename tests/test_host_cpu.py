@@ -179,3 +179,25 @@ def test_dp_kernels_have_no_inflight_scalar_load_reads(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
     assert "Li8ELb0ELb0ELb1ELb0E" in r.stdout  # (the production kernel was among those looked at)
+
+
+def test_fasta_gzip_in_and_out(tmp_path):
+    """Files ending in .gz are read and written through zlib, as the reference does with its
+    boost::iostreams gzip filters (rw_fasta.cpp:200-202,358-360): same sequences as the plain files."""
+    import gzip
+    refs = synth.make_refs(40, length=200, width=1500, seed=91, amb_rate=0.02, lower_rate=0.05)
+    text = "".join(">seq%d some description\n; key = value\n%s\n" % (i, synth.aligned_string(refs.seq(i), refs.width))
+                   for i in range(refs.n))
+    plain, packed = tmp_path / "in.fasta", tmp_path / "in.fasta.gz"
+    plain.write_text(text)
+    with gzip.open(packed, "wt") as f:
+        f.write(text)
+    out_plain, out_gz, out_gz2 = tmp_path / "o1.fasta", tmp_path / "o2.fasta", tmp_path / "o3.fasta.gz"
+    assert pipeline.fasta_roundtrip(str(plain), str(out_plain)) == (refs.n, 0)
+    assert pipeline.fasta_roundtrip(str(packed), str(out_gz)) == (refs.n, 0)
+    assert pipeline.fasta_roundtrip(str(plain), str(out_gz2)) == (refs.n, 0)
+    want = out_plain.read_text()
+    assert want.count(">") == refs.n
+    assert out_gz.read_text() == want
+    with gzip.open(out_gz2, "rt") as f:
+        assert f.read() == want
