@@ -79,6 +79,8 @@ struct GraphArgs {
     uint32_t *sizes;           // [nq][4]: N, raw edge entries, n_spill, status (0 ok, 2 N cap, 4 spill rows)
     uint32_t width, ncap;
     uint32_t tile_bytes;       // LDS bytes of the tile tables (reused by the slot allocation)
+    uint32_t member_off;       // LDS offset of the per-member arrays (behind the tile tables), entries each
+    uint32_t member_cap;
     int W;                     // DP ring depth: edges longer than this need a spill row
 };
 
@@ -118,11 +120,14 @@ __device__ uint32_t block_exscan(const In *in, Out *out, uint32_t n, uint32_t *t
 
 __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t s_ids[kMaxFam];
-    __shared__ uint32_t s_len[kMaxFam];
-    __shared__ uint64_t s_beg[kMaxFam];
-    __shared__ uint32_t s_cur[kMaxFam], s_curn[kMaxFam];      // first base of member j at/after the tile
-    __shared__ uint32_t s_carry[kMaxFam], s_carryn[kMaxFam];  // node of member j's last base before the tile
+    // per family member (sized by the launch's largest family, at least 16: s_ids doubles as the
+    // slot allocator's per-segment counters) -- dynamic, so that small families leave the LDS to a
+    // fourth workgroup per CU
+    uint64_t *s_beg = reinterpret_cast<uint64_t *>(smem + a.member_off);
+    uint32_t *s_ids = reinterpret_cast<uint32_t *>(s_beg + a.member_cap);
+    uint32_t *s_len = s_ids + a.member_cap;
+    uint32_t *s_cur = s_len + a.member_cap, *s_curn = s_cur + a.member_cap;      // first base of member j at/after the tile
+    uint32_t *s_carry = s_curn + a.member_cap, *s_carryn = s_carry + a.member_cap;  // node of member j's last base before the tile
     __shared__ uint32_t s_tmp[kGT / 64 + 8];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t nwords = (a.width + 31) / 32;
@@ -572,6 +577,11 @@ size_t graph_lds_bytes(uint32_t width, uint32_t max_family) {
     return ((6 * nwords + 15) & ~(size_t)15) + (size_t)kTC * (4 + 4 + 4 + 1 + 1) + 2 * 2 * (size_t)kTC * fs +
            (size_t)kTC * std::max<size_t>(32, fs) + 64;
 }
+// the per-member arrays behind that: offset (8-byte aligned) and total
+size_t graph_member_cap(uint32_t max_family) { return std::max<size_t>(16, (max_family + 1) & ~(size_t)1); }
+size_t graph_lds_total(uint32_t width, uint32_t max_family) {
+    return ((graph_lds_bytes(width, max_family) + 7) & ~(size_t)7) + 32 * graph_member_cap(max_family);
+}
 
 }  // namespace
 }  // namespace sina_hip
@@ -624,7 +634,8 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
             bg->pred_off[q] = pred_total;
             pred_total += elems[q] + 8;  // +8: slack behind every list
         }
-        const size_t glds = graph_lds_bytes(c->st->width, max_f);
+        const size_t glds_tables = graph_lds_bytes(c->st->width, max_f);
+        const size_t glds = graph_lds_total(c->st->width, max_f);
         if (glds > 160 * 1024) SH_FAIL("align_families: family too wide for the device DAG build");
         if (c->g_fam_ids.reserve(4 * std::max<uint64_t>(foff[bq], 1)) || c->g_fam_off.reserve(8 * ((uint64_t)bq + 1)) ||
             c->g_tmp1.reserve(8 * (uint64_t)bq) ||
@@ -651,7 +662,9 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         ga.sizes = c->g_sizes.as<uint32_t>();
         ga.width = c->st->width;
         ga.ncap = ncap;
-        ga.tile_bytes = (uint32_t)(glds - ((6 * (size_t)((c->st->width + 31) / 32) + 15) & ~(size_t)15) - 64);
+        ga.tile_bytes = (uint32_t)(glds_tables - ((6 * (size_t)((c->st->width + 31) / 32) + 15) & ~(size_t)15) - 64);
+        ga.member_off = (uint32_t)((glds_tables + 7) & ~(size_t)7);
+        ga.member_cap = (uint32_t)graph_member_cap(max_f);
         ga.W = W;
         SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(family_graph_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
