@@ -223,8 +223,11 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     const uint32_t qi = orderv[blockIdx.x];
     const QDesc d = qdv[qi];
     const uint32_t N = uniform(d.N), L = uniform(d.L);
-    const uint32_t S = n_strips;
-    const uint32_t Lp = S * (uint32_t)kStrip;  // row stride of the trace-back plane and of the spill rows
+    const uint32_t Lp = n_strips * (uint32_t)kStrip;  // row stride of the trace-back plane and of the spill rows
+    // strips this query needs: those up to the one that holds its last column (a launch's geometry
+    // follows its longest query; a short one beside it is done after its own strips -- the columns
+    // beyond L are read by nothing)
+    const uint32_t S = min(n_strips, (L - 1) / (uint32_t)kStrip + 1);
     const uint64_t node_off = uniform(d.node_off);
 
     // ---- LDS: W row slots, each value[kStrip] | gapm_val[kStrip] | value of the column left of the strip

@@ -261,6 +261,30 @@ def test_famfinder_option_fuzz(oracle, world, seed):
     pl.close()
 
 
+@pytest.mark.parametrize("geom", [None, "128,4", "64,8", "128,12"])
+@pytest.mark.parametrize("insertion", ["shift", "forbid"])
+def test_pipeline_mixed_query_lengths(oracle, world, monkeypatch, geom, insertion):
+    """Queries of 40 to 310 bases in ONE launch: the geometry follows the longest, every query sweeps
+    only the strips up to its own last column (mesh_dp_kernel: S per query)."""
+    refs, cs, idx, st = world
+    if geom:
+        monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+    parts = [synth.make_queries(refs, 6, seed=70 + i, window=w, ins=0.01, dele=0.01)
+             for i, w in enumerate([(0.4, 40), (0.2, 130), (0.1, 260), None])]
+    masks = [p.seq(i) for p in parts for i in range(p.n)]
+    order = np.random.default_rng(77).permutation(len(masks))
+    masks = [masks[i] for i in order]
+    off = np.zeros(len(masks) + 1, np.int64)
+    off[1:] = np.cumsum([len(m) for m in masks])
+    qs = synth.QuerySet(mask=np.concatenate(masks), off=off, src=np.zeros(len(masks), np.int64))
+    pl = pipeline.Pipeline(st, famfinder={"fs-min-len": 100, "fs-full-len": 250}, aligner={"insertion": insertion})
+    pl.run(qs.mask, qs.off, batch=qs.n, inflight=1)
+    n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250),
+                     al=dict(insertion=1 if insertion == "forbid" else 0))
+    assert n_dp >= 20
+    pl.close()
+
+
 def test_driver_worker_handles_many_batches(oracle, world):
     """One worker of the host driver taking batch after batch (20 queries in batches of 3, one in
     flight): every result -- log text and status included -- is that query's alone.  (The driver reuses
