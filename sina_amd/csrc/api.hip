@@ -345,13 +345,14 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
             // value_midx of a gap-extending deletion is the predecessor's gapm_idx (common.h, Ext / OpLast)
             const uint4 *rec = hp.rec.data() + d.node_off;
             const uint32_t *pr = hp.pred.data() + d.edge_off;
-            const uint32_t ext_bit = forbid ? kTbExt : kTb16Ext, oplast_bit = forbid ? kTbOpLast : kTb16OpLast;
+            const uint32_t ext_bit = forbid ? kTbExt : kTb16Ext;
             auto gapm_idx = [&](uint32_t x, uint32_t col) -> uint32_t {
                 for (;;) {
                     const uint32_t np = rec[x].z & 0xffu;
                     if (np == 0) return 0;
                     const uint32_t lastp = pr[rec[x].x + np - 1] & 0xffffu;
-                    if (tbh[(size_t)x * Lp + col] & oplast_bit) return lastp;
+                    const uint32_t cx = tbh[(size_t)x * Lp + col];
+                    if (forbid ? (cx & kTbOpLast) != 0 : !(cx & kTb16XLast)) return lastp;
                     x = lastp;
                 }
             };

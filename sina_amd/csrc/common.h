@@ -163,7 +163,7 @@ static_assert(sizeof(EdgeRec) == 16, "read back with one 16-byte scalar load");
 // Trace-back cell: what backtrack() needs of a DP cell -- the only per-cell HBM traffic.  Two formats:
 //
 // * 16 bits (every scheme except --insertion=forbid): bits 1..0 type, bit 2 kTb16Ext, bit 3
-//   kTb16OpLast, bits 11..4 the ORDINAL of the winning predecessor in the row's predecessor list.
+//   kTb16XLast (the inverse of OpLast below), bits 11..4 the ORDINAL of the winning predecessor in the row's predecessor list.
 //   value_midx is that predecessor (a deletion / match cell), the row itself (an insertion cell) or 0
 //   (an untouched cell); value_sidx follows from the type: a match came from column s-1, a deletion
 //   from s, an untouched cell keeps 0, and an insertion from the column where the run of insertion
@@ -186,7 +186,7 @@ constexpr uint32_t kTbOpLast = 1u << 14;
 constexpr uint32_t kTbTypeMask = 3u;
 constexpr uint32_t kTbDel = 0u, kTbMatch = 1u, kTbIns = 2u, kTbNone = 3u;
 constexpr uint32_t kTb16Ext = 1u << 2;
-constexpr uint32_t kTb16OpLast = 1u << 3;
+constexpr uint32_t kTb16XLast = 1u << 3;   // NOT OpLast: the row's gapm at this column EXTENDS its last predecessor's
 constexpr int kTb16OrdShift = 4;  // 8 bits: a row has at most 255 predecessors (rec.z & 0xff)
 // bytes per trace-back cell of a launch
 inline size_t tb_cell_bytes(bool forbid) { return forbid ? 4 : 2; }

@@ -70,26 +70,16 @@ __device__ __forceinline__ uint32_t lane_shr1(uint32_t x) {
 }
 __device__ __forceinline__ float lane_shr1(float x) { return __uint_as_float(lane_shr1(__float_as_uint(x))); }
 
-// v_min_f32 / v_min3_f32 without the operand canonicalisation (v_max x, x) that fminf() drags in:
-// the values here are never NaN, and the extra instruction would sit on the cell-to-cell critical path
-__device__ __forceinline__ float min2_raw(float a, float b) {
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float min3_raw(float a, float b, float c) {
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// plain v_add_f32 (the compiler otherwise pairs unrelated adds into v_pk_add_f32 and pays two
-// register moves per pair to line the operands up)
-__device__ __forceinline__ float add_raw(float a, float b) {
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// Bare v_min_f32 / v_add_f32 as the compiler's own instructions.  This file is built with
+// -fno-honor-nans -mno-amdgpu-ieee (no operand canonicalisation `v_max x, x` in front of a minimum:
+// the values here are never NaN; infinities ARE used and stay honoured) and -fno-slp-vectorize (the
+// SLP vectoriser otherwise pairs unrelated adds into v_pk_add_f32 and pays two register moves per
+// pair to line the operands up).  Until round 3 these three were inline asm, which the hazard
+// recogniser cannot see through: every v_cmp -> v_cndmask pair with such an asm in between was
+// padded with an s_nop, and asm operands forced SGPR -> VGPR copies.
+__device__ __forceinline__ float min2_raw(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float min3_raw(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+__device__ __forceinline__ float add_raw(float a, float b) { return a + b; }
 // keeps a wave-uniform float in a VGPR as an opaque value (stops the compiler from re-deriving it
 // per use from its scalar inputs with vector multiplies)
 __device__ __forceinline__ float opaque_v(float x) {
@@ -265,7 +255,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     constexpr bool kLazy = !FORBID;
     constexpr bool kGsi = WEIGHTED || FORBID;
     constexpr uint32_t kTagNone = kLazy ? kTbNone : 0u;
-    constexpr uint32_t kTagOpLast = kLazy ? kTb16OpLast : kTbOpLast;
+    constexpr uint32_t kTagOpLast = kTbOpLast;  // (32-bit cells; 16-bit cells carry the inverse, kTb16XLast)
     // BELOW_INIT (chosen by the host per launch, dp_below_init()): no value of this launch can reach
     // the 1e6 initial value of rows with predecessors, so their first deletion candidate always
     // replaces it and needs no compare.
@@ -784,7 +774,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             uint32_t tc[B];
 #pragma unroll
             for (int k = 0; k < B; k++)
-                tc[k] = kLazy ? (fvm[k] | (oplast[k] ? kTagOpLast : 0u)) : (fvm[k] | fvs[k] | (oplast[k] ? kTagOpLast : 0u));
+                tc[k] = kLazy ? (fvm[k] | (oplast[k] ? 0u : kTb16XLast)) : (fvm[k] | fvs[k] | (oplast[k] ? kTagOpLast : 0u));
             if constexpr (kLazy) {
                 uint32_t tp[B / 2];  // two 16-bit cells per word
 #pragma unroll
@@ -899,6 +889,455 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             ev = v1min;
         }
         // sinks x columns, strict <, scan order (t asc, x asc)
+        if (all_any && all_min < ev) {
+            em = all_m;
+            es = all_s;
+            ev = all_min;
+        }
+        if (!all_any) r.status = -2;
+        r.end_m = em;
+        r.end_s = es;
+        r.raw = ev;
+        resv[qi] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same recurrence for the case every BASELINE configuration runs: scoring_scheme_simple (constant
+// gap costs, gap_open >= gap_extend), transition_simple, 16-bit trace-back cells, a launch whose values
+// provably stay below the 1e6 initial value (dp_below_init).  Same data structures, same strips, same
+// scalar prefetch, same edge records as mesh_dp_kernel above -- what differs is the instruction
+// count per row, the binding resource of this kernel (VALU issue):
+//   * comp(row base, query base) for a row with a single-base mask (all but IUPAC ambiguity rows) is ONE
+//     v_cmp_class_f32 per cell: the row's base is handed over as a float of one of four classes
+//     (+0, +1, +inf, -1), the query base of a cell is kept as the matching class mask -- instead of
+//     and + compare;
+//   * the insertion chain needs ONE compare per cell: with loc = min(deletion, match candidates),
+//     the gap candidate gs wins the cell iff gs <= loc (it beats the deletions on <=, mesh.h:351,
+//     and a match only wins on <, :369), the cell's value is then gs itself, and "gaps_val == value",
+//     the extend condition of the next cell (:340), is that same predicate; which of deletion / match
+//     a cell falls back to is decided once, off the chain (ltag);
+//   * "extends" flags travel between lanes as a shifted wave mask (one scalar shift), values by DPP;
+//   * the OpLast bit of a trace-back cell is not kept as a lane mask per cell and merged with two
+//     instructions: the deletion tag of an extending predecessor carries a second bit (kTb16XLast)
+//     and one bit-field insert moves the LAST predecessor's into the finished cell;
+//   * no inline asm in the recurrence (the hazard recogniser pads v_cmp -> v_cndmask pairs it cannot
+//     see through).
+// Everything else (weighted scheme, --insertion=forbid, gap_open < gap_extend, huge gap costs) runs
+// mesh_dp_kernel.  Results are bit-identical between the two: tests/test_gpu_parity.py runs every
+// simple-scheme plane test through both (SINA_HIP_DP_GENERIC=1 forces the generic kernel).
+template <int B, bool DBG>
+__global__ void __launch_bounds__(64, (B <= 4 ? 4 : (B <= 8 ? 3 : 2)))
+mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ orderv, const uint4 *__restrict__ recv,
+                      const uint32_t *__restrict__ predv, const uint8_t *__restrict__ qmaskv, void *__restrict__ tbv,
+                      float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev, uint64_t edge_stride,
+                      uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe) {
+    static_assert(B % 4 == 0, "16-byte accesses per array");
+    constexpr int kStrip = 64 * B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t qi = orderv[blockIdx.x];
+    const QDesc d = qdv[qi];
+    const uint32_t N = uniform(d.N), L = uniform(d.L);
+    const uint32_t Lp = n_strips * (uint32_t)kStrip;
+    const uint32_t S = min(n_strips, (L - 1) / (uint32_t)kStrip + 1);
+    const uint64_t node_off = uniform(d.node_off);
+    unsigned char *ring = smem;
+    constexpr size_t kValBytes = (size_t)kStrip * 4;
+    constexpr size_t kSlotBytes = 2 * kValBytes + 16;
+    const uint4 *__restrict__ rec = recv + node_off;
+    const uint32_t *__restrict__ pred = predv + uniform(d.edge_off);
+    uint16_t *__restrict__ tb = reinterpret_cast<uint16_t *>(tbv) + uniform(d.tb_off);
+    float *spill = spillv + uniform(d.spill_off) * (size_t)(2 * Lp);
+    const uint64_t q_off = uniform(d.q_off);
+
+    // end-cell search (mesh.h:567-592), accumulated over the strips
+    const uint32_t strip_last = (L - 1) / (uint32_t)kStrip;
+    const int lane_last = (int)(((L - 1) / B) & 63u);
+    const int k_last = (int)((L - 1) % B);
+    float lc_min = 0.f, lc_snk0 = 0.f;
+    uint32_t lc_arg = 0;
+    bool lc_any = false;
+    float all_min = __builtin_inff();
+    uint32_t all_m = 0, all_s = 0xffffffffu, snk0 = 0;
+    bool all_any = false;
+
+    // trace-back tags (16-bit cells, common.h)
+    constexpr uint32_t kXL = kTb16XLast, kExtXL = kTb16Ext | kTb16XLast;
+    const float gpv = opaque_v(gp), gpev = opaque_v(gpe);  // gap costs as select operands
+
+    for (uint32_t strip = 0; strip < S; ++strip) {
+    const uint32_t s0 = (strip * 64u + (uint32_t)lane) * B;
+    const bool lane0 = lane == 0;
+    const bool col0_mine = (strip == 0) && lane0;  // my cell 0 is query column 0
+    const uint64_t e_in = uniform((uint64_t)(edgev + (size_t)(strip ? strip - 1 : 0) * edge_stride + node_off));
+    EdgeRec *e_out = edgev + (size_t)strip * edge_stride + node_off;
+    const bool have_left_strip = strip > 0, have_right_strip = strip + 1 < S;
+
+    // the query base of my columns as v_cmp_class_f32 masks: A -> +0, G -> +normal, C -> +inf,
+    // U -> -normal (class bits 6, 8, 9, 3); 0 beyond L: matches nothing
+    uint32_t qcls[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        const uint32_t s = s0 + k;
+        const uint32_t q = (s < L) ? (uint32_t)(qmaskv[q_off + s] & 0xf) : 0u;
+        qcls[k] = ((q & 1u) << 6) | ((q & 2u) << 7) | ((q & 4u) << 7) | (q & 8u);
+    }
+    const bool own_last = (strip == strip_last) && (lane == lane_last);
+    float sk_min = __builtin_inff();
+    uint32_t sk_m = 0, sk_s = 0xffffffffu;
+    bool sk_any = false;
+
+    const uint64_t pred_addr = uniform((uint64_t)pred);
+    uint4 cur = rec[0];
+    u32x4 cur_pe = sload16(pred_addr + (uint64_t)cur.x * 4);
+    u32x4 cur_edge = {0, 0, 0, 0};
+    if (have_left_strip) cur_edge = sload16(e_in);
+    sload_wait(cur_pe);
+    sload_wait(cur_edge);
+    Cells<B> prev_v, prev_g;  // the row just finished (common.h: a row whose only successor is the next row is kept nowhere else)
+    float prev_edge_val = 0.f;
+#pragma unroll
+    for (int i = 0; i < B / 4; i++) prev_v.v[i] = prev_g.v[i] = typename Cells<B>::V{0.f, 0.f, 0.f, 0.f};
+
+    for (uint32_t m = 0; m < N; ++m) {
+        const uint32_t m_next = m + 1 < N ? m + 1 : m;
+        const uint4 nrec = rec[m_next];
+        u32x4 nedge = {0, 0, 0, 0};
+        if (have_left_strip) nedge = sload16(e_in + (uint64_t)m_next * sizeof(EdgeRec));
+
+        // ---- row scalars
+        const uint32_t r_pb = cur.x, r_z = cur.z, r_keep = cur.w;
+        const uint32_t npred = r_z & 0xffu, mmask = (r_z >> 8) & 0xfu;
+        const float wgt = __uint_as_float(cur.y);
+        const float vM = ms * wgt, vX = mms * wgt;  // scoring_schemes.h:154
+        const float edge_val = __uint_as_float(cur_edge.x);
+        const bool is_sink = (r_z & kRecSink) != 0;
+
+        // ---- match / mismatch score of my cells against this row: comp() = (row mask & query mask) != 0
+        // (aligned_base.h:153), one class test per set bit of the row's mask
+        float csel[B];
+        {
+            auto base_float = [](uint32_t bit) -> float {  // class of the lowest set bit of `bit`
+                return __uint_as_float((bit & 1u) ? 0u : ((bit & 2u) ? 0x3f800000u : ((bit & 4u) ? 0x7f800000u : 0xbf800000u)));
+            };
+            const float rf = base_float(mmask);
+#pragma unroll
+            for (int k = 0; k < B; k++) csel[k] = (mmask != 0 && __builtin_amdgcn_classf(rf, (int)qcls[k])) ? vM : vX;
+            for (uint32_t mm = mmask & (mmask - 1); mm != 0; mm &= mm - 1) {  // IUPAC ambiguity rows: further bases
+                const float rf2 = base_float(mm);
+#pragma unroll
+                for (int k = 0; k < B; k++) csel[k] = __builtin_amdgcn_classf(rf2, (int)qcls[k]) ? vM : csel[k];
+            }
+        }
+
+        // ---- phase 1: deletion / match candidates from the predecessor rows, in ascending id order
+        // (first minimum wins; the LAST predecessor defines gapm, mesh.h:315-323)
+        float dv[B], gm[B], mt[B];
+        uint32_t dvm[B], mtp[B], tl[B];  // tags of the best deletion / match, deletion tag of the last predecessor
+        if (npred == 0) {  // a source row: every cell starts at 1 (init_edge) and stays untouched
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                dv[k] = gm[k] = 1.0f;
+                mt[k] = __builtin_inff();
+                dvm[k] = kTbNone;
+                mtp[k] = 0;
+                tl[k] = 0;
+            }
+        }
+        auto relax = [&](auto first_tag, uint32_t ord, const Cells<B> &sv, const Cells<B> &sg, float svl) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const uint32_t p_open = ord << kTb16OrdShift;  // kTbDel == 0
+            const uint32_t p_ext = p_open | kExtXL;
+            const uint32_t p_match = p_open | kTbMatch;
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                // deletion (mesh.h:307-330)
+                const float v = sv[k] + gp;
+                const float g = sg[k] + gpe;
+                const bool op = v < g;
+                const float cand = op ? v : g;
+                const uint32_t ts = op ? p_open : p_ext;
+                gm[k] = cand;  // (every predecessor overwrites: the last one stays)
+                tl[k] = ts;
+                if constexpr (FIRST) {
+                    if (k > 0) {  // below_init: the first candidate always beats the 1e6 initial value
+                        dv[k] = cand;
+                        dvm[k] = ts;
+                    } else {      // ... but my cell 0 may be column 0, initial value 1
+                        const bool better = !col0_mine || cand < 1.0f;
+                        dv[k] = better ? cand : 1.0f;
+                        dvm[k] = better ? ts : kTbNone;
+                    }
+                } else {
+                    const bool better = cand < dv[k];
+                    dv[k] = better ? cand : dv[k];
+                    dvm[k] = better ? ts : dvm[k];
+                }
+                // match from (p, s-1) (mesh.h:360-374)
+                const float mv = ((k == 0) ? svl : sv[k - 1]) + csel[k];
+                if constexpr (FIRST) {
+                    if (k > 0) {
+                        mt[k] = mv;  // (values are finite: beats the initial +inf)
+                        mtp[k] = p_match;
+                    } else {
+                        mt[k] = col0_mine ? __builtin_inff() : mv;  // no match step at s == 0
+                        mtp[k] = col0_mine ? 0u : p_match;
+                    }
+                } else {
+                    const bool mb = (k > 0) ? (mv < mt[k]) : (!col0_mine && mv < mt[k]);
+                    mt[k] = mb ? mv : mt[k];
+                    mtp[k] = mb ? p_match : mtp[k];
+                }
+            }
+        };
+        for (uint32_t e = 0; e < npred; ++e) {
+            const uint32_t pe = e == 0 ? cur_pe.x : (e == 1 ? cur_pe.y : (e == 2 ? cur_pe.z : (e == 3 ? cur_pe.w : pred[r_pb + e])));
+            const uint32_t p = pe & 0xffffu;
+            Cells<B> sv, sg;
+            float left_of_strip = 0.f;
+            if (p + 1 == m) {  // the previous row: still in registers
+                sv = prev_v;
+                sg = prev_g;
+                left_of_strip = prev_edge_val;
+            } else if (pe & kPredSpilled) {
+                const float *row = spill + (size_t)((pe >> 16) & 0x7FFFu) * (2 * Lp);
+                sv.load(row + s0);
+                sg.load(row + Lp + s0);
+                if (lane0 && have_left_strip) left_of_strip = row[s0 - 1];
+                // (consume the global loads inside this rare branch: mesh_dp_kernel)
+#pragma unroll
+                for (int i = 0; i < B / 4; i++) {
+                    asm volatile("" : "+v"(sv.v[i]));
+                    asm volatile("" : "+v"(sg.v[i]));
+                }
+                asm volatile("" : "+v"(left_of_strip));
+            } else {
+                const unsigned char *slot = ring + (size_t)(pe >> 16) * kSlotBytes;
+                sv.load_slot(reinterpret_cast<const float *>(slot), lane);
+                sg.load_slot(reinterpret_cast<const float *>(slot + kValBytes), lane);
+                if (have_left_strip) left_of_strip = *reinterpret_cast<const float *>(slot + 2 * kValBytes);
+            }
+            float svl = lane_shr1(sv[B - 1]);  // value[p][s0-1] lives in the lane to my left
+            if (lane0) svl = left_of_strip;
+            if (e == 0) relax(std::true_type{}, e, sv, sg, svl);
+            else relax(std::false_type{}, e, sv, sg, svl);
+        }
+        uint32_t next_pb = nrec.x;
+        asm volatile("" : "+s"(next_pb));
+        u32x4 npe = sload16(pred_addr + (uint64_t)next_pb * 4);
+
+        // ---- phase 2: the insertion chain.  loc = what a cell is worth without a gap from its left;
+        // ltag = the tag it then gets (a match only wins on <, the first deletion keeps a tie)
+        float loc[B];
+        uint32_t ltag[B];
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            loc[k] = min2_raw(dv[k], mt[k]);
+            ltag[k] = (mt[k] < dv[k]) ? mtp[k] : dvm[k];
+        }
+        // 1. my cells as if no gap entered from the left (cell 0 then takes no gap at all)
+        float fv[B];
+        uint32_t fvm[B];
+        fv[0] = loc[0];
+        fvm[0] = ltag[0];
+        // column 0 has no insertion step and keeps gaps_val = 1 (init_edge): it "extends" iff its value is 1
+        bool e_prev = col0_mine && (fv[0] == 1.0f);
+#pragma unroll
+        for (int k = 1; k < B; k++) {
+            const float gsx = fv[k - 1] + (e_prev ? gpev : gpv);  // mesh.h:340-349
+            const bool ins = gsx <= loc[k];                        // :351; = "gaps_val == value" of this cell
+            fv[k] = ins ? gsx : loc[k];
+            fvm[k] = ins ? kTbIns : ltag[k];
+            e_prev = ins;
+        }
+        const float sx_v = fv[B - 1];
+        const bool sx_e = e_prev;
+        // 2. exit states lane to lane (see mesh_dp_kernel): a gap that enters my cells either runs
+        // through all of them or dies inside and leaves my exit state as computed above
+        const float sl_v = have_left_strip ? __uint_as_float(cur_edge.y) : __builtin_inff();  // left of lane 0
+        const uint64_t sl_e = have_left_strip ? (uint64_t)(cur_edge.z >> 31) : 0ull;
+        float ex_v = sx_v;
+        bool ex_e = sx_e;
+        {
+            float left_v = lane_shr1(sx_v);
+            if (lane0) left_v = sl_v;
+            bool left_e = __builtin_amdgcn_inverse_ballot_w64((__builtin_amdgcn_ballot_w64(sx_e) << 1) | sl_e);
+            float g0 = left_v + (left_e ? gpev : gpv);
+            bool enter = g0 <= loc[0];  // (column 0: left_v = +inf)
+            if (__any(enter)) {
+                float g[B];
+                bool pass[B];
+                for (int guard = 0; guard < (1 << 20); ++guard) {
+                    g[0] = g0;
+                    pass[0] = enter;
+#pragma unroll
+                    for (int k = 1; k < B; k++) {
+                        g[k] = g[k - 1] + gpe;
+                        pass[k] = pass[k - 1] && (g[k] <= loc[k]);
+                    }
+                    const float nv = pass[B - 1] ? g[B - 1] : sx_v;
+                    const bool ne = pass[B - 1] || sx_e;
+                    const bool changed = (nv != ex_v) || (ne != ex_e);
+                    ex_v = nv;
+                    ex_e = ne;
+                    if (!__any(changed)) break;
+                    if (guard == 0) {
+                        // a gap runs through a whole lane: GUESS all exit states with a log-step scan, the
+                        // iterations then verify the guess (mesh_dp_kernel; single fused multiply-adds
+                        // stand for the cells' repeated adds -- a guess may be off at a rounding)
+                        float th = loc[0];
+#pragma unroll
+                        for (int k = 1; k < B; k++) th = min2_raw(th, __builtin_fmaf(-(float)k, gpe, loc[k]));
+                        const float th1 = lane_shr1(th);
+                        th = min2_raw(th1, __builtin_fmaf(-(float)B, gpe, th));
+                        if (lane <= 1) th = -__builtin_inff();
+                        float cv = ex_v;
+                        bool ce = ex_e;
+#pragma unroll
+                        for (int o = 2; o < 64; o *= 2) {
+                            const int src = (lane - o) << 2;
+                            const float xout = cv + (ce ? gpev : gpv);
+                            const float pth = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(th)));
+                            const float x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(xout)));
+                            const bool valid = lane >= o;
+                            const bool hit = valid && (x <= th);
+                            cv = hit ? __builtin_fmaf((float)(o * B - 1), gpe, x) : cv;
+                            ce = hit || ce;
+                            th = valid ? min2_raw(pth, __builtin_fmaf(-(float)(o * B), gpe, th)) : th;
+                        }
+                        ex_v = cv;
+                        ex_e = ce;
+                    }
+                    left_v = lane_shr1(ex_v);
+                    if (lane0) left_v = sl_v;
+                    left_e = __builtin_amdgcn_inverse_ballot_w64((__builtin_amdgcn_ballot_w64(ex_e) << 1) | sl_e);
+                    g0 = left_v + (left_e ? gpev : gpv);
+                    enter = g0 <= loc[0];
+                }
+                // 3. the cells the entering gap wins (a prefix of mine) become insertion cells
+#pragma unroll
+                for (int k = 0; k < B; k++) {
+                    fv[k] = pass[k] ? g[k] : fv[k];
+                    fvm[k] = pass[k] ? kTbIns : fvm[k];
+                }
+            }
+        }
+
+        sload_wait(npe);
+        if (have_left_strip) sload_wait(nedge);
+        // ---- publish: edge record for the strip to my right, the row for its successors
+        if (lane == 63 && have_right_strip) {
+            EdgeRec er;
+            er.bnd = fv[B - 1];
+            er.xv = ex_v;
+            er.xe = ex_e ? 0x80000000u : 0u;
+            er.gmax = 0u;
+            e_out[m] = er;
+        }
+        if (r_keep != kRowNone) {
+            if (!(r_keep & kRowSpilled)) {
+                unsigned char *myslot = ring + (size_t)r_keep * kSlotBytes;
+                store_slot<B>(reinterpret_cast<float *>(myslot), lane, fv);
+                store_slot<B>(reinterpret_cast<float *>(myslot + kValBytes), lane, gm);
+                if (lane0 && have_left_strip) *reinterpret_cast<float *>(myslot + 2 * kValBytes) = edge_val;
+            } else {
+                float *row = spill + (size_t)(r_keep & ~kRowSpilled) * (2 * Lp);
+                store_cells<B>(row + s0, fv);
+                store_cells<B>(row + Lp + s0, gm);
+            }
+        }
+        // ---- trace-back cells: tag of the winner, XLast from the last predecessor's deletion tag
+        {
+            uint32_t tp[B / 2];
+#pragma unroll
+            for (int k = 0; k < B / 2; k++) {
+                const uint32_t w = fvm[2 * k] | (fvm[2 * k + 1] << 16);
+                const uint32_t x = tl[2 * k] | (tl[2 * k + 1] << 16);
+                tp[k] = (w & ~(kXL | (kXL << 16))) | (x & (kXL | (kXL << 16)));
+            }
+            store_cells<B / 2>(reinterpret_cast<uint32_t *>(tb + (size_t)m * Lp + s0), tp);
+        }
+        if constexpr (DBG) {
+            if (qi == 0) store_cells<B>(dbg_value + (size_t)m * Lp + s0, fv);
+        }
+
+        // ---- end-cell search, step 1: rows at the last query column (one lane of one strip)
+        if (strip == strip_last) {
+            float v = fv[0];
+#pragma unroll
+            for (int k = 1; k < B; k++) v = (k_last == k) ? fv[k] : v;  // (k_last is wave-uniform: scalar masks)
+            if (own_last && (!lc_any || v < lc_min)) {
+                lc_min = v;
+                lc_arg = m;
+                lc_any = true;
+            }
+            if (own_last && is_sink && !sk_any) lc_snk0 = v;
+        }
+        // step 2: sink rows x every column of this strip
+        if (is_sink) {
+            float bv = __builtin_inff();
+            uint32_t bs = 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                const uint32_t s = s0 + k;
+                const bool b = (s < L) && (fv[k] < bv);
+                bv = b ? fv[k] : bv;
+                bs = b ? s : bs;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const uint32_t os = __shfl_xor(bs, off);
+                const bool b = (ov < bv) || (ov == bv && os < bs);
+                bv = b ? ov : bv;
+                bs = b ? os : bs;
+            }
+            if (!sk_any) snk0 = m;
+            if (bv < sk_min) {
+                sk_min = bv;
+                sk_m = m;
+                sk_s = bs;
+            }
+            sk_any = true;
+        }
+        cur = nrec;
+        cur_edge = nedge;
+        cur_pe = npe;
+#pragma unroll
+        for (int i = 0; i < B / 4; i++) {
+            prev_v.v[i] = typename Cells<B>::V{fv[4 * i], fv[4 * i + 1], fv[4 * i + 2], fv[4 * i + 3]};
+            prev_g.v[i] = typename Cells<B>::V{gm[4 * i], gm[4 * i + 1], gm[4 * i + 2], gm[4 * i + 3]};
+        }
+        prev_edge_val = edge_val;
+    }
+    if (sk_any && (!all_any || sk_min < all_min || (sk_min == all_min && sk_m < all_m))) {
+        all_min = sk_min;
+        all_m = sk_m;
+        all_s = sk_s;
+    }
+    all_any = all_any || sk_any;
+    // my edge records and spill rows must have left this CU before the next strip reads them back
+    // (through the scalar cache, whose lines of this query's records -- none can be cached yet, the
+    // region is 64-byte aligned and read by this wave only -- are dropped for good measure)
+    if (have_right_strip) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_dcache_inv();
+    }
+    }  // strips
+
+    const float v1min = __shfl(lc_min, lane_last);
+    const float v_snk0 = __shfl(lc_snk0, lane_last);
+    const uint32_t v1arg = __shfl(lc_arg, lane_last);
+    if (lane == 0) {
+        DpResult r;
+        r.status = 0;
+        uint32_t em = snk0, es = L - 1;
+        float ev = v_snk0;
+        if (v1min < v_snk0) {
+            em = v1arg;
+            ev = v1min;
+        }
         if (all_any && all_min < ev) {
             em = all_m;
             es = all_s;
@@ -1035,7 +1474,7 @@ __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
 
     // value_midx of a cell whose deletion extends the gap of predecessor x: gapm_idx[x][col]
     // (common.h, Ext / OpLast) -- follow last predecessors to the row that opened the gap
-    constexpr uint32_t ext_bit = LAZY ? kTb16Ext : kTbExt, oplast_bit = LAZY ? kTb16OpLast : kTbOpLast;
+    constexpr uint32_t ext_bit = LAZY ? kTb16Ext : kTbExt;
     auto gapm_idx = [&](uint32_t x, uint32_t col) -> uint32_t {
         for (uint32_t guard = 0; guard < 65536u; ++guard) {
             const uint32_t cx = cell_at(x, col);  // (first: a refill brings the row's record along)
@@ -1043,7 +1482,7 @@ __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
             const uint32_t np = rx.z & 0xffu;
             if (np == 0) return 0u;  // an edge row keeps its initial gapm_idx
             const uint32_t lastp = pred_at(x, rx.x, np - 1);
-            if (cx & oplast_bit) return lastp;
+            if (LAZY ? !(cx & kTb16XLast) : (cx & kTbOpLast) != 0) return lastp;
             x = lastp;
         }
         return 0u;
@@ -1124,7 +1563,15 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
                            a.qmask, a.weights, a.n_weights, a.tb, a.dbg_value, a.spill, a.edge, a.edge_stride, \
                            n_strips, a.res, a.ms, a.mms, a.gp, a.gpe);                                   \
     } while (0)
-    if (!weighted && !forbid && a.below_init) SH_LAUNCH(false, false, true);
+    // the simple scheme with gap_open >= gap_extend in a launch below the initial value (every BASELINE
+    // configuration): the specialised kernel; SINA_HIP_DP_GENERIC=1 keeps the generic one (parity tests)
+    static const bool generic_only = getenv("SINA_HIP_DP_GENERIC") != nullptr && atoi(getenv("SINA_HIP_DP_GENERIC")) != 0;
+    if (!weighted && !forbid && a.below_init && a.gp >= a.gpe && !generic_only) {
+        auto kfn = a.dbg_value ? mesh_dp_simple_kernel<B, true> : mesh_dp_simple_kernel<B, false>;
+        SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.qmask, a.tb, a.dbg_value, a.spill,
+                           a.edge, a.edge_stride, n_strips, a.res, a.ms, a.mms, a.gp, a.gpe);
+    } else if (!weighted && !forbid && a.below_init) SH_LAUNCH(false, false, true);
     else if (!weighted && !forbid) SH_LAUNCH(false, false, false);
     else if (weighted && !forbid) SH_LAUNCH(true, false, false);
     else if (!weighted && forbid) SH_LAUNCH(false, true, false);
