@@ -195,6 +195,10 @@ __device__ __forceinline__ uint64_t uniform(uint64_t x) {
     return (uint64_t)uniform((uint32_t)x) | ((uint64_t)uniform((uint32_t)(x >> 32)) << 32);
 }
 
+// "is the predicate true in any lane": the wave mask itself (HIP's __any() goes through a 0 / 1 VGPR and
+// a second compare)
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 template <int B, bool WEIGHTED, bool FORBID, bool BELOW_INIT, bool DBG>
 __global__ void __launch_bounds__(64, (B <= 4 ? 4 : (B <= 8 ? 3 : 2)))
 mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ orderv, const uint4 *__restrict__ recv, const uint32_t *__restrict__ predv,
@@ -927,7 +931,10 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
 // mesh_dp_kernel.  Results are bit-identical between the two: tests/test_gpu_parity.py runs every
 // simple-scheme plane test through both (SINA_HIP_DP_GENERIC=1 forces the generic kernel).
 template <int B, bool DBG>
-__global__ void __launch_bounds__(64, (B <= 4 ? 4 : (B <= 8 ? 3 : 2)))
+#ifndef SINA_DP_SIMPLE_WAVES8
+#define SINA_DP_SIMPLE_WAVES8 3  // waves per SIMD the B = 8 kernel is compiled for
+#endif
+__global__ void __launch_bounds__(64, (B <= 4 ? 4 : (B <= 8 ? SINA_DP_SIMPLE_WAVES8 : 2)))
 mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ orderv, const uint4 *__restrict__ recv,
                       const uint32_t *__restrict__ predv, const uint8_t *__restrict__ qmaskv, void *__restrict__ tbv,
                       float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev, uint64_t edge_stride,
@@ -972,7 +979,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     const bool col0_mine = (strip == 0) && lane0;  // my cell 0 is query column 0
     const uint64_t e_in = uniform((uint64_t)(edgev + (size_t)(strip ? strip - 1 : 0) * edge_stride + node_off));
     EdgeRec *e_out = edgev + (size_t)strip * edge_stride + node_off;
-    const bool have_left_strip = strip > 0, have_right_strip = strip + 1 < S;
+    const bool have_left_strip = uniform((uint32_t)(strip > 0)) != 0, have_right_strip = strip + 1 < S;
 
     // the query base of my columns as v_cmp_class_f32 masks: A -> +0, G -> +normal, C -> +inf,
     // U -> -normal (class bits 6, 8, 9, 3); 0 beyond L: matches nothing
@@ -1015,15 +1022,15 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         const bool is_sink = (r_z & kRecSink) != 0;
 
         // ---- match / mismatch score of my cells against this row: comp() = (row mask & query mask) != 0
-        // (aligned_base.h:153), one class test per set bit of the row's mask
+        // (aligned_base.h:153), one class test per set bit of the row's mask (an empty mask: NaN, in no class mask)
         float csel[B];
         {
             auto base_float = [](uint32_t bit) -> float {  // class of the lowest set bit of `bit`
-                return __uint_as_float((bit & 1u) ? 0u : ((bit & 2u) ? 0x3f800000u : ((bit & 4u) ? 0x7f800000u : 0xbf800000u)));
+                return __uint_as_float((bit & 1u) ? 0u : ((bit & 2u) ? 0x3f800000u : ((bit & 4u) ? 0x7f800000u : ((bit & 8u) ? 0xbf800000u : 0x7fc00000u))));
             };
             const float rf = base_float(mmask);
 #pragma unroll
-            for (int k = 0; k < B; k++) csel[k] = (mmask != 0 && __builtin_amdgcn_classf(rf, (int)qcls[k])) ? vM : vX;
+            for (int k = 0; k < B; k++) csel[k] = __builtin_amdgcn_classf(rf, (int)qcls[k]) ? vM : vX;
             for (uint32_t mm = mmask & (mmask - 1); mm != 0; mm &= mm - 1) {  // IUPAC ambiguity rows: further bases
                 const float rf2 = base_float(mm);
 #pragma unroll
@@ -1032,78 +1039,18 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         }
 
         // ---- phase 1: deletion / match candidates from the predecessor rows, in ascending id order
-        // (first minimum wins; the LAST predecessor defines gapm, mesh.h:315-323)
-        float dv[B], gm[B], mt[B];
-        uint32_t dvm[B], mtp[B], tl[B];  // tags of the best deletion / match, deletion tag of the last predecessor
-        if (npred == 0) {  // a source row: every cell starts at 1 (init_edge) and stays untouched
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-                dv[k] = gm[k] = 1.0f;
-                mt[k] = __builtin_inff();
-                dvm[k] = kTbNone;
-                mtp[k] = 0;
-                tl[k] = 0;
-            }
-        }
-        auto relax = [&](auto first_tag, uint32_t ord, const Cells<B> &sv, const Cells<B> &sg, float svl) {
-            constexpr bool FIRST = decltype(first_tag)::value;
-            const uint32_t p_open = ord << kTb16OrdShift;  // kTbDel == 0
-            const uint32_t p_ext = p_open | kExtXL;
-            const uint32_t p_match = p_open | kTbMatch;
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-                // deletion (mesh.h:307-330)
-                const float v = sv[k] + gp;
-                const float g = sg[k] + gpe;
-                const bool op = v < g;
-                const float cand = op ? v : g;
-                const uint32_t ts = op ? p_open : p_ext;
-                gm[k] = cand;  // (every predecessor overwrites: the last one stays)
-                tl[k] = ts;
-                if constexpr (FIRST) {
-                    if (k > 0) {  // below_init: the first candidate always beats the 1e6 initial value
-                        dv[k] = cand;
-                        dvm[k] = ts;
-                    } else {      // ... but my cell 0 may be column 0, initial value 1
-                        const bool better = !col0_mine || cand < 1.0f;
-                        dv[k] = better ? cand : 1.0f;
-                        dvm[k] = better ? ts : kTbNone;
-                    }
-                } else {
-                    const bool better = cand < dv[k];
-                    dv[k] = better ? cand : dv[k];
-                    dvm[k] = better ? ts : dvm[k];
-                }
-                // match from (p, s-1) (mesh.h:360-374)
-                const float mv = ((k == 0) ? svl : sv[k - 1]) + csel[k];
-                if constexpr (FIRST) {
-                    if (k > 0) {
-                        mt[k] = mv;  // (values are finite: beats the initial +inf)
-                        mtp[k] = p_match;
-                    } else {
-                        mt[k] = col0_mine ? __builtin_inff() : mv;  // no match step at s == 0
-                        mtp[k] = col0_mine ? 0u : p_match;
-                    }
-                } else {
-                    const bool mb = (k > 0) ? (mv < mt[k]) : (!col0_mine && mv < mt[k]);
-                    mt[k] = mb ? mv : mt[k];
-                    mtp[k] = mb ? p_match : mtp[k];
-                }
-            }
-        };
-        for (uint32_t e = 0; e < npred; ++e) {
-            const uint32_t pe = e == 0 ? cur_pe.x : (e == 1 ? cur_pe.y : (e == 2 ? cur_pe.z : (e == 3 ? cur_pe.w : pred[r_pb + e])));
-            const uint32_t p = pe & 0xffffu;
-            Cells<B> sv, sg;
-            float left_of_strip = 0.f;
-            if (p + 1 == m) {  // the previous row: still in registers
-                sv = prev_v;
-                sg = prev_g;
-                left_of_strip = prev_edge_val;
-            } else if (pe & kPredSpilled) {
+        // (first minimum wins; the LAST predecessor defines gapm, mesh.h:315-323).  What the chain needs
+        // of it: loc = the best of them, ltag = its tag (a match only wins on <, the first deletion keeps
+        // a tie), gm = the last predecessor's deletion candidate, tl = that candidate's tag.
+        float loc[B], gm[B];
+        uint32_t ltag[B], tl[B];
+        // a predecessor row {value, gapm_val} of my columns + value[p][s0-1]: out of its LDS slot or spill row
+        auto load_pred = [&](uint32_t pe, Cells<B> &sv, Cells<B> &sg, float &left_of_strip) {
+            if (pe & kPredSpilled) {
                 const float *row = spill + (size_t)((pe >> 16) & 0x7FFFu) * (2 * Lp);
                 sv.load(row + s0);
                 sg.load(row + Lp + s0);
+                left_of_strip = 0.f;
                 if (lane0 && have_left_strip) left_of_strip = row[s0 - 1];
                 // (consume the global loads inside this rare branch: mesh_dp_kernel)
 #pragma unroll
@@ -1116,26 +1063,129 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                 const unsigned char *slot = ring + (size_t)(pe >> 16) * kSlotBytes;
                 sv.load_slot(reinterpret_cast<const float *>(slot), lane);
                 sg.load_slot(reinterpret_cast<const float *>(slot + kValBytes), lane);
+                left_of_strip = 0.f;
                 if (have_left_strip) left_of_strip = *reinterpret_cast<const float *>(slot + 2 * kValBytes);
             }
+        };
+        // the last predecessor (only it can be the previous row, ids ascend): out of the registers the
+        // previous row left it in, or loaded INTO them -- the previous row is needed by nothing else then
+        auto last_pred = [&](uint32_t pe, float &left_of_strip) {
+            if ((pe & 0xffffu) + 1 == m) left_of_strip = prev_edge_val;
+            else load_pred(pe, prev_v, prev_g, left_of_strip);
+        };
+        auto left_value = [&](const Cells<B> &sv, float left_of_strip) -> float {
             float svl = lane_shr1(sv[B - 1]);  // value[p][s0-1] lives in the lane to my left
             if (lane0) svl = left_of_strip;
-            if (e == 0) relax(std::true_type{}, e, sv, sg, svl);
-            else relax(std::false_type{}, e, sv, sg, svl);
+            return svl;
+        };
+        if (npred == 1) {
+            // ---- one predecessor (60 % of the rows): its candidates ARE the best ones
+            float los;
+            last_pred(cur_pe.x, los);
+            const float svl = left_value(prev_v, los);
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                const float v = prev_v[k] + gp;  // deletion (mesh.h:307-330)
+                const float g = prev_g[k] + gpe;
+                const bool op = v < g;
+                const float cand = op ? v : g;
+                const uint32_t ts = op ? 0u : kExtXL;  // ordinal 0, kTbDel == 0
+                gm[k] = cand;
+                tl[k] = ts;
+                const float mv = ((k == 0) ? svl : prev_v[k - 1]) + csel[k];  // match from (p, s-1) (:360-374)
+                if (k > 0) {  // below_init: the deletion candidate always beats the 1e6 initial value
+                    loc[k] = min2_raw(cand, mv);
+                    ltag[k] = (mv < cand) ? kTbMatch : ts;
+                } else {      // ... but my cell 0 may be column 0: initial value 1, no match step
+                    const bool better = !col0_mine || cand < 1.0f;
+                    const float dv0 = better ? cand : 1.0f;
+                    const uint32_t dvm0 = better ? ts : kTbNone;
+                    const bool mwin = !col0_mine && mv < dv0;
+                    loc[k] = mwin ? mv : dv0;
+                    ltag[k] = mwin ? kTbMatch : dvm0;
+                }
+            }
+        } else if (npred == 0) {
+            // ---- a source row: every cell starts at 1 (init_edge) and stays untouched
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                loc[k] = gm[k] = 1.0f;
+                ltag[k] = kTbNone;
+                tl[k] = 0;
+            }
+        } else {
+            // ---- several predecessors
+            float dv[B], mt[B];
+            uint32_t dvm[B], mtp[B];
+            auto relax = [&](auto first_tag, auto last_tag, uint32_t ord, const Cells<B> &sv, const Cells<B> &sg, float svl) {
+                constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+                const uint32_t p_open = ord << kTb16OrdShift;  // kTbDel == 0
+                const uint32_t p_ext = p_open | kExtXL;
+                const uint32_t p_match = p_open | kTbMatch;
+#pragma unroll
+                for (int k = 0; k < B; k++) {
+                    const float v = sv[k] + gp;
+                    const float g = sg[k] + gpe;
+                    const bool op = v < g;
+                    const float cand = op ? v : g;
+                    const uint32_t ts = op ? p_open : p_ext;
+                    if constexpr (LAST) {
+                        gm[k] = cand;
+                        tl[k] = ts;
+                    }
+                    const float mv = ((k == 0) ? svl : sv[k - 1]) + csel[k];
+                    if constexpr (FIRST) {
+                        if (k > 0) {
+                            dv[k] = cand;
+                            dvm[k] = ts;
+                            mt[k] = mv;  // (values are finite: beats the initial +inf)
+                            mtp[k] = p_match;
+                        } else {
+                            const bool better = !col0_mine || cand < 1.0f;
+                            dv[k] = better ? cand : 1.0f;
+                            dvm[k] = better ? ts : kTbNone;
+                            mt[k] = col0_mine ? __builtin_inff() : mv;
+                            mtp[k] = col0_mine ? 0u : p_match;
+                        }
+                    } else {
+                        const bool better = cand < dv[k];
+                        dv[k] = better ? cand : dv[k];
+                        dvm[k] = better ? ts : dvm[k];
+                        const bool mb = (k > 0) ? (mv < mt[k]) : (!col0_mine && mv < mt[k]);
+                        mt[k] = mb ? mv : mt[k];
+                        mtp[k] = mb ? p_match : mtp[k];
+                    }
+                }
+            };
+            {
+                Cells<B> sv, sg;
+                float los;
+                load_pred(cur_pe.x, sv, sg, los);
+                relax(std::true_type{}, std::false_type{}, 0u, sv, sg, left_value(sv, los));
+                for (uint32_t e = 1; e + 1 < npred; ++e) {
+                    const uint32_t pe = e == 1 ? cur_pe.y : (e == 2 ? cur_pe.z : (e == 3 ? cur_pe.w : pred[r_pb + e]));
+                    load_pred(pe, sv, sg, los);
+                    relax(std::false_type{}, std::false_type{}, e, sv, sg, left_value(sv, los));
+                }
+            }
+            {
+                const uint32_t e = npred - 1;
+                const uint32_t pe = e == 1 ? cur_pe.y : (e == 2 ? cur_pe.z : (e == 3 ? cur_pe.w : pred[r_pb + e]));
+                float los;
+                last_pred(pe, los);
+                relax(std::false_type{}, std::true_type{}, e, prev_v, prev_g, left_value(prev_v, los));
+            }
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                loc[k] = min2_raw(dv[k], mt[k]);
+                ltag[k] = (mt[k] < dv[k]) ? mtp[k] : dvm[k];
+            }
         }
         uint32_t next_pb = nrec.x;
         asm volatile("" : "+s"(next_pb));
         u32x4 npe = sload16(pred_addr + (uint64_t)next_pb * 4);
 
-        // ---- phase 2: the insertion chain.  loc = what a cell is worth without a gap from its left;
-        // ltag = the tag it then gets (a match only wins on <, the first deletion keeps a tie)
-        float loc[B];
-        uint32_t ltag[B];
-#pragma unroll
-        for (int k = 0; k < B; k++) {
-            loc[k] = min2_raw(dv[k], mt[k]);
-            ltag[k] = (mt[k] < dv[k]) ? mtp[k] : dvm[k];
-        }
+        // ---- phase 2: the insertion chain
         // 1. my cells as if no gap entered from the left (cell 0 then takes no gap at all)
         float fv[B];
         uint32_t fvm[B];
@@ -1152,36 +1202,38 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             e_prev = ins;
         }
         const float sx_v = fv[B - 1];
-        const bool sx_e = e_prev;
+        // ("extends" flags of the whole wave as 64-bit lane masks in scalar registers from here on: a
+        // neighbour's flag is a shift away, and the compiler cannot turn them into byte vectors)
+        const uint64_t sx_em = __builtin_amdgcn_ballot_w64(e_prev);
         // 2. exit states lane to lane (see mesh_dp_kernel): a gap that enters my cells either runs
         // through all of them or dies inside and leaves my exit state as computed above
         const float sl_v = have_left_strip ? __uint_as_float(cur_edge.y) : __builtin_inff();  // left of lane 0
         const uint64_t sl_e = have_left_strip ? (uint64_t)(cur_edge.z >> 31) : 0ull;
         float ex_v = sx_v;
-        bool ex_e = sx_e;
+        uint64_t ex_em = sx_em;
         {
+            auto mask = [](uint64_t m) -> bool { return __builtin_amdgcn_inverse_ballot_w64(m); };
             float left_v = lane_shr1(sx_v);
             if (lane0) left_v = sl_v;
-            bool left_e = __builtin_amdgcn_inverse_ballot_w64((__builtin_amdgcn_ballot_w64(sx_e) << 1) | sl_e);
-            float g0 = left_v + (left_e ? gpev : gpv);
-            bool enter = g0 <= loc[0];  // (column 0: left_v = +inf)
-            if (__any(enter)) {
+            float g0 = left_v + (mask((sx_em << 1) | sl_e) ? gpev : gpv);
+            uint64_t enter = __builtin_amdgcn_ballot_w64(g0 <= loc[0]);  // (column 0: left_v = +inf)
+            if (enter != 0) {
                 float g[B];
-                bool pass[B];
+                uint64_t pass[B];
                 for (int guard = 0; guard < (1 << 20); ++guard) {
                     g[0] = g0;
                     pass[0] = enter;
 #pragma unroll
                     for (int k = 1; k < B; k++) {
                         g[k] = g[k - 1] + gpe;
-                        pass[k] = pass[k - 1] && (g[k] <= loc[k]);
+                        pass[k] = pass[k - 1] & __builtin_amdgcn_ballot_w64(g[k] <= loc[k]);
                     }
-                    const float nv = pass[B - 1] ? g[B - 1] : sx_v;
-                    const bool ne = pass[B - 1] || sx_e;
-                    const bool changed = (nv != ex_v) || (ne != ex_e);
+                    const float nv = mask(pass[B - 1]) ? g[B - 1] : sx_v;
+                    const uint64_t ne = pass[B - 1] | sx_em;
+                    const uint64_t changed = __builtin_amdgcn_ballot_w64(nv != ex_v) | (ne ^ ex_em);
                     ex_v = nv;
-                    ex_e = ne;
-                    if (!__any(changed)) break;
+                    ex_em = ne;
+                    if (changed == 0) break;
                     if (guard == 0) {
                         // a gap runs through a whole lane: GUESS all exit states with a log-step scan, the
                         // iterations then verify the guess (mesh_dp_kernel; single fused multiply-adds
@@ -1193,36 +1245,36 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                         th = min2_raw(th1, __builtin_fmaf(-(float)B, gpe, th));
                         if (lane <= 1) th = -__builtin_inff();
                         float cv = ex_v;
-                        bool ce = ex_e;
+                        uint64_t cem = ex_em;
 #pragma unroll
                         for (int o = 2; o < 64; o *= 2) {
                             const int src = (lane - o) << 2;
-                            const float xout = cv + (ce ? gpev : gpv);
+                            const float xout = cv + (mask(cem) ? gpev : gpv);
                             const float pth = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(th)));
                             const float x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(xout)));
-                            const bool valid = lane >= o;
-                            const bool hit = valid && (x <= th);
-                            cv = hit ? __builtin_fmaf((float)(o * B - 1), gpe, x) : cv;
-                            ce = hit || ce;
-                            th = valid ? min2_raw(pth, __builtin_fmaf(-(float)(o * B), gpe, th)) : th;
+                            const uint64_t valid = ~0ull << o;  // lane >= o
+                            const uint64_t hit = valid & __builtin_amdgcn_ballot_w64(x <= th);
+                            cv = mask(hit) ? __builtin_fmaf((float)(o * B - 1), gpe, x) : cv;
+                            cem |= hit;
+                            th = mask(valid) ? min2_raw(pth, __builtin_fmaf(-(float)(o * B), gpe, th)) : th;
                         }
                         ex_v = cv;
-                        ex_e = ce;
+                        ex_em = cem;
                     }
                     left_v = lane_shr1(ex_v);
                     if (lane0) left_v = sl_v;
-                    left_e = __builtin_amdgcn_inverse_ballot_w64((__builtin_amdgcn_ballot_w64(ex_e) << 1) | sl_e);
-                    g0 = left_v + (left_e ? gpev : gpv);
-                    enter = g0 <= loc[0];
+                    g0 = left_v + (mask((ex_em << 1) | sl_e) ? gpev : gpv);
+                    enter = __builtin_amdgcn_ballot_w64(g0 <= loc[0]);
                 }
                 // 3. the cells the entering gap wins (a prefix of mine) become insertion cells
 #pragma unroll
                 for (int k = 0; k < B; k++) {
-                    fv[k] = pass[k] ? g[k] : fv[k];
-                    fvm[k] = pass[k] ? kTbIns : fvm[k];
+                    fv[k] = mask(pass[k]) ? g[k] : fv[k];
+                    fvm[k] = mask(pass[k]) ? kTbIns : fvm[k];
                 }
             }
         }
+        const bool ex_e = __builtin_amdgcn_inverse_ballot_w64(ex_em);
 
         sload_wait(npe);
         if (have_left_strip) sload_wait(nedge);
@@ -1637,7 +1689,7 @@ size_t dp_fixed_lds_bytes(const DpGeom &) { return 0; }
 int dp_max_ring(const DpGeom &) { return 8; }  // the slot allocators keep 8 slot states; deeper rings gain nothing
 // LDS per workgroup (= per wave) that still lets the kernel's register budget decide the occupancy
 size_t dp_default_lds_budget(const DpGeom &g) {
-    const int waves_per_simd = g.B <= 4 ? 4 : (g.B <= 8 ? 3 : 2);
+    const int waves_per_simd = g.B <= 4 ? 4 : (g.B <= 8 ? SINA_DP_SIMPLE_WAVES8 : 2);
     return (size_t)160 * 1024 / (4 * waves_per_simd) - 64;
 }
 

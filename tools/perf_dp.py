@@ -4,18 +4,24 @@ import numpy as np
 from oracle import pyoracle as po
 from sina_amd import synth, capi
 from tests import util
+import pickle
 nq=int(sys.argv[1]) if len(sys.argv)>1 else 256
 refs=synth.make_refs(2000, length=1500, width=50000, seed=2)
-qs=synth.make_queries(refs, nq, seed=3)
-cs=util.cseqs_from_refs(refs)
-idx=po.Index(cs,k=10)
 t=time.time()
-graphs=[];qms=[]
-for qi in range(nq):
-    q=util.query_cseq(qs,qi)
-    ids,sc,_=idx.famfinder(q)
-    graphs.append(util.graph_dict([cs[i] for i in ids]))
-    qms.append((q.packed()>>24).astype(np.uint8))
+cache="/tmp/perf_dp_prep_%d.pkl" % nq   # (the oracle-side preparation, reused by later runs on the same box)
+if os.path.exists(cache):
+    graphs,qms=pickle.load(open(cache,"rb"))
+else:
+    qs=synth.make_queries(refs, nq, seed=3)
+    cs=util.cseqs_from_refs(refs)
+    idx=po.Index(cs,k=10)
+    graphs=[];qms=[]
+    for qi in range(nq):
+        q=util.query_cseq(qs,qi)
+        ids,sc,_=idx.famfinder(q)
+        graphs.append(util.graph_dict([cs[i] for i in ids]))
+        qms.append((q.packed()>>24).astype(np.uint8))
+    pickle.dump((graphs,qms),open(cache,"wb"))
 print("prep",time.time()-t)
 qoff=np.zeros(nq+1,np.uint64); qoff[1:]=np.cumsum([len(m) for m in qms])
 ctx=capi.Context(0)

@@ -7,11 +7,14 @@ TAG=$1; NQ=${2:-512}
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
 i=0
-for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+# (QUICK=1: the two groups that decide what bounds the kernel)
+GRPS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" \
            "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" \
            "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_BRANCH" \
-           "SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_MISC"; do
+           "SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_MISC")
+[ -n "$QUICK" ] && GRPS=("${GRPS[@]:0:2}")
+for grp in "${GRPS[@]}"; do
   i=$((i+1))
   rocprofv3 --output-format csv --pmc $grp -d $OUT/p$i -o pmc -- python3 tools/perf_dp.py $NQ > $OUT/run$i.log 2>&1
 done
@@ -21,7 +24,7 @@ d = sys.argv[1]
 agg = collections.Counter(); n = collections.Counter()
 for f in glob.glob(d + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "mesh_dp_kernel" not in r["Kernel_Name"]:
+        if "mesh_dp_" not in r["Kernel_Name"]:
             continue
         agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 out = []
