@@ -195,6 +195,15 @@ __device__ __forceinline__ uint64_t uniform(uint64_t x) {
     return (uint64_t)uniform((uint32_t)x) | ((uint64_t)uniform((uint32_t)(x >> 32)) << 32);
 }
 
+// c ? a : b as a v_cndmask (2-cycle class) even where the condition is the operands' own compare, which
+// the compiler would turn into v_min_f32 (4-cycle class, tools/ubench/valu_rate.hip): the kernel needs
+// the compare for the trace-back tags anyway.  (An integer select; the empty asm hides the pairing.)
+__device__ __forceinline__ float sel(bool c, float a, float b) {
+    uint32_t bu = __float_as_uint(b);
+    asm("" : "+v"(bu));
+    return __uint_as_float(c ? __float_as_uint(a) : bu);
+}
+
 // "is the predicate true in any lane": the wave mask itself (HIP's __any() goes through a 0 / 1 VGPR and
 // a second compare)
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
@@ -1088,14 +1097,15 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                 const float v = prev_v[k] + gp;  // deletion (mesh.h:307-330)
                 const float g = prev_g[k] + gpe;
                 const bool op = v < g;
-                const float cand = op ? v : g;
+                const float cand = sel(op, v, g);
                 const uint32_t ts = op ? 0u : kExtXL;  // ordinal 0, kTbDel == 0
                 gm[k] = cand;
                 tl[k] = ts;
                 const float mv = ((k == 0) ? svl : prev_v[k - 1]) + csel[k];  // match from (p, s-1) (:360-374)
                 if (k > 0) {  // below_init: the deletion candidate always beats the 1e6 initial value
-                    loc[k] = min2_raw(cand, mv);
-                    ltag[k] = (mv < cand) ? kTbMatch : ts;
+                    const bool mwin = mv < cand;
+                    loc[k] = sel(mwin, mv, cand);
+                    ltag[k] = mwin ? kTbMatch : ts;
                 } else {      // ... but my cell 0 may be column 0: initial value 1, no match step
                     const bool better = !col0_mine || cand < 1.0f;
                     const float dv0 = better ? cand : 1.0f;
@@ -1127,7 +1137,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                     const float v = sv[k] + gp;
                     const float g = sg[k] + gpe;
                     const bool op = v < g;
-                    const float cand = op ? v : g;
+                    const float cand = sel(op, v, g);
                     const uint32_t ts = op ? p_open : p_ext;
                     if constexpr (LAST) {
                         gm[k] = cand;
@@ -1149,10 +1159,10 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                         }
                     } else {
                         const bool better = cand < dv[k];
-                        dv[k] = better ? cand : dv[k];
+                        dv[k] = sel(better, cand, dv[k]);
                         dvm[k] = better ? ts : dvm[k];
                         const bool mb = (k > 0) ? (mv < mt[k]) : (!col0_mine && mv < mt[k]);
-                        mt[k] = mb ? mv : mt[k];
+                        mt[k] = sel(mb, mv, mt[k]);
                         mtp[k] = mb ? p_match : mtp[k];
                     }
                 }
@@ -1177,8 +1187,9 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             }
 #pragma unroll
             for (int k = 0; k < B; k++) {
-                loc[k] = min2_raw(dv[k], mt[k]);
-                ltag[k] = (mt[k] < dv[k]) ? mtp[k] : dvm[k];
+                const bool mwin = mt[k] < dv[k];
+                loc[k] = sel(mwin, mt[k], dv[k]);
+                ltag[k] = mwin ? mtp[k] : dvm[k];
             }
         }
         uint32_t next_pb = nrec.x;
