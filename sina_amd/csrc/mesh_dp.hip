@@ -978,6 +978,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     uint32_t all_m = 0, all_s = 0xffffffffu, snk0 = 0;
     bool all_any = false;
 
+    SH_PROF_DECL
     // trace-back tags (16-bit cells, common.h)
     constexpr uint32_t kXL = kTb16XLast, kExtXL = kTb16Ext | kTb16XLast;
     const float gpv = opaque_v(gp), gpev = opaque_v(gpe);  // gap costs as select operands
@@ -1022,6 +1023,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         u32x4 nedge = {0, 0, 0, 0};
         if (have_left_strip) nedge = sload16(e_in + (uint64_t)m_next * sizeof(EdgeRec));
 
+        SH_PROF(0)
         // ---- row scalars
         const uint32_t r_pb = cur.x, r_z = cur.z, r_keep = cur.w;
         const uint32_t npred = r_z & 0xffu, mmask = (r_z >> 8) & 0xfu;
@@ -1047,6 +1049,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             }
         }
 
+        SH_PROF(1)
         // ---- phase 1: deletion / match candidates from the predecessor rows, in ascending id order
         // (first minimum wins; the LAST predecessor defines gapm, mesh.h:315-323).  What the chain needs
         // of it: loc = the best of them, ltag = its tag (a match only wins on <, the first deletion keeps
@@ -1196,6 +1199,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         asm volatile("" : "+s"(next_pb));
         u32x4 npe = sload16(pred_addr + (uint64_t)next_pb * 4);
 
+        SH_PROF(3)
         // ---- phase 2: the insertion chain
         // 1. my cells as if no gap entered from the left (cell 0 then takes no gap at all)
         float fv[B];
@@ -1213,6 +1217,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             e_prev = ins;
         }
         const float sx_v = fv[B - 1];
+        SH_PROF(4)
         // ("extends" flags of the whole wave as 64-bit lane masks in scalar registers from here on: a
         // neighbour's flag is a shift away, and the compiler cannot turn them into byte vectors)
         const uint64_t sx_em = __builtin_amdgcn_ballot_w64(e_prev);
@@ -1286,6 +1291,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             }
         }
         const bool ex_e = __builtin_amdgcn_inverse_ballot_w64(ex_em);
+        SH_PROF(5)
 
         sload_wait(npe);
         if (have_left_strip) sload_wait(nedge);
@@ -1310,6 +1316,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                 store_cells<B>(row + Lp + s0, gm);
             }
         }
+        SH_PROF(6)
         // ---- trace-back cells: tag of the winner, XLast from the last predecessor's deletion tag
         {
             uint32_t tp[B / 2];
@@ -1364,6 +1371,8 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             }
             sk_any = true;
         }
+        SH_PROF(7)
+        SH_PROF_CNT(8, 1)
         cur = nrec;
         cur_edge = nedge;
         cur_pe = npe;
@@ -1388,6 +1397,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         __builtin_amdgcn_s_dcache_inv();
     }
     }  // strips
+    SH_PROF_FLUSH
 
     const float v1min = __shfl(lc_min, lane_last);
     const float v_snk0 = __shfl(lc_snk0, lane_last);

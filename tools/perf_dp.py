@@ -45,7 +45,7 @@ for mask in masks:
 if prof:
     a = (ctypes.c_ulonglong * 32)()
     lib.sina_hip_debug_dp_profile(a, 1)
-    names = ["-", "row setup", "-", "preds", "chain first pass", "propagate+scan+overwrite", "publish", "tb+end"]
+    names = ["scalar prefetch issue", "row setup + match scores", "-", "preds", "chain first pass", "propagate+scan+overwrite", "wait scalars + publish + prefetch", "tb+end"]
     tot = float(sum(a[:8]))
     rows = a[8]
     for i, n in enumerate(names):
