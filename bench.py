@@ -26,14 +26,9 @@ import time
 
 import numpy as np
 
-# The pipeline keeps 6 HIP streams busy (3 aligner, 2 k-mer search contexts, the store's own).  With
-# the runtime's default of 4 hardware queues, streams share a queue and a DP launch waits for an
-# unrelated backtrack / k-mer kernel queued before it (rocprofv3 kernel trace: 10 % of the time no DP
-# kernel resident).  Must be set before the HIP runtime starts, i.e. before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import sina_amd  # noqa: E402,F401  (first: the package sets the HIP runtime's hardware-queue default before anything starts it)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DP_BYTES_PER_CELL = 8          # two u32 trace-back indices per mesh cell (algorithmic)
@@ -319,6 +314,20 @@ def main():
     verify_failed = False
     if rank == 0 and os.environ.get("SINA_HOST_PROFILE"):
         print(pl.profile(), file=sys.stderr)
+        # CPU time of every thread of this process so far (the stage driver's threads are gone by now;
+        # what is left are the loop pool, the interpreter and the HIP / ROCr runtime's own threads)
+        try:
+            tck = os.sysconf("SC_CLK_TCK")
+            rows = []
+            for tid in os.listdir("/proc/self/task"):
+                f = open("/proc/self/task/%s/stat" % tid).read()
+                comm = f[f.index("(") + 1:f.rindex(")")]
+                rest = f[f.rindex(")") + 2:].split()
+                rows.append(((int(rest[11]) + int(rest[12])) / tck, int(rest[11]) / tck, int(rest[12]) / tck, comm, tid))
+            for tot, u, k, comm, tid in sorted(rows, reverse=True)[:24]:
+                print("thread %-18s tid %-8s user %7.2f s  kernel %7.2f s" % (comm, tid, u, k), file=sys.stderr)
+        except Exception as e:  # noqa: BLE001
+            print("thread times unavailable: %s" % e, file=sys.stderr)
     if rank == 0:
         out = {
             "metric": "aligned sequences/sec (whole node), 100k full-length 16S vs SILVA-NR-scale ref",

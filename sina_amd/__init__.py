@@ -1,0 +1,9 @@
+"""MI355X-native hot path of SINA (k-mer search + mesh DP aligner) behind its stage surface."""
+import os
+
+# The pipeline keeps half a dozen HIP streams busy (aligner and k-mer search contexts, the store's heavy
+# stream).  With the runtime's default of 4 hardware queues, streams share a queue and a DP launch
+# waits for an unrelated backtrack / k-mer kernel queued before it (rocprofv3 kernel trace: 10 % of
+# the time no DP kernel resident).  The runtime reads this once, when it starts: set here, at package
+# import, and again by libsina_hip.so's load-time constructor for non-Python hosts (csrc/api.hip).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

@@ -142,17 +142,13 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     const int Lp = pl.geom.Lp();
     const bool weighted = p->weights != nullptr && p->n_weights > 0;
     const bool forbid = p->insertion == SINA_INSERTION_FORBID;
-    // The trace-back plane is the one buffer whose size follows the batch (tens of GB for 16S): a
-    // context that needs a big one gets the whole budget at once instead of growing again and again
-    // -- a reallocation of that size stalls every stream of the device for milliseconds.
+    // The trace-back plane is the one buffer whose size follows the batch (tens of GB for 16S): borrowed
+    // from the device's pool of two (ctx.h) until this launch's results are on the host.
     const uint64_t tb_bytes = tb_cell_bytes(forbid) * tb_cells;
-    if (tb_bytes > c->tb.cap && tb_bytes > ((uint64_t)4 << 30) && c->tb_budget_bytes >= tb_bytes) {
-        if (c->tb.reserve_exact(c->tb_budget_bytes)) {  // (not enough memory for the whole budget: grow as usual)
-            (void)hipGetLastError();
-            set_error("");
-        }
-    }
-    if (c->tb.reserve(tb_bytes) || c->spill.reserve(std::max<uint64_t>(spill_rows, 1) * 8 * (uint64_t)Lp) ||
+    tb_plane_lease plane;
+    if (plane.acquire(c, std::max<uint64_t>(tb_bytes, 16))) return 1;
+    c->last_tb = plane.ptr;
+    if (c->spill.reserve(std::max<uint64_t>(spill_rows, 1) * 8 * (uint64_t)Lp) ||
         c->edge.reserve(std::max<uint64_t>(1, (uint64_t)(pl.geom.T / 64 - 1) * n_node_entries) * sizeof(EdgeRec)) ||
         c->res.reserve(sizeof(DpResult) * bq) || c->out.reserve(sizeof(sina_hip_align_out) * bq) ||
         c->out_pos.reserve(4 * std::max<uint64_t>(nqm, 1)))
@@ -174,7 +170,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     a.node_pos = c->node_pos.as<uint32_t>();
     a.succ_minpos = c->succ_minpos.as<uint32_t>();
     a.qmask = c->qmask.as<uint8_t>();
-    a.tb = c->tb.p;
+    a.tb = plane.ptr;
     a.dbg_value = want_dbg_value ? c->dbg.as<float>() : nullptr;
     a.spill = c->spill.as<float>();
     a.edge = c->edge.as<EdgeRec>();
@@ -292,7 +288,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
     const int Lp = pl.geom.Lp();
     if (upload_weights(c, p)) return 1;
 
-    const uint64_t tb_budget_cells = c->tb_budget_bytes / tb_cell_bytes(forbid);
+    const uint64_t tb_budget_cells = tb_plane_budget(c) / tb_cell_bytes(forbid);
     HostPrep hp;
     uint32_t q0 = 0;
     while (q0 < nq) {
@@ -331,10 +327,10 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
             const QDesc &d = hp.qd[0];
             std::vector<uint32_t> tbh((size_t)d.N * Lp);
             if (forbid) {
-                SH_CHECK(hipMemcpy(tbh.data(), c->tb.p, 4 * tbh.size(), hipMemcpyDeviceToHost));
+                SH_CHECK(hipMemcpy(tbh.data(), c->last_tb, 4 * tbh.size(), hipMemcpyDeviceToHost));
             } else {  // 16-bit cells (common.h)
                 std::vector<uint16_t> t16(tbh.size());
-                SH_CHECK(hipMemcpy(t16.data(), c->tb.p, 2 * t16.size(), hipMemcpyDeviceToHost));
+                SH_CHECK(hipMemcpy(t16.data(), c->last_tb, 2 * t16.size(), hipMemcpyDeviceToHost));
                 for (size_t i = 0; i < tbh.size(); i++) tbh[i] = t16[i];
             }
             std::vector<float> vh;
@@ -412,6 +408,11 @@ static int finish_ctx(sina_hip_ctx *c) {  // streams + events of a new context
     return 0;
 }
 
+// Runs when the library is loaded, i.e. normally before the HIP runtime has started: the pipeline's
+// streams need more hardware queues than the runtime's default of four (see sina_amd/__init__.py).
+// An explicit setting in the environment wins.
+__attribute__((constructor)) static void sina_hip_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 int sina_hip_init(int device, sina_hip_ctx **ctx) {
     if (!ctx) SH_FAIL("init: null ctx pointer");
     int ndev = 0;
@@ -430,7 +431,6 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
         return 1;
     }
     c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 0) * 1024;
-    c->tb_budget_bytes = env_size("SINA_HIP_TB_GB", 32) << 30;
     if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 1) {
         (void)hipGetLastError();
         c->n_cu = 256;
@@ -447,7 +447,6 @@ int sina_hip_fork(sina_hip_ctx *parent, sina_hip_ctx **ctx) {
     c->st = parent->st;  // same reference store, index and counters; never freed by the fork
     c->owns_store = false;
     c->lds_budget = parent->lds_budget;
-    c->tb_budget_bytes = parent->tb_budget_bytes;
     c->n_cu = parent->n_cu;
     if (finish_ctx(c) || c->adopt_hints()) {
         const std::string why = sina_hip_last_error();

@@ -2,6 +2,8 @@
 #pragma once
 
 #include <atomic>
+#include <algorithm>
+#include <condition_variable>
 #include <cmath>
 #include <cstring>
 
@@ -39,6 +41,21 @@ struct sina_hip_store {
     // these at once (hipMalloc / hipFree synchronise the device; never in steady state)
     size_t cap_hint[64] = {};  // (indexed like sina_hip_ctx::scratch(): kNumScratch entries)
     sina_hip_stats stats;
+    // Trace-back planes -- tens of GB each, the one allocation whose size follows the launch -- belong
+    // to the DEVICE, not to a context: only one DP kernel runs at a time, so two planes serve any number
+    // of contexts (one being written by the DP kernel, one being walked by the previous launch's
+    // backtrack).  A context borrows a plane from its DP launch until its results are on the host.
+    // Size per plane: SINA_HIP_TB_GB if set, else 42 % of the memory that is free when the first DP
+    // launch is planned (hipMemGetInfo): 288 GB parts run 3072-query 23S launches (107 GB) unprompted.
+    struct tb_pool_t {
+        static constexpr int kMax = 4;
+        std::mutex mu;
+        std::condition_variable cv;
+        sina_hip::DevBuf plane[kMax];
+        bool busy[kMax] = {false, false, false, false};
+        int n = 2;            // SINA_HIP_TB_PLANES
+        uint64_t budget = 0;  // bytes per plane; 0 = not decided yet
+    } tb_pool;
 };
 
 struct sina_hip_ctx {
@@ -53,7 +70,8 @@ struct sina_hip_ctx {
     bool owns_store = false;
 
     // per-batch scratch, grown on demand and reused
-    sina_hip::DevBuf qd, order, rec, node_pos, pred, succ_minpos, qmask, tb, spill, edge, res, weights, out, out_pos, dbg;
+    sina_hip::DevBuf qd, order, rec, node_pos, pred, succ_minpos, qmask, spill, edge, res, weights, out, out_pos, dbg;
+    void *last_tb = nullptr;  // the plane of the last launch (debug read-back: sina_hip_debug_mesh)
     sina_hip::DevBuf k_qoff, k_scores, k_out_ids, k_out_scores, k_out_n, k_tmp0, k_tmp1, k_tmp2;
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes, g_wtab;
     sina_hip::DevBuf s_qab, s_qoff, s_cand, s_coff, s_out;  // search-stage comparison
@@ -62,12 +80,11 @@ struct sina_hip_ctx {
     float wtab_fs_weight = NAN;  // fs_weight the device weight table was computed for
 
     size_t lds_budget = 0;  // LDS per DP workgroup; 0 = what keeps the register-limited occupancy (dp_default_lds_budget)
-    uint64_t tb_budget_bytes = (uint64_t)32 << 30;
 
-    static constexpr int kNumScratch = 35;
+    static constexpr int kNumScratch = 34;
     static_assert(kNumScratch <= 64, "sina_hip_store::cap_hint is too short");
     void scratch(sina_hip::DevBuf **all) {
-        sina_hip::DevBuf *list[kNumScratch] = {&qd, &rec, &node_pos, &pred, &succ_minpos, &qmask, &tb, &spill, &res,
+        sina_hip::DevBuf *list[kNumScratch] = {&qd, &rec, &node_pos, &pred, &succ_minpos, &qmask, &spill, &res,
                                                &weights, &out, &out_pos, &k_qoff, &k_scores, &k_out_ids,
                                                &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2, &g_fam_ids,
                                                &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab, &order,
@@ -109,6 +126,7 @@ struct sina_hip_ctx {
             st->idx_ids.release();
             st->dense_id.release();
             st->dense_bits.release();
+            for (auto &pl : st->tb_pool.plane) pl.release();
             delete st;
         }
         st = nullptr;
@@ -116,6 +134,72 @@ struct sina_hip_ctx {
 };
 
 namespace sina_hip {
+// bytes one trace-back plane may have (decided once per store, see sina_hip_store::tb_pool)
+inline uint64_t tb_plane_budget(sina_hip_ctx *c) {
+    auto &tp = c->st->tb_pool;
+    std::lock_guard<std::mutex> lk(tp.mu);
+    if (tp.budget == 0) {
+        if (const char *e = getenv("SINA_HIP_TB_PLANES")) tp.n = std::max(1, std::min((int)sina_hip_store::tb_pool_t::kMax, atoi(e)));
+        const char *gb = getenv("SINA_HIP_TB_GB");
+        size_t free_b = 0, total_b = 0;
+        if (gb && atof(gb) > 0) {
+            tp.budget = (uint64_t)(atof(gb) * 1073741824.0);
+        } else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+            tp.budget = (uint64_t)((double)free_b * 0.84 / tp.n);
+        } else {
+            (void)hipGetLastError();
+            tp.budget = (uint64_t)32 << 30;
+        }
+        if (tp.budget < ((uint64_t)1 << 28)) tp.budget = (uint64_t)1 << 28;
+    }
+    return tp.budget;
+}
+// a free plane of at least `bytes` (waits for one; grows it -- rarely: sizes repeat -- up to the budget)
+struct tb_plane_lease {
+    sina_hip_store *st = nullptr;
+    int idx = -1;
+    void *ptr = nullptr;
+    int acquire(sina_hip_ctx *c, uint64_t bytes) {
+        const uint64_t budget = tb_plane_budget(c);
+        auto &tp = c->st->tb_pool;
+        std::unique_lock<std::mutex> lk(tp.mu);
+        for (;;) {
+            int pick = -1;
+            for (int i = 0; i < tp.n; i++)  // (prefer one that is big enough already)
+                if (!tp.busy[i] && (pick < 0 || (tp.plane[i].cap >= bytes && tp.plane[pick].cap < bytes))) pick = i;
+            if (pick >= 0) {
+                idx = pick;
+                break;
+            }
+            tp.cv.wait(lk);
+        }
+        tp.busy[idx] = true;
+        st = c->st;
+        lk.unlock();
+        DevBuf &b = tp.plane[idx];
+        if (b.cap < bytes) {
+            // (a launch near the budget gets exactly the budget: the next one is no bigger)
+            const uint64_t want = std::max<uint64_t>(bytes, std::min<uint64_t>(budget, bytes + bytes / 8));
+            if (b.reserve_exact(want)) {
+                release();
+                return 1;
+            }
+        }
+        ptr = b.p;
+        return 0;
+    }
+    void release() {
+        if (!st || idx < 0) return;
+        {
+            std::lock_guard<std::mutex> lk(st->tb_pool.mu);
+            st->tb_pool.busy[idx] = false;
+        }
+        st->tb_pool.cv.notify_all();
+        idx = -1;
+        st = nullptr;
+    }
+    ~tb_plane_lease() { release(); }
+};
 // The host copy of the reference offsets, complete.  upload_refs fills it; a store that arrived by
 // broadcast (sina_hip_store_alloc_like) re-reads it from the device on first use -- exactly once,
 // under the store's mutex, whichever forked context gets here first.
@@ -173,13 +257,13 @@ inline bool serialize_kernels() {
 // third of the process's CPU time.  Poll-and-sleep instead: the wake-up is at most ~100 us late,
 // which only matters if nothing else is queued behind on the heavy stream.
 inline hipError_t wait_event(hipEvent_t ev) {
-    long ns = 50000;  // 50 us, growing to 400: short waits are answered fast, a 20 ms DP kernel costs ~60 wake-ups
+    long ns = 50000;  // 50 us, growing to 1 ms: short waits are answered fast, a 17 ms DP kernel costs ~25 wake-ups
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
         timespec ts{0, ns};
         nanosleep(&ts, nullptr);
-        if (ns < 400000) ns += ns / 2;
+        if (ns < 1000000) ns += ns / 2;
     }
 }
 inline hipError_t wait_stream(sina_hip_ctx *c, hipStream_t s) {

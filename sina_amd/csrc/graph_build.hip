@@ -728,7 +728,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
     const int Lp = pl.geom.Lp();
     if (upload_weights(c, p)) return 1;
 
-    const uint64_t tb_budget_cells = c->tb_budget_bytes / tb_cell_bytes(p->insertion == SINA_INSERTION_FORBID);
+    const uint64_t tb_budget_cells = tb_plane_budget(c) / tb_cell_bytes(p->insertion == SINA_INSERTION_FORBID);
     // queries per DAG build: two rounds of DP wave slots (one DP wave per query); the DP launches
     // below are whole rounds of them where the trace-back budget cuts a chunk
     const uint32_t slots = dp_wave_slots(c, pl.geom.B);

@@ -26,10 +26,24 @@ int fail(const std::exception &e) {
 }
 
 struct result {
+    // (between runs a result keeps its heap blocks: fresh memory per query is a page fault per query)
+    void reset() {
+        status = 2;
+        head = tail = qual = 0;
+        width = 0;
+        ab.clear();
+        log.clear();
+        family.clear();
+        idty = -1.f;
+        searched = false;
+        sr_ids.clear();
+        sr_scores.clear();
+        attrs.clear();
+    }
     int status = 2;  // 0 aligned by DP, 1 alignment copied from a reference, 2 not aligned
     int head = 0, tail = 0, qual = 0;
     uint32_t width = 0;
-    std::vector<uint32_t> ab;
+    std::vector<aligned_base> ab;  // (taken over from the tray's aligned sequence, not copied)
     std::string log, family;
     float idty = -1.f;              // align_ident_slv (--calc-idty), -1 if not computed
     bool searched = false;          // search stage ran and produced a result vector
@@ -330,7 +344,8 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                            uint32_t inflight) {
     pipeline *p = (pipeline *)pp;
     try {
-        p->results.assign(nq, result());
+        p->results.resize(nq);
+        for (result &r : p->results) r.reset();
         if (batch == 0) batch = nq ? nq : 1;
         if (inflight == 0) inflight = 1;
         std::atomic<uint32_t> next{0};
@@ -350,20 +365,25 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                 parallel_for(it.b1 - it.b0, [&](size_t i) {  // (what SINA's reader stage does per sequence)
                     const uint32_t q = it.b0 + (uint32_t)i;
                     tray &t = it.trays[i];
+                    uint64_t tk = host_tsc();
                     t.seqno = q;
                     // (the item's trays are reused from batch to batch: a fresh log -- destroy() frees the
                     // sequences but leaves the text, and the previous occupant's would lead this one's)
                     t.log.str(std::string());
                     t.log.clear();
                     const std::string name = "query" + std::to_string(q);
-                    t.input_sequence = new cseq(name.c_str());
-                    // (an unaligned query: base i in column i -- built in one piece, not by per-base appends)
-                    std::vector<aligned_base> ab((size_t)(qoff[q + 1] - qoff[q]));
-                    for (size_t x = 0; x < ab.size(); x++)
-                        ab[x] = aligned_base::from_raw((uint32_t)x | ((uint32_t)qmask[qoff[q] + x] << 24));
-                    const uint32_t n_bases = (uint32_t)ab.size();
-                    t.input_sequence->setAlignedBases(std::move(ab));
+                    t.input_sequence = object_cache<cseq>::take();
+                    t.input_sequence->setName(name);
+                    tk = host_tick("build: log reset + new cseq", tk);
+                    // (an unaligned query: base i in column i -- written in one piece, not by per-base appends)
+                    std::vector<aligned_base> &ab = t.input_sequence->mutableAlignedBases();
+                    const uint32_t n_bases = (uint32_t)(qoff[q + 1] - qoff[q]);
+                    ab.resize(n_bases);
+                    uint32_t *raw = reinterpret_cast<uint32_t *>(ab.data());
+                    const uint8_t *m = qmask + qoff[q];
+                    for (uint32_t x = 0; x < n_bases; x++) raw[x] = x | ((uint32_t)m[x] << 24);
                     t.input_sequence->setWidth(n_bases);
+                    host_tick("build: bases", tk);
                 });
             }
             const auto a = std::chrono::steady_clock::now();
@@ -391,25 +411,26 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                 const uint32_t q = b0 + (uint32_t)i;
                 tray &t = trays[i];
                 result &r = p->results[q];
-                const double c_a = host_thread_cpu_seconds();
+                uint64_t tk = host_tsc();
                 r.log = t.log.str();
                 r.family = t.input_sequence->get_attr<std::string>(fn::family);
                 if (t.input_sequence->has_attr(fn::turn)) r.attrs[fn::turn] = t.input_sequence->get_attr<std::string>(fn::turn);
+                tk = host_tick("extract: log + family + turn", tk);
                 if (t.aligned_sequence) {
-                    const cseq &c = *t.aligned_sequence;
+                    cseq &c = *t.aligned_sequence;
                     r.qual = c.get_attr<int>(fn::qual);
                     r.head = c.get_attr<int>(fn::head);
                     r.tail = c.get_attr<int>(fn::tail);
                     r.width = c.getWidth();
-                    r.ab.assign(c.packed(), c.packed() + c.size());
                     r.status = (r.log.find("copied alignment from") != std::string::npos) ? 1 : 0;
                     for (const auto &kv : c.get_attrs()) {
-                        const std::string &k = kv.first;
+                        const std::string &k = kv.key();
                         if (k == search_filter::fn_nearest || k.compare(0, 4, "lca_") == 0 ||
                             k.compare(0, 5, "copy_") == 0)
                             r.attrs[k] = c.get_attr<std::string>(k);
                     }
                     r.idty = c.has_attr(fn::idty) ? c.get_attr<float>(fn::idty) : -1.f;
+                    r.ab.assign(c.begin(), c.end());  // (copied: the sequence keeps its heap block for its next life)
                 }
                 if (t.search_result) {
                     r.searched = true;
@@ -418,11 +439,9 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                         r.sr_scores.push_back(sr.score);
                     }
                 }
-                const double c_b = host_thread_cpu_seconds();
+                tk = host_tick("extract: aligned attrs + bases", tk);
                 t.destroy();
-                const double c_c = host_thread_cpu_seconds();
-                host_profile_add_cpu("drv.extract: copy out", c_b - c_a);
-                host_profile_add_cpu("drv.extract: tray.destroy", c_c - c_b);
+                host_tick("extract: tray.destroy", tk);
             });
         };
         auto take = [&](item &it) -> bool {
@@ -510,6 +529,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
             std::vector<std::thread> th;
             for (uint32_t i = 0; i < n_find; i++)
                 th.emplace_back([&] {
+                    struct cpu_report { ~cpu_report() { host_profile_add_cpu("thread: finder (whole run)", host_thread_cpu_seconds()); } } rep;
                     try {
                         item it;
                         while (take(it)) {
@@ -525,6 +545,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                 });
             for (uint32_t i = 0; i < n_align; i++)
                 th.emplace_back([&] {
+                    struct cpu_report { ~cpu_report() { host_profile_add_cpu("thread: aligner (whole run)", host_thread_cpu_seconds()); } } rep;
                     try {
                         item it;
                         while (found.pop(it)) {
@@ -540,6 +561,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                 });
             for (uint32_t i = 0; i < n_sink; i++)
                 th.emplace_back([&] {
+                    struct cpu_report { ~cpu_report() { host_profile_add_cpu("thread: sink (whole run)", host_thread_cpu_seconds()); } } rep;
                     try {
                         item it;
                         while (aligned.pop(it)) {
@@ -577,7 +599,9 @@ int sina_host_result(void *pp, uint32_t q, int *status, int *head, int *tail, in
     *n_bases = (uint32_t)r.ab.size();
     return 0;
 }
-const uint32_t *sina_host_result_bases(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].ab.data(); }
+const uint32_t *sina_host_result_bases(void *pp, uint32_t q) {
+    return reinterpret_cast<const uint32_t *>(((pipeline *)pp)->results[q].ab.data());
+}
 const char *sina_host_result_log(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].log.c_str(); }
 const char *sina_host_result_family(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].family.c_str(); }
 // search stage: number of results (-1: stage did not run for this query), ids/scores best first,

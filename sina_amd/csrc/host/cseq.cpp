@@ -5,6 +5,8 @@
 #include "cseq.h"
 
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 #include <algorithm>
 
@@ -166,6 +168,44 @@ char cseq_base::operator[](vidx_type i) const {
 }
 
 std::ostream &operator<<(std::ostream &out, const cseq_base &c) { return out << c.getName(); }
+
+// ---- attribute names, interned.  A per-thread table in front of the process-wide one: the few dozen
+// names are looked up millions of times and added a few dozen times.
+namespace {
+const std::string *intern_attr_name(std::string_view key) {
+    struct sv_hash {
+        size_t operator()(std::string_view v) const { return std::hash<std::string_view>()(v); }
+    };
+    static std::mutex mu;
+    static std::unordered_map<std::string_view, const std::string *, sv_hash> all;  // (keys view the interned strings)
+    thread_local std::unordered_map<std::string_view, const std::string *, sv_hash> mine;
+    auto it = mine.find(key);
+    if (it != mine.end()) return it->second;
+    const std::string *name;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto jt = all.find(key);
+        if (jt == all.end()) {
+            const std::string *fresh = new std::string(key);  // (never freed: the table lives as long as the process)
+            jt = all.emplace(std::string_view(*fresh), fresh).first;
+        }
+        name = jt->second;
+    }
+    mine.emplace(std::string_view(*name), name);
+    return name;
+}
+}  // namespace
+
+annotated_cseq::variant &annotated_cseq::slot(std::string_view key) {
+    size_t at = 0;
+    for (; at < attributes.size(); at++) {
+        const int c = attributes[at].name->compare(key);
+        if (c == 0) return attributes[at].second;
+        if (c > 0) break;  // (kept in key order: what iterating the reference's std::map gives)
+    }
+    attributes.insert(attributes.begin() + (std::ptrdiff_t)at, attr{intern_attr_name(key), variant()});
+    return attributes[at].second;
+}
 
 // NAST insertion fix-up (reference src/cseq.cpp:456-594).
 //

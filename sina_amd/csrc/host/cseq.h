@@ -11,6 +11,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <variant>
 #include <vector>
 
@@ -61,7 +62,8 @@ class aligned_base {
 public:
     using idx_type = uint32_t;
     using base_type = base_iupac;
-    aligned_base(idx_type pos = 0, unsigned char c = '-') : raw((pos & 0xFFFFFFu) | ((uint32_t)base_iupac::from_char(c) << 24)) {}
+    aligned_base() : raw(0) {}  // column 0, no base ('-'): a plain zero, so that vectors of them start as a memset
+    explicit aligned_base(idx_type pos, unsigned char c = '-') : raw((pos & 0xFFFFFFu) | ((uint32_t)base_iupac::from_char(c) << 24)) {}
     aligned_base(idx_type pos, base_iupac b) : raw((pos & 0xFFFFFFu) | ((uint32_t)b.mask() << 24)) {}
     static aligned_base from_raw(uint32_t r) {
         aligned_base a;
@@ -108,6 +110,8 @@ public:
     void setAlignedBases(const std::vector<aligned_base> &vab) { bases = vab; }
     void setAlignedBases(std::vector<aligned_base> &&vab) { bases = std::move(vab); }
     std::vector<aligned_base> takeAlignedBases() { return std::move(bases); }  // leaves the sequence empty
+    // the base list itself, for writing it in place (a recycled sequence keeps its heap block: resize, fill)
+    std::vector<aligned_base> &mutableAlignedBases() { return bases; }
     vidx_type getWidth() const { return alignment_width; }
     void setWidth(vidx_type newWidth);
     void fix_duplicate_positions(std::ostream &log, bool lowercase, bool remove);
@@ -144,25 +148,60 @@ private:
 
 std::ostream &operator<<(std::ostream &out, const cseq_base &c);
 
-// attribute map of annotated_cseq (src/cseq.h:233-272); boost::variant -> std::variant
+// attribute map of annotated_cseq (src/cseq.h:233-272); boost::variant -> std::variant.
+// The reference keeps a std::map<string, variant>.  Here: a short vector of {key, value} sorted by key
+// (same iteration order), the keys INTERNED -- a sequence has half a dozen attributes out of a few dozen
+// distinct names, a map costs two heap blocks per attribute (node + key longer than 15 characters) and
+// the pipeline creates and destroys a dozen of them per query.
 class annotated_cseq : public cseq_base {
 public:
     using variant = std::variant<std::string, char, int, float>;
+    struct attr {
+        const std::string *name;  // interned: lives as long as the process
+        variant second;
+        const std::string &key() const { return *name; }
+    };
+    using attr_list = std::vector<attr>;
+
     annotated_cseq(const char *_name, const char *_data = nullptr) : cseq_base(_name, _data) {}
     annotated_cseq() = default;
-
-    template <typename T> void set_attr(const std::string &key, T val) { attributes[key] = variant(val); }
-    void set_attr(const std::string &key, const char *val) { attributes[key] = variant(std::string(val)); }
-    bool has_attr(const std::string &key) const { return attributes.find(key) != attributes.end(); }
-    template <typename T> T get_attr(const std::string &attr) const { return get_attr<T>(attr, T()); }
-    template <typename T> T get_attr(const std::string &attr, T dflt) const {
-        const auto it = attributes.find(attr);
-        if (it == attributes.end()) return dflt;
-        return std::visit([&](const auto &v) { return convert<T>(v); }, it->second);
+    // name, width and attributes of `o` WITHOUT its bases (the aligner's working copy: its bases are
+    // written once, when the alignment is known -- copying the query's first would be 6 KB for nothing)
+    struct meta_only {};
+    annotated_cseq(const annotated_cseq &o, meta_only) : attributes(o.attributes) {
+        setName(o.getName());
+        setWidth(o.getWidth());
     }
-    const std::map<std::string, variant> &get_attrs() const { return attributes; }
+    void copy_meta(const annotated_cseq &o) {  // the same into an existing (recycled) object
+        clearSequence();
+        setName(o.getName());
+        setWidth(o.getWidth());
+        attributes = o.attributes;
+    }
+    void clear_all() {  // back to the default-constructed state, keeping the heap blocks
+        clearSequence();
+        setName(std::string());
+        attributes.clear();
+    }
+
+    template <typename T> void set_attr(std::string_view key, T val) { slot(key) = variant(std::move(val)); }
+    void set_attr(std::string_view key, const char *val) { slot(key) = variant(std::string(val)); }
+    bool has_attr(std::string_view key) const { return find(key) != nullptr; }
+    template <typename T> T get_attr(std::string_view attr) const { return get_attr<T>(attr, T()); }
+    template <typename T> T get_attr(std::string_view attr, T dflt) const {
+        const variant *v = find(attr);
+        if (v == nullptr) return dflt;
+        return std::visit([&](const auto &x) { return convert<T>(x); }, *v);
+    }
+    const attr_list &get_attrs() const { return attributes; }
 
 private:
+    const variant *find(std::string_view key) const {
+        for (const attr &a : attributes)
+            if (*a.name == key) return &a.second;
+        return nullptr;
+    }
+    variant &slot(std::string_view key);  // the value of `key`, inserted in key order if new (cseq.cpp)
     template <typename T, typename S> static T convert(const S &s) {
         if constexpr (std::is_same<T, S>::value) {
             return s;
@@ -179,7 +218,7 @@ private:
             }
         }
     }
-    std::map<std::string, variant> attributes;
+    attr_list attributes;
 };
 
 typedef annotated_cseq cseq;

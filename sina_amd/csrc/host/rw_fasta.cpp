@@ -1,21 +1,29 @@
 // FASTA source / sink stages and the --show-dist accuracy metrics.
 //
-// Restates reference src/rw_fasta.cpp (reader::operator() :229-315, writer :332-541) and
-// Log::printer (src/log.cpp:279-325 show_dist, :364-430 operator()) on std::fstream: name / full_name
-// split, ";key=value" comment attributes, skipping of sequences with characters outside the IUPAC
-// alphabet, --fasta-idx/--fasta-block slicing; on output the three text meta formats and the csv
-// side file, dots vs dashes, DNA vs RNA, line wrapping, the --min-idty filter, --add-relatives.
-// gzip in/out (boost::iostreams filters in the reference) is not provided.
+// Behaviour of the reference's src/rw_fasta.cpp (reader :229-315, writer :332-541) and Log::printer
+// (src/log.cpp:279-325 show_dist, :364-430 operator()), written from that behaviour on this
+// repository's own I/O layer:
+//   * input goes through a block-buffered LINE CUTTER (4 MB blocks, memchr for the line ends) over a
+//     byte source -- a plain file descriptor or a gzip stream (".gz" by extension; zlib is looked up at
+//     run time) -- and a record is parsed as spans of that buffer: header, "; key = value" comments,
+//     sequence lines; name / full_name split at the first blank, sequences with characters outside the
+//     IUPAC alphabet are skipped and counted, --fasta-idx / --fasta-block slice the file by byte offset;
+//   * output composes ONE text buffer per sequence (header + meta in one of three styles, the csv side
+//     file's row, the sequence wrapped to --line-length) and hands it to a byte sink in one call; dots
+//     vs dashes, DNA vs RNA, the --min-idty filter and --add-relatives as in the reference.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
-#include <fstream>
 #include <memory>
-#include <vector>
 #include <sstream>
 #include <stdexcept>
+#include <string_view>
 #include <unordered_set>
+#include <vector>
 
 #include "stages.h"
 
@@ -56,22 +64,23 @@ void rw_fasta::set_option(const std::string &name, const std::string &value) {
     else throw std::logic_error("fasta: unknown option " + name);
 }
 
-// ---------------------------------------------------------------- reader
+// ---------------------------------------------------------------- byte sources and sinks
 
-// (aligned FASTA is 50 KB a sequence: with the streams' default 8 KB buffers every sequence costs
-// half a dozen system calls each way)
-static constexpr size_t kStreamBuffer = 4u << 20;
+// (aligned FASTA is 50 KB a sequence: whole blocks per system call, both ways)
+static constexpr size_t kBlockBytes = 4u << 20;
 
-// gzip'ed files (reference: boost::iostreams gzip filters when the extension is ".gz",
-// src/rw_fasta.cpp:200-202,358-360).  zlib is looked up at run time -- libz.so.1 is part of every
-// base image, its development link is not, and nothing else of the library needs it.
 namespace {
+
+// zlib, looked up at run time: libz.so.1 is part of every base image, its development link is not,
+// and nothing else of the library needs it (reference: boost::iostreams gzip filters when the file
+// name ends in ".gz", src/rw_fasta.cpp:200-202,358-360)
 struct zlib_api {
     void *(*open)(const char *, const char *) = nullptr;
     int (*read)(void *, void *, unsigned) = nullptr;
     int (*write)(void *, const void *, unsigned) = nullptr;
     int (*close)(void *) = nullptr;
     int (*buffer)(void *, unsigned) = nullptr;
+    const char *(*error)(void *, int *) = nullptr;
     static const zlib_api &get() {
         static const zlib_api api = [] {
             zlib_api a;
@@ -83,155 +92,288 @@ struct zlib_api {
             a.write = reinterpret_cast<int (*)(void *, const void *, unsigned)>(dlsym(h, "gzwrite"));
             a.close = reinterpret_cast<int (*)(void *)>(dlsym(h, "gzclose"));
             a.buffer = reinterpret_cast<int (*)(void *, unsigned)>(dlsym(h, "gzbuffer"));
+            a.error = reinterpret_cast<const char *(*)(void *, int *)>(dlsym(h, "gzerror"));
             if (!a.open || !a.read || !a.write || !a.close) throw std::runtime_error("zlib without the gz* functions");
             return a;
         }();
         return api;
     }
+    std::string why(void *f) const {
+        int code = 0;
+        const char *msg = (error && f) ? error(f, &code) : nullptr;
+        return msg ? msg : "unknown zlib error";
+    }
 };
-class gz_streambuf : public std::streambuf {
-public:
-    gz_streambuf(const std::string &path, bool writing) : z(zlib_api::get()), wr(writing), buf(kStreamBuffer) {
-        f = z.open(path.c_str(), writing ? "wb" : "rb");
-        if (f && z.buffer) z.buffer(f, 1u << 20);
-        if (writing) setp(buf.data(), buf.data() + buf.size());
-    }
-    ~gz_streambuf() override {
-        if (f) {
-            if (wr) sync();
-            z.close(f);
-        }
-    }
-    bool is_open() const { return f != nullptr; }
 
-protected:
-    int_type underflow() override {
-        if (wr || !f) return traits_type::eof();
-        const int n = z.read(f, buf.data(), (unsigned)buf.size());
-        if (n <= 0) return traits_type::eof();
-        setg(buf.data(), buf.data(), buf.data() + n);
-        return traits_type::to_int_type(*gptr());
+bool has_gz_extension(const std::string &path) { return path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0; }
+
+struct byte_source {
+    virtual ~byte_source() = default;
+    virtual size_t pull(char *dst, size_t n) = 0;  // 0 at the end of the input; throws on a damaged one
+};
+struct fd_source : byte_source {
+    int fd;
+    explicit fd_source(const std::string &path) : fd(::open(path.c_str(), O_RDONLY | O_CLOEXEC)) {}
+    ~fd_source() override {
+        if (fd >= 0) ::close(fd);
     }
-    int_type overflow(int_type ch) override {
-        if (!wr || !f || sync() != 0) return traits_type::eof();
-        if (!traits_type::eq_int_type(ch, traits_type::eof())) {
-            *pptr() = traits_type::to_char_type(ch);
-            pbump(1);
+    size_t pull(char *dst, size_t n) override {
+        for (;;) {
+            const ssize_t got = ::read(fd, dst, n);
+            if (got >= 0) return (size_t)got;
+            if (errno != EINTR) throw std::runtime_error("read error on FASTA input");
         }
-        return traits_type::not_eof(ch);
     }
-    int sync() override {
-        if (!wr || !f) return 0;
-        const std::ptrdiff_t n = pptr() - pbase();
-        if (n > 0 && z.write(f, pbase(), (unsigned)n) != (int)n) return -1;
-        setp(buf.data(), buf.data() + buf.size());
-        return 0;
+};
+struct gz_source : byte_source {
+    const zlib_api &z = zlib_api::get();
+    void *f;
+    explicit gz_source(const std::string &path) : f(z.open(path.c_str(), "rb")) {
+        if (f && z.buffer) z.buffer(f, 1u << 20);
     }
+    ~gz_source() override {
+        if (f) z.close(f);
+    }
+    size_t pull(char *dst, size_t n) override {
+        const int got = z.read(f, dst, (unsigned)std::min<size_t>(n, 1u << 30));
+        // (a corrupt or truncated archive must not look like a short file)
+        // (zlib hands out what it could decode and then reports 0 bytes with an error pending)
+        int code = 0;
+        if (got <= 0 && z.error) z.error(f, &code);
+        if (got < 0 || code < 0) throw std::runtime_error("gzip'ed FASTA input is damaged: " + z.why(f));
+        return (size_t)got;
+    }
+};
+
+struct byte_sink {
+    virtual ~byte_sink() = default;
+    virtual void push(const char *src, size_t n) = 0;
+    virtual void flush() = 0;
+};
+struct fd_sink : byte_sink {  // collects up to a block, then one write(2)
+    int fd;
+    std::string pending;
+    explicit fd_sink(const std::string &path) : fd(::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666)) {
+        pending.reserve(kBlockBytes + (64u << 10));
+    }
+    ~fd_sink() override {
+        if (fd >= 0) {
+            try {
+                flush();
+            } catch (...) {
+            }
+            ::close(fd);
+        }
+    }
+    void push(const char *src, size_t n) override {
+        pending.append(src, n);
+        if (pending.size() >= kBlockBytes) flush();
+    }
+    void flush() override {
+        size_t done = 0;
+        while (done < pending.size()) {
+            const ssize_t put = ::write(fd, pending.data() + done, pending.size() - done);
+            if (put < 0) {
+                if (errno == EINTR) continue;
+                throw std::runtime_error("write error on FASTA output");
+            }
+            done += (size_t)put;
+        }
+        pending.clear();
+    }
+};
+struct gz_sink : byte_sink {
+    const zlib_api &z = zlib_api::get();
+    void *f;
+    explicit gz_sink(const std::string &path) : f(z.open(path.c_str(), "wb")) {
+        if (f && z.buffer) z.buffer(f, 1u << 20);
+    }
+    ~gz_sink() override {
+        if (f) z.close(f);  // (errors at this point have nobody to go to: flush() is where they surface)
+    }
+    void push(const char *src, size_t n) override {
+        while (n > 0) {
+            const unsigned part = (unsigned)std::min<size_t>(n, 1u << 30);
+            if (z.write(f, src, part) != (int)part) throw std::runtime_error("gzip'ed FASTA output failed: " + z.why(f));
+            src += part;
+            n -= part;
+        }
+    }
+    void flush() override {}
+};
+
+// Cuts the input into lines.  A line is handed out as a span of the block buffer, NUL-terminated in
+// place (the '\n' is overwritten), together with whether it ended in a line feed at all -- the last
+// line of a file may not.
+class line_cutter {
+public:
+    explicit line_cutter(std::unique_ptr<byte_source> s, uint64_t start_offset = 0)
+        : src(std::move(s)), buf(kBlockBytes + 1), base(start_offset) {}
+    // first byte of the next line, -1 at the end of the input
+    int next_byte() {
+        if (head == tail && !refill()) return -1;
+        return (unsigned char)buf[head];
+    }
+    // the next line; false at the end of the input
+    bool cut(char *&line, size_t &len, bool &had_newline) {
+        size_t from = head;  // (where the search for the line end goes on after a refill)
+        for (;;) {
+            if (char *nl = static_cast<char *>(memchr(buf.data() + from, '\n', tail - from))) {
+                line = buf.data() + head;
+                len = (size_t)(nl - line);
+                *nl = 0;
+                head += len + 1;
+                had_newline = true;
+                return true;
+            }
+            from = tail;
+            const size_t shift = head;
+            if (!refill()) break;
+            from -= shift - head;  // (refill moved the unread bytes to the front)
+        }
+        if (head == tail) return false;
+        line = buf.data() + head;
+        len = tail - head;
+        buf[tail] = 0;  // (one spare byte behind the block)
+        head = tail;
+        had_newline = false;
+        return true;
+    }
+    // file offset of the next unread byte
+    uint64_t offset() const { return base + head; }
+    bool exhausted() const { return drained && head == tail; }
 
 private:
-    const zlib_api &z;
-    void *f = nullptr;
-    bool wr;
+    bool refill() {  // more bytes behind the unread ones; false if the source has none
+        if (drained) return false;
+        if (head > 0) {
+            memmove(buf.data(), buf.data() + head, tail - head);
+            base += head;
+            tail -= head;
+            head = 0;
+        }
+        if (tail + 1 >= buf.size()) buf.resize(buf.size() * 2);  // a line longer than the block
+        const size_t got = src->pull(buf.data() + tail, buf.size() - 1 - tail);
+        if (got == 0) {
+            drained = true;
+            return false;
+        }
+        tail += got;
+        return true;
+    }
+    std::unique_ptr<byte_source> src;
     std::vector<char> buf;
+    size_t head = 0, tail = 0;
+    uint64_t base;
+    bool drained = false;
 };
-bool has_gz_extension(const std::string &path) { return path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0; }
+
+std::string_view strip(std::string_view s) {  // without blanks at either end
+    while (!s.empty() && isspace((unsigned char)s.front())) s.remove_prefix(1);
+    while (!s.empty() && isspace((unsigned char)s.back())) s.remove_suffix(1);
+    return s;
+}
+
 }  // namespace
 
+// ---------------------------------------------------------------- reader
+
 struct rw_fasta::reader::priv_data {
-    std::vector<char> buf = std::vector<char>(kStreamBuffer);
-    std::ifstream file;
-    std::unique_ptr<gz_streambuf> gz;
-    std::unique_ptr<std::istream> gz_in;
-    std::istream *inp = nullptr;  // the plain file, or the gzip filter over it
+    std::unique_ptr<line_cutter> lines;
     std::string filename;
     int lineno = 0, seqno = 0, skipped = 0;
+    uint64_t block_end = 0;  // --fasta-block: records that start behind this offset belong to the next slice
+
+    // One record.  0: none left; 1: `c` filled; -1: dropped for a character outside the alphabet.
+    int record(cseq &c);
 };
 
 rw_fasta::reader::reader(const std::string &infile) : data(new priv_data) {
+    const options &o = fa_opts();
     data->filename = infile;
+    uint64_t start = 0;
+    std::unique_ptr<byte_source> src;
     if (has_gz_extension(infile)) {
-        if (fa_opts().fasta_block > 0) throw std::logic_error("Cannot use --fasta-idx with gzip'ed input");
-        data->gz.reset(new gz_streambuf(infile, false));
-        if (!data->gz->is_open()) throw std::runtime_error("Unable to open file \"" + infile + "\" for reading.");
-        data->gz_in.reset(new std::istream(data->gz.get()));
-        data->inp = data->gz_in.get();
-        return;
+        if (o.fasta_block > 0) throw std::logic_error("Cannot use --fasta-idx with gzip'ed input");
+        auto gz = std::make_unique<gz_source>(infile);
+        if (!gz->f) throw std::runtime_error("Unable to open file \"" + infile + "\" for reading.");
+        src = std::move(gz);
+    } else {
+        auto fd = std::make_unique<fd_source>(infile);
+        if (fd->fd < 0) throw std::runtime_error("Unable to open file \"" + infile + "\" for reading.");
+        if (o.fasta_block > 0) {
+            start = (uint64_t)o.fasta_block * (uint64_t)o.fasta_idx;
+            if (::lseek(fd->fd, (off_t)start, SEEK_SET) < 0) start = 0;
+            data->block_end = (uint64_t)o.fasta_block * (uint64_t)(o.fasta_idx + 1);
+        }
+        src = std::move(fd);
     }
-    data->file.rdbuf()->pubsetbuf(data->buf.data(), (std::streamsize)data->buf.size());  // (before open)
-    data->file.open(infile, std::ios_base::binary);
-    if (!data->file.is_open()) throw std::runtime_error("Unable to open file \"" + infile + "\" for reading.");
-    data->inp = &data->file;
-    if (fa_opts().fasta_block > 0) data->file.seekg(fa_opts().fasta_block * fa_opts().fasta_idx);
+    data->lines = std::make_unique<line_cutter>(std::move(src), start);
 }
 rw_fasta::reader::reader(const reader &) = default;
 rw_fasta::reader &rw_fasta::reader::operator=(const reader &) = default;
 rw_fasta::reader::~reader() = default;
 int rw_fasta::reader::skipped() const { return data->skipped; }
 
-static std::string trim(const std::string &s) {  // boost::trim
-    size_t a = 0, b = s.size();
-    while (a < b && isspace((unsigned char)s[a])) a++;
-    while (b > a && isspace((unsigned char)s[b - 1])) b--;
-    return s.substr(a, b - a);
+int rw_fasta::reader::priv_data::record(cseq &c) {
+    line_cutter &in = *lines;
+    char *text;
+    size_t len;
+    bool whole;
+    // a slice of the file ends with the first record that starts behind its last byte
+    if (block_end != 0 && !in.exhausted() && in.offset() > block_end) return 0;
+    // whatever precedes the header line (the tail of a record cut by --fasta-block, stray text) is passed over;
+    // like every line that is not sequence data, a header only counts if its line is complete
+    for (int b; (b = in.next_byte()) != '>';) {
+        if (b < 0 || !in.cut(text, len, whole) || !whole) return 0;
+        lineno++;
+    }
+    if (!in.cut(text, len, whole) || !whole) return 0;
+    lineno++;
+    {
+        std::string_view header(text, len);
+        if (!header.empty() && header.back() == '\r') header.remove_suffix(1);
+        header.remove_prefix(1);  // '>'
+        const size_t blank = header.find_first_of(" \t");
+        c.setName(std::string(header.substr(0, blank)));
+        if (blank != std::string_view::npos) c.set_attr<std::string>(fn::fullname, std::string(header.substr(blank + 1)));
+    }
+    // "; key = value" lines behind the header become attributes, other ';' lines are comments
+    while (in.next_byte() == ';') {
+        if (!in.cut(text, len, whole) || !whole) break;
+        lineno++;
+        const std::string_view note(text + 1, len - 1);
+        const size_t eq = note.find('=');
+        if (eq != std::string_view::npos)
+            c.set_attr(std::string(strip(note.substr(0, eq))), std::string(strip(note.substr(eq + 1))));
+    }
+    // everything up to the next header line (or the end of the input) is sequence
+    bool bad = false;
+    for (int b; (b = in.next_byte()) != '>' && b >= 0;) {
+        in.cut(text, len, whole);
+        lineno++;
+        if (bad) continue;
+        try {
+            c.append(text);
+        } catch (base_iupac::bad_character_exception &) {
+            bad = true;  // (the reference reports name, file and line here; the rest of the record is passed over)
+        }
+    }
+    return bad ? -1 : 1;
 }
 
-bool rw_fasta::reader::operator()(tray &t) {  // :229-315
-    const options &o = fa_opts();
-    std::istream &in = *data->inp;
+bool rw_fasta::reader::operator()(tray &t) {
     for (;;) {
-        t.seqno = ++data->seqno;
-        t.input_sequence = new cseq();
-        cseq &c = *t.input_sequence;
-        auto give_up = [&]() {
-            delete t.input_sequence;
-            t.input_sequence = nullptr;
-            return false;
-        };
-        if (in.fail()) return give_up();
-        // if fasta blocking enabled, check if we've passed block boundary in last sequence
-        if (o.fasta_block > 0 && in.tellg() > o.fasta_block * (o.fasta_idx + 1)) return give_up();
-
-        std::string line;
-        // skip lines not beginning with '>'
-        while (in.peek() != '>' && std::getline(in, line).good()) data->lineno++;
-
-        // parse title
-        data->lineno++;
-        if (std::getline(in, line).good()) {
-            if (!line.empty() && line[line.size() - 1] == '\r') line.resize(line.size() - 1);
-            // set name to text between first '>' and first ' '
-            unsigned int blank = (unsigned int)line.find_first_of(" \t");
-            if (blank == 0) blank = (unsigned int)line.size();
-            c.setName(line.substr(1, blank - 1));
-            if (blank < line.size()) c.set_attr<std::string>(fn::fullname, line.substr(blank + 1));
-        } else {  // didn't get a title
-            return give_up();
+        t.seqno = ++data->seqno;  // (dropped sequences keep their number)
+        std::unique_ptr<cseq> c(new cseq());
+        const int got = data->record(*c);
+        if (got > 0) {
+            t.input_sequence = c.release();
+            return true;
         }
-
-        // handle comments: "; key = value" becomes an attribute, others are ignored
-        while (in.peek() == ';' && std::getline(in, line).good()) {
-            data->lineno++;
-            const size_t equalsign = line.find_first_of('=');
-            if (equalsign != std::string::npos)
-                c.set_attr(trim(line.substr(1, equalsign - 1)), trim(line.substr(equalsign + 1)));
-        }
-
-        try {
-            // all lines until eof or next /^>/ are data
-            while (in.peek() != '>' && in.good()) {
-                std::getline(in, line);
-                data->lineno++;
-                c.append(line);
-            }
-        } catch (base_iupac::bad_character_exception &) {
-            // "Skipping sequence N (>name) at file:line (contains character 'x')"
-            while (in.peek() != '>' && std::getline(in, line).good()) data->lineno++;
-            delete t.input_sequence;
-            t.input_sequence = nullptr;
-            data->skipped++;
-            continue;  // (the reference recurses here)
-        }
-        return true;
+        t.input_sequence = nullptr;
+        if (got == 0) return false;
+        data->skipped++;
     }
 }
 
@@ -247,23 +389,73 @@ static std::string attr_to_string(const cseq::variant &v) {
     return buf;
 }
 
-static std::string escape_string(const std::string &in) {  // :378-392
-    if (in.find_first_of("\",\r\n") == std::string::npos) return in;
-    std::stringstream tmp;
-    tmp << "\"";
-    size_t j = 0;
-    for (size_t i = in.find('"'); i != std::string::npos; j = i + 1, i = in.find('"', i + 1))
-        tmp << in.substr(j, i - j) << "\"\"";
-    tmp << in.substr(j) << "\"";
-    return tmp.str();
+namespace {
+
+// one csv field behind `row`: as it is, or -- if it holds a quote, a comma or a line break -- in
+// quotes with its own quotes doubled
+void csv_field(std::string &row, std::string_view field) {
+    bool plain = true;
+    for (const char ch : field) plain = plain && ch != '"' && ch != ',' && ch != '\r' && ch != '\n';
+    if (plain) {
+        row.append(field);
+        return;
+    }
+    row.push_back('"');
+    for (const char ch : field) {
+        if (ch == '"') row.push_back('"');
+        row.push_back(ch);
+    }
+    row.push_back('"');
 }
 
+// How a sequence's attributes appear in the output (--meta-fmt).  A style adds to the record's header
+// line, to the lines between header and sequence, and -- csv -- to the side file.
+using attr_map = std::remove_cv_t<std::remove_reference_t<decltype(std::declval<const cseq &>().get_attrs())>>;
+struct meta_style {
+    virtual ~meta_style() = default;
+    // (the alignment family is too long for any of them; the full name already follows the name)
+    static bool in_fasta(const std::string &key) { return key != fn::family && key != fn::fullname; }
+    virtual void on_header_line(std::string &, const attr_map &) const {}
+    virtual void below_header(std::string &, const attr_map &) const {}
+    virtual void side_file(std::string &, const cseq &, const attr_map &, bool /*first*/) const {}
+};
+struct meta_in_header : meta_style {  // >name full name [key=value] [key=value]
+    void on_header_line(std::string &rec, const attr_map &attrs) const override {
+        for (const auto &kv : attrs) {
+            if (!in_fasta(kv.key())) continue;
+            const std::string val = attr_to_string(kv.second);
+            if (val.empty()) continue;
+            rec.append(" [").append(kv.key()).append("=").append(val).append("]");
+        }
+    }
+};
+struct meta_in_comments : meta_style {  // ; key=value lines
+    void below_header(std::string &rec, const attr_map &attrs) const override {
+        for (const auto &kv : attrs)
+            if (in_fasta(kv.key())) rec.append("; ").append(kv.key()).append("=").append(attr_to_string(kv.second)).append("\n");
+    }
+};
+struct meta_in_csv : meta_style {  // <output>.csv: a title row with the first sequence's keys, a row per sequence
+    void side_file(std::string &rows, const cseq &c, const attr_map &attrs, bool first) const override {
+        if (first) {
+            rows.append("name");
+            for (const auto &kv : attrs)
+                if (kv.key() != fn::family) csv_field(rows.append(","), kv.key());
+            rows.append("\r\n");
+        }
+        rows.append(c.getName());
+        for (const auto &kv : attrs)
+            if (kv.key() != fn::family) csv_field(rows.append(","), attr_to_string(kv.second));
+        rows.append("\r\n");
+    }
+};
+
+}  // namespace
+
 struct rw_fasta::writer::priv_data {
-    std::vector<char> buf = std::vector<char>(kStreamBuffer);
-    std::ofstream file, out_csv;
-    std::unique_ptr<gz_streambuf> gz;
-    std::unique_ptr<std::ostream> gz_out;
-    std::ostream *outp = nullptr;  // the plain file, or the gzip filter over it
+    std::unique_ptr<byte_sink> out, out_csv;
+    std::unique_ptr<meta_style> style;
+    std::string rec, rows;  // the record / csv rows being composed
     int count = 0, excluded = 0;
     std::unordered_set<std::string> relatives_written;
     unsigned long copy_relatives = 0;
@@ -272,23 +464,31 @@ struct rw_fasta::writer::priv_data {
 
 rw_fasta::writer::writer(const std::string &outfile, unsigned int copy_relatives) : data(new priv_data) {
     data->copy_relatives = copy_relatives;
+    const std::string cannot = "Unable to open file \"" + outfile;
     if (has_gz_extension(outfile)) {
-        data->gz.reset(new gz_streambuf(outfile, true));
-        if (!data->gz->is_open()) throw std::runtime_error("Unable to open file \"" + outfile + "\" for writing.");
-        data->gz_out.reset(new std::ostream(data->gz.get()));
-        data->outp = data->gz_out.get();
+        auto gz = std::make_unique<gz_sink>(outfile);
+        if (!gz->f) throw std::runtime_error(cannot + "\" for writing.");
+        data->out = std::move(gz);
     } else {
-        data->file.rdbuf()->pubsetbuf(data->buf.data(), (std::streamsize)data->buf.size());  // (before open)
-        data->file.open(outfile, std::ios_base::binary);
-        if (!data->file.is_open()) throw std::runtime_error("Unable to open file \"" + outfile + "\" for writing.");
-        data->outp = &data->file;
+        auto fd = std::make_unique<fd_sink>(outfile);
+        if (fd->fd < 0) throw std::runtime_error(cannot + "\" for writing.");
+        data->out = std::move(fd);
     }
-    if (fa_opts().fastameta == FASTA_META_CSV) {
+    switch (fa_opts().fastameta) {
+    case FASTA_META_NONE: data->style = std::make_unique<meta_style>(); break;
+    case FASTA_META_HEADER: data->style = std::make_unique<meta_in_header>(); break;
+    case FASTA_META_COMMENT: data->style = std::make_unique<meta_in_comments>(); break;
+    case FASTA_META_CSV: {
+        data->style = std::make_unique<meta_in_csv>();
+        // beside the output, its extension replaced
         const size_t dot = outfile.find_last_of('.'), slash = outfile.find_last_of('/');
-        const std::string stem =
-            (dot != std::string::npos && (slash == std::string::npos || dot > slash)) ? outfile.substr(0, dot) : outfile;
-        data->out_csv.open(stem + ".csv");
-        if (data->out_csv.fail()) throw std::runtime_error("Unable to open file \"" + outfile + ".csv\" for writing.");
+        const bool has_ext = dot != std::string::npos && (slash == std::string::npos || dot > slash);
+        auto csv = std::make_unique<fd_sink>((has_ext ? outfile.substr(0, dot) : outfile) + ".csv");
+        if (csv->fd < 0) throw std::runtime_error(cannot + ".csv\" for writing.");
+        data->out_csv = std::move(csv);
+        break;
+    }
+    default: throw std::runtime_error("Unknown meta-fmt output option");
     }
 }
 rw_fasta::writer::writer(const writer &) = default;
@@ -297,8 +497,8 @@ rw_fasta::writer::~writer() = default;
 int rw_fasta::writer::written() const { return data->count; }
 int rw_fasta::writer::excluded() const { return data->excluded; }
 void rw_fasta::writer::flush() {
-    data->outp->flush();
-    if (data->out_csv.is_open()) data->out_csv.flush();
+    data->out->flush();
+    if (data->out_csv) data->out_csv->flush();
 }
 
 tray rw_fasta::writer::operator()(tray t) {  // :394-435
@@ -328,62 +528,35 @@ tray rw_fasta::writer::operator()(tray t) {  // :394-435
     return t;
 }
 
-void rw_fasta::writer::priv_data::write(const cseq &c) {  // :437-541
+// One sequence = one buffer: ">name[ full name][ meta]\n[meta lines]sequence lines", pushed to the sink
+// in a single call (and its csv row to the side file).
+void rw_fasta::writer::priv_data::write(const cseq &c) {
     const options &o = fa_opts();
     const auto &attrs = c.get_attrs();
-    std::ostream &out = *outp;
-    out << ">" << c.getName();
-    const std::string fname = c.get_attr<std::string>(fn::fullname, "");
-    if (!fname.empty()) out << " " << fname;
-    switch (o.fastameta) {
-    case FASTA_META_NONE: out << "\n"; break;
-    case FASTA_META_HEADER:
-        for (auto &ap : attrs) {
-            if (ap.first == fn::family) continue;    // alignment family is too much
-            if (ap.first == fn::fullname) continue;  // already written as description in header
-            const std::string val = attr_to_string(ap.second);
-            if (!val.empty()) out << " [" << ap.first << "=" << val << "]";
-        }
-        out << "\n";
-        break;
-    case FASTA_META_COMMENT:
-        out << "\n";
-        for (auto &ap : attrs) {
-            if (ap.first == fn::family) continue;
-            if (ap.first == fn::fullname) continue;
-            out << "; " << ap.first << "=" << attr_to_string(ap.second) << "\n";
-        }
-        break;
-    case FASTA_META_CSV:
-        out << "\n";
-        if (count == 0) {  // print header
-            out_csv << "name";
-            for (auto &ap : attrs) {
-                if (ap.first == fn::family) continue;
-                out_csv << "," << escape_string(ap.first);
-            }
-            out_csv << "\r\n";
-        }
-        out_csv << c.getName();
-        for (auto &ap : attrs) {
-            if (ap.first == fn::family) continue;
-            out_csv << "," << escape_string(attr_to_string(ap.second));
-        }
-        out_csv << "\r\n";
-        break;
-    default: throw std::runtime_error("Unknown meta-fmt output option");
+    rec.clear();
+    rec.append(">").append(c.getName());
+    const std::string full_name = c.get_attr<std::string>(fn::fullname, "");
+    if (!full_name.empty()) rec.append(" ").append(full_name);
+    style->on_header_line(rec, attrs);
+    rec.push_back('\n');
+    style->below_header(rec, attrs);
+    if (out_csv) {
+        rows.clear();
+        style->side_file(rows, c, attrs, count == 0);
+        out_csv->push(rows.data(), rows.size());
     }
     const std::string seq = c.getAligned(!o.out_dots, o.out_dna);
-    const int len = (int)seq.size();
-    if (o.line_length > 0) {
-        for (int i = 0; i < len; i += o.line_length) {
-            out.write(seq.data() + i, std::min(o.line_length, len - i));
-            out.put('\n');
-        }
-    } else {
-        out.write(seq.data(), len);
-        out.put('\n');
-    }
+    const size_t per_line = o.line_length > 0 ? (size_t)o.line_length : seq.size();
+    rec.reserve(rec.size() + seq.size() + (per_line ? seq.size() / per_line : 0) + 2);
+    size_t at = 0;
+    do {  // (an empty sequence still gets its empty line -- unless lines are wrapped)
+        const size_t n = std::min(per_line, seq.size() - at);
+        rec.append(seq, at, n);
+        rec.push_back('\n');
+        at += n;
+    } while (at < seq.size());
+    if (o.line_length > 0 && seq.empty()) rec.pop_back();
+    out->push(rec.data(), rec.size());
     count++;
 }
 
@@ -467,7 +640,7 @@ tray log_printer::operator()(tray t, std::ostream &log) {  // src/log.cpp:364-43
         aligned.set_attr("align_startpos_slv", 0);
         aligned.set_attr("align_stoppos_slv", 0);
     }
-    for (auto &ap : aligned.get_attrs()) log << ap.first << ": " << attr_to_string(ap.second) << "\n";
+    for (auto &ap : aligned.get_attrs()) log << ap.key() << ": " << attr_to_string(ap.second) << "\n";
     search::result_vector ref;
     if (t.search_result != nullptr) ref = *t.search_result;
     else if (t.alignment_reference != nullptr) ref = *t.alignment_reference;

@@ -88,6 +88,35 @@ struct scoped_phase {
 }  // namespace
 
 void host_profile_add_cpu(const char *what, double seconds) { add_cpu(what, seconds); }
+
+namespace {
+struct tick_slot {
+    std::atomic<const char *> name{nullptr};
+    std::atomic<uint64_t> cycles{0}, samples{0};
+};
+tick_slot g_ticks[64];
+}  // namespace
+uint64_t host_tsc() { return prof().on ? __builtin_ia32_rdtsc() : 0; }
+uint64_t host_tick(const char *what, uint64_t since) {
+    if (!prof().on) return 0;
+    const uint64_t now = __builtin_ia32_rdtsc();
+    // (slots are keyed by the literal's address: a short probe sequence, names are few)
+    size_t h = (reinterpret_cast<uintptr_t>(what) >> 3) % 64;
+    for (int probe = 0; probe < 64; probe++, h = (h + 1) % 64) {
+        const char *cur = g_ticks[h].name.load(std::memory_order_acquire);
+        if (cur == nullptr) {
+            const char *expect = nullptr;
+            if (g_ticks[h].name.compare_exchange_strong(expect, what)) cur = what;
+            else cur = expect;
+        }
+        if (cur == what) {
+            g_ticks[h].cycles.fetch_add(now - since, std::memory_order_relaxed);
+            g_ticks[h].samples.fetch_add(1, std::memory_order_relaxed);
+            break;
+        }
+    }
+    return now;
+}
 double host_thread_cpu_seconds() { return thread_cpu_s(); }
 host_phase::host_phase(const char *n) : impl(new scoped_phase(n)) {}
 host_phase::~host_phase() { delete static_cast<scoped_phase *>(impl); }
@@ -101,6 +130,31 @@ std::string host_profile_dump(bool reset) {
         snprintf(buf, sizeof(buf), "%-28s %9.3f s  %6llu calls\n", kv.first.c_str(), kv.second.first,
                  (unsigned long long)kv.second.second);
         out += buf;
+    }
+    {   // time-stamp-counter slots: cycles -> seconds by a one-off calibration against the steady clock
+        static const double tsc_hz = [] {
+            const auto t0 = std::chrono::steady_clock::now();
+            const uint64_t c0 = __builtin_ia32_rdtsc();
+            while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.02) {
+            }
+            return (double)(__builtin_ia32_rdtsc() - c0) / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }();
+        std::vector<std::pair<std::string, std::pair<double, unsigned long long>>> rows;
+        for (auto &t : g_ticks) {
+            const char *n = t.name.load();
+            if (!n) continue;
+            rows.push_back({n, {(double)t.cycles.load() / tsc_hz, (unsigned long long)t.samples.load()}});
+            if (reset) {
+                t.cycles.store(0);
+                t.samples.store(0);
+            }
+        }
+        std::sort(rows.begin(), rows.end());
+        for (auto &r : rows) {
+            snprintf(buf, sizeof(buf), "%-36s %9.3f s  %8llu samples  %7.2f us each [tsc]\n", r.first.c_str(), r.second.first,
+                     r.second.second, r.second.second ? 1e6 * r.second.first / (double)r.second.second : 0.0);
+            out += buf;
+        }
     }
     if (reset) p.acc.clear();
     if (p.trace_path && !p.events.empty()) {
@@ -124,6 +178,7 @@ class pool {
         const std::function<void(size_t)> *fn;
         const char *phase;
         size_t n;
+        size_t chunk = 1;  // indices taken per grab (one shared counter: a grab per query was a cache-line fight)
         std::atomic<size_t> next{0}, done{0};
         std::mutex err_mu;
         std::exception_ptr error;
@@ -149,6 +204,7 @@ public:
         j->fn = &fn;
         j->phase = tl_phase;
         j->n = n;
+        j->chunk = std::max<size_t>(1, n / ((workers.size() + 1) * 8));
         {
             std::lock_guard<std::mutex> lk(mu);
             jobs.push_back(j);
@@ -198,15 +254,18 @@ private:
             }
         } acc{helper && prof().on, j.phase, c0};
         for (;;) {
-            const size_t i = j.next.fetch_add(1);
-            if (i >= j.n) break;
-            try {
-                (*j.fn)(i);
-            } catch (...) {
-                std::lock_guard<std::mutex> lk(j.err_mu);
-                if (!j.error) j.error = std::current_exception();
+            const size_t i0 = j.next.fetch_add(j.chunk);
+            if (i0 >= j.n) break;
+            const size_t i1 = std::min(j.n, i0 + j.chunk);
+            for (size_t i = i0; i < i1; i++) {
+                try {
+                    (*j.fn)(i);
+                } catch (...) {
+                    std::lock_guard<std::mutex> lk(j.err_mu);
+                    if (!j.error) j.error = std::current_exception();
+                }
             }
-            if (j.done.fetch_add(1) + 1 == j.n) {
+            if (j.done.fetch_add(i1 - i0) + (i1 - i0) == j.n) {
                 std::lock_guard<std::mutex> lk(mu);  // (pairs with the waiter's predicate check)
                 done_cv.notify_all();
             }
@@ -252,7 +311,8 @@ unsigned host_threads() { return pool::get().size(); }
 
 tray::tray(const tray &o)
     : seqno(o.seqno), input_sequence(o.input_sequence), aligned_sequence(o.aligned_sequence),
-      alignment_reference(o.alignment_reference), search_result(o.search_result), astats(o.astats) {
+      alignment_reference(o.alignment_reference), search_result(o.search_result), astats(o.astats),
+      family_scores_kmer_k(o.family_scores_kmer_k) {
     log.str(o.log.str());
     log.seekp(0, std::ios_base::end);
 }
@@ -265,14 +325,19 @@ tray &tray::operator=(const tray &o) {
     log.str(o.log.str());
     log.seekp(0, std::ios_base::end);
     astats = o.astats;
+    family_scores_kmer_k = o.family_scores_kmer_k;
     return *this;
 }
-void tray::destroy() {
-    delete input_sequence;
-    delete aligned_sequence;
-    delete alignment_reference;
-    delete search_result;
-    delete astats;
+alignment_stats *alignment_stats::shared_default() {
+    static alignment_stats none;
+    return &none;
+}
+void tray::destroy() {  // (src/tray.cpp:77-86; the objects go back to their caches, see object_cache)
+    object_cache<cseq>::give(input_sequence);
+    object_cache<cseq>::give(aligned_sequence);
+    object_cache<search::result_vector>::give(alignment_reference);
+    object_cache<search::result_vector>::give(search_result);
+    if (astats != alignment_stats::shared_default()) delete astats;
     input_sequence = aligned_sequence = nullptr;
     alignment_reference = search_result = nullptr;
     astats = nullptr;
@@ -552,7 +617,9 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
                              unsigned int max) {
     reference_store &st = *pimpl->store;
     const unsigned n = st.size();
-    results.assign(queries.size(), result_vector());
+    // (the callers' vectors are kept -- famfinder hands in recycled ones -- and only emptied)
+    results.resize(queries.size());
+    for (auto &r : results) r.clear();
     if (max > n) max = n;
     if (max == 0 || queries.empty()) return;
     st.ensure_index(pimpl->k, pimpl->nofast);
@@ -574,11 +641,11 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
                                          sc.data(), cnt.data()),
                       "kmer_topk");
         }
-        for (size_t i = 0; i < queries.size(); i++) {
+        parallel_for(queries.size(), [&](size_t i) {
             results[i].reserve(cnt[i]);
             for (uint32_t x = 0; x < cnt[i]; x++)
                 results[i].emplace_back(sc[i * max + x], &st.getCseq(ids[i * max + x]));
-        }
+        });
     } else {
         // rare escalation (famfinder asks for >4096 candidates): the GPU still does the
         // counting; ranking the full score vector is the reference's own partial_sort
@@ -803,7 +870,7 @@ void famfinder::impl::select_astats(tray &t) {
                 astats = new alignment_stats(as);  // trays own (and delete) their astats
         }
     }
-    if (astats == nullptr) astats = new alignment_stats();
+    if (astats == nullptr) astats = alignment_stats::shared_default();
     t.astats = astats;
 }
 
@@ -862,7 +929,9 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
     }
     orient_batch(searchable);
     for (tray *t : searchable) {
-        t->alignment_reference = new search::result_vector();
+        t->alignment_reference = object_cache<search::result_vector>::take();
+        // (what the scores below are: raw k-mer counts of this engine -- the aligner's containment pre-filter asks)
+        t->family_scores_kmer_k = o.engine == ENGINE_SINA_KMER ? (o.fs_no_fast ? -(int)o.fs_kmer_len : (int)o.fs_kmer_len) : 0;
         todo.push_back(t);
     }
     size_t max_results = (size_t)o.fs_max + 1;
@@ -870,7 +939,8 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
     while (!todo.empty()) {
         std::vector<const cseq *> qs;
         for (tray *t : todo) qs.push_back(t->input_sequence);
-        std::vector<search::result_vector> found;
+        std::vector<search::result_vector> found(todo.size());
+        for (size_t i = 0; i < todo.size(); i++) found[i].swap(*todo[i]->alignment_reference);  // (their heap blocks, recycled)
         {
             scoped_phase ph_find("ff.find_batch");
             index->find_batch(qs, found, (unsigned)std::min<size_t>(max_results, isize));
@@ -879,7 +949,7 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
         scoped_phase ph_match("ff.match_pass");
         parallel_for(todo.size(), [&](size_t i) {
             search::result_vector &res = *todo[i]->alignment_reference;
-            res = std::move(found[i]);
+            res.swap(found[i]);
             if (res.empty()) {
                 done[i] = 1;
                 return;
@@ -903,6 +973,7 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
         }
         auto &vc = *t.alignment_reference;
         cseq &c = *t.input_sequence;
+        uint64_t tk = host_tsc();
         std::string fam;
         char buf[64];
         fam.reserve(vc.size() * 24);
@@ -935,7 +1006,9 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
             }
             fam += buf;
         }
+        tk = host_tick("ff.post: family string", tk);
         c.set_attr(fn::family, fam);
+        tk = host_tick("ff.post: set family attr", tk);
         if (o.fs_req_gaps != 0) {  // :472-480
             auto too_few_gaps = [&](search::result_item &it) {
                 return 0 == it.sequence->size() ||
@@ -944,9 +1017,10 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
             vc.erase(std::remove_if(vc.begin(), vc.end(), too_few_gaps), vc.end());
         }
         select_astats(t);
+        host_tick("ff.post: gaps filter + astats", tk);
         if (vc.size() < o.fs_req) {  // :486-491
             t.log << "unable to align: too few relatives (" << vc.size() << ");";
-            delete t.alignment_reference;
+            object_cache<search::result_vector>::give(t.alignment_reference);
             t.alignment_reference = nullptr;
         }
     });
@@ -1153,18 +1227,18 @@ void aligner::operator()(std::vector<tray> &batch) {
             if (prep_store && !batch.empty() && prep_store->size() > 0) prep_store->upper_bases(0);  // (fills the cache outside the loop)
         }
     }
-    // (the scores of alignment_reference are k-mer counts when famfinder's internal engine made them)
-    const bool search_scores_are_kmer_counts = ff_opts.engine == ENGINE_SINA_KMER && !ff_opts.database.empty();
-    auto query_kmer_count = [](const cseq &c) -> unsigned {
-        // |K(q)|: windows of k unambiguous bases ending before the last base, first base A in "fast"
-        // mode (src/kmer.h:69-83,122-124,188-201)
-        const unsigned k = ff_opts.fs_kmer_len;
+    // |K(q)|: windows of k unambiguous bases ending before the last base, first base A in "fast" mode
+    // (src/kmer.h:69-83,122-124,188-201) -- for a family whose scores famfinder stamped as
+    // raw k-mer counts (tray::family_scores_kmer_k: k, negative = no-fast)
+    auto query_kmer_count = [](const cseq &c, int stamp) -> unsigned {
+        const unsigned k = (unsigned)(stamp < 0 ? -stamp : stamp);
+        const bool nofast = stamp < 0;
         const auto &b = c.getAlignedBases();
         unsigned run = 0, n = 0;
         for (size_t e = 0; e + 1 < b.size(); e++) {
             const unsigned m = (b[e].raw >> 24) & 0xfu;
-            run = (__builtin_popcount(m) == 1) ? run + 1 : 0;
-            if (run >= k && (ff_opts.fs_no_fast || ((b[e + 1 - k].raw >> 24) & 0xfu) == 1u)) n++;
+            run = (m & (m - 1)) == 0 && m != 0 ? run + 1 : 0;  // exactly one base bit
+            if (run >= k && (nofast || ((b[e + 1 - k].raw >> 24) & 0xfu) == 1u)) n++;
         }
         return n;
     };
@@ -1175,13 +1249,17 @@ void aligner::operator()(std::vector<tray> &batch) {
             t.log << "unable to align: sequence of " << t.input_sequence->size() << " bases (device limit 8191);";
             return;
         }
-        cseq &c = *(new cseq(*t.input_sequence));
+        uint64_t tk = host_tsc();
+        // (the working copy starts without bases: they are written once, below or when the DP is back)
+        cseq &c = *object_cache<cseq>::take();
+        c.copy_meta(*t.input_sequence);
+        tk = host_tick("prepare: working copy", tk);
         search::result_vector &vc = *t.alignment_reference;
         // (the query's upper-case base string: only built if a family member passes the k-mer-count
         // test below and has to be searched for it -- exact relatives only)
         std::string ubases_store;
         bool have_ubases = false;
-        const size_t n_bases = c.size();
+        const size_t n_bases = t.input_sequence->size();
         auto ubases_of_query = [&]() -> const std::string & {
             if (!have_ubases) {
                 ubases_store = upper_copy(t.input_sequence->getBases());
@@ -1189,8 +1267,6 @@ void aligner::operator()(std::vector<tray> &batch) {
             }
             return ubases_store;
         };
-        if (o.lowercase != LOWERCASE_ORIGINAL) c.upperCaseAll();
-
         // upper-case bases of a family member: cached per store (40 members x every query)
         auto ref_ubases = [&](const cseq *r, std::string &tmp) -> const std::string & {
             if (prep_store && prep_store->owns(r)) return prep_store->upper_bases(prep_store->id_of(r));
@@ -1200,47 +1276,49 @@ void aligner::operator()(std::vector<tray> &batch) {
         // A family member can only contain the query's bases if it has every one of the query's
         // k-mers, i.e. if its k-mer score (what famfinder ranked it by) is the query's k-mer count --
         // which spares the string search for all but exact relatives.
-        const float all_kmers = search_scores_are_kmer_counts ? (float)query_kmer_count(c) : -1.f;
-        auto not_contains_query = [&](search::result_item &item) {
+        const float all_kmers = t.family_scores_kmer_k != 0 ? (float)query_kmer_count(*t.input_sequence, t.family_scores_kmer_k) : -1.f;
+        auto lacks_query = [&](search::result_item &item) {
             if (item.score < all_kmers) return true;
             std::string tmp;
             return ref_ubases(item.sequence, tmp).find(ubases_of_query()) == std::string::npos;
         };
-        auto begin_containing = std::partition(vc.begin(), vc.end(), not_contains_query);
-        if (begin_containing != vc.end()) {
+        tk = host_tick("prepare: kmer count", tk);
+        auto holders = std::partition(vc.begin(), vc.end(), lacks_query);
+        tk = host_tick("prepare: partition", tk);
+        if (holders != vc.end()) {
             if (o.realign) {  // :337-348
                 t.log << "sequences ";
-                for (auto it = begin_containing; it != vc.end(); ++it)
+                for (auto it = holders; it != vc.end(); ++it)
                     t.log << it->sequence->get_attr<std::string>(fn::acc) << " ";
                 t.log << "containing exact candidate removed from family;";
-                vc.erase(begin_containing, vc.end());
+                vc.erase(holders, vc.end());
                 if (vc.empty()) {
                     t.log << "that's ALL of them. skipping sequence;";
-                    delete &c;
+                    object_cache<cseq>::give(&c);
                     return;
                 }
             } else {  // :349-388 steal the alignment
-                auto same_as_query = [&](search::result_item &item) {
+                auto is_query_itself = [&](search::result_item &item) {
                     std::string tmp;
                     return ref_ubases(item.sequence, tmp) == ubases_of_query();
                 };
-                auto exact = std::find_if(begin_containing, vc.end(), same_as_query);
+                auto exact = std::find_if(holders, vc.end(), is_query_itself);
                 if (exact != vc.end()) {
                     c.setAlignedBases(exact->sequence->getAlignedBases());
                     t.log << "copied alignment from identical template sequence "
                           << exact->sequence->get_attr<std::string>(fn::acc) << ":"
                           << exact->sequence->get_attr<std::string>(fn::start, "0") << "; ";
                 } else {
-                    const auto &refal = begin_containing->sequence->getAlignedBases();
+                    const auto &refal = holders->sequence->getAlignedBases();
                     std::string tmp;
-                    const size_t at = ref_ubases(begin_containing->sequence, tmp).find(ubases_of_query());
+                    const size_t at = ref_ubases(holders->sequence, tmp).find(ubases_of_query());
                     std::vector<aligned_base> sub(refal.begin() + at, refal.begin() + at + n_bases);
                     c.setAlignedBases(sub);
                     t.log << "copied alignment from (longer) template sequence "
-                          << begin_containing->sequence->get_attr<std::string>(fn::acc) << ":"
-                          << begin_containing->sequence->get_attr<std::string>(fn::start, "0") << "; ";
+                          << holders->sequence->get_attr<std::string>(fn::acc) << ":"
+                          << holders->sequence->get_attr<std::string>(fn::start, "0") << "; ";
                 }
-                c.setWidth(begin_containing->sequence->getWidth());
+                c.setWidth(holders->sequence->getWidth());
                 c.set_attr(fn::date, make_datetime());
                 c.set_attr(fn::qual, 100);
                 if (o.calc_idty) c.set_attr(fn::idty, 100.f);
@@ -1255,6 +1333,7 @@ void aligner::operator()(std::vector<tray> &batch) {
         jobs[i].c = &c;
         for (auto &r : vc) jobs[i].family.push_back(r.sequence);
         need_dp[i] = 1;
+        host_tick("prepare: family list", tk);
     });
 
     ph.reset();
@@ -1288,11 +1367,13 @@ void aligner::operator()(std::vector<tray> &batch) {
 
         ph.reset(), ph.reset(new scoped_phase("al.pack_queries"));  // (the old phase ends first: the new one names the pool jobs)
         std::vector<uint64_t> qoff(nq + 1, 0);
-        for (size_t x = 0; x < nq; x++) qoff[x + 1] = qoff[x] + jobs[idx[x]].c->size();
+        for (size_t x = 0; x < nq; x++) qoff[x + 1] = qoff[x] + jobs[idx[x]].t->input_sequence->size();
         std::vector<uint8_t> qmask(qoff.back() ? qoff.back() : 1);
-        parallel_for(nq, [&](size_t x) {
-            const auto &b = jobs[idx[x]].c->getAlignedBases();
-            for (size_t y = 0; y < b.size(); y++) qmask[qoff[x] + y] = (uint8_t)(b[y].raw >> 24);
+        parallel_for(nq, [&](size_t x) {  // (the DP looks at the four base bits only: case does not matter)
+            const uint32_t *b = jobs[idx[x]].t->input_sequence->packed();
+            const size_t nb = jobs[idx[x]].t->input_sequence->size();
+            uint8_t *dst = qmask.data() + qoff[x];
+            for (size_t y = 0; y < nb; y++) dst[y] = (uint8_t)(b[y] >> 24);
         });
         std::vector<sina_hip_align_out> out(nq);
         std::vector<uint32_t> out_pos(qoff.back() ? qoff.back() : 1);
@@ -1360,41 +1441,64 @@ void aligner::operator()(std::vector<tray> &batch) {
             cseq &c = *jb.c;
             const sina_hip_align_out &r = out[x];
             if (r.status != 0) throw std::runtime_error("device alignment failed for " + c.getName());
-            const std::vector<aligned_base> q = c.takeAlignedBases();  // query bases (maybe upper-cased); c is empty now
-            const uint32_t L = (uint32_t)q.size();
+            uint64_t tk = host_tsc();
+            // query bases: the input's, upper-cased unless --lowercase=original (src/align.cpp:324-326)
+            const uint32_t *qraw = t.input_sequence->packed();
+            const uint32_t L = (uint32_t)t.input_sequence->size();
+            const uint32_t keep_case = o.lowercase == LOWERCASE_ORIGINAL ? 0xFFFFFFFFu : ~((uint32_t)16 << 24);
+            const uint32_t lower_bit = o.lowercase == LOWERCASE_UNALIGNED ? (uint32_t)16 << 24 : 0u;
+            auto qbase = [&](uint32_t i, bool overhang_base) -> uint32_t {  // base bits of query base i, in place
+                return ((qraw[i] & keep_case) & 0xFF000000u) | (overhang_base ? lower_bit : 0u);
+            };
             const uint32_t *pos = out_pos.data() + qoff[x];
-            c.clearSequence();
             const bool keep_over = (o.overhang != OVERHANG_REMOVE);
             const uint32_t tail = keep_over ? (uint32_t)r.cutoff_tail : 0;
             const uint32_t head = keep_over ? (uint32_t)r.cutoff_head : 0;
-            uint32_t n = 0;
-            for (uint32_t k = 0; k < tail; k++, n++) {  // it = slave.rbegin()
-                base_iupac b = q[L - 1 - k].getBase();
-                if (o.lowercase == LOWERCASE_UNALIGNED) b.setLowerCase();
-                c.append(aligned_base(pos[n], b));
+            const uint32_t n_out = tail + (uint32_t)r.aligned_bases + head;
+            // The container steps of backtrack() (src/mesh.h:603-726) in one pass: every emitted base is
+            // appended under the container rule (a column left of the current width is moved up to it,
+            // src/cseq.cpp:79-95), then the sequence is reversed (order and columns, :283-289).  The
+            // columns after the rule never decrease, so the result is written back to front directly.
+            c.clearSequence();
+            std::vector<aligned_base> &fin = c.mutableAlignedBases();  // (a recycled sequence: no allocation)
+            fin.resize(n_out);
+            uint32_t reach = 0;  // alignment_width while appending (clearSequence: 0)
+            bool direct = true;
+            {
+                uint32_t n = 0;
+                auto put = [&](uint32_t column, uint32_t base_bits) {
+                    if (column >= reach) reach = column;
+                    else column = reach;
+                    if (column >= width) direct = false;  // (setWidth would have to repack: the general way below)
+                    fin[n_out - 1 - n] = aligned_base::from_raw(((width - 1 - column) & 0xFFFFFFu) | base_bits);
+                    n++;
+                };
+                for (uint32_t k = 0; k < tail; k++) put(pos[n], qbase(L - 1 - k, true));
+                for (int k = 0; k < r.aligned_bases; k++) put(pos[n], qbase((uint32_t)r.end_s - (uint32_t)k, false));
+                for (uint32_t k = 0; k < head; k++) put(pos[n], qbase((uint32_t)r.cutoff_head - 1 - k, true));
             }
-            for (int k = 0; k < r.aligned_bases; k++, n++) c.append(aligned_base(pos[n], q[r.end_s - k].getBase()));
-            if (o.overhang == OVERHANG_ATTACH) {
-                for (uint32_t k = 0; k < head; k++, n++) {
-                    aligned_base ab(pos[n], q[(uint32_t)r.cutoff_head - 1 - k].getBase());
-                    if (o.lowercase == LOWERCASE_UNALIGNED) ab.setLowerCase();
-                    c.append(ab);
-                }
-            } else if (o.overhang == OVERHANG_EDGE) {
-                for (uint32_t k = 0; k < head; k++, n++) {
-                    aligned_base ab(pos[n], q[(uint32_t)r.cutoff_head - 1 - k].getBase());
-                    if (o.lowercase == LOWERCASE_UNALIGNED) ab.setLowerCase();
-                    c.append(ab);
-                }
+            if (direct) {
+                c.setWidth(width);
+            } else {  // the same through the container's own operations
+                c.clearSequence();
+                uint32_t n = 0;
+                for (uint32_t k = 0; k < tail; k++, n++) c.append(aligned_base::from_raw((pos[n] & 0xFFFFFFu) | qbase(L - 1 - k, true)));
+                for (int k = 0; k < r.aligned_bases; k++, n++)
+                    c.append(aligned_base::from_raw((pos[n] & 0xFFFFFFu) | qbase((uint32_t)r.end_s - (uint32_t)k, false)));
+                for (uint32_t k = 0; k < head; k++, n++)
+                    c.append(aligned_base::from_raw((pos[n] & 0xFFFFFFu) | qbase((uint32_t)r.cutoff_head - 1 - k, true)));
+                c.setWidth(width);
+                c.reverse();
             }
-            c.setWidth(width);
-            c.reverse();
+            tk = host_tick("finish: assemble", tk);
             c.fix_duplicate_positions(t.log, o.lowercase == LOWERCASE_UNALIGNED, o.insertion == INSERTION_REMOVE);
+            tk = host_tick("finish: NAST fix-up", tk);
             if (c.getWidth() > width) t.log << "warning: result sequence too wide!";
             const float rval = r.raw, sum_weight = r.sum_weight;
             const float score = rval / sum_weight;
             t.log << "scoring: raw=" << rval << ", weight=" << sum_weight << ", query-len=" << L
                   << ", aligned-bases=" << r.aligned_bases << ", score=" << score << "; ";
+            tk = host_tick("finish: score log text", tk);
             c.set_attr(fn::head, r.cutoff_head);
             c.set_attr(fn::tail, r.cutoff_tail);
             c.set_attr(fn::qual, (int)std::min(100.f, std::max(0.f, 100.f * score)));
@@ -1406,6 +1510,7 @@ void aligner::operator()(std::vector<tray> &batch) {
             c.set_attr(fn::date, make_datetime());
             c.set_attr(fn::filter, t.astats->getName());
             t.aligned_sequence = &c;
+            host_tick("finish: attributes", tk);
         });
 
         // --calc-idty (src/align.cpp:443-453): best overlap identity of the aligned query with a member

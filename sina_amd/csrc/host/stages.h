@@ -77,10 +77,54 @@ public:
     const std::string &getName() const { return name; }
     unsigned int getWidth() const { return (unsigned int)weights.size(); }
     const std::vector<float> &getWeights() const { return weights; }
+    // the default-constructed statistics ("no filter": simple scoring scheme).  One immutable
+    // instance shared by every tray that needs nothing else; tray::destroy() leaves it alone.
+    static alignment_stats *shared_default();
 
 private:
     std::string name;
     std::vector<float> weights;
+};
+
+// ---------------------------------------------------------------- recycling of per-query heap objects
+// A query's way through the stages creates and destroys two sequences, a result vector and their
+// innards -- two dozen heap blocks, allocated by one pool thread and freed by another, at 100 000+
+// queries a second: the allocator's locks were a third of the host's CPU time.  Objects that trays
+// own go back to a per-thread free list instead (tray::destroy) and are handed out again in their
+// default state WITH their heap blocks (the 6 KB base list above all), by the stages and the driver.
+template <typename T> struct object_cache {
+    static T *take() {
+        auto &f = mine().free;
+        if (f.empty()) return new T();
+        T *o = f.back();
+        f.pop_back();
+        return o;
+    }
+    static void give(T *o) {
+        if (o == nullptr) return;
+        auto &f = mine().free;
+        if (f.size() >= kKeep) {
+            delete o;
+            return;
+        }
+        reset(*o);
+        f.push_back(o);
+    }
+
+private:
+    static constexpr size_t kKeep = 8192;  // per thread
+    struct list {
+        std::vector<T *> free;
+        ~list() {
+            for (T *o : free) delete o;
+        }
+    };
+    static list &mine() {
+        thread_local list l;
+        return l;
+    }
+    static void reset(cseq &c) { c.clear_all(); }
+    template <typename V> static void reset(std::vector<V> &v) { v.clear(); }
 };
 
 // ---------------------------------------------------------------- tray
@@ -93,6 +137,10 @@ public:
     search::result_vector *search_result{nullptr};
     std::stringstream log;
     alignment_stats *astats{nullptr};
+    // set by famfinder when the scores of alignment_reference are raw k-mer counts of its internal
+    // engine (value: k, negative with --fs-kmer-no-fast); 0 = unknown.  The aligner's containment
+    // pre-filter (a member with fewer k-mers than the query cannot contain it) is only valid then.
+    int family_scores_kmer_k{0};
 
     tray() = default;
     tray(const tray &o);
@@ -472,6 +520,11 @@ void set_host_threads(unsigned n);
 unsigned host_threads();
 std::string host_profile_dump(bool reset);  // per-phase wall time when SINA_HOST_PROFILE is set
 void host_profile_add_cpu(const char *what, double seconds);  // (no-op unless SINA_HOST_PROFILE is set)
+// Fine-grained timers for per-query code (SINA_HOST_PROFILE=1): time-stamp-counter deltas summed in
+// per-slot atomics -- no system call and no lock per sample, unlike host_profile_add_cpu.
+//   uint64_t t = host_tsc();  ...  t = host_tick("al.finish: assemble", t);   // adds, returns "now"
+uint64_t host_tsc();
+uint64_t host_tick(const char *what, uint64_t since);
 double host_thread_cpu_seconds();
 class host_phase {                           // a named phase of the calling thread (profile / SINA_HOST_TRACE)
 public:

@@ -167,3 +167,52 @@ def test_fasta_reader_and_writer_rules(tmp_path):
     assert pipeline.fasta_roundtrip(src, dst, {"meta-fmt": "csv"}) == (3, 1)
     csv = open(str(tmp_path / "out.csv"), newline="").read()
     assert csv.startswith("name,acc,full_name\r\nseq1,AB000001,Escherichia coli K12\r\nseq2\r\n")
+
+
+def test_fasta_reader_edge_cases(tmp_path):
+    """Line-cutter corners of the FASTA source (behaviour of src/rw_fasta.cpp:229-315 on std::istream):
+    a last sequence line without a line feed is data, a header line without one is not a record, a line
+    longer than the reader's block, CR LF files, records cut by --fasta-block, csv quoting, damaged gzip."""
+    import gzip
+    src, dst = str(tmp_path / "in.fasta"), str(tmp_path / "out.fasta")
+    # (1) the file ends inside a sequence line / inside a header line
+    open(src, "w").write(">a\nAC-GU\n>b x y\nAC\nGU")
+    assert pipeline.fasta_roundtrip(src, dst) == (2, 0)
+    assert open(dst).read() == ">a\nAC-GU\n>b x y\nACGU\n"
+    open(src, "w").write(">a\nACGU\n>b")
+    assert pipeline.fasta_roundtrip(src, dst) == (1, 0)
+    open(src, "w").write("")
+    assert pipeline.fasta_roundtrip(src, dst) == (0, 0) and open(dst).read() == ""
+    # (2) CR LF throughout, empty lines inside a record, a comment line with '=' in its value
+    open(src, "wb").write(b">a  two blanks\r\n; k = v=w \r\nAC\r\n\r\nGU\r\n>c\r\n\r\n")
+    assert pipeline.fasta_roundtrip(src, dst, {"meta-fmt": "comment"}) == (2, 0)
+    assert open(dst).read() == ">a  two blanks\n; k=v=w\nACGU\n>c\n\n"
+    # (3) one 9 MB sequence line (longer than the 4 MB block) between two ordinary records
+    big = "-" * 4_500_000 + "ACGU" + "-" * 4_500_000
+    open(src, "w").write(">s\nAC\n>big\n" + big + "\n>t\nGU\n")
+    assert pipeline.fasta_roundtrip(src, dst) == (3, 0)
+    out = open(dst).read().split("\n")
+    assert out[0:2] == [">s", "AC"] and out[2] == ">big" and out[3] == big and out[4:6] == [">t", "GU"]
+    # (4) --fasta-block / --fasta-idx: every record is read by exactly one slice
+    recs = "".join(">r%d\n%s\n" % (i, "ACGU" * (3 + i % 5)) for i in range(40))
+    open(src, "w").write(recs)
+    seen = []
+    for idx in range((len(recs) + 99) // 100):
+        n, _ = pipeline.fasta_roundtrip(src, dst, {"fasta-block": 100, "fasta-idx": idx})
+        seen += [l[1:] for l in open(dst).read().splitlines() if l.startswith(">")]
+    # (a slice takes the records that START in it, plus the one its last byte falls into -- the
+    # reference's rule, rw_fasta.cpp:239-242 -- so neighbours may both hold a boundary record)
+    assert sorted(set(seen), key=lambda s: int(s[1:])) == ["r%d" % i for i in range(40)]
+    # (5) csv quoting: quotes doubled, fields with comma / quote / line break in quotes
+    open(src, "w").write(">q say \"hi\", twice\n; note = a,b\nACGU\n")
+    assert pipeline.fasta_roundtrip(src, dst, {"meta-fmt": "csv"}) == (1, 0)
+    assert open(str(tmp_path / "out.csv"), newline="").read() == \
+        'name,full_name,note\r\nq,"say ""hi"", twice","a,b"\r\n'
+    # (6) a truncated gzip file is an error, not a short input
+    gz = str(tmp_path / "in.fasta.gz")
+    with gzip.open(gz, "wt") as f:
+        f.write("".join(">r%d\n%s\n" % (i, "ACGU" * 500) for i in range(200)))
+    whole = open(gz, "rb").read()
+    open(gz, "wb").write(whole[:len(whole) // 2])
+    with pytest.raises(pipeline.HostError):
+        pipeline.fasta_roundtrip(gz, dst)
