@@ -45,9 +45,11 @@ def parse():
     ap.add_argument("--width", type=int, default=50000)
     ap.add_argument("--window", type=int, default=0, help="cut queries to this many bases (V4: 250)")
     ap.add_argument("--inflight", type=int, default=4, help="batches worked on concurrently per rank")
-    ap.add_argument("--sub-batch", type=int, default=3072,
-                    help="queries per GPU launch inside a step (one DP wave per query: 3072 = every wave slot of "
-                         "an MI355X at three waves per SIMD)")
+    ap.add_argument("--sub-batch", type=int, default=6144,
+                    help="queries per GPU launch inside a step (one DP wave per query; an MI355X has 3072 wave slots "
+                         "at three waves per SIMD: 6144 = two rounds, the second filling the slots as the first "
+                         "round's shorter queries end -- 34.2 instead of 2 x 17.6 ms of DP per 6144 queries; the "
+                         "trace-back planes come from the device's pool of two, csrc/ctx.h)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="CPU baseline: queries per thread and thread count (0 = 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=8,
@@ -220,7 +222,8 @@ def main():
     qs = synth.make_queries(refs, n_q, seed=3 + 1000 * rank, window=window)
 
     # ---- resident state: references + index in HBM, stages constructed
-    store = pipeline.Store(":mem:bench", refs, device=local_rank)
+    # (ranks other than 0 do not upload: the references arrive with the index, by broadcast)
+    store = pipeline.Store(":mem:bench", refs, device=local_rank, upload=(dist is None or rank == 0))
     t_idx = time.time()
     if dist is not None:
         n_post = sdist.broadcast_device_index(store, 10, False, rank, dist, device)
@@ -288,7 +291,13 @@ def main():
     s2 = store.stats()
     iso = {k: s2[k] - s1[k] for k in s1}
 
+    per_rank = None
     if dist is not None:
+        # per rank: its own rate and host load (the job's rate below is total work / slowest rank's time)
+        mine = torch.tensor([n_aligned / elapsed, host_cores, host_cores_sys], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(max(world, 1))]
+        dist.all_gather(every, mine)
+        per_rank = [[float(x) for x in t.cpu()] for t in every]
         elapsed = sdist.reduce_max(elapsed, dist, device)
         n_aligned = int(sdist.reduce_sum(n_aligned, dist, device))
     dp_ms = s1["dp_ms"] - s0["dp_ms"]
@@ -404,6 +413,18 @@ def main():
                 "backtrack_kernel": (s1["backtrack_ms"] - s0["backtrack_ms"]) / a.steps,
             },
         }
+        quota = cpu_quota()
+        out["container_cpu_quota"] = quota
+        if per_rank is not None:
+            rates = [r[0] for r in per_rank]
+            out["per_rank"] = {"sequences_per_s": rates, "min": min(rates), "max": max(rates),
+                               "host_cores_busy": [r[1] for r in per_rank],
+                               "host_cores_busy_kernel_mode": [r[2] for r in per_rank]}
+            need = sum(r[1] for r in per_rank)
+            if quota and need > 0.9 * quota:
+                out["per_rank"]["warning"] = ("the ranks keep %.1f host cores busy and the container's CPU quota is %.1f: "
+                                              "the job is host-bound, not GPU-bound" % (need, quota))
+                print("warning: " + out["per_rank"]["warning"], file=sys.stderr)
         if not a.no_cpu_baseline and world == 1:
             if pinned and full_mask:
                 os.sched_setaffinity(0, full_mask)  # the CPU baseline gets the whole machine

@@ -166,10 +166,16 @@ typedef struct sina_hip_align_params {
 } sina_hip_align_params;
 void sina_hip_align_params_default(sina_hip_align_params *p);
 
+/* Longest query (bases) any entry point takes: k-mer search, family alignment, graph alignment.
+ * (The k-mer count kernel keeps a query's k-mer cursors in LDS beside its 64 KiB score tile: 9 bytes
+ * per base; the DP itself takes any number of 512-column strips.)  The reference aligns any length
+ * (src/mesh.h:76,119-121); the stage functors fail a longer query softly, alone. */
+#define SINA_HIP_MAX_QUERY_LEN 10240u
+
 /* A batch of family DAGs in CSR form (node id == topological rank == mesh row).
  * All arrays are concatenated over the nq queries of the batch.  Limits (the call fails, nothing is
  * truncated): at most 65535 nodes per DAG, at most 255 predecessors per node, every predecessor id
- * smaller than its node's id, queries of 1..8191 bases. */
+ * smaller than its node's id, queries of 1..SINA_HIP_MAX_QUERY_LEN bases. */
 typedef struct sina_hip_graph_batch {
     uint32_t nq;
     const uint64_t *node_off;  /* [nq+1] into the node arrays                      */

@@ -19,7 +19,7 @@ static size_t env_size(const char *name, size_t dflt) {
 }
 
 int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl) {
-    if (!pick_geom(maxL, &pl->geom)) SH_FAIL("align: query longer than the largest DP geometry (8192)");
+    if (!pick_geom(maxL, &pl->geom)) SH_FAIL("align: query longer than SINA_HIP_MAX_QUERY_LEN bases");
     const size_t slot = dp_slot_bytes(pl->geom), fixed = dp_fixed_lds_bytes(pl->geom);
     size_t budget = c->lds_budget ? c->lds_budget : dp_default_lds_budget(pl->geom);
     if (budget < fixed + slot) budget = fixed + slot;
@@ -280,7 +280,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         const uint64_t L = qoff[q + 1] - qoff[q];
         const uint64_t N = g->node_off[q + 1] - g->node_off[q];
         if (L == 0 || N == 0) SH_FAIL("align_graphs: empty query or graph");
-        if (L > kTbSMask || N > 65535) SH_FAIL("align_graphs: N or L exceeds the trace-back cell fields");
+        if (L > SINA_HIP_MAX_QUERY_LEN || N > 65535) SH_FAIL("align_graphs: query longer than SINA_HIP_MAX_QUERY_LEN bases or DAG of more than 65535 nodes");
         maxL = std::max<uint32_t>(maxL, (uint32_t)L);
     }
     DpPlan pl;

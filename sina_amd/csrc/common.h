@@ -171,7 +171,7 @@ static_assert(sizeof(EdgeRec) == 16, "read back with one 16-byte scalar load");
 //   exactly for insertion cells).  So the recurrence carries neither row nor column indices, and
 //   backtrack looks the few of them on the final path up.
 // * 32 bits (--insertion=forbid, where a cell that may not take a gap keeps its initial gaps_val and
-//   the insertion-run rule above does not hold): bits 31..16 value_midx, bits 12..0 value_sidx,
+//   the insertion-run rule above does not hold): bits 31..16 value_midx, bits 13..0 value_sidx,
 //   kTbExt, kTbOpLast.
 //
 // Two bits replace carrying gapm_idx through the recurrence (it is only ever needed on the final path):
@@ -180,9 +180,10 @@ static_assert(sizeof(EdgeRec) == 16, "read back with one 16-byte scalar load");
 //   OpLast: this row's own gapm at this column was OPENED from its last predecessor, i.e.
 //           gapm_idx = last predecessor; otherwise gapm_idx = the last predecessor's gapm_idx.
 // backtrack resolves Ext by walking last predecessors until an OpLast cell.
-constexpr uint32_t kTbSMask = 0x1FFFu;
-constexpr uint32_t kTbExt = 1u << 13;
-constexpr uint32_t kTbOpLast = 1u << 14;
+constexpr uint32_t kTbSMask = 0x3FFFu;
+constexpr uint32_t kTbExt = 1u << 14;
+constexpr uint32_t kTbOpLast = 1u << 15;
+static_assert(SINA_HIP_MAX_QUERY_LEN <= kTbSMask, "value_sidx field of the 32-bit trace-back cell");
 constexpr uint32_t kTbTypeMask = 3u;
 constexpr uint32_t kTbDel = 0u, kTbMatch = 1u, kTbIns = 2u, kTbNone = 3u;
 constexpr uint32_t kTb16Ext = 1u << 2;

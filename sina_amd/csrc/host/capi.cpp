@@ -3,6 +3,7 @@
 // and the famfinder/aligner classes above it); this only lets Python feed trays
 // through the stages and read the results back.
 #include <malloc.h>
+#include <sys/mman.h>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -31,7 +32,8 @@ struct result {
         status = 2;
         head = tail = qual = 0;
         width = 0;
-        ab.clear();
+        ab = nullptr;
+        n_ab = 0;
         log.clear();
         family.clear();
         idty = -1.f;
@@ -43,7 +45,8 @@ struct result {
     int status = 2;  // 0 aligned by DP, 1 alignment copied from a reference, 2 not aligned
     int head = 0, tail = 0, qual = 0;
     uint32_t width = 0;
-    std::vector<aligned_base> ab;  // (taken over from the tray's aligned sequence, not copied)
+    const aligned_base *ab = nullptr;  // the aligned bases, in the pipeline's base arena
+    uint32_t n_ab = 0;
     std::string log, family;
     float idty = -1.f;              // align_ident_slv (--calc-idty), -1 if not computed
     bool searched = false;          // search stage ran and produced a result vector
@@ -52,7 +55,34 @@ struct result {
     std::map<std::string, std::string> attrs;  // nearest_slv, lca_*, copy_*
 };
 
+// Where the aligned bases of a run's results live: one block for the whole run (a query's result has
+// at most as many bases as the query), kept between runs, on transparent huge pages -- 6 KB of fresh
+// heap per query were two page faults per query, a third of a core in kernel mode.
+struct base_arena {
+    aligned_base *p = nullptr;
+    size_t cap = 0;
+    aligned_base *reserve(size_t n) {
+        if (n <= cap) return p;
+        release();
+        const size_t huge = (size_t)2 << 20;
+        const size_t bytes = ((n * sizeof(aligned_base) + huge - 1) / huge) * huge;
+        void *m = nullptr;
+        if (posix_memalign(&m, huge, bytes) != 0) throw std::bad_alloc();
+        (void)madvise(m, bytes, MADV_HUGEPAGE);
+        p = static_cast<aligned_base *>(m);
+        cap = bytes / sizeof(aligned_base);
+        return p;
+    }
+    void release() {
+        free(p);
+        p = nullptr;
+        cap = 0;
+    }
+    ~base_arena() { release(); }
+};
+
 struct pipeline {
+    base_arena bases;
     famfinder ff;
     aligner al;
     std::unique_ptr<search_filter> sf;  // only with sina_host_pipeline_create_search()
@@ -72,6 +102,17 @@ int sina_host_store_from_packed(const char *key, const uint32_t *ab, const uint6
     try {
         auto s = reference_store::from_packed(key, ab, off, n, width);
         s->set_device(device);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+// A store of a rank other than 0: its device buffers are allocated like rank 0's
+// (sina_hip_store_alloc_like) and filled by the start-up broadcast instead of an upload of its own.
+int sina_host_store_expect_broadcast(const char *key) {
+    try {
+        reference_store::get(key)->expect_broadcast();
         return 0;
     } catch (const std::exception &e) {
         return fail(e);
@@ -346,6 +387,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
     try {
         p->results.resize(nq);
         for (result &r : p->results) r.reset();
+        aligned_base *const base_block = p->bases.reserve(nq ? (size_t)qoff[nq] : 0);
         if (batch == 0) batch = nq ? nq : 1;
         if (inflight == 0) inflight = 1;
         std::atomic<uint32_t> next{0};
@@ -430,7 +472,11 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                             r.attrs[k] = c.get_attr<std::string>(k);
                     }
                     r.idty = c.has_attr(fn::idty) ? c.get_attr<float>(fn::idty) : -1.f;
-                    r.ab.assign(c.begin(), c.end());  // (copied: the sequence keeps its heap block for its next life)
+                    // (copied: the sequence keeps its heap block for its next life; a result has no more
+                    // bases than its query -- a copied alignment exactly as many)
+                    r.n_ab = std::min<uint32_t>(c.size(), (uint32_t)(qoff[q + 1] - qoff[q]));
+                    r.ab = base_block + qoff[q];
+                    memcpy(base_block + qoff[q], c.packed(), sizeof(aligned_base) * (size_t)r.n_ab);
                 }
                 if (t.search_result) {
                     r.searched = true;
@@ -596,11 +642,11 @@ int sina_host_result(void *pp, uint32_t q, int *status, int *head, int *tail, in
     *tail = r.tail;
     *qual = r.qual;
     *width = r.width;
-    *n_bases = (uint32_t)r.ab.size();
+    *n_bases = r.n_ab;
     return 0;
 }
 const uint32_t *sina_host_result_bases(void *pp, uint32_t q) {
-    return reinterpret_cast<const uint32_t *>(((pipeline *)pp)->results[q].ab.data());
+    return reinterpret_cast<const uint32_t *>(((pipeline *)pp)->results[q].ab);
 }
 const char *sina_host_result_log(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].log.c_str(); }
 const char *sina_host_result_family(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].family.c_str(); }

@@ -488,6 +488,7 @@ sina_hip_ctx *reference_store::device() {
     std::lock_guard<std::mutex> lk(gpu_mu);
     if (ctx) return ctx;
     hip_check(sina_hip_init(device_id, &ctx), "sina_hip_init");
+    if (refs_by_broadcast) return ctx;  // (filled in place by the start-up broadcast, sina_amd/dist.py)
     std::vector<uint32_t> ab;
     std::vector<uint64_t> off(seqs.size() + 1, 0);
     size_t total = 0;
@@ -916,12 +917,12 @@ bool match_pass(search::result_vector &results, const cseq &query, match_state &
 void famfinder::impl::run(std::vector<tray *> &batch) {
     const ff_options &o = ff_opts;
     std::vector<tray *> todo;
-    // (the device searches queries of up to 8192 bases; a longer one fails alone, softly, like a
-    // sequence without relatives -- not the whole batch)
+    // (the device takes queries of up to SINA_HIP_MAX_QUERY_LEN bases; a longer one fails alone, softly,
+    // like a sequence without relatives -- not the whole batch)
     std::vector<tray *> searchable;
     for (tray *t : batch) {
-        if (t->input_sequence->size() > 8192u) {
-            t->log << "unable to align: sequence longer than 8192 bases;";
+        if (t->input_sequence->size() > SINA_HIP_MAX_QUERY_LEN) {
+            t->log << "unable to align: sequence longer than " << SINA_HIP_MAX_QUERY_LEN << " bases;";
             t->input_sequence->set_attr(fn::turn, "turn-check disabled");
         } else {
             searchable.push_back(t);
@@ -1245,8 +1246,9 @@ void aligner::operator()(std::vector<tray> &batch) {
     parallel_for(batch.size(), [&](size_t i) {
         tray &t = batch[i];
         if (t.input_sequence == nullptr || t.alignment_reference == nullptr || t.astats == nullptr) return;  // :310-318
-        if (t.input_sequence->size() > 8191u) {  // (device limit: soft failure of this tray)
-            t.log << "unable to align: sequence of " << t.input_sequence->size() << " bases (device limit 8191);";
+        if (t.input_sequence->size() > SINA_HIP_MAX_QUERY_LEN) {  // (device limit: soft failure of this tray)
+            t.log << "unable to align: sequence of " << t.input_sequence->size() << " bases (device limit "
+                  << SINA_HIP_MAX_QUERY_LEN << ");";
             return;
         }
         uint64_t tk = host_tsc();
@@ -1339,9 +1341,14 @@ void aligner::operator()(std::vector<tray> &batch) {
     ph.reset();
     // group DP jobs by scoring scheme: default-constructed astats (width 0) => simple
     // scheme, otherwise weighted with that tray's weights (src/align.cpp:404-416)
-    std::map<std::vector<float>, std::vector<size_t>> groups;
+    // ... and by where the family's DAG is built: on the device (families of up to 128 members: the
+    // DAG-build kernel's LDS tables) or, for the rare larger family (--fs-max beyond 128), by the host
+    // twin of that kernel (build_family_graph) and handed over as a graph (sina_hip_align_graphs)
+    constexpr size_t kDeviceFamilyMax = 128;
+    std::map<std::pair<std::vector<float>, bool>, std::vector<size_t>> groups;
     for (size_t i = 0; i < batch.size(); i++)
-        if (need_dp[i]) groups[batch[i].astats->getWeights()].push_back(i);
+        if (need_dp[i])
+            groups[{batch[i].astats->getWeights(), o.device_graph && jobs[i].family.size() <= kDeviceFamilyMax}].push_back(i);
 
     std::shared_ptr<reference_store> store;
     if (!groups.empty()) {
@@ -1349,7 +1356,8 @@ void aligner::operator()(std::vector<tray> &batch) {
         store = reference_store::get(db);
     }
     for (auto &grp : groups) {
-        const std::vector<float> &weights = grp.first;
+        const std::vector<float> &weights = grp.first.first;
+        const bool graph_on_device = grp.first.second;
         const std::vector<size_t> &idx = grp.second;
         const size_t nq = idx.size();
         sina_hip_align_params p;
@@ -1381,7 +1389,7 @@ void aligner::operator()(std::vector<tray> &batch) {
         sina_hip_ctx *ctx = dev.get();
         uint32_t width = 0;
 
-        if (o.device_graph) {
+        if (graph_on_device) {
             std::vector<uint64_t> foff(nq + 1, 0);
             for (size_t x = 0; x < nq; x++) foff[x + 1] = foff[x] + jobs[idx[x]].family.size();
             std::vector<uint32_t> fids(foff.back() ? foff.back() : 1);

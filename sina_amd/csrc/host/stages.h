@@ -191,6 +191,9 @@ public:
 
     // device side
     void set_device(int device) { device_id = device; }
+    // ranks other than 0 of a multi-GPU run: the device copy of the references (and the index) arrives by
+    // broadcast into buffers made by sina_hip_store_alloc_like -- device() then uploads nothing
+    void expect_broadcast() { refs_by_broadcast = true; }
     sina_hip_ctx *device();                    // lazily creates the context and uploads the references
     void ensure_index(unsigned k, bool nofast);  // builds the k-mer index on the GPU once per (k, nofast)
     void adopt_index(unsigned k, bool nofast) {  // index already in HBM (broadcast from another rank)
@@ -230,6 +233,7 @@ private:
     unsigned int width{0};
     std::vector<alignment_stats> vastats;
     int device_id{0};
+    bool refs_by_broadcast{false};
     sina_hip_ctx *ctx{nullptr};
     std::vector<sina_hip_ctx *> idle_forks[dev_roles];  // guarded by gpu_mu
     int idx_k{-1};

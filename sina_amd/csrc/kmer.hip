@@ -35,7 +35,8 @@ namespace {
 constexpr int kCountThreads = 1024;
 constexpr int kTileRefs = 32768;            // refs per LDS histogram tile (64 KiB)
 constexpr int kWide = 2;                    // 1 KiB loads a wave of the count kernel keeps in flight
-constexpr int kMaxQueryLen = 8192;          // k-mer list capacity in LDS (32 KiB)
+constexpr int kMaxQueryLen = (int)SINA_HIP_MAX_QUERY_LEN;  // k-mer list capacity in LDS: 64 KiB tile + 9 B per base <= 160 KiB
+static_assert((size_t)kTileRefs * 2 + ((size_t)kMaxQueryLen + 63) / 64 * 64 * 9 + 64 <= 160 * 1024, "LDS of the count kernel");
 constexpr int kSelThreads = 256;
 constexpr int kSelMax = 4096;               // candidates sortable in LDS
 
@@ -407,8 +408,8 @@ __global__ void __launch_bounds__(kSelThreads) kmer_select_kernel(SelectArgs a) 
     // the number of scores above it come out of that histogram: two passes instead of four or five;
     // otherwise the search below starts from [0, T0).  The histogram borrows cand[] (unused so far).
     constexpr uint32_t kSample = 16;
-    if (nvec >= 2048) {
-        uint32_t *hist = reinterpret_cast<uint32_t *>(cand);  // bins 0..top (top < 8192: kMaxQueryLen)
+    if (nvec >= 2048 && top < 2 * kSelMax) {  // (a query of more k-mers than bins: the general search below)
+        uint32_t *hist = reinterpret_cast<uint32_t *>(cand);  // bins 0..top
         __shared__ int f_t;
         __shared__ uint32_t f_above, f_at;
         const uint32_t nb = (uint32_t)top + 1;
@@ -854,7 +855,7 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
     if (max > (uint32_t)kSelMax) SH_FAIL("kmer_topk: max > 4096 not supported by the LDS select kernel");
     uint32_t max_qlen = 1;
     for (uint32_t q = 0; q < nq; q++) {
-        if (qoff[q + 1] - qoff[q] > (uint64_t)kMaxQueryLen) SH_FAIL("kmer_topk: query longer than 8192 bases");
+        if (qoff[q + 1] - qoff[q] > (uint64_t)kMaxQueryLen) SH_FAIL("kmer_topk: query longer than SINA_HIP_MAX_QUERY_LEN bases");
         max_qlen = std::max<uint32_t>(max_qlen, (uint32_t)(qoff[q + 1] - qoff[q]));
     }
     hipStream_t s = c->stream;
@@ -896,7 +897,7 @@ int sina_hip_kmer_scores(sina_hip_ctx *c, const uint8_t *qmask, uint32_t qlen, i
     if (!c || !qmask || !scores) SH_FAIL("kmer_scores: null argument");
     std::lock_guard<std::mutex> lk(c->mu);
     if (index_ready(c)) return 1;
-    if (qlen > (uint32_t)kMaxQueryLen) SH_FAIL("kmer_scores: query longer than 8192 bases");
+    if (qlen > (uint32_t)kMaxQueryLen) SH_FAIL("kmer_scores: query longer than SINA_HIP_MAX_QUERY_LEN bases");
     SH_CHECK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const uint64_t rel[2] = {0, qlen};

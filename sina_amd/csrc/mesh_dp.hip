@@ -1665,7 +1665,7 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
 // the smallest padded width / throughput.
 static const int kLaneCells[] = {4, 8, 12};
 static const double kLaneRate[] = {226.0, 461.0, 403.0};  // Gcell/s of the B = 4, 8, 12 kernels (above)
-constexpr int kMaxStrips = 16;
+constexpr int kMaxStrips = 40;  // 40 x 256 columns (B = 4) cover SINA_HIP_MAX_QUERY_LEN
 
 bool pick_geom(uint32_t maxL, DpGeom *g) {
     // tuning override: SINA_HIP_DP_GEOM="T,B" (used if it covers the batch's longest query)
@@ -1692,7 +1692,7 @@ bool pick_geom(uint32_t maxL, DpGeom *g) {
     for (int i = 1; i < 3; i++) {
         const int b = kLaneCells[i];
         const uint32_t strips = (maxL + 64u * b - 1) / (64u * b);
-        if (strips > (uint32_t)kMaxStrips || strips * 64u * b > 8192u) continue;  // (13-bit value_sidx, common.h)
+        if (strips > (uint32_t)kMaxStrips) continue;
         const double cost = (double)(strips * 64u * b) / kLaneRate[i];
         if (!found || cost < best) {
             best = cost;

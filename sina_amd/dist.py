@@ -65,6 +65,21 @@ def reduce_sum(value, dist, device=None):
     return float(t.item())
 
 
+def merge_by_seqno(local, dist, dst=0):
+    """--preserve-order across ranks (reference src/sina.cpp:529-538 orders trays by seqno before the
+    writers): every rank hands in its [(seqno, payload), ...]; rank `dst` gets them all, ascending by
+    seqno, the others get None.  `dist` None: a single process, just sorted."""
+    if dist is None:
+        return sorted(local, key=lambda x: x[0])
+    every = [None] * dist.get_world_size()
+    dist.all_gather_object(every, list(local))
+    if dist.get_rank() != dst:
+        return None
+    merged = [item for part in every for item in part]
+    merged.sort(key=lambda x: x[0])
+    return merged
+
+
 class _DevView:
     """Exposes a raw device pointer through __cuda_array_interface__ so that torch can wrap
     it without copying (torch.as_tensor)."""

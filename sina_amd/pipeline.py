@@ -61,6 +61,7 @@ def load_host():
                                       C.POINTER(C.c_uint64)]
     H.sina_host_sidx_store.argtypes = [C.c_char_p, C.c_uint, C.c_int, C.c_uint32, capi.u32p, capi.u32p, C.c_uint64]
     H.sina_host_store_open.argtypes = [C.c_char_p, C.c_int]
+    H.sina_host_store_expect_broadcast.argtypes = [C.c_char_p]
     H.sina_host_run_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint32,
                                       C.POINTER(C.c_double)]
     H.sina_host_fasta_roundtrip.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -92,13 +93,17 @@ def _chk(rc):
 class Store:
     """A reference store registered under `key` (what SINA calls --db)."""
 
-    def __init__(self, key, refs, device=0):
+    def __init__(self, key, refs, device=0, upload=True):
+        """upload=False: a rank other than 0 of a multi-GPU run -- the host side (the cseq objects the
+        results point into) is built here, the device copy arrives by broadcast (dist.broadcast_device_index)."""
         self.H = load_host()
         self.key = key
         ab = np.ascontiguousarray(refs.ab, np.uint32)
         off = np.ascontiguousarray(refs.off, np.uint64)
         _chk(self.H.sina_host_store_from_packed(key.encode(), ab.ctypes.data_as(capi.u32p),
                                                 off.ctypes.data_as(capi.u64p), refs.n, refs.width, device))
+        if not upload:
+            _chk(self.H.sina_host_store_expect_broadcast(key.encode()))
 
     @classmethod
     def open(cls, path, device=0):

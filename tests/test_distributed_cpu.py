@@ -86,3 +86,45 @@ def test_two_rank_sharding_and_broadcast(tmp_path, oracle):
         q = oracle.Cseq.from_packed("q", np.arange(len(m), dtype=np.uint32) | (m.astype(np.uint32) << 24), len(m))
         fids, _, _ = idx.famfinder(q, oracle.ff_opts(fs_min_len=50, fs_full_len=150))
         assert merged[qi] == oracle.align([cs[i] for i in fids], q)["aligned"]
+
+
+def _worker3(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from sina_amd import dist as sdist
+    r, lr, w, dist = sdist.init(backend="gloo")
+    n = 20  # 20 queries over 3 ranks: blocks of 7, 7, 6
+    lo, hi = sdist.shard_range(n, rank, world)
+    # results arrive out of order inside a rank (batches finish as they finish): merged by seqno
+    local = [(q, "aligned-%d-by-rank-%d" % (q, rank)) for q in reversed(range(lo, hi))]
+    merged = sdist.merge_by_seqno(local, dist)
+    total = sdist.reduce_sum(hi - lo, dist)
+    slowest = sdist.reduce_max(float(hi - lo), dist)
+    assert total == n and slowest == 7.0
+    if rank == 0:
+        np.save(os.path.join(out_dir, "merged.npy"), np.array(merged, dtype=object), allow_pickle=True)
+    else:
+        assert merged is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_remainder_shards_and_ordered_merge(tmp_path):
+    """World size 3 (gloo): the query stream does not divide evenly -- every query belongs to exactly one
+    rank, block sizes differ by at most one -- and the per-rank results come back to rank 0 in sequence
+    order (--preserve-order, src/sina.cpp:529-538)."""
+    from sina_amd import dist as sdist
+    blocks = [sdist.shard_range(20, r, 3) for r in range(3)]
+    assert blocks == [(0, 7), (7, 14), (14, 20)]
+    for n in (0, 1, 2, 3, 7, 100001):
+        for w in (1, 2, 3, 8):
+            b = [sdist.shard_range(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(y - x for x, y in b) - min(y - x for x, y in b) <= 1
+    port = _free_port()
+    mp.spawn(_worker3, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    merged = np.load(os.path.join(str(tmp_path), "merged.npy"), allow_pickle=True)
+    assert [int(q) for q, _ in merged] == list(range(20))
+    assert [str(p) for _, p in merged] == ["aligned-%d-by-rank-%d" % (q, 0 if q < 7 else (1 if q < 14 else 2)) for q in range(20)]
+    assert sdist.merge_by_seqno([(2, "c"), (0, "a"), (1, "b")], None) == [(0, "a"), (1, "b"), (2, "c")]

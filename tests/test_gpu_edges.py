@@ -127,10 +127,10 @@ def test_ragged_batch_mixed_lengths(oracle, gpu_ctx):
         assert aligned == want["aligned"]
 
 
-@pytest.mark.parametrize("ref_len,lo,hi", [(6000, 100, 5900), (8400, 60, 8251)])
+@pytest.mark.parametrize("ref_len,lo,hi", [(6000, 100, 5900), (8400, 60, 8251), (10400, 30, 10270)])
 def test_largest_geometry(oracle, gpu_ctx, ref_len, lo, hi):
-    """A 5800-base query (768x8: 12 strips) and one of 8191 bases -- the longest the DP kernel takes,
-    16 strips of 512 columns -- against a 3-member family of references that long: 70 - 140 M cells,
+    """A 5800-base query (768x8: 12 strips), one of 8191 bases (16 strips of 512 columns, round 2's limit)
+    and one of 10240 = SINA_HIP_MAX_QUERY_LEN -- against a 3-member family of references that long: 70 - 140 M cells,
     planes bit-exact."""
     refs = synth.make_refs(6, length=ref_len, width=8 * ref_len, seed=321, n_clades=2)
     cs = util.cseqs_from_refs(refs)
@@ -145,9 +145,9 @@ def test_error_returns(oracle, gpu_ctx):
     refs = synth.make_refs(140, length=100, width=700, seed=331)
     cs = util.cseqs_from_refs(refs)
     g = util.graph_dict([cs[0], cs[1]])
-    too_long = np.ones(8193, np.uint8)
+    too_long = np.ones(10241, np.uint8)
     with pytest.raises(capi.SinaHipError):
-        gpu_ctx.align_graphs(gpu_ctx.graph_batch([g], refs.width), too_long, np.array([0, 8193], np.uint64),
+        gpu_ctx.align_graphs(gpu_ctx.graph_batch([g], refs.width), too_long, np.array([0, 10241], np.uint64),
                              gpu_ctx.params())
     with pytest.raises(capi.SinaHipError):   # empty query
         gpu_ctx.align_graphs(gpu_ctx.graph_batch([g], refs.width), np.ones(1, np.uint8), np.array([0, 0], np.uint64),

@@ -333,13 +333,13 @@ def test_baseline_config_shapes(oracle, shape):
 
 
 def test_overlong_query_fails_alone(oracle, world):
-    """A sequence beyond the device limits (8192 bases for the k-mer search, 8191 for the DP) is a soft
+    """A sequence beyond the device limit (SINA_HIP_MAX_QUERY_LEN = 10240 bases) is a soft
     failure of THAT tray -- reason in the log, no aligned sequence -- and the rest of its batch is
     aligned as usual (the reference aligns any length; this engine does not abort the run)."""
     refs, cs, idx, st = world
     qs = synth.make_queries(refs, 6, seed=61)
     rng = np.random.default_rng(62)
-    long_q = synth.CODE_TO_MASK[rng.integers(0, 4, size=9000)]
+    long_q = synth.CODE_TO_MASK[rng.integers(0, 4, size=11000)]
     masks = [qs.seq(i) for i in range(3)] + [long_q] + [qs.seq(i) for i in range(3, 6)]
     off = np.zeros(len(masks) + 1, np.int64)
     off[1:] = np.cumsum([len(m) for m in masks])
@@ -347,7 +347,7 @@ def test_overlong_query_fails_alone(oracle, world):
     pl = pipeline.Pipeline(st, famfinder=ff)
     pl.run(np.concatenate(masks), off, batch=7, inflight=1)
     got = [pl.result(i) for i in range(7)]
-    assert got[3]["status"] == 2 and "longer than 8192 bases" in got[3]["log"]
+    assert got[3]["status"] == 2 and "longer than 10240 bases" in got[3]["log"]
     sub = synth.QuerySet(mask=qs.mask, off=qs.off, src=qs.src)
     for k, qi in enumerate([0, 1, 2, None, 3, 4, 5]):
         if qi is None:
@@ -357,3 +357,42 @@ def test_overlong_query_fails_alone(oracle, world):
         if want["status"] != 2:
             assert (got[k]["packed"] == want["packed"]).all()
     pl.close()
+
+
+def test_pipeline_9000_base_queries_and_families_of_200(oracle):
+    """What round 2 failed softly: queries longer than 8191 bases (18 strips of 512 columns; the k-mer
+    kernel's cursor list grows with the query) and families larger than the DAG-build kernel's 128
+    (--fs-max 200: the host builds those DAGs, the device aligns them) -- whole pipeline against the
+    oracle, with and without --insertion=forbid (32-bit cells: the widened value_sidx field)."""
+    refs = synth.make_refs(260, length=9400, width=30000, seed=771, n_clades=2)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    st = pipeline.Store(":mem:gpu-long", refs)
+    try:
+        qs = synth.make_queries(refs, 3, seed=772)
+        assert max(len(qs.seq(i)) for i in range(qs.n)) > 9000
+        for al, oal in (({}, {}), ({"insertion": "forbid"}, dict(insertion=1))):
+            ff = {"fs-min-len": 100, "fs-full-len": 250}
+            pl = pipeline.Pipeline(st, famfinder=ff, aligner=al)
+            pl.run(qs.mask, qs.off, batch=3, inflight=1)
+            n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250), al=oal)
+            assert n_dp == 3
+            pl.close()
+    finally:
+        st.close()
+    # families of 200
+    refs = synth.make_refs(400, length=300, width=2400, seed=773, n_clades=1)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    st = pipeline.Store(":mem:gpu-bigfam", refs)
+    try:
+        qs = synth.make_queries(refs, 12, seed=774)
+        ff = {"fs-min-len": 100, "fs-full-len": 250, "fs-min": 200, "fs-max": 200}
+        pl = pipeline.Pipeline(st, famfinder=ff)
+        pl.run(qs.mask, qs.off, batch=12, inflight=1)
+        n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250, fs_min=200, fs_max=200))
+        assert n_dp >= 10
+        assert all(pl.result(i)["family"].count(":") >= 190 for i in range(qs.n) if pl.result(i)["status"] == 0)
+        pl.close()
+    finally:
+        st.close()
