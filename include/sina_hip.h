@@ -163,6 +163,8 @@ typedef struct sina_hip_align_params {
     int32_t insertion;      /* SINA_INSERTION_* */
     const float *weights;   /* posvar weights => scoring_scheme_weighted, or NULL */
     uint32_t n_weights;
+    int32_t assemble;       /* 1: also do the cseq container steps of backtrack() on the device where they
+                             * are plain (see sina_hip_align_out::assembled); 0 (default): columns only */
 } sina_hip_align_params;
 void sina_hip_align_params_default(sina_hip_align_params *p);
 
@@ -202,6 +204,15 @@ typedef struct sina_hip_align_out {
     int32_t cutoff_head, cutoff_tail;
     uint32_t n_out;          /* number of appended bases written to pos[]          */
     int32_t status;          /* 0 ok; <0 device-side failure                       */
+    /* With sina_hip_align_params::assemble: 1 if out_pos holds this query's FINISHED alignment -- n_out
+     * packed aligned_base words (column | iupac mask << 24, case bit included) in sequence order,
+     * after the append rule, setWidth, reverse and the NAST fix-up (src/mesh.h:603-726,
+     * src/cseq.cpp:456-594) -- and the fix-up's log facts below; 0 if out_pos holds the appended
+     * columns as without the switch (an insertion that does not fit its gap and makes neighbours
+     * move, a column beyond the alignment, more than 4096 bases: the host finishes those). */
+    uint32_t assembled;
+    uint32_t nast_total, nast_longest, nast_last_run; /* "total inserted bases", "longest insertion",
+                                                        * "total inserted bases before shifting"     */
 } sina_hip_align_out;
 
 /* Aligns nq queries (upper-cased or not is the caller's business: masks are
@@ -210,7 +221,8 @@ typedef struct sina_hip_align_out {
  *   out        : [nq]
  *   out_pos    : concatenated like qmask; for query q, out_pos[qoff[q] + i] is
  *                the column handed to the i-th cseq::append() call of
- *                backtrack() (i.e. in reverse query order, tail overhang first).
+ *                backtrack() (i.e. in reverse query order, tail overhang first) --
+ *                or, with p->assemble and out[q].assembled, the finished alignment.
  */
 int sina_hip_align_graphs(sina_hip_ctx *ctx, const sina_hip_graph_batch *g, const uint8_t *qmask,
                           const uint64_t *qoff, const sina_hip_align_params *p,

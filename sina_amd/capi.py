@@ -35,7 +35,7 @@ class AlignParams(C.Structure):
     _fields_ = [("match_score", C.c_float), ("mismatch_score", C.c_float), ("gap_penalty", C.c_float),
                 ("gap_ext_penalty", C.c_float), ("fs_weight", C.c_float), ("overhang", C.c_int32),
                 ("lowercase", C.c_int32), ("insertion", C.c_int32), ("weights", f32p),
-                ("n_weights", C.c_uint32)]
+                ("n_weights", C.c_uint32), ("assemble", C.c_int32)]
 
 
 class GraphBatch(C.Structure):
@@ -47,12 +47,14 @@ class GraphBatch(C.Structure):
 class AlignOut(C.Structure):
     _fields_ = [("end_m", C.c_uint32), ("end_s", C.c_uint32), ("raw", C.c_float), ("sum_weight", C.c_float),
                 ("aligned_bases", C.c_int32), ("cutoff_head", C.c_int32), ("cutoff_tail", C.c_int32),
-                ("n_out", C.c_uint32), ("status", C.c_int32)]
+                ("n_out", C.c_uint32), ("status", C.c_int32), ("assembled", C.c_uint32),
+                ("nast_total", C.c_uint32), ("nast_longest", C.c_uint32), ("nast_last_run", C.c_uint32)]
 
 
 ALIGN_OUT_DTYPE = np.dtype([("end_m", "<u4"), ("end_s", "<u4"), ("raw", "<f4"), ("sum_weight", "<f4"),
                             ("aligned_bases", "<i4"), ("cutoff_head", "<i4"), ("cutoff_tail", "<i4"),
-                            ("n_out", "<u4"), ("status", "<i4")])
+                            ("n_out", "<u4"), ("status", "<i4"), ("assembled", "<u4"), ("nast_total", "<u4"),
+                            ("nast_longest", "<u4"), ("nast_last_run", "<u4")])
 
 
 class StoreView(C.Structure):

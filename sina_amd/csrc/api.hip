@@ -50,18 +50,20 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
     hp->rec.resize(nn);
     hp->pred.resize(g->edge_off[q1] - ebase + 8);
     hp->tb_cells = hp->spill_rows = hp->cells = 0;
+    uint32_t erec_cursor = 0;
     for (uint32_t q = q0; q < q1; q++) {
         QDesc &d = hp->qd[q - q0];
         const uint64_t no = g->node_off[q], eo = g->edge_off[q];
         const uint32_t N = (uint32_t)(g->node_off[q + 1] - no);
         d.node_off = no - nbase;
+        d.erec_off = erec_cursor;
+        erec_cursor += dp_edge_entries(N);
         d.edge_off = eo - ebase;
         d.q_off = qoff[q] - qoff[q0];
         d.tb_off = hp->tb_cells;
         d.spill_off = hp->spill_rows;
         d.N = N;
         d.L = (uint32_t)(qoff[q + 1] - qoff[q]);
-        d.pad = 0;
         const uint32_t *po = g->pred_off + no + q;  // N+1 entries, relative to eo
         uint4 *rec = hp->rec.data() + d.node_off;
         for (uint32_t m = 0; m < N; m++) {
@@ -142,6 +144,11 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     const int Lp = pl.geom.Lp();
     const bool weighted = p->weights != nullptr && p->n_weights > 0;
     const bool forbid = p->insertion == SINA_INSERTION_FORBID;
+    // edge records per strip boundary: every query's region starts on a 64-byte line (common.h, EdgeRec);
+    // the callers laid the same offsets into QDesc::erec_off
+    uint64_t edge_entries = 0;
+    for (uint32_t q = 0; q < bq; q++) edge_entries += dp_edge_entries(qd_host[q].N);
+    (void)n_node_entries;
     // The trace-back plane is the one buffer whose size follows the batch (tens of GB for 16S): borrowed
     // from the device's pool of two (ctx.h) until this launch's results are on the host.
     const uint64_t tb_bytes = tb_cell_bytes(forbid) * tb_cells;
@@ -149,7 +156,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     if (plane.acquire(c, std::max<uint64_t>(tb_bytes, 16))) return 1;
     c->last_tb = plane.ptr;
     if (c->spill.reserve(std::max<uint64_t>(spill_rows, 1) * 8 * (uint64_t)Lp) ||
-        c->edge.reserve(std::max<uint64_t>(1, (uint64_t)(pl.geom.T / 64 - 1) * n_node_entries) * sizeof(EdgeRec)) ||
+        c->edge.reserve(std::max<uint64_t>(1, (uint64_t)(pl.geom.T / 64 - 1) * edge_entries) * sizeof(EdgeRec)) ||
         c->res.reserve(sizeof(DpResult) * bq) || c->out.reserve(sizeof(sina_hip_align_out) * bq) ||
         c->out_pos.reserve(4 * std::max<uint64_t>(nqm, 1)))
         return 1;
@@ -174,7 +181,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     a.dbg_value = want_dbg_value ? c->dbg.as<float>() : nullptr;
     a.spill = c->spill.as<float>();
     a.edge = c->edge.as<EdgeRec>();
-    a.edge_stride = n_node_entries;
+    a.edge_stride = edge_entries;
     a.res = c->res.as<DpResult>();
     a.weights = weighted ? c->weights.as<float>() : nullptr;
     a.n_weights = weighted ? p->n_weights : 0;
@@ -221,7 +228,10 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     b.ms = a.ms;
     b.overhang = p->overhang;
     b.lazy_sidx = forbid ? 0 : 1;
+    b.qmask = a.qmask;
+    b.lowercase = p->lowercase;
     if (launch_backtrack(b, s)) return 1;
+    if (p->assemble && launch_assemble(b, s)) return 1;
     if (getenv("SINA_HIP_DEBUG_SYNC")) {
         SH_CHECK(hipStreamSynchronize(s));
         fprintf(stderr, "[sina_hip] backtrack kernel done\n");

@@ -117,7 +117,8 @@ struct QDesc {
     uint64_t tb_off;     // into traceback plane (u32 cells), row stride = Lp
     uint64_t spill_off;  // into spill rows (row units)
     uint32_t N, L;
-    uint32_t n_spill, pad;
+    uint32_t n_spill;
+    uint32_t erec_off;   // into a strip boundary's edge records: regions start on 64-byte lines (4 records), see EdgeRec
 };
 
 // Row record of one DAG node, read through the scalar cache once per row:
@@ -152,6 +153,11 @@ __host__ __device__ inline uint32_t dp_slot_segment(uint32_t n_rows) {
 // What a strip of the DP leaves behind per row for the strip to its right (mesh_dp.hip): the value of
 // its last column (the match candidate's source for the next strip's first column) and the exit
 // state of the insertion chain there.  One record per row and strip boundary, in global memory.
+// They are written with vector stores and read back through the scalar cache, which is not coherent
+// with them: a query's records therefore start on a 64-byte line of their own (QDesc::erec_off is a
+// multiple of 4 records, dp_edge_entries() rounds every query up), so that no other wave's reads can
+// pull a line holding records this wave has yet to write; the wave waits for its stores and drops its
+// scalar-cache lines (s_dcache_inv) before the next strip reads them.
 struct EdgeRec {
     float bnd;      // value[m][last column of the strip]
     float xv;       // chain exit state: value ...
@@ -159,6 +165,7 @@ struct EdgeRec {
     uint32_t gmax;  // ... gaps_max (--insertion=forbid)
 };
 static_assert(sizeof(EdgeRec) == 16, "read back with one 16-byte scalar load");
+inline uint32_t dp_edge_entries(uint32_t n_rows) { return (n_rows + 3u) & ~3u; }  // records a query takes per strip boundary
 
 // Trace-back cell: what backtrack() needs of a DP cell -- the only per-cell HBM traffic.  Two formats:
 //
@@ -241,6 +248,9 @@ struct BtArgs {
     float ms;
     int overhang;
     int lazy_sidx;  // trace-back cells hold a type code, not value_sidx (see kTbTypeMask)
+    // assemble_kernel (sina_hip_align_params::assemble): the query masks the bases come from, --lowercase
+    const uint8_t *qmask;
+    int lowercase;
 };
 
 // Picks the (threads, cells per thread) geometry for the longest query of a batch.
@@ -256,6 +266,9 @@ size_t dp_default_lds_budget(const DpGeom &g);  // LDS per workgroup that keeps 
 int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
                    size_t lds_bytes, hipStream_t s);
 int launch_backtrack(const BtArgs &a, hipStream_t s);
+int launch_assemble(const BtArgs &a, hipStream_t s);  // (after launch_backtrack, same stream)
+// raises a kernel's dynamic-LDS ceiling to a CU's 160 KB, once per kernel and process (mesh_dp.hip)
+int allow_full_lds(const void *kernel);
 
 // geometry + LDS ring depth chosen for a batch
 struct DpPlan {

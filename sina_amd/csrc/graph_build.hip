@@ -666,8 +666,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         ga.member_off = (uint32_t)((glds_tables + 7) & ~(size_t)7);
         ga.member_cap = (uint32_t)graph_member_cap(max_f);
         ga.W = W;
-        SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(family_graph_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+        if (allow_full_lds(reinterpret_cast<const void *>(family_graph_kernel))) return 1;
         bg->sizes.resize(4 * (size_t)bq);
         {
             heavy_launch hl(c, s);  // (a device-filling kernel: ctx.h)
@@ -742,6 +741,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
         while (r0 < bq) {
             uint32_t r1 = r0;
             uint64_t tbc = 0, sprows = 0, cells = 0;
+            uint32_t erec_cursor = 0;
             std::vector<QDesc> qd;
             while (r1 < bq) {
                 const uint32_t N = bg.sizes[4 * r1];
@@ -755,7 +755,8 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
                 d.N = N;
                 d.L = (uint32_t)(qoff[q0 + r1 + 1] - qoff[q0 + r1]);
                 d.n_spill = bg.sizes[4 * r1 + 2];
-                d.pad = 0;
+                d.erec_off = erec_cursor;
+                erec_cursor += dp_edge_entries(N);
                 qd.push_back(d);
                 tbc += (uint64_t)N * Lp;
                 sprows += d.n_spill;

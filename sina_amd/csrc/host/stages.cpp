@@ -1372,6 +1372,7 @@ void aligner::operator()(std::vector<tray> &batch) {
         p.insertion = (int)o.insertion;
         p.weights = weights.empty() ? nullptr : weights.data();
         p.n_weights = (uint32_t)weights.size();
+        p.assemble = 1;  // (the device finishes what it can: sina_hip_align_out::assembled)
 
         ph.reset(), ph.reset(new scoped_phase("al.pack_queries"));  // (the old phase ends first: the new one names the pool jobs)
         std::vector<uint64_t> qoff(nq + 1, 0);
@@ -1450,15 +1451,30 @@ void aligner::operator()(std::vector<tray> &batch) {
             const sina_hip_align_out &r = out[x];
             if (r.status != 0) throw std::runtime_error("device alignment failed for " + c.getName());
             uint64_t tk = host_tsc();
+            const uint32_t L = (uint32_t)t.input_sequence->size();
+            const uint32_t *pos = out_pos.data() + qoff[x];
+            if (r.assembled) {
+                // the device did the container steps (append rule, setWidth, reverse) and a NAST fix-up
+                // in which every insertion fitted its gap: the finished bases, and the fix-up's log line
+                c.clearSequence();
+                std::vector<aligned_base> &fin = c.mutableAlignedBases();  // (a recycled sequence: no allocation)
+                fin.resize(r.n_out);
+                memcpy(static_cast<void *>(fin.data()), pos, sizeof(aligned_base) * (size_t)r.n_out);
+                c.setWidth(width);
+                tk = host_tick("finish: assemble", tk);
+                if (o.insertion == INSERTION_REMOVE) t.log << "insertion=remove not implemented, using shift; ";
+                if (r.nast_total > 0)
+                    t.log << "total inserted bases=" << r.nast_total << ";"
+                          << "longest insertion=" << r.nast_longest << ";"
+                          << "total inserted bases before shifting=" << r.nast_last_run << ";";
+            } else {
             // query bases: the input's, upper-cased unless --lowercase=original (src/align.cpp:324-326)
             const uint32_t *qraw = t.input_sequence->packed();
-            const uint32_t L = (uint32_t)t.input_sequence->size();
             const uint32_t keep_case = o.lowercase == LOWERCASE_ORIGINAL ? 0xFFFFFFFFu : ~((uint32_t)16 << 24);
             const uint32_t lower_bit = o.lowercase == LOWERCASE_UNALIGNED ? (uint32_t)16 << 24 : 0u;
             auto qbase = [&](uint32_t i, bool overhang_base) -> uint32_t {  // base bits of query base i, in place
                 return ((qraw[i] & keep_case) & 0xFF000000u) | (overhang_base ? lower_bit : 0u);
             };
-            const uint32_t *pos = out_pos.data() + qoff[x];
             const bool keep_over = (o.overhang != OVERHANG_REMOVE);
             const uint32_t tail = keep_over ? (uint32_t)r.cutoff_tail : 0;
             const uint32_t head = keep_over ? (uint32_t)r.cutoff_head : 0;
@@ -1501,11 +1517,16 @@ void aligner::operator()(std::vector<tray> &batch) {
             tk = host_tick("finish: assemble", tk);
             c.fix_duplicate_positions(t.log, o.lowercase == LOWERCASE_UNALIGNED, o.insertion == INSERTION_REMOVE);
             tk = host_tick("finish: NAST fix-up", tk);
+            }
             if (c.getWidth() > width) t.log << "warning: result sequence too wide!";
             const float rval = r.raw, sum_weight = r.sum_weight;
             const float score = rval / sum_weight;
-            t.log << "scoring: raw=" << rval << ", weight=" << sum_weight << ", query-len=" << L
-                  << ", aligned-bases=" << r.aligned_bases << ", score=" << score << "; ";
+            {   // (the stream's default float format is printf's %g; one formatting call instead of nine inserts)
+                char line[160];
+                const int len = snprintf(line, sizeof line, "scoring: raw=%g, weight=%g, query-len=%u, aligned-bases=%d, score=%g; ",
+                                         (double)rval, (double)sum_weight, L, r.aligned_bases, (double)score);
+                t.log.write(line, len);
+            }
             tk = host_tick("finish: score log text", tk);
             c.set_attr(fn::head, r.cutoff_head);
             c.set_attr(fn::tail, r.cutoff_tail);

@@ -684,8 +684,7 @@ static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint6
     ca.dense_bits = c->st->dense_bits.as<uint32_t>();
     ca.dense_words = c->st->dense_words;
     const size_t clds = (size_t)kTileRefs * 2 + (size_t)ca.kmax * 9 + 64;
-    SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kmer_count_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+    if (allow_full_lds(reinterpret_cast<const void *>(kmer_count_kernel))) return 1;
     heavy_launch hl(c, s);  // (count + select: device-filling kernels, ctx.h)
     const hipStream_t hs = hl.stream();
     SH_CHECK(hipEventRecord(c->ev[3], hs));

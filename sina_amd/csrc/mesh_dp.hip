@@ -184,7 +184,9 @@ using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 // records are written earlier by this very wave -- but the wave has waited for its stores
 // (vmcnt(0) at the end of a strip) and nothing else writes them.
 __device__ __forceinline__ u32x4 sload16(uint64_t addr) {
-    typedef const __attribute__((address_space(4))) u32x4 *cptr;
+    // (predecessor entries are 4-byte aligned: the load's type says so -- s_load_dwordx4 needs no more)
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef const __attribute__((address_space(4))) u32x4_a4 *cptr;
     return *reinterpret_cast<cptr>(addr);
 }
 // the point where the loaded value must have arrived (an empty asm that reads it: the compiler puts
@@ -232,6 +234,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     // beyond L are read by nothing)
     const uint32_t S = min(n_strips, (L - 1) / (uint32_t)kStrip + 1);
     const uint64_t node_off = uniform(d.node_off);
+    const uint64_t erec_off = uniform(d.erec_off);  // (a multiple of 4 records: 64-byte lines of this query's own)
 
     // ---- LDS: W row slots, each value[kStrip] | gapm_val[kStrip] | value of the column left of the strip
     unsigned char *ring = smem;
@@ -322,8 +325,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     const bool col0_mine = (strip == 0) && (lane == 0);      // my cell 0 is query column 0
     const bool has_col_left = !col0_mine;                     // something is to the left of my cells
     // edge records: what the strip to my left left behind per row (read), what I leave behind (written)
-    const uint64_t e_in = uniform((uint64_t)(edgev + (size_t)(strip ? strip - 1 : 0) * edge_stride + node_off));
-    EdgeRec *e_out = edgev + (size_t)strip * edge_stride + node_off;
+    const uint64_t e_in = uniform((uint64_t)(edgev + (size_t)(strip ? strip - 1 : 0) * edge_stride + erec_off));
+    EdgeRec *e_out = edgev + (size_t)strip * edge_stride + erec_off;
     const bool have_left_strip = strip > 0, have_right_strip = strip + 1 < S;
 
     // query masks of my columns (0 beyond L: never matches, never stored)
@@ -883,7 +886,10 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     all_any = all_any || sk_any;
     // my edge records and spill rows must have left this CU before the next strip reads them back
     // (through the scalar cache / from another lane)
-    if (have_right_strip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (have_right_strip) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_dcache_inv();  // (the scalar cache is not coherent with those stores)
+    }
     }  // strips
     SH_PROF_FLUSH
 
@@ -958,6 +964,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     const uint32_t Lp = n_strips * (uint32_t)kStrip;
     const uint32_t S = min(n_strips, (L - 1) / (uint32_t)kStrip + 1);
     const uint64_t node_off = uniform(d.node_off);
+    const uint64_t erec_off = uniform(d.erec_off);  // (a multiple of 4 records: 64-byte lines of this query's own)
     unsigned char *ring = smem;
     constexpr size_t kValBytes = (size_t)kStrip * 4;
     constexpr size_t kSlotBytes = 2 * kValBytes + 16;
@@ -987,8 +994,8 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     const uint32_t s0 = (strip * 64u + (uint32_t)lane) * B;
     const bool lane0 = lane == 0;
     const bool col0_mine = (strip == 0) && lane0;  // my cell 0 is query column 0
-    const uint64_t e_in = uniform((uint64_t)(edgev + (size_t)(strip ? strip - 1 : 0) * edge_stride + node_off));
-    EdgeRec *e_out = edgev + (size_t)strip * edge_stride + node_off;
+    const uint64_t e_in = uniform((uint64_t)(edgev + (size_t)(strip ? strip - 1 : 0) * edge_stride + erec_off));
+    EdgeRec *e_out = edgev + (size_t)strip * edge_stride + erec_off;
     const bool have_left_strip = uniform((uint32_t)(strip > 0)) != 0, have_right_strip = strip + 1 < S;
 
     // the query base of my columns as v_cmp_class_f32 masks: A -> +0, G -> +normal, C -> +inf,
@@ -1460,6 +1467,7 @@ __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
     o.aligned_bases = 0;
     o.cutoff_head = o.cutoff_tail = 0;
     o.n_out = 0;
+    o.assembled = o.nast_total = o.nast_longest = o.nast_last_run = 0;
     if (r.status != 0) {
         if (lane == 0) a.out[q] = o;
         return;
@@ -1625,13 +1633,130 @@ __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
     if (lane == 0) a.out[q] = o;
 }
 
+
+// The cseq container steps that follow the cell walk in backtrack() (src/mesh.h:603-726), for the
+// queries where they are plain -- one wave per query, behind backtrack_kernel on the same stream:
+//   * every emitted base is appended under the container rule (a column left of the sequence's
+//     current width is moved up to it, src/cseq.cpp:79-95): a running maximum over the emitted columns;
+//   * setWidth(width) + reverse() (:283-289): written back to front, column c -> width - 1 - c;
+//   * fix_duplicate_positions (src/cseq.cpp:456-594): bases sharing a column are an
+//     insertion; where the free columns up to the next base suffice they are placed right-aligned
+//     there (and lower-cased with --lowercase=unaligned) -- the only case handled here.  An insertion
+//     that does not fit and makes its neighbours move, a column at or beyond the alignment's width,
+//     or more than kAsmMax bases leave out_pos as backtrack_kernel wrote it (assembled = 0): the host
+//     finishes those with the container's own code.
+// out_pos is rewritten in place: columns in, packed aligned bases (column | mask << 24) out.
+constexpr int kAsmMax = 4096;
+__global__ void __launch_bounds__(64) assemble_kernel(BtArgs a) {
+    __shared__ uint32_t colm[kAsmMax];                           // column of emission i after the append rule
+    __shared__ unsigned long long dupm[kAsmMax / 64], movedm[kAsmMax / 64];
+    __shared__ uint32_t facts[4];                                // ok, total, longest, last run
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    if (q >= a.nq) return;
+    const QDesc d = a.qd[q];
+    const sina_hip_align_out o = a.out[q];
+    const uint32_t n = o.n_out, width = a.width;
+    if (o.status != 0 || n == 0 || n > (uint32_t)kAsmMax) return;
+    uint32_t *pos = a.out_pos + d.q_off;
+    const uint8_t *qm = a.qmask + d.q_off;
+    const bool keep_over = a.overhang != SINA_OVERHANG_REMOVE;
+    const uint32_t tail = keep_over ? (uint32_t)o.cutoff_tail : 0u;
+    const uint32_t n_aligned = (uint32_t)o.aligned_bases;
+    // ---- append rule: prefix maximum of the emitted columns; equal neighbours are insertions
+    uint32_t carry = 0;
+    bool beyond = false;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        uint32_t v = i < n ? pos[i] : 0u;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(v, off);
+            if ((int)lane >= off) v = max(v, y);
+        }
+        v = max(v, carry);
+        uint32_t prev = __shfl_up(v, 1);
+        if (lane == 0) prev = carry;
+        const bool dup = i < n && i > 0 && v == prev;
+        const unsigned long long dm = __builtin_amdgcn_ballot_w64(dup);
+        if (lane == 0) {
+            dupm[base >> 6] = dm;
+            movedm[base >> 6] = 0ull;
+        }
+        if (i < n) {
+            colm[i] = v;
+            beyond = beyond || v >= width;
+        }
+        carry = __shfl(v, 63);
+    }
+    const bool any_beyond = __builtin_amdgcn_ballot_w64(beyond) != 0ull;
+    __syncthreads();
+    // ---- insertions that fit their gap (one lane: a handful of runs per query)
+    if (lane == 0) {
+        uint32_t total = 0, longest = 0, last_run = 0, ok = any_beyond ? 0u : 1u;
+        bool first = true;
+        uint32_t i = 1;
+        while (ok && i < n) {
+            const unsigned long long word = dupm[i >> 6] >> (i & 63);
+            if (word == 0ull) {
+                i = ((i >> 6) + 1) << 6;
+                continue;
+            }
+            i += (uint32_t)__ffsll((long long)word) - 1u;  // emission i shares its column with i-1
+            const uint32_t i0 = i - 1;                      // first emission of the run = its LAST base in sequence order
+            uint32_t r = 0;                                 // bases to place: emissions i0 .. i0+r-1 (i0+r stays: the anchor)
+            while (i < n && ((dupm[i >> 6] >> (i & 63)) & 1ull)) {
+                r++;
+                i++;
+            }
+            const uint32_t anchor_col = width - 1 - colm[i0];
+            const uint32_t next_col = i0 > 0 ? width - 1 - colm[i0 - 1] : width;  // the next base in sequence order, or the end
+            if (next_col - (anchor_col + 1) < r) {  // does not fit: neighbours would have to move
+                ok = 0;
+                break;
+            }
+            for (uint32_t t = 0; t < r; t++) {  // right-aligned in the gap: emission i0 next to next_col
+                colm[i0 + t] = width - next_col + t;
+                movedm[(i0 + t) >> 6] |= 1ull << ((i0 + t) & 63);
+            }
+            total += r;
+            longest = max(longest, r);
+            if (first) last_run = r;  // (the host walks the sequence left to right: its last run is the first one here)
+            first = false;
+        }
+        facts[0] = ok;
+        facts[1] = total;
+        facts[2] = longest;
+        facts[3] = last_run;
+    }
+    __syncthreads();
+    if (!facts[0]) return;
+    // ---- reverse + bases: sequence position n-1-i <- emission i
+    const uint32_t keep_case = a.lowercase == SINA_LOWERCASE_ORIGINAL ? 0xFFu : 0xEFu;
+    const uint32_t lower = a.lowercase == SINA_LOWERCASE_UNALIGNED ? 0x10u : 0u;
+    const uint32_t first_q = (uint32_t)o.end_s + tail;  // query index of emission 0
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        if (i >= n) break;
+        const bool overhang_base = i < tail || i >= tail + n_aligned;
+        const bool moved = (movedm[i >> 6] >> (i & 63)) & 1ull;
+        const uint32_t bits = ((uint32_t)qm[first_q - i] & keep_case) | ((overhang_base || moved) ? lower : 0u);
+        pos[n - 1 - i] = ((width - 1 - colm[i]) & 0xFFFFFFu) | (bits << 24);
+    }
+    if (lane == 0) {
+        sina_hip_align_out *out = a.out + q;
+        out->assembled = 1;
+        out->nast_total = facts[1];
+        out->nast_longest = facts[2];
+        out->nast_last_run = facts[3];
+    }
+}
+
 template <int B>
 int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t n_strips, size_t lds, hipStream_t s) {
 #define SH_LAUNCH(WG, FB, BL)                                                                              \
     do {                                                                                                \
         auto kfn = a.dbg_value ? mesh_dp_kernel<B, WG, FB, BL, true> : mesh_dp_kernel<B, WG, FB, BL, false>;     \
-        SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                               \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+        if (allow_full_lds(reinterpret_cast<const void *>(kfn))) return 1;                               \
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.node_pos, a.succ_minpos, \
                            a.qmask, a.weights, a.n_weights, a.tb, a.dbg_value, a.spill, a.edge, a.edge_stride, \
                            n_strips, a.res, a.ms, a.mms, a.gp, a.gpe);                                   \
@@ -1641,7 +1766,7 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
     static const bool generic_only = getenv("SINA_HIP_DP_GENERIC") != nullptr && atoi(getenv("SINA_HIP_DP_GENERIC")) != 0;
     if (!weighted && !forbid && a.below_init && a.gp >= a.gpe && !generic_only) {
         auto kfn = a.dbg_value ? mesh_dp_simple_kernel<B, true> : mesh_dp_simple_kernel<B, false>;
-        SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (allow_full_lds(reinterpret_cast<const void *>(kfn))) return 1;
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.qmask, a.tb, a.dbg_value, a.spill,
                            a.edge, a.edge_stride, n_strips, a.res, a.ms, a.mms, a.gp, a.gpe);
     } else if (!weighted && !forbid && a.below_init) SH_LAUNCH(false, false, true);
@@ -1655,6 +1780,22 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
 }
 
 }  // namespace
+
+// The dynamic-LDS ceiling of a kernel is a process-wide attribute: raised ONCE per kernel to all of a
+// CU's 160 KB (a per-launch size would race between contexts launching from different host threads).
+int allow_full_lds(const void *kernel) {
+    static std::mutex mu;
+    static std::vector<const void *> done;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const void *k : done)
+        if (k == kernel) return 0;
+    hipFuncAttributes fa;
+    SH_CHECK(hipFuncGetAttributes(&fa, kernel));  // (the ceiling is what the kernel's static LDS leaves of the 160 KB)
+    const int room = 160 * 1024 - (int)fa.sharedSizeBytes;
+    SH_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, room));
+    done.push_back(kernel);
+    return 0;
+}
 
 // A geometry is (columns per lane B, strips S): one wave sweeps S strips of 64*B columns; T = 64 * S
 // is kept as the geometry's "virtual thread count" (T * B columns).  Fat lanes amortise the per-row
@@ -1737,6 +1878,12 @@ extern "C" int sina_hip_debug_dp_profile(unsigned long long *out32, int reset) {
     return 0;
 }
 #endif
+
+int launch_assemble(const BtArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(assemble_kernel, dim3(a.nq), dim3(64), 0, s, a);
+    SH_CHECK(hipGetLastError());
+    return 0;
+}
 
 int launch_backtrack(const BtArgs &a, hipStream_t s) {
     if (a.lazy_sidx) hipLaunchKernelGGL(backtrack_kernel<true>, dim3(a.nq), dim3(64), 0, s, a);

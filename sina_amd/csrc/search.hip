@@ -227,8 +227,7 @@ extern "C" int sina_hip_compare(sina_hip_ctx *c, const uint32_t *q_ab, const uin
     a.n_refs = c->st->n_refs;
     a.iupac = iupac_rule;
     a.filter_lc = filter_lowercase ? 1 : 0;
-    SH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(compare_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (allow_full_lds(reinterpret_cast<const void *>(compare_kernel))) return 1;
     SH_CHECK(hipEventRecord(c->ev[3], s));
     hipLaunchKernelGGL(compare_kernel, dim3(nq), dim3(kCT), lds, s, a);
     SH_CHECK(hipGetLastError());

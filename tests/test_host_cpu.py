@@ -160,10 +160,12 @@ def test_affinity_plan_without_numa_information():
 
 
 def test_dp_kernels_have_no_inflight_scalar_load_reads(tmp_path):
-    """Guard for a bug this repository had: a hand-placed asynchronous scalar load whose destination
-    SGPRs the compiler spilled before the load had landed (B = 12 --insertion=forbid kernels: wild
-    addresses on the GPU).  Compiles mesh_dp.hip to ISA exactly as the Makefile does and lets
-    tools/check_inflight_spills.py look for reads of an in-flight inline-asm s_load destination."""
+    """Guard for a bug this repository had: a hand-placed asynchronous scalar load in inline asm whose
+    destination SGPRs the compiler spilled before the load had landed (B = 12 --insertion=forbid kernels:
+    wild addresses on the GPU).  Compiles mesh_dp.hip to ISA exactly as the Makefile does (`make isa`) and
+    lets tools/check_inflight_spills.py assert that no memory instruction sits inside inline asm in any DP
+    kernel variant, that it saw the compiler's own scalar loads, and that the production kernels
+    were among those looked at; tools/isa_mix.py must find their row loops."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -172,13 +174,15 @@ def test_dp_kernels_have_no_inflight_scalar_load_reads(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, "sina_amd", "csrc")
     out = str(tmp_path / "mesh_dp.s")
-    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
-                    "-I" + os.path.join(root, "include"), "-I" + src, "-S", "--cuda-device-only",
-                    os.path.join(src, "mesh_dp.hip"), "-o", out], check=True, capture_output=True, timeout=600)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_inflight_spills.py"), out],
+    subprocess.run(["make", "-C", src, "isa", "B=" + str(tmp_path)], check=True, capture_output=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_inflight_spills.py"), out,
+                        "mesh_dp_simple_kernelILi8ELb0E", "mesh_dp_kernelILi8ELb1ELb1ELb0ELb0E",
+                        "mesh_dp_kernelILi12ELb0ELb1ELb0ELb0E"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
-    assert "Li8ELb0ELb0ELb1ELb0E" in r.stdout  # (the production kernel was among those looked at)
+    m = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_mix.py"), out, "simple,8,0"],
+                       capture_output=True, text=True)
+    assert m.returncode == 0 and "mesh_dp_simple_kernel<8,0> row loop" in m.stdout, m.stdout + m.stderr
 
 
 def test_fasta_gzip_in_and_out(tmp_path):
