@@ -306,18 +306,28 @@ def main():
     achieved = DP_BYTES_PER_CELL * dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
 
     # HBM bytes per DP launch from the PMC passes of this same command (tools/prof_bench.sh ->
-    # profiles/r01_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); null if not collected
+    # profiles/r03_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), and the DP kernel's VALU
+    # wave-instructions per cell from its SQ pass (tools/prof_dp_pmc.sh -> profiles/r03_dp_valu.json);
+    # both only if they were recorded on this kernel source revision, else null
+    dp_kernel_name = "mesh_dp_simple_kernel"  # (SINA defaults: simple scheme, gap_open >= gap_extend; mesh_dp.hip)
     dp_traffic, traffic_note = None, "no PMC profile recorded for this kernel source + configuration"
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
         meta = tj.get("_meta", {})
         if (meta.get("kernel_source_rev") == kernel_source_rev() and meta.get("batch") == a.batch and
                 meta.get("sub_batch") == a.sub_batch and meta.get("refs") == a.refs and
                 meta.get("length") == a.length and meta.get("window") == a.window):
-            dp_traffic = tj["mesh_dp_kernel"]["hbm_bytes"]
+            dp_traffic = tj[dp_kernel_name]["hbm_bytes"]
             traffic_note = ("HBM bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from the separate "
-                            "--pmc passes of this same command recorded in profiles/r02_traffic.json (same kernel "
+                            "--pmc passes of this same command recorded in profiles/r03_traffic.json (same kernel "
                             "source revision and configuration as this run; not measured by this run)")
+    except Exception:
+        pass
+    valu_per_cell = None
+    try:
+        vj = json.load(open(os.path.join(ROOT, "profiles", "r03_dp_valu.json")))
+        if vj.get("kernel_source_rev") == kernel_source_rev():
+            valu_per_cell = float(vj["valu_wave_instructions_per_cell"])
     except Exception:
         pass
     verify_failed = False
@@ -369,7 +379,7 @@ def main():
                 "index_build_s": idx_s,
             },
             "roofline": {
-                "kernel": "mesh_dp_kernel",
+                "kernel": dp_kernel_name,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -381,15 +391,31 @@ def main():
                 "cells_per_launch": dp_cells / dp_launches if dp_launches else 0,
                 "ms_per_launch": dp_ms / dp_launches if dp_launches else 0,
                 "gcells_per_s": dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0,
-                "note": "timed region: batches overlap on separate streams, so this duration includes the "
-                        "time the DP kernel shares the GPU with the other kernels; `isolated` = the same "
-                        "kernel on the same inputs with one batch in flight (one extra untimed step)",
+                "note": "contractual accounting (SURVEY 8d): 8 algorithmic bytes per mesh cell against the HBM peak; "
+                        "the kernel writes 2 B per cell and is bound by VALU issue, see roofline_valu.  Timed "
+                        "region: HIP events on the store's FIFO stream, where every device-filling kernel of "
+                        "every batch runs alone; `isolated` = one extra untimed step with a single batch in flight",
                 "isolated": {
                     "achieved": DP_BYTES_PER_CELL * iso["dp_cells"] / (iso["dp_ms"] * 1e-3) / 1e9,
                     "frac": DP_BYTES_PER_CELL * iso["dp_cells"] / (iso["dp_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "ms_per_launch": iso["dp_ms"] / max(1, iso["dp_launches"]),
                     "gcells_per_s": iso["dp_cells"] / (iso["dp_ms"] * 1e-3) / 1e9,
                 },
+            },
+            # what actually binds the kernel: VALU wave-instructions (SQ_INSTS_VALU of the same kernel source,
+            # profiles/r03_dp_sq_counters.txt) at the guide's 2 cycles per wave-instruction and SIMD
+            "roofline_valu": None if valu_per_cell is None or dp_ms <= 0 else {
+                "kernel": dp_kernel_name,
+                "bound": "valu",
+                "achieved": valu_per_cell * dp_cells / (dp_ms * 1e-3) / 1e12,
+                "peak": 1024 * 2.4e9 / 2 / 1e12,
+                "unit": "T wave-instructions/s",
+                "frac": valu_per_cell * dp_cells / (dp_ms * 1e-3) / (1024 * 2.4e9 / 2),
+                "valu_wave_instructions_per_cell": valu_per_cell,
+                "note": "SQ_INSTS_VALU per launch / cells per launch of the DP kernel alone (tools/prof_dp_pmc.sh), "
+                        "x this run's cells; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave-instruction "
+                        "(MI355X_MICROARCH.md); min/compare/DPP class instructions issue at about half that "
+                        "rate (profiles/r02_valu_issue_rates.txt), so 0.6-0.7 here is a saturated VALU",
             },
             "kernels_ms_per_step_isolated": {
                 "kmer_count_kernel": iso["kmer_count_ms"],

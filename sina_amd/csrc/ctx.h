@@ -221,7 +221,7 @@ namespace sina_hip {
 // last round; a launch of 4/3 of it runs the last third on a quarter-filled device (measured, 16S:
 // 3072 queries 27.7 ms, 4096 41.1 ms, 6144 49.7 ms).
 inline uint32_t dp_wave_slots(const sina_hip_ctx *c, int B) {
-    const int waves_per_simd = B <= 4 ? 4 : (B <= 8 ? 3 : 2);
+    const int waves_per_simd = B <= 4 ? 5 : (B <= 8 ? 3 : 2);  // (mesh_dp.hip, dp_default_lds_budget)
     return (uint32_t)(waves_per_simd * 4 * (c->n_cu > 0 ? c->n_cu : 256));
 }
 // End of a DP launch range that the trace-back budget cut short (q1 < limit): whole rounds of wave

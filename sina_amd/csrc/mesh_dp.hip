@@ -38,7 +38,13 @@
 //     writes it, and the next strip -- the same wave, a whole sweep later -- reads it back through
 //     the scalar cache together with the row record.  There is no other wave to wait for: the
 //     kernel has no barrier, no flag and no spin loop at all;
-//   * the only per-cell HBM traffic is the write-once trace-back cell (4 bytes), row-major.
+//   * the only per-cell HBM traffic is the write-once trace-back cell (2 bytes; 4 with
+//     --insertion=forbid), row-major.
+//
+// Two kernels share this design: mesh_dp_kernel<B, WEIGHTED, FORBID, BELOW_INIT> is the general one;
+// mesh_dp_simple_kernel<B> further down is the same recurrence written for the default scheme (what every
+// BASELINE configuration runs) with a third fewer instructions per row.  assemble_kernel finishes the
+// alignments behind backtrack_kernel (container steps + NAST fix-up) where that is plain.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -942,6 +948,13 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
 //     and one bit-field insert moves the LAST predecessor's into the finished cell;
 //   * no inline asm in the recurrence (the hazard recogniser pads v_cmp -> v_cndmask pairs it cannot
 //     see through).
+// Measured and NOT kept (round 3, 3072 16S queries, tools/perf_dp.py; kept version 600 Gcell/s):
+// scalar loads two rows ahead + the first predecessor's LDS row fetched while the previous row is
+// being finished (605 with spill rows sharing the prefetch registers -- every row then waits for the
+// previous row's trace-back store --, 563 with three code copies per source, 587 with the scalar
+// prefetch alone: the loop is bound by instruction issue of its three waves per SIMD, not by these
+// latencies); four waves per SIMD (128 VGPRs, 12 spilled dwords, two LDS slots: 437 against 466 on
+// a 4096-query launch); B = 12 (418).
 // Everything else (weighted scheme, --insertion=forbid, gap_open < gap_extend, huge gap costs) runs
 // mesh_dp_kernel.  Results are bit-identical between the two: tests/test_gpu_parity.py runs every
 // simple-scheme plane test through both (SINA_HIP_DP_GENERIC=1 forces the generic kernel).
@@ -1851,7 +1864,9 @@ size_t dp_fixed_lds_bytes(const DpGeom &) { return 0; }
 int dp_max_ring(const DpGeom &) { return 8; }  // the slot allocators keep 8 slot states; deeper rings gain nothing
 // LDS per workgroup (= per wave) that still lets the kernel's register budget decide the occupancy
 size_t dp_default_lds_budget(const DpGeom &g) {
-    const int waves_per_simd = g.B <= 4 ? 4 : (g.B <= 8 ? SINA_DP_SIMPLE_WAVES8 : 2);
+    // (B = 4: the simple kernel needs 87 VGPRs, five waves per SIMD -- 5120-query launches of V4 amplicons
+    // run 11 % faster per query than 4096-query ones; the general B = 4 kernels stay at four)
+    const int waves_per_simd = g.B <= 4 ? 5 : (g.B <= 8 ? SINA_DP_SIMPLE_WAVES8 : 2);
     return (size_t)160 * 1024 / (4 * waves_per_simd) - 64;
 }
 

@@ -39,7 +39,7 @@ for mask in masks:
         t = time.time(); out, pos = ctx.align_graphs(gb, qm, qoff); dt = time.time() - t
         st = ctx.stats()
         dp = st['dp_ms'] - s0['dp_ms']; cells = st['dp_cells'] - s0['dp_cells']
-        print("abl %d wall %.3fs dp %.2f ms bt %.2f ms cells %.3g  -> %.1f Gcell/s  q/s(dp) %.0f" % (
+        print("abl %d wall %.3fs dp %.2f ms bt %.2f ms cells %.0f  -> %.1f Gcell/s  q/s(dp) %.0f" % (
             mask, dt, dp, st['backtrack_ms'] - s0['backtrack_ms'], cells, cells / dp / 1e6, nq / dp * 1e3))
 # profiling build (make -C sina_amd/csrc PROFILE=1): per-phase share of wave time
 if prof:

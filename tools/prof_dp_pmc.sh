@@ -43,4 +43,22 @@ if g("SQ_WAVE_CYCLES"):
         g("SQ_INSTS_VMEM_WR") + g("SQ_INSTS_VMEM_RD")))
 print("\n".join(out))
 open(d + "/summary.txt", "w").write("\n".join(out) + "\n")
+# VALU wave-instructions per mesh cell, for bench.py's roofline_valu (cells per launch: the run's own log)
+import json, os, re
+sys.path.insert(0, os.getcwd())
+try:
+    import bench
+    cells = None
+    for f in sorted(glob.glob(d + "/run*.log")):
+        for l in open(f):
+            m = re.search(r"cells ([0-9.e+]+)", l)
+            if m:
+                cells = float(m.group(1))
+    if cells and g("SQ_INSTS_VALU"):
+        json.dump({"kernel_source_rev": bench.kernel_source_rev(), "valu_wave_instructions_per_launch": g("SQ_INSTS_VALU"),
+                   "cells_per_launch": cells, "valu_wave_instructions_per_cell": g("SQ_INSTS_VALU") / cells,
+                   "what": "tools/prof_dp_pmc.sh: SQ_INSTS_VALU of the DP kernel alone, tools/perf_dp.py workload"},
+                  open(d + "/dp_valu.json", "w"), indent=1)
+except Exception as e:
+    print("no dp_valu.json:", e)
 PY

@@ -43,7 +43,7 @@ js = {}
 for k in agg:
     f = agg[k].get("FETCH_SIZE", 0.0) * 1024 / max(1, len(cnt[(k, "FETCH_SIZE")]))
     w = agg[k].get("WRITE_SIZE", 0.0) * 1024 / max(1, len(cnt[(k, "WRITE_SIZE")]))
-    name = next((n for n in ("mesh_dp_kernel", "backtrack_kernel", "family_graph_kernel", "kmer_count_kernel",
+    name = next((n for n in ("mesh_dp_simple_kernel", "mesh_dp_kernel", "backtrack_kernel", "assemble_kernel", "family_graph_kernel", "kmer_count_kernel",
                              "kmer_select_kernel", "ref_kmer_keys", "mark_unique", "scatter_unique") if n in k), k[:48])
     js[name] = {"fetch_bytes_raw": f, "fetch_bytes_x2": 2 * f, "write_bytes": w, "hbm_bytes": 2 * f + w,
                 "launches": len(cnt[(k, "WRITE_SIZE")])}
