@@ -230,6 +230,8 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     b.lazy_sidx = forbid ? 0 : 1;
     b.qmask = a.qmask;
     b.lowercase = p->lowercase;
+    b.asm_cap = 0;
+    for (uint32_t q = 0; q < bq; q++) b.asm_cap = std::max<uint32_t>(b.asm_cap, qd_host[q].L);
     if (launch_backtrack(b, s)) return 1;
     if (p->assemble && launch_assemble(b, s)) return 1;
     if (getenv("SINA_HIP_DEBUG_SYNC")) {

@@ -251,6 +251,7 @@ struct BtArgs {
     // assemble_kernel (sina_hip_align_params::assemble): the query masks the bases come from, --lowercase
     const uint8_t *qmask;
     int lowercase;
+    uint32_t asm_cap;  // bases of the launch's longest query (the kernel's LDS follows it)
 };
 
 // Picks the (threads, cells per thread) geometry for the longest query of a batch.

@@ -1659,17 +1659,21 @@ __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
 //     or more than kAsmMax bases leave out_pos as backtrack_kernel wrote it (assembled = 0): the host
 //     finishes those with the container's own code.
 // out_pos is rewritten in place: columns in, packed aligned bases (column | mask << 24) out.
+// LDS: 4 bytes per base of the launch's longest query + 1 KB (16S: 7 KB -- what a resident DP kernel
+// leaves free on a CU, so the wave runs beside it like backtrack_kernel does).
 constexpr int kAsmMax = 4096;
 __global__ void __launch_bounds__(64) assemble_kernel(BtArgs a) {
-    __shared__ uint32_t colm[kAsmMax];                           // column of emission i after the append rule
-    __shared__ unsigned long long dupm[kAsmMax / 64], movedm[kAsmMax / 64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char asm_lds[];
+    unsigned long long *dupm = reinterpret_cast<unsigned long long *>(asm_lds);  // [kAsmMax / 64]
+    unsigned long long *movedm = dupm + kAsmMax / 64;                              // [kAsmMax / 64]
+    uint32_t *colm = reinterpret_cast<uint32_t *>(movedm + kAsmMax / 64);          // [a.asm_cap] column of emission i after the append rule
     __shared__ uint32_t facts[4];                                // ok, total, longest, last run
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     if (q >= a.nq) return;
     const QDesc d = a.qd[q];
     const sina_hip_align_out o = a.out[q];
     const uint32_t n = o.n_out, width = a.width;
-    if (o.status != 0 || n == 0 || n > (uint32_t)kAsmMax) return;
+    if (o.status != 0 || n == 0 || n > a.asm_cap) return;
     uint32_t *pos = a.out_pos + d.q_off;
     const uint8_t *qm = a.qmask + d.q_off;
     const bool keep_over = a.overhang != SINA_OVERHANG_REMOVE;
@@ -1894,8 +1898,11 @@ extern "C" int sina_hip_debug_dp_profile(unsigned long long *out32, int reset) {
 }
 #endif
 
-int launch_assemble(const BtArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(assemble_kernel, dim3(a.nq), dim3(64), 0, s, a);
+int launch_assemble(const BtArgs &a0, hipStream_t s) {
+    BtArgs a = a0;
+    a.asm_cap = std::min<uint32_t>((a.asm_cap + 63u) & ~63u, (uint32_t)kAsmMax);  // (longer queries: the host finishes them)
+    const size_t lds = 2 * (size_t)(kAsmMax / 64) * 8 + 4 * (size_t)a.asm_cap;
+    hipLaunchKernelGGL(assemble_kernel, dim3(a.nq), dim3(64), lds, s, a);
     SH_CHECK(hipGetLastError());
     return 0;
 }

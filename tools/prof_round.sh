@@ -1,0 +1,20 @@
+#!/bin/bash
+# usage: tools/prof_round.sh <tag>  -- everything profiles/<tag>_* is made of, in one GPU session:
+# the bench command under rocprofv3 (kernel trace + the two HBM-traffic PMC passes), the DP kernel's SQ
+# counters and phase timers, the other BASELINE shapes with their kernel statistics, and plain bench lines.
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+TAG=$1
+O=gpurun_out/$TAG
+mkdir -p $O
+bash tools/prof_bench.sh $TAG --no-cpu-baseline > $O/prof_bench.log 2>&1
+python3 tools/perf_dp.py 3072 > /dev/null 2>&1
+bash tools/prof_dp_pmc.sh $TAG 3072 > $O/dp_pmc.log 2>&1
+SINA_HIP_LIB=sina_amd/libsina_hip_prof1.so python3 tools/perf_dp.py 3072 > $O/dp_phase_profile.txt 2>&1
+python3 tools/perf_dp.py 3072 > $O/perf_dp.txt 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt_v4 -o kt -- python3 bench.py --no-cpu-baseline --window 250 --batch 16384 --sub-batch 5120 > $O/v4_bench.json 2> $O/v4.err
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt_23s -o kt -- python3 bench.py --no-cpu-baseline --length 3000 --width 150000 --batch 6144 --sub-batch 3072 --inflight 2 --steps 6 --warmup 1 > $O/23s_bench.json 2> $O/23s.err
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt_500k -o kt -- python3 bench.py --no-cpu-baseline --refs 500000 > $O/500k_bench.json 2> $O/500k.err
+python3 bench.py --steps 20 --warmup 5 > $O/bench_line_plain.json 2> $O/bench_plain.err
+python3 bench.py > $O/bench_line_default.json 2> $O/bench_default.err
+ls -la $O
