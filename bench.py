@@ -61,11 +61,15 @@ def parse():
 
 
 def kernel_source_rev():
-    """Hash of the DP kernel's sources: a recorded PMC profile only describes the kernel it was taken on."""
+    """Hash of the DP kernel's sources without comments and blank space: a recorded PMC profile only
+    describes the code it was taken on (a comment may change, an instruction may not)."""
     import hashlib
+    import re
     h = hashlib.sha1()
     for f in ("mesh_dp.hip", "common.h"):
-        h.update(open(os.path.join(ROOT, "sina_amd", "csrc", f), "rb").read())
+        text = open(os.path.join(ROOT, "sina_amd", "csrc", f), "r").read()
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update(re.sub(r"\s+", " ", text).encode())
     return h.hexdigest()[:16]
 
 

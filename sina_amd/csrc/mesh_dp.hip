@@ -954,7 +954,8 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
 // previous row's trace-back store --, 563 with three code copies per source, 587 with the scalar
 // prefetch alone: the loop is bound by instruction issue of its three waves per SIMD, not by these
 // latencies); four waves per SIMD (128 VGPRs, 12 spilled dwords, two LDS slots: 437 against 466 on
-// a 4096-query launch); B = 12 (418).
+// a 4096-query launch); B = 12 (418); the relaxation's adds two at a time as v_pk_add_f32 (2.6 % fewer VALU
+// instructions, 592: a packed add issues slower than the two adds it replaces).
 // Everything else (weighted scheme, --insertion=forbid, gap_open < gap_extend, huge gap costs) runs
 // mesh_dp_kernel.  Results are bit-identical between the two: tests/test_gpu_parity.py runs every
 // simple-scheme plane test through both (SINA_HIP_DP_GENERIC=1 forces the generic kernel).

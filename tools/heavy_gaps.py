@@ -4,7 +4,7 @@ of a bench run, and what sits in front of the idle gaps."""
 import csv
 import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-HEAVY = ("mesh_dp_kernel", "family_graph_kernel", "kmer_count_kernel", "kmer_select_kernel")
+HEAVY = ("mesh_dp_", "family_graph_kernel", "kmer_count_kernel", "kmer_select_kernel")
 def short(n):
     for k in HEAVY + ("backtrack_kernel", "copyBuffer", "fillBuffer"):
         if k in n:
@@ -12,7 +12,7 @@ def short(n):
     return n[:24]
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in rows)
 hv = [x for x in iv if x[2] in HEAVY]
-dp = [x for x in hv if x[2] == "mesh_dp_kernel"]
+dp = [x for x in hv if x[2] == "mesh_dp_"]
 # steady part: skip the set-up launches
 t0, t1 = dp[len(dp) // 3][0], dp[-3][1]
 hv = [x for x in hv if x[0] >= t0 and x[1] <= t1]
