@@ -418,8 +418,9 @@ def main():
                 "valu_wave_instructions_per_cell": valu_per_cell,
                 "note": "SQ_INSTS_VALU per launch / cells per launch of the DP kernel alone (tools/prof_dp_pmc.sh), "
                         "x this run's cells; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave-instruction "
-                        "(MI355X_MICROARCH.md); min/compare/DPP class instructions issue at about half that "
-                        "rate (profiles/r02_valu_issue_rates.txt), so 0.6-0.7 here is a saturated VALU",
+                        "(MI355X_MICROARCH.md).  At three waves per SIMD the instruction classes of this kernel "
+                        "issue at 3.5 (add / select / logic) and 5.5 (compare / min / DPP) cycles per wave-instruction "
+                        "(profiles/r02_valu_issue_rates.txt): 0.35 at the 2-cycle rate is a VALU that is ~85 % busy",
             },
             "kernels_ms_per_step_isolated": {
                 "kmer_count_kernel": iso["kmer_count_ms"],
