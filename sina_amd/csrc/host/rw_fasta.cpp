@@ -80,6 +80,7 @@ struct zlib_api {
     int (*write)(void *, const void *, unsigned) = nullptr;
     int (*close)(void *) = nullptr;
     int (*buffer)(void *, unsigned) = nullptr;
+    int (*flush)(void *, int) = nullptr;
     const char *(*error)(void *, int *) = nullptr;
     static const zlib_api &get() {
         static const zlib_api api = [] {
@@ -92,6 +93,7 @@ struct zlib_api {
             a.write = reinterpret_cast<int (*)(void *, const void *, unsigned)>(dlsym(h, "gzwrite"));
             a.close = reinterpret_cast<int (*)(void *)>(dlsym(h, "gzclose"));
             a.buffer = reinterpret_cast<int (*)(void *, unsigned)>(dlsym(h, "gzbuffer"));
+            a.flush = reinterpret_cast<int (*)(void *, int)>(dlsym(h, "gzflush"));
             a.error = reinterpret_cast<const char *(*)(void *, int *)>(dlsym(h, "gzerror"));
             if (!a.open || !a.read || !a.write || !a.close) throw std::runtime_error("zlib without the gz* functions");
             return a;
@@ -191,15 +193,23 @@ struct gz_sink : byte_sink {
     ~gz_sink() override {
         if (f) z.close(f);  // (errors at this point have nobody to go to: flush() is where they surface)
     }
+    bool dirty = false;
     void push(const char *src, size_t n) override {
         while (n > 0) {
             const unsigned part = (unsigned)std::min<size_t>(n, 1u << 30);
             if (z.write(f, src, part) != (int)part) throw std::runtime_error("gzip'ed FASTA output failed: " + z.why(f));
             src += part;
             n -= part;
+            dirty = true;
         }
     }
-    void flush() override {}
+    // finishes the compressed stream written so far (a later write starts a new gzip member, which every
+    // reader concatenates): what a deferred write error would otherwise only show at close
+    void flush() override {
+        if (!dirty || !z.flush) return;
+        if (z.flush(f, 4 /* Z_FINISH */) != 0) throw std::runtime_error("gzip'ed FASTA output failed: " + z.why(f));
+        dirty = false;
+    }
 };
 
 // Cuts the input into lines.  A line is handed out as a span of the block buffer, NUL-terminated in
