@@ -191,6 +191,15 @@ typedef struct sina_hip_graph_batch {
     const uint32_t *succ_minpos; /* min column over successors, 1000000 if none
                                   (src/mesh.h:480-484); may be NULL unless FORBID  */
     uint32_t width;            /* alignment width (mseq::getWidth)                 */
+    /* --fs-no-graph (src/pseq.{h,cpp}, scoring_scheme_profile src/scoring_schemes.h:37-100): the family
+     * as a profile -- one node per column, every node's one predecessor the node before it -- whose
+     * match term is base_profile::comp(node, query base) instead of (mask & base) ? match : mismatch.
+     * node_score16[16 * node + m]: that term for a query base with iupac mask m (1..15; entry 0 unused),
+     * self_score16[m]: comp of a base's own profile with itself (the sum_weight term of backtrack(),
+     * src/mesh.h:631-638).  Both NULL (the default) for DAG batches; node_mask / node_weight are
+     * ignored when they are set. */
+    const float *node_score16;
+    const float *self_score16;
 } sina_hip_graph_batch;
 
 /* Per-query result of DP + backtrack walk, before the cseq container steps

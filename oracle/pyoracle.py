@@ -40,7 +40,7 @@ class AlignOpts(C.Structure):
     _fields_ = [("match_score", C.c_float), ("mismatch_score", C.c_float), ("gap_penalty", C.c_float),
                 ("gap_ext_penalty", C.c_float), ("fs_weight", C.c_float), ("overhang", C.c_int),
                 ("lowercase", C.c_int), ("insertion", C.c_int), ("realign", C.c_int),
-                ("weights", f32p), ("n_weights", C.c_uint32)]
+                ("weights", f32p), ("n_weights", C.c_uint32), ("fs_no_graph", C.c_int)]
 
 
 class AlignResult(C.Structure):
@@ -51,7 +51,7 @@ class AlignResult(C.Structure):
 class Graph(C.Structure):
     _fields_ = [("n", C.c_uint32), ("width", C.c_uint32), ("pos", u32p), ("mask", u8p), ("weight", f32p),
                 ("pred_off", u32p), ("pred", u32p), ("succ_off", u32p), ("succ", u32p),
-                ("n_src", C.c_uint32), ("src", u32p), ("n_snk", C.c_uint32), ("snk", u32p)]
+                ("n_src", C.c_uint32), ("src", u32p), ("n_snk", C.c_uint32), ("snk", u32p), ("prof", f32p)]
 
 
 class MatchCounts(C.Structure):
@@ -137,6 +137,10 @@ def lib():
                                    C.POINTER(Log)]
         L.so_mseq_build.restype = C.POINTER(Graph)
         L.so_mseq_build.argtypes = [C.POINTER(vp), C.c_uint32, C.c_float]
+        L.so_pseq_build.restype = C.POINTER(Graph)
+        L.so_pseq_build.argtypes = [C.POINTER(vp), C.c_uint32]
+        L.so_profile_comp.restype = C.c_float
+        L.so_profile_comp.argtypes = [f32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
         L.so_graph_free.argtypes = [C.POINTER(Graph)]
         L.so_align_opts_default.argtypes = [C.POINTER(AlignOpts)]
         L.so_mesh_compute.argtypes = [C.POINTER(Graph), u32p, C.c_uint32, C.POINTER(AlignOpts), vp]
@@ -414,11 +418,30 @@ def mseq_build(fam, weight=1.0):
     return d
 
 
+def pseq_build(fam):
+    """The family as a profile (--fs-no-graph): dict(n, width, pos, prof[n, 6])."""
+    g = lib().so_pseq_build(handles(fam), len(fam))
+    G = g.contents
+    n = G.n
+    d = dict(n=n, width=G.width,
+             pos=np.ctypeslib.as_array(G.pos, shape=(n,)).copy() if n else np.zeros(0, np.uint32),
+             prof=np.ctypeslib.as_array(G.prof, shape=(n, 6)).copy() if n else np.zeros((0, 6), np.float32))
+    lib().so_graph_free(g)
+    return d
+
+
+def profile_comp(prof, smask, match, mismatch, gap, gap_ext):
+    """base_profile::comp of a column (6 floats; None: the base's own profile) with a query base."""
+    p = None if prof is None else _p(np.ascontiguousarray(prof, dtype=np.float32), f32p)
+    return np.float32(lib().so_profile_comp(p, smask, match, mismatch, gap, gap_ext))
+
+
 def mesh_compute(fam, query, opts=None, weight=None):
     """Full cell plane (structured array [N, L]) for family x query."""
     opts = opts or align_opts()
     h = handles(fam)
-    g = lib().so_mseq_build(h, len(fam), opts.fs_weight if weight is None else weight)
+    g = (lib().so_pseq_build(h, len(fam)) if opts.fs_no_graph else
+         lib().so_mseq_build(h, len(fam), opts.fs_weight if weight is None else weight))
     n = g.contents.n
     q = query.packed()
     cells = np.zeros((n, len(q)), CELL_DTYPE)

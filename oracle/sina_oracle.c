@@ -1016,7 +1016,124 @@ void so_graph_free(so_graph *g) {
     free(g->succ);
     free(g->src);
     free(g->snk);
+    free(g->prof);
     free(g);
+}
+
+/* ------------------------------------------------------------- pseq (--fs-no-graph) */
+
+/* base_profile(const base_iupac&), pseq.h:65-86: the share 1 / ambig_order for every base the code stands for */
+static void profile_of_base(int mask, float out[6]) {
+    const int order = __builtin_popcount(mask & 0xf);
+    for (int i = 0; i < 6; i++) out[i] = 0.f;
+    if (order > 0) {
+        const float val = 1.f / (float)order;
+        if (mask & 1) out[0] = val; /* A */
+        if (mask & 2) out[1] = val; /* G */
+        if (mask & 4) out[2] = val; /* C */
+        if (mask & 8) out[3] = val; /* T/U */
+    }
+}
+/* base_profile::comp(const base_profile&, ...), pseq.h:100-113: sixteen products added up in i-outer, j-inner
+ * order (float, no contraction), then the two gap terms */
+static float profile_comp2(const float a[6], const float b[6], float match, float mismatch, float gap, float gap_ext) {
+    float res = 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            if (i == j) res += match * a[i] * b[j];
+            else res += mismatch * a[i] * b[j];
+        }
+    return res + gap * a[4] + gap_ext * a[5];
+}
+float so_profile_comp(const float *prof, int smask, float match, float mismatch, float gap, float gap_ext) {
+    float b[6];
+    profile_of_base(smask, b);
+    return profile_comp2(prof ? prof : b, b, match, mismatch, gap, gap_ext);
+}
+
+/* pseq::pseq, pseq.cpp:41-112: walk the alignment's occupied columns (column 0 first, occupied or not);
+ * per column every family member either shows a base -- 12 / ambig_order points for each base it may
+ * be -- or is in a gap, which counts as opened (its previous column had a base) or extended */
+so_graph *so_pseq_build(const so_cseq *const *fam, uint32_t F) {
+    so_graph *g = (so_graph *)calloc(1, sizeof(so_graph));
+    const uint32_t width = F ? fam[0]->width : 0;
+    g->width = width;
+    uint32_t *it = (uint32_t *)calloc(F ? F : 1, sizeof(uint32_t));
+    uint8_t *gap = (uint8_t *)malloc(F ? F : 1);
+    for (uint32_t i = 0; i < F; i++) gap[i] = 1;
+    uint32_t cap = 1024, n = 0;
+    g->pos = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+    g->prof = (float *)malloc(sizeof(float) * 6 * cap);
+    uint32_t current = 0;
+    while (current < width) {
+        uint32_t next = width;
+        int A = 0, G = 0, Cc = 0, T = 0, gap_open = 0, gap_extend = 0;
+        for (uint32_t row = 0; row < F; row++) {
+            const so_cseq *s = fam[row];
+            if (it[row] < s->n && SO_POS(s->ab[it[row]]) == current) {
+                const int m = SO_MASK(s->ab[it[row]]);
+                const int order = __builtin_popcount(m & 0xf);
+                if (order > 0) {
+                    const int points = 12 / order;
+                    if (m & 1) A += points;
+                    if (m & 2) G += points;
+                    if (m & 4) Cc += points;
+                    if (m & 8) T += points;
+                    gap[row] = 0;
+                }
+                ++it[row];
+            } else {
+                if (gap[row]) ++gap_extend;
+                else {
+                    gap[row] = 1;
+                    ++gap_open;
+                }
+            }
+            if (it[row] < s->n && SO_POS(s->ab[it[row]]) < next) next = SO_POS(s->ab[it[row]]);
+        }
+        if (n == cap) {
+            cap *= 2;
+            g->pos = (uint32_t *)realloc(g->pos, sizeof(uint32_t) * cap);
+            g->prof = (float *)realloc(g->prof, sizeof(float) * 6 * cap);
+        }
+        { /* base_profile(a, g, c, t, open * 12, extend * 12), pseq.h:54-63 */
+            const int open = gap_open * 12, extend = gap_extend * 12;
+            const int sum = A + G + Cc + T + open + extend;
+            float *p = g->prof + 6 * (size_t)n;
+            p[0] = (float)A / sum;
+            p[1] = (float)G / sum;
+            p[2] = (float)Cc / sum;
+            p[3] = (float)T / sum;
+            p[4] = (float)open / sum;
+            p[5] = (float)extend / sum;
+        }
+        g->pos[n++] = current;
+        current = next;
+    }
+    free(it);
+    free(gap);
+    g->n = n;
+    /* a chain: node m follows node m - 1 (pseq.h prev_begin / next_begin); first and last are the only
+     * source and sink (pn_first_* / pn_last_*) */
+    g->mask = (uint8_t *)calloc(n ? n : 1, 1);
+    g->weight = (float *)calloc(n ? n : 1, sizeof(float));
+    g->pred_off = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    g->succ_off = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    g->pred = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    g->succ = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    g->pred_off[0] = g->succ_off[0] = 0;
+    for (uint32_t m = 0; m < n; m++) {
+        g->pred_off[m + 1] = g->pred_off[m] + (m > 0 ? 1u : 0u);
+        if (m > 0) g->pred[g->pred_off[m]] = m - 1;
+        g->succ_off[m + 1] = g->succ_off[m] + (m + 1 < n ? 1u : 0u);
+        if (m + 1 < n) g->succ[g->succ_off[m]] = m + 1;
+    }
+    g->n_src = g->n_snk = n ? 1 : 0;
+    g->src = (uint32_t *)malloc(sizeof(uint32_t));
+    g->snk = (uint32_t *)malloc(sizeof(uint32_t));
+    g->src[0] = 0;
+    g->snk[0] = n ? n - 1 : 0;
+    return g;
 }
 
 /* ------------------------------------------------------------- mesh DP */
@@ -1043,6 +1160,11 @@ typedef struct {
     const float *w;
     uint32_t nw;
 } scheme;
+/* scoring_scheme_profile::match (scoring_schemes.h:84-92): prev + comp(); its gap costs are the
+ * constant ones of the simple scheme (:47-82) */
+static float s_match_profile(const scheme *s, float prev, const float *prof, uint8_t smask) {
+    return prev + so_profile_comp(prof, smask, s->ms, s->mms, s->gp, s->gpe);
+}
 static float sw(const scheme *s, uint32_t i) { return s->w[i < s->nw ? i : s->nw - 1]; }
 static float s_insertion(const scheme *s, float prev, uint32_t mpos) {
     if (!s->w) return prev + s->gp;
@@ -1070,7 +1192,7 @@ static void scheme_from_opts(scheme *s, const so_align_opts *o) {
     s->mms = -o->mismatch_score;
     s->gp = o->gap_penalty;
     s->gpe = o->gap_ext_penalty;
-    s->w = (o->weights && o->n_weights) ? o->weights : NULL;
+    s->w = (o->weights && o->n_weights && !o->fs_no_graph) ? o->weights : NULL;
     s->nw = o->n_weights;
 }
 
@@ -1172,7 +1294,8 @@ void so_mesh_compute(const so_graph *g, const uint32_t *q, uint32_t L, const so_
                 for (uint32_t e = pb; e < pe; e++) { /* match, mesh.h:360-374 */
                     uint32_t mi = g->pred[e];
                     const so_cell *msrc = &cells[(size_t)mi * L + sidx];
-                    float value = s_match(&s, msrc->value, g->mask[m], SO_MASK(q[si]), mpos, g->weight[m]);
+                    float value = g->prof ? s_match_profile(&s, msrc->value, g->prof + 6 * (size_t)m, SO_MASK(q[si]))
+                                          : s_match(&s, msrc->value, g->mask[m], SO_MASK(q[si]), mpos, g->weight[m]);
                     if (value < d.value) {
                         d.value = value;
                         d.value_midx = mi;
@@ -1244,7 +1367,8 @@ float so_backtrack(const so_graph *g, const uint32_t *q, uint32_t L, const so_ce
     so_cseq_append_base(out, SO_AB(pos, SO_MASK(q[s])), NULL); /* :626-628 */
     aligned_bases++;
     /* :631-638: master node copy with the slave's base => comp() is true */
-    sum_weight = s_match(&sch, sum_weight, SO_MASK(q[s]), SO_MASK(q[s]), g->pos[m], g->weight[m]);
+    sum_weight = g->prof ? s_match_profile(&sch, sum_weight, NULL, SO_MASK(q[s]))
+                         : s_match(&sch, sum_weight, SO_MASK(q[s]), SO_MASK(q[s]), g->pos[m], g->weight[m]);
 
     while (s != sbegin && !in_set(g->src, g->n_src, m)) { /* :642-685 */
         uint32_t snew = MESH(m, s).value_sidx;
@@ -1257,7 +1381,8 @@ float so_backtrack(const so_graph *g, const uint32_t *q, uint32_t L, const so_ce
             --s;
             so_cseq_append_base(out, SO_AB(pos, SO_MASK(q[s])), NULL);
             aligned_bases++;
-            sum_weight = s_match(&sch, sum_weight, SO_MASK(q[s]), SO_MASK(q[s]), g->pos[m], g->weight[m]);
+            sum_weight = g->prof ? s_match_profile(&sch, sum_weight, NULL, SO_MASK(q[s]))
+                                 : s_match(&sch, sum_weight, SO_MASK(q[s]), SO_MASK(q[s]), g->pos[m], g->weight[m]);
         }
     }
 
@@ -1401,7 +1526,8 @@ part_done:;
     }
 
     {
-        so_graph *g = so_mseq_build(vc, nfam, o->fs_weight); /* :399-402 */
+        so_graph *g = o->fs_no_graph ? so_pseq_build(vc, nfam)                 /* :429 */
+                                     : so_mseq_build(vc, nfam, o->fs_weight); /* :399-402 */
         if (!g) {
             res->status = -1;
             goto done;

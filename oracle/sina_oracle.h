@@ -156,8 +156,18 @@ typedef struct so_graph {
     uint32_t *succ_off, *succ;
     uint32_t n_src, *src;
     uint32_t n_snk, *snk;
+    /* --fs-no-graph (pseq, src/pseq.{h,cpp}): the family as a PROFILE -- one node per column, a linear
+     * chain -- instead of a DAG.  prof[6 * m] = {A, G, C, T/U share, gap-open share, gap-extend share}
+     * of node m (base_profile, pseq.h:54-63); NULL for an mseq graph (mask / weight are unused then). */
+    float *prof;
 } so_graph;
 so_graph *so_mseq_build(const so_cseq *const *fam, uint32_t F, float weight); /* NULL: throw */
+/* pseq::pseq, src/pseq.cpp:41-112 */
+so_graph *so_pseq_build(const so_cseq *const *fam, uint32_t F);
+/* base_profile::comp (pseq.h:100-117) of node profile `prof` (6 floats) against the base with iupac mask
+ * `smask`, or -- prof NULL -- of that base's own profile against itself (the "had there been a match"
+ * term of backtrack(), mesh.h:631-638) */
+float so_profile_comp(const float *prof, int smask, float match, float mismatch, float gap, float gap_ext);
 void so_graph_free(so_graph *g);
 
 /* ---- mesh DP: src/mesh.h:263-528, src/scoring_schemes.h:102-241 */
@@ -177,6 +187,7 @@ typedef struct so_align_opts {
     int overhang, lowercase, insertion, realign;
     const float *weights; /* posvar weights (scoring_scheme_weighted) or NULL */
     uint32_t n_weights;
+    int fs_no_graph;      /* --fs-no-graph: pseq + scoring_scheme_profile (align.cpp:428-433) */
 } so_align_opts;
 void so_align_opts_default(so_align_opts *o);
 

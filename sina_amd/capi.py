@@ -41,7 +41,7 @@ class AlignParams(C.Structure):
 class GraphBatch(C.Structure):
     _fields_ = [("nq", C.c_uint32), ("node_off", u64p), ("edge_off", u64p), ("node_pos", u32p),
                 ("node_mask", u8p), ("node_weight", f32p), ("pred_off", u32p), ("pred", u32p),
-                ("succ_minpos", u32p), ("width", C.c_uint32)]
+                ("succ_minpos", u32p), ("width", C.c_uint32), ("node_score16", f32p), ("self_score16", f32p)]
 
 
 class AlignOut(C.Structure):

@@ -189,6 +189,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     a.mms = -p->mismatch_score;
     a.gp = p->gap_penalty;
     a.gpe = p->gap_ext_penalty;
+    a.prof16 = c->profile_batch ? c->prof16.as<float>() : nullptr;
     {
         uint32_t max_n = 0;
         for (uint32_t q = 0; q < bq; q++) max_n = std::max<uint32_t>(max_n, qd_host[q].N);
@@ -230,6 +231,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     b.lazy_sidx = forbid ? 0 : 1;
     b.qmask = a.qmask;
     b.lowercase = p->lowercase;
+    b.self16 = c->profile_batch ? c->self16.as<float>() : nullptr;
     b.asm_cap = 0;
     for (uint32_t q = 0; q < bq; q++) b.asm_cap = std::max<uint32_t>(b.asm_cap, qd_host[q].L);
     if (launch_backtrack(b, s)) return 1;
@@ -277,6 +279,8 @@ int upload_weights(sina_hip_ctx *c, const sina_hip_align_params *p) {
     }
     return 0;
 }
+
+static bool weighted_scheme(const sina_hip_align_params *p) { return p->weights != nullptr && p->n_weights > 0; }
 
 static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, const uint8_t *qmask,
                              const uint64_t *qoff, const sina_hip_align_params *p, sina_hip_align_out *out,
@@ -332,6 +336,14 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         if (g->succ_minpos)
             SH_CHECK(hipMemcpyAsync(c->succ_minpos.p, g->succ_minpos + nbase, 4 * nn, hipMemcpyHostToDevice, s));
         SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qbase, nqm, hipMemcpyHostToDevice, s));
+        c->profile_batch = g->node_score16 != nullptr;
+        if (c->profile_batch) {  // --fs-no-graph: the profile's match-term tables (sina_hip.h)
+            if (!g->self_score16) SH_FAIL("align_graphs: node_score16 without self_score16");
+            if (weighted_scheme(p)) SH_FAIL("align_graphs: a profile batch takes no positional weights (scoring_scheme_profile)");
+            if (c->prof16.reserve(64 * std::max<uint64_t>(nn, 1)) || c->self16.reserve(64)) return 1;
+            SH_CHECK(hipMemcpyAsync(c->prof16.p, g->node_score16 + 16 * nbase, 64 * nn, hipMemcpyHostToDevice, s));
+            SH_CHECK(hipMemcpyAsync(c->self16.p, g->self_score16, 64, hipMemcpyHostToDevice, s));
+        }
         if (run_dp_device(c, pl, hp.qd.data(), bq, nn, hp.tb_cells, hp.spill_rows, hp.cells, nqm, p, g->width, out + q0,
                           out_pos + qbase, dbg_value_host != nullptr))
             return 1;

@@ -231,6 +231,7 @@ struct DpArgs {
     const float *weights;       // posvar weights (device) or nullptr
     uint32_t n_weights;
     float ms, mms, gp, gpe;     // scheme ctor args: -match, -mismatch, gap, gapext
+    const float *prof16;        // --fs-no-graph: match term per node and query mask [16 * node + mask], else nullptr
 };
 
 struct BtArgs {
@@ -252,6 +253,7 @@ struct BtArgs {
     const uint8_t *qmask;
     int lowercase;
     uint32_t asm_cap;  // bases of the launch's longest query (the kernel's LDS follows it)
+    const float *self16;  // --fs-no-graph: comp(base, base) per iupac mask (sum_weight's term), else nullptr
 };
 
 // Picks the (threads, cells per thread) geometry for the longest query of a batch.

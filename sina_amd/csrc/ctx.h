@@ -71,6 +71,8 @@ struct sina_hip_ctx {
 
     // per-batch scratch, grown on demand and reused
     sina_hip::DevBuf qd, order, rec, node_pos, pred, succ_minpos, qmask, spill, edge, res, weights, out, out_pos, dbg;
+    sina_hip::DevBuf prof16, self16;  // --fs-no-graph: match-term tables of a profile batch (sina_hip_graph_batch)
+    bool profile_batch = false;       // the launch being prepared is one (set by sina_hip_align_graphs)
     void *last_tb = nullptr;  // the plane of the last launch (debug read-back: sina_hip_debug_mesh)
     sina_hip::DevBuf k_qoff, k_scores, k_out_ids, k_out_scores, k_out_n, k_tmp0, k_tmp1, k_tmp2;
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes, g_wtab;
@@ -81,14 +83,14 @@ struct sina_hip_ctx {
 
     size_t lds_budget = 0;  // LDS per DP workgroup; 0 = what keeps the register-limited occupancy (dp_default_lds_budget)
 
-    static constexpr int kNumScratch = 34;
+    static constexpr int kNumScratch = 36;
     static_assert(kNumScratch <= 64, "sina_hip_store::cap_hint is too short");
     void scratch(sina_hip::DevBuf **all) {
         sina_hip::DevBuf *list[kNumScratch] = {&qd, &rec, &node_pos, &pred, &succ_minpos, &qmask, &spill, &res,
                                                &weights, &out, &out_pos, &k_qoff, &k_scores, &k_out_ids,
                                                &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2, &g_fam_ids,
                                                &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab, &order,
-                                               &s_qab, &s_qoff, &s_cand, &s_coff, &s_out, &edge};
+                                               &s_qab, &s_qoff, &s_cand, &s_coff, &s_out, &edge, &prof16, &self16};
         for (int i = 0; i < kNumScratch; i++) all[i] = list[i];
     }
     void publish_hints() {  // after a call: remember how big my buffers had to be

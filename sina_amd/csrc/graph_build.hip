@@ -778,6 +778,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
             if (c->qd.reserve(sizeof(QDesc) * rq) || c->qmask.reserve(std::max<uint64_t>(nqm, 1))) return 1;
             if (upload(c, 5, c->qd.p, qd.data(), sizeof(QDesc) * rq, s) || upload(c, 6, c->qmask.p, qmask + qbase, nqm, s))
                 return 1;
+            c->profile_batch = false;  // (device-built DAGs: never a profile)
             if (run_dp_device(c, pl, qd.data(), rq, (uint64_t)bq * bg.ncap, tbc, sprows, cells, nqm, p, c->st->width,
                               out + q0 + r0, out_pos + qbase, false))
                 return 1;

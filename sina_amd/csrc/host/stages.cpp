@@ -1042,6 +1042,99 @@ void famfinder::operator()(std::vector<tray> &batch) {
 // ================================================================ host DAG build
 
 // src/mseq.cpp:47-118 + src/graph.h:332-357,466-488, flat arrays.
+// ---- --fs-no-graph: pseq + scoring_scheme_profile (src/pseq.{h,cpp}, src/scoring_schemes.h:37-100)
+namespace {
+struct base_shares {  // base_profile: shares of A, G, C, T/U, opened gaps, extended gaps in a column
+    float v[6];
+};
+base_shares shares_of_base(unsigned mask) {  // base_profile(const base_iupac&), pseq.h:65-86
+    base_shares b{};
+    const int order = __builtin_popcount(mask & 0xfu);
+    if (order > 0) {
+        const float val = 1.f / (float)order;
+        for (int i = 0; i < 4; i++)
+            if (mask & (1u << i)) b.v[i] = val;
+    }
+    return b;
+}
+// base_profile::comp, pseq.h:100-113: sixteen products in i-outer, j-inner order, then the gap terms
+float profile_comp(const base_shares &a, const base_shares &b, float match, float mismatch, float gap, float gap_ext) {
+    float res = 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            if (i == j) res += match * a.v[i] * b.v[j];
+            else res += mismatch * a.v[i] * b.v[j];
+        }
+    return res + gap * a.v[4] + gap_ext * a.v[5];
+}
+}  // namespace
+
+void profile_self_scores(float match, float mismatch, float gap, float gap_ext, float *out16) {
+    out16[0] = 0.f;
+    for (unsigned m = 1; m < 16; m++) {
+        const base_shares b = shares_of_base(m);
+        out16[m] = profile_comp(b, b, match, mismatch, gap, gap_ext);
+    }
+}
+
+void build_family_profile(const std::vector<const cseq *> &fam, float match, float mismatch, float gap, float gap_ext,
+                          host_graph *g) {
+    const size_t F = fam.size();
+    g->pos.clear(); g->mask.clear(); g->weight.clear(); g->score16.clear();
+    g->pred_off.assign(1, 0); g->pred.clear(); g->succ_minpos.clear();
+    g->width = F ? fam[0]->getWidth() : 0;
+    std::vector<uint32_t> at(F, 0);   // next unread base of every member
+    std::vector<char> in_gap(F, 1);   // (a member's leading gap counts as extended)
+    base_shares code[16];
+    for (unsigned m = 0; m < 16; m++) code[m] = shares_of_base(m);
+    uint32_t column = 0;
+    while (column < g->width) {  // column 0 first, occupied or not; then from occupied column to occupied column
+        uint32_t next = g->width;
+        int cnt[4] = {0, 0, 0, 0}, opened = 0, extended = 0;
+        for (size_t j = 0; j < F; j++) {
+            const auto &b = fam[j]->getAlignedBases();
+            if (at[j] < b.size() && b[at[j]].getPosition() == column) {
+                const unsigned mask = (b[at[j]].raw >> 24) & 0xfu;
+                const int order = __builtin_popcount(mask);
+                if (order > 0) {
+                    const int points = 12 / order;
+                    for (int i = 0; i < 4; i++)
+                        if (mask & (1u << i)) cnt[i] += points;
+                    in_gap[j] = 0;
+                }
+                ++at[j];
+            } else if (in_gap[j]) {
+                ++extended;
+            } else {
+                in_gap[j] = 1;
+                ++opened;
+            }
+            if (at[j] < b.size()) next = std::min(next, (uint32_t)b[at[j]].getPosition());
+        }
+        base_shares col;
+        {
+            const int open = opened * 12, ext = extended * 12;
+            const int sum = cnt[0] + cnt[1] + cnt[2] + cnt[3] + open + ext;
+            for (int i = 0; i < 4; i++) col.v[i] = (float)cnt[i] / sum;
+            col.v[4] = (float)open / sum;
+            col.v[5] = (float)ext / sum;
+        }
+        const uint32_t node = (uint32_t)g->pos.size();
+        g->pos.push_back(column);
+        g->mask.push_back(0);
+        g->weight.push_back(0.f);
+        g->score16.push_back(std::numeric_limits<float>::infinity());  // (mask 0: no query base has it)
+        for (unsigned m = 1; m < 16; m++) g->score16.push_back(profile_comp(col, code[m], match, mismatch, gap, gap_ext));
+        if (node > 0) g->pred.push_back(node - 1);
+        g->pred_off.push_back((uint32_t)g->pred.size());
+        column = next;
+    }
+    // successor minima (for --insertion=forbid): the next node's column, 1000000 behind the last (mesh.h:480-484)
+    const size_t N = g->pos.size();
+    g->succ_minpos.resize(N);
+    for (size_t m = 0; m < N; m++) g->succ_minpos[m] = m + 1 < N ? g->pos[m + 1] : 1000000u;
+}
+
 void build_family_graph(const std::vector<const cseq *> &fam, float fs_weight, host_graph *g) {
     const size_t F = fam.size();
     g->pos.clear(); g->mask.clear(); g->weight.clear();
@@ -1160,7 +1253,8 @@ void aligner::set_option(const std::string &name, const std::string &value) {
     else if (name == "pen-gapext") o.gap_ext_penalty = std::stof(value);
     else if (name == "write-used-rels") o.write_used_rels = to_bool(value);
     else if (name == "calc-idty") o.calc_idty = to_bool(value);
-    else if (name == "fs-no-graph" || name == "use-subst-matrix" || name == "debug-graph") {
+    else if (name == "fs-no-graph") o.fs_no_graph = to_bool(value);
+    else if (name == "use-subst-matrix" || name == "debug-graph") {
         if (to_bool(value)) throw std::logic_error("aligner: --" + name + " is outside the accelerated path");
     } else if (name == "device-graph") o.device_graph = to_bool(value);
     else if (name == "db") o.database = value;
@@ -1346,9 +1440,13 @@ void aligner::operator()(std::vector<tray> &batch) {
     // twin of that kernel (build_family_graph) and handed over as a graph (sina_hip_align_graphs)
     constexpr size_t kDeviceFamilyMax = 128;
     std::map<std::pair<std::vector<float>, bool>, std::vector<size_t>> groups;
+    // (--fs-no-graph: the family as a profile, built by the host; scoring_scheme_profile takes no positional
+    // weights, src/align.cpp:428-433)
     for (size_t i = 0; i < batch.size(); i++)
-        if (need_dp[i])
-            groups[{batch[i].astats->getWeights(), o.device_graph && jobs[i].family.size() <= kDeviceFamilyMax}].push_back(i);
+        if (need_dp[i]) {
+            if (o.fs_no_graph) groups[{std::vector<float>(), false}].push_back(i);
+            else groups[{batch[i].astats->getWeights(), o.device_graph && jobs[i].family.size() <= kDeviceFamilyMax}].push_back(i);
+        }
 
     std::shared_ptr<reference_store> store;
     if (!groups.empty()) {
@@ -1405,7 +1503,13 @@ void aligner::operator()(std::vector<tray> &batch) {
         } else {
             std::vector<host_graph> gs(nq);
             ph.reset(), ph.reset(new scoped_phase("al.host_graph_build"));  // (the old phase ends first: the new one names the pool jobs)
-            parallel_for(nq, [&](size_t x) { build_family_graph(jobs[idx[x]].family, o.fs_weight, &gs[x]); });
+            parallel_for(nq, [&](size_t x) {
+                if (o.fs_no_graph)
+                    build_family_profile(jobs[idx[x]].family, -o.match_score, -o.mismatch_score, o.gap_penalty,
+                                         o.gap_ext_penalty, &gs[x]);
+                else
+                    build_family_graph(jobs[idx[x]].family, o.fs_weight, &gs[x]);
+            });
             ph.reset(), ph.reset(new scoped_phase("al.host_graph_concat"));  // (the old phase ends first: the new one names the pool jobs)
             sina_hip_graph_batch gb;
             std::vector<uint64_t> node_off(nq + 1, 0), edge_off(nq + 1, 0);
@@ -1417,6 +1521,9 @@ void aligner::operator()(std::vector<tray> &batch) {
                 poff(node_off.back() + nq), smin(node_off.back());
             std::vector<uint8_t> nmask(node_off.back());
             std::vector<float> nw(node_off.back());
+            std::vector<float> nscore(o.fs_no_graph ? 16 * (size_t)node_off.back() : 0);
+            float self16[16];
+            if (o.fs_no_graph) profile_self_scores(-o.match_score, -o.mismatch_score, o.gap_penalty, o.gap_ext_penalty, self16);
             parallel_for(nq, [&](size_t x) {
                 const host_graph &g = gs[x];
                 std::copy(g.pos.begin(), g.pos.end(), npos.begin() + node_off[x]);
@@ -1425,6 +1532,7 @@ void aligner::operator()(std::vector<tray> &batch) {
                 std::copy(g.succ_minpos.begin(), g.succ_minpos.end(), smin.begin() + node_off[x]);
                 std::copy(g.pred_off.begin(), g.pred_off.end(), poff.begin() + node_off[x] + x);
                 std::copy(g.pred.begin(), g.pred.end(), pred.begin() + edge_off[x]);
+                if (o.fs_no_graph) std::copy(g.score16.begin(), g.score16.end(), nscore.begin() + 16 * node_off[x]);
             });
             width = gs[0].width;
             gb.nq = (uint32_t)nq;
@@ -1437,6 +1545,8 @@ void aligner::operator()(std::vector<tray> &batch) {
             gb.pred = pred.data();
             gb.succ_minpos = smin.data();
             gb.width = width;
+            gb.node_score16 = o.fs_no_graph ? nscore.data() : nullptr;
+            gb.self_score16 = o.fs_no_graph ? self16 : nullptr;
             ph.reset(), ph.reset(new scoped_phase("al.align_graphs(C-ABI)"));  // (the old phase ends first: the new one names the pool jobs)
             hip_check(sina_hip_align_graphs(ctx, &gb, qmask.data(), qoff.data(), &p, out.data(), out_pos.data()),
                       "align_graphs");

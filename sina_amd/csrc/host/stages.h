@@ -548,7 +548,15 @@ struct host_graph {
     std::vector<float> weight;
     std::vector<uint32_t> pred_off, pred, succ_minpos;
     uint32_t width = 0;
+    std::vector<float> score16;  // --fs-no-graph only: match term per node and query iupac mask (16 per node)
 };
 void build_family_graph(const std::vector<const cseq *> &family, float fs_weight, host_graph *g);
+// --fs-no-graph (src/pseq.cpp:41-112, src/pseq.h:42-117): the family as a profile -- one node per column, a
+// chain -- with base_profile::comp() of every node against the fifteen iupac codes tabulated for the
+// scoring_scheme_profile(match, mismatch, gap, gap_ext) the aligner builds (src/align.cpp:429-433)
+void build_family_profile(const std::vector<const cseq *> &family, float match, float mismatch, float gap,
+                          float gap_ext, host_graph *g);
+// comp() of a base's own profile with itself, per iupac mask (16 entries; the sum_weight term of backtrack())
+void profile_self_scores(float match, float mismatch, float gap, float gap_ext, float *out16);
 
 }  // namespace sina

@@ -223,7 +223,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                const uint8_t *__restrict__ qmaskv, const float *__restrict__ weights, uint32_t n_weights,
                void *__restrict__ tbv, float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev,
                uint64_t edge_stride, uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp,
-               float gpe) {
+               float gpe, const float *__restrict__ prof16v) {
     static_assert(B % 4 == 0, "16-byte accesses per array");
     constexpr int kStrip = 64 * B;  // columns per strip
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -402,6 +402,13 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
             gde_v = vge;
 #pragma unroll
             for (int k = 0; k < B; k++) csel[k] = (r.mmask & qm[k]) ? vM : vX;  // comp(): optimistic IUPAC match (aligned_base.h:153)
+            if (prof16v != nullptr) {
+                // --fs-no-graph: the row is a profile column, its match term a table over the query's base
+                // (scoring_scheme_profile::match, scoring_schemes.h:84-92; the table is the host's, exact)
+                const float *tab = prof16v + 16 * (size_t)(node_off + m);
+#pragma unroll
+                for (int k = 0; k < B; k++) csel[k] = tab[qm[k]];
+            }
         }
         // (FIRST: the row's first predecessor meets the initial values -- constants -- instead of
         // registers that would have to be initialised first)
@@ -1551,7 +1558,10 @@ __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
             emit((uint32_t)(p > 0 ? p : 0));
         }
     }
-    auto mscore = [&](const uint4 &rx) -> float {  // tr.s.match(sum, ab2, ab1) with comp()==true
+    const uint8_t *qmb = a.qmask + d.q_off;
+    auto mscore_at = [&](const uint4 &rx, uint32_t si) -> float {  // tr.s.match(sum, ab2, ab1) with comp()==true
+        // (--fs-no-graph: the master copy takes the slave's base, its profile is compared with itself)
+        if (a.self16 != nullptr) return a.self16[qmb[si] & 0xfu];
         const float wgt = __uint_as_float(rx.y);
         if (a.weights != nullptr) {
             const uint32_t nw1 = a.n_weights - 1;
@@ -1565,7 +1575,7 @@ __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
     int aligned = 0;
     emit(pos);
     aligned++;
-    sum_weight = sum_weight + mscore(rm);
+    sum_weight = sum_weight + mscore_at(rm, s);
 
     // value_midx of a cell whose deletion extends the gap of predecessor x: gapm_idx[x][col]
     // (common.h, Ext / OpLast) -- follow last predecessors to the row that opened the gap
@@ -1620,12 +1630,11 @@ __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
         rm = rec_at(m);
         npred_m = rm.z & 0xffu;
         pos = width - 1 - rm.w;
-        const float ms_w = mscore(rm);
         while (s != snew) {
             --s;
             emit(pos);
             aligned++;
-            sum_weight = sum_weight + ms_w;
+            sum_weight = sum_weight + mscore_at(rm, s);
         }
     }
     // left hand overhang (:690-721)
@@ -1777,12 +1786,12 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
         if (allow_full_lds(reinterpret_cast<const void *>(kfn))) return 1;                               \
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.node_pos, a.succ_minpos, \
                            a.qmask, a.weights, a.n_weights, a.tb, a.dbg_value, a.spill, a.edge, a.edge_stride, \
-                           n_strips, a.res, a.ms, a.mms, a.gp, a.gpe);                                   \
+                           n_strips, a.res, a.ms, a.mms, a.gp, a.gpe, a.prof16);                         \
     } while (0)
     // the simple scheme with gap_open >= gap_extend in a launch below the initial value (every BASELINE
     // configuration): the specialised kernel; SINA_HIP_DP_GENERIC=1 keeps the generic one (parity tests)
     static const bool generic_only = getenv("SINA_HIP_DP_GENERIC") != nullptr && atoi(getenv("SINA_HIP_DP_GENERIC")) != 0;
-    if (!weighted && !forbid && a.below_init && a.gp >= a.gpe && !generic_only) {
+    if (!weighted && !forbid && a.below_init && a.gp >= a.gpe && !generic_only && a.prof16 == nullptr) {
         auto kfn = a.dbg_value ? mesh_dp_simple_kernel<B, true> : mesh_dp_simple_kernel<B, false>;
         if (allow_full_lds(reinterpret_cast<const void *>(kfn))) return 1;
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.qmask, a.tb, a.dbg_value, a.spill,

@@ -84,6 +84,31 @@ def test_pipeline_aligner_options(oracle, world, al, oal):
     pl.close()
 
 
+@pytest.mark.parametrize("geom", [None, "128,12", "128,4"])
+@pytest.mark.parametrize("al,oal", [
+    ({}, {}),
+    ({"insertion": "forbid", "overhang": "remove"}, dict(insertion=1, overhang=1)),
+    ({"lowercase": "unaligned", "overhang": "edge", "pen-gap": 4, "pen-gapext": 1.5, "match-score": 3,
+      "mismatch-score": -2}, dict(lowercase=2, overhang=2, gap_penalty=4, gap_ext_penalty=1.5, match_score=3,
+                                  mismatch_score=-2)),
+])
+def test_pipeline_fs_no_graph_profile(oracle, world, monkeypatch, geom, al, oal):
+    """--fs-no-graph (src/align.cpp:428-433): the family as a profile (pseq) scored with
+    scoring_scheme_profile.  The host builds the column chain and tabulates base_profile::comp per node
+    and iupac code; the DP kernel reads the match term from that table."""
+    refs, cs, idx, st = world
+    if geom:
+        monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+    qs = synth.make_queries(refs, 24, seed=57, window=(0.3, 120), ins=0.02, dele=0.02, lower_rate=0.05, amb_rate=0.02)
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    pl = pipeline.Pipeline(st, famfinder=ff, aligner=dict(al, **{"fs-no-graph": True}))
+    pl.run(qs.mask, qs.off, batch=24, inflight=1)
+    n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250),
+                     al=dict(oal, fs_no_graph=1))
+    assert n_dp >= 20
+    pl.close()
+
+
 @pytest.mark.parametrize("geom", ["128,12", "256,12", "128,8", "384,4"])
 @pytest.mark.parametrize("insertion", ["forbid", "shift"])
 def test_pipeline_forced_multi_strip_geometries(oracle, world, monkeypatch, geom, insertion):
@@ -222,6 +247,9 @@ def test_pipeline_option_fuzz(oracle, world, monkeypatch, seed):
     oal = dict(overhang={"attach": 0, "remove": 1, "edge": 2}[overhang], lowercase={"none": 0, "original": 1, "unaligned": 2}[lowercase],
                insertion=1 if insertion == "forbid" else 0, match_score=ms, mismatch_score=mms, gap_penalty=gp,
                gap_ext_penalty=gpe, fs_weight=fsw)
+    if seed % 4 == 3:  # every fourth case: the family as a profile (positional weights then play no part)
+        al["fs-no-graph"] = True
+        oal["fs_no_graph"] = 1
     ff = {"fs-min-len": 100, "fs-full-len": 250}
     if weighted:
         w = rng.uniform(0.3, 1.4, size=refs.width).astype(np.float32)

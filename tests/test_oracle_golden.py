@@ -358,3 +358,60 @@ def test_mesh_planes_equal_reference_parts_hashes(oracle):
         assert cells.shape == tuple(shapes[ci]), ci
         got = [util.plane_hash(cells[f]) for f in util.MESH_PLANES]
         assert got == list(hashes[ci]), (ci, case["scheme"])
+
+
+# ---- --fs-no-graph: pseq + scoring_scheme_profile (src/pseq.{h,cpp}, src/scoring_schemes.h:37-100).
+# The reference holds no test or fixture for this option and pseq.h cannot be compiled here (it
+# includes cseq.h, which needs Boost): the restatement is checked against values worked by hand from
+# the published formulas -- "parity unpinned" for this option, as DESIGN.md says.
+def test_profile_columns_by_hand(oracle):
+    fam = [oracle.Cseq("a", "AC-GU"), oracle.Cseq("b", "A--GR"), oracle.Cseq("c", "-CNG-")]
+    p = oracle.pseq_build(fam)
+    assert p["width"] == 5 and list(p["pos"]) == [0, 1, 2, 3, 4]
+    f = np.float32
+    # column 0: A, A, leading gap (extended): 12, 12 points + 12 for the gap
+    assert np.array_equal(p["prof"][0], np.array([24, 0, 0, 0, 0, 12], f) / f(36))
+    # column 1: C, gap opened (b), C
+    assert np.array_equal(p["prof"][1], np.array([0, 0, 24, 0, 12, 0], f) / f(36))
+    # column 2: gap opened (a), gap extended (b), N = 3 points each
+    assert np.array_equal(p["prof"][2], np.array([3, 3, 3, 3, 12, 12], f) / f(36))
+    # column 3: G G G
+    assert np.array_equal(p["prof"][3], np.array([0, 36, 0, 0, 0, 0], f) / f(36))
+    # column 4: U, R = A|G 6 points each, gap opened (c)
+    assert np.array_equal(p["prof"][4], np.array([6, 6, 0, 12, 12, 0], f) / f(36))
+
+
+def test_profile_skips_unoccupied_columns_but_keeps_column_zero(oracle):
+    fam = [oracle.Cseq("a", "--A---C-"), oracle.Cseq("b", "--A---G-")]
+    p = oracle.pseq_build(fam)
+    assert list(p["pos"]) == [0, 2, 6]  # column 0 first, occupied or not (pseq.cpp:67-69)
+    assert np.array_equal(p["prof"][0], np.array([0, 0, 0, 0, 0, 1], np.float32))
+    assert np.array_equal(p["prof"][2], np.array([0, .5, .5, 0, 0, 0], np.float32))
+
+
+def test_profile_comp_by_hand(oracle):
+    f = np.float32
+    col = np.array([6, 6, 0, 12, 12, 0], f) / f(36)
+    ms, mms, gp, gpe = f(-2), f(1), f(5), f(2)
+    for mask, shares in [(1, [1, 0, 0, 0]), (8, [0, 0, 0, 1]), (3, [.5, .5, 0, 0]), (15, [.25] * 4),
+                         (14, [0, f(1) / f(3), f(1) / f(3), f(1) / f(3)])]:
+        res = f(0)
+        for i in range(4):          # sixteen products, i outer and j inner, each rounded to float
+            for j in range(4):
+                res = f(res + f(f((ms if i == j else mms) * col[i]) * f(shares[j])))
+        want = f(f(res + f(gp * col[4])) + f(gpe * col[5]))
+        assert oracle.profile_comp(col, mask, ms, mms, gp, gpe) == want
+    # a base against itself: the "had there been a match" weight of backtrack()
+    assert oracle.profile_comp(None, 1, ms, mms, gp, gpe) == f(-2)
+    assert oracle.profile_comp(None, 3, ms, mms, gp, gpe) == f(f(-2 * .25) * 2 + f(1 * .25) * 2)
+
+
+def test_profile_alignment_without_family_gaps_keeps_the_columns(oracle):
+    fam = [oracle.Cseq("a", "--ACGGUUAGCAAUGCAGGCU-"), oracle.Cseq("b", "--ACAGUUCGCAAUGCAGGCU-"),
+           oracle.Cseq("c", "--ACGGUUAGCUAUGCAGCCU-")]
+    q = oracle.Cseq("q", "ACGGUUAGCAAUGGAGGCU")  # (one substitution: no member contains it, no copy shortcut)
+    r = oracle.align(fam, q, oracle.align_opts(fs_no_graph=1))
+    assert r["status"] == 0
+    assert r["aligned"].replace(".", "-") == "--ACGGUUAGCAAUGGAGGCU-"
+    # 18 of 19 bases scored (the first one starts the path): raw = 1 + sum of comp(), weight = 19 * -2
+    assert "weight=-38, query-len=19, aligned-bases=19" in r["log"]
