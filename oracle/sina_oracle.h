@@ -162,7 +162,8 @@ typedef struct so_graph {
     float *prof;
 } so_graph;
 so_graph *so_mseq_build(const so_cseq *const *fam, uint32_t F, float weight); /* NULL: throw */
-/* pseq::pseq, src/pseq.cpp:41-112 */
+/* pseq::pseq, src/pseq.cpp:41-112.  PARITY UNPINNED for --fs-no-graph: the reference holds no test or vector
+ * for it and pseq.h does not compile here (Boost); checked against hand-worked values only */
 so_graph *so_pseq_build(const so_cseq *const *fam, uint32_t F);
 /* base_profile::comp (pseq.h:100-117) of node profile `prof` (6 floats) against the base with iupac mask
  * `smask`, or -- prof NULL -- of that base's own profile against itself (the "had there been a match"

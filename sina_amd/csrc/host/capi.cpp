@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "stages.h"
+#include "id_order.h"
 
 #include <fstream>
 #include <map>
@@ -281,6 +282,40 @@ int sina_host_store_open(const char *path, int device) {
         return fail(e);
     }
 }
+// the same with the sequences numbered as the reference numbers an ARB database's (host/id_order.h)
+int sina_host_store_open_arb_order(const char *path, int device) {
+    try {
+        auto s = reference_store::open(path, true);
+        s->set_device(device);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+// order[i] = database position of the sequence the reference gives id i (query_arb.cpp:160,470-474,732-739);
+// hashes[j] (optional) = boost::hash<std::string> of names[j]; returns the number of ids (distinct names)
+uint32_t sina_host_reference_order(const char *const *names, uint32_t n, uint32_t *order, uint64_t *hashes,
+                                   uint64_t *bucket_count) {
+    std::vector<std::string> v(names, names + n);
+    std::size_t buckets = 0;
+    const std::vector<uint32_t> o = arb_name_order(v, &buckets);
+    std::copy(o.begin(), o.end(), order);
+    if (hashes)
+        for (uint32_t i = 0; i < n; i++) hashes[i] = (uint64_t)arb_name_hash(v[i]);
+    if (bucket_count) *bucket_count = buckets;
+    return (uint32_t)o.size();
+}
+// name of reference `id` of a store (empty string: no such id)
+const char *sina_host_store_name(const char *key, uint32_t id) {
+    static thread_local std::string s;
+    try {
+        auto st = reference_store::get(key);
+        s = id < st->size() ? st->getCseq(id).getName() : std::string();
+    } catch (const std::exception &) {
+        s.clear();
+    }
+    return s.c_str();
+}
 const char *sina_host_store_index_origin(const char *key) {
     static thread_local std::string s;
     try {
@@ -476,7 +511,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                     // bases than its query -- a copied alignment exactly as many)
                     r.n_ab = std::min<uint32_t>(c.size(), (uint32_t)(qoff[q + 1] - qoff[q]));
                     r.ab = base_block + qoff[q];
-                    memcpy(base_block + qoff[q], c.packed(), sizeof(aligned_base) * (size_t)r.n_ab);
+                    memcpy((void *)(base_block + qoff[q]), c.packed(), sizeof(aligned_base) * (size_t)r.n_ab);
                 }
                 if (t.search_result) {
                     r.searched = true;

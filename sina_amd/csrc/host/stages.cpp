@@ -3,6 +3,7 @@
 // lifting goes through the C ABI (include/sina_hip.h).  No CPU fallback: if the
 // HIP library reports an error, the stage throws.
 #include "stages.h"
+#include "id_order.h"
 
 #include <algorithm>
 #include <atomic>
@@ -387,7 +388,7 @@ std::shared_ptr<reference_store> reference_store::from_packed(const std::string 
 }
 
 // Minimal aligned-FASTA reader ('>' name [description], sequence lines; '-'/'.' are gaps).
-std::shared_ptr<reference_store> reference_store::open(const std::string &path) {
+std::shared_ptr<reference_store> reference_store::open(const std::string &path, bool arb_id_order) {
     std::ifstream in(path);
     if (!in) throw std::logic_error("Reference database file " + path + " does not exist");
     std::shared_ptr<reference_store> s(new reference_store());
@@ -411,6 +412,16 @@ std::shared_ptr<reference_store> reference_store::open(const std::string &path) 
         }
     }
     flush();
+    if (arb_id_order) {
+        std::vector<std::string> names;
+        names.reserve(s->seqs.size());
+        for (const auto &c : s->seqs) names.push_back(c.getName());
+        const std::vector<uint32_t> order = arb_name_order(names);
+        std::vector<cseq> sorted;
+        sorted.reserve(order.size());
+        for (uint32_t from : order) sorted.push_back(std::move(s->seqs[from]));
+        s->seqs.swap(sorted);
+    }
     for (const auto &c : s->seqs) s->width = std::max(s->width, c.getWidth());
     for (auto &c : s->seqs) c.setWidth(s->width);
     std::lock_guard<std::mutex> lk(stores_mu);

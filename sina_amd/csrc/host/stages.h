@@ -156,7 +156,10 @@ public:
 class reference_store {
 public:
     // register / look up by "database path" (famfinder --db)
-    static std::shared_ptr<reference_store> open(const std::string &path);  // aligned FASTA file
+    // aligned FASTA file.  arb_id_order: number the sequences as the reference numbers an ARB database's
+    // (host/id_order.h) instead of in file order -- tie-exact family order against a stock SINA binary,
+    // and the order of names a .sidx written by it holds
+    static std::shared_ptr<reference_store> open(const std::string &path, bool arb_id_order = false);
     static std::shared_ptr<reference_store> from_packed(const std::string &path_key, const uint32_t *ab,
                                                          const uint64_t *off, uint32_t n, uint32_t width,
                                                          const char *const *names = nullptr);

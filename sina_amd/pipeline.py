@@ -61,6 +61,11 @@ def load_host():
                                       C.POINTER(C.c_uint64)]
     H.sina_host_sidx_store.argtypes = [C.c_char_p, C.c_uint, C.c_int, C.c_uint32, capi.u32p, capi.u32p, C.c_uint64]
     H.sina_host_store_open.argtypes = [C.c_char_p, C.c_int]
+    H.sina_host_store_open_arb_order.argtypes = [C.c_char_p, C.c_int]
+    H.sina_host_reference_order.restype = C.c_uint32
+    H.sina_host_reference_order.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, capi.u32p, capi.u64p, capi.u64p]
+    H.sina_host_store_name.restype = C.c_char_p
+    H.sina_host_store_name.argtypes = [C.c_char_p, C.c_uint32]
     H.sina_host_store_expect_broadcast.argtypes = [C.c_char_p]
     H.sina_host_run_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint32,
                                       C.POINTER(C.c_double)]
@@ -90,6 +95,20 @@ def _chk(rc):
         raise HostError(load_host().sina_host_last_error().decode())
 
 
+def reference_order(names):
+    """(order, hashes, bucket_count): order[i] = position in `names` (database order) of the sequence the
+    reference gives id i -- the walk of its unordered_map<string, ..., boost::hash<string>>."""
+    H = load_host()
+    n = len(names)
+    arr = (C.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    order = np.zeros(max(n, 1), np.uint32)
+    hashes = np.zeros(max(n, 1), np.uint64)
+    buckets = np.zeros(1, np.uint64)
+    m = H.sina_host_reference_order(arr, n, order.ctypes.data_as(capi.u32p), hashes.ctypes.data_as(capi.u64p),
+                                    buckets.ctypes.data_as(capi.u64p))
+    return order[:m].copy(), hashes[:n].copy(), int(buckets[0])
+
+
 class Store:
     """A reference store registered under `key` (what SINA calls --db)."""
 
@@ -106,14 +125,21 @@ class Store:
             _chk(self.H.sina_host_store_expect_broadcast(key.encode()))
 
     @classmethod
-    def open(cls, path, device=0):
+    def open(cls, path, device=0, id_order="file"):
         """An aligned-FASTA database file; its k-mer index is cached beside it as <name>.sidx in the
-        reference's own format (kmer_search.cpp:213-243)."""
+        reference's own format (kmer_search.cpp:213-243).  id_order="arb": number the sequences as the
+        reference numbers an ARB database's (host/id_order.h; query_arb.cpp:160,732-739)."""
         self = cls.__new__(cls)
         self.H = load_host()
         self.key = path
-        _chk(self.H.sina_host_store_open(path.encode(), device))
+        if id_order not in ("file", "arb"):
+            raise ValueError("id_order: 'file' or 'arb'")
+        _chk((self.H.sina_host_store_open_arb_order if id_order == "arb" else self.H.sina_host_store_open)(
+            path.encode(), device))
         return self
+
+    def name(self, i):
+        return self.H.sina_host_store_name(self.key.encode(), i).decode()
 
     def index_origin(self):
         return self.H.sina_host_store_index_origin(self.key.encode()).decode()

@@ -216,3 +216,62 @@ def test_fasta_reader_edge_cases(tmp_path):
     open(gz, "wb").write(whole[:len(whole) // 2])
     with pytest.raises(pipeline.HostError):
         pipeline.fasta_roundtrip(gz, dst)
+
+
+# ---- reference id order of an ARB database (host/id_order.h; query_arb.cpp:160,470-474,732-739)
+def _boost_hash_string(s):
+    """boost::hash<std::string>, Boost 1.62 ... 1.80 on a 64-bit target: hash_range over the characters with
+    the 64-bit hash_combine (boost/container_hash/hash.hpp), written here from the published algorithm."""
+    M64 = (1 << 64) - 1
+    m = 0xc6a4a7935bd1e995
+    seed = 0
+    for ch in s.encode():
+        k = ch if ch < 128 else ch | 0xFFFFFFFFFFFFFF00  # (plain char is signed on x86-64)
+        k = (k * m) & M64
+        k ^= k >> 47
+        k = (k * m) & M64
+        seed ^= k
+        seed = (seed * m) & M64
+        seed = (seed + 0xe6546b64) & M64
+    return seed
+
+
+def test_reference_order_is_the_walk_of_a_hash_table():
+    from sina_amd import pipeline
+    rng = np.random.default_rng(5)
+    names = ["%s%05d.%d" % ("".join(chr(65 + int(c)) for c in rng.integers(0, 26, 2)), int(rng.integers(0, 99999)), i)
+             for i in range(5000)]
+    order, hashes, buckets = pipeline.reference_order(names)
+    assert sorted(order.tolist()) == list(range(5000))          # a permutation of the database order
+    assert order.tolist() != list(range(5000))
+    assert [int(h) for h in hashes[:200]] == [_boost_hash_string(s) for s in names[:200]]
+    assert _boost_hash_string("") == 0 and int(pipeline.reference_order(["\xe9"])[1][0]) == _boost_hash_string("\xe9")
+    assert buckets >= 5000                                      # (load factor <= 1)
+    # a walk of the table visits a bucket's names together: the bucket of consecutive ids changes
+    # exactly (number of occupied buckets - 1) times
+    b = [int(hashes[j]) % buckets for j in order]
+    changes = sum(1 for x, y in zip(b, b[1:]) if x != y)
+    assert changes == len(set(b)) - 1
+    # the same names, the same order; a repeated name keeps one id
+    assert pipeline.reference_order(names)[0].tolist() == order.tolist()
+    assert len(pipeline.reference_order(["a", "b", "a"])[0]) == 2
+
+
+def test_store_opened_in_arb_order(tmp_path):
+    from sina_amd import pipeline
+    rng = np.random.default_rng(6)
+    names = ["Seq%04d" % int(x) for x in rng.permutation(3000)[:400]]
+    p = tmp_path / "db.fasta"
+    with open(p, "w") as f:
+        for i, nm in enumerate(names):
+            f.write(">%s\n%s\n" % (nm, "-" * (i % 7) + "ACGU" * 5 + "-" * (7 - i % 7)))
+    order, _, _ = pipeline.reference_order(names)
+    st = pipeline.Store.open(str(p), id_order="arb")
+    assert [st.name(i) for i in range(400)] == [names[j] for j in order]
+    assert st.name(400) == ""
+    st.close()
+    st = pipeline.Store.open(str(p))
+    assert [st.name(i) for i in range(400)] == names
+    st.close()
+    with pytest.raises(ValueError):
+        pipeline.Store.open(str(p), id_order="sorted")
