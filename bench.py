@@ -268,6 +268,18 @@ def main():
     torch.cuda.synchronize(device)
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
+
+    def thread_times():  # (SINA_HOST_PROFILE: which threads the region's CPU time belongs to)
+        out = {}
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                f = open("/proc/self/task/%s/stat" % tid).read()
+                rest = f[f.rindex(")") + 2:].split()
+                out[tid] = (int(rest[11]), int(rest[12]), int(rest[7]))
+            except OSError:
+                pass
+        return out
+    tt0 = thread_times() if os.environ.get("SINA_HOST_PROFILE") else None
     if os.environ.get("SINA_HIP_TRACE_ALLOC"):
         print("[bench] %.3f timed region starts" % (time.clock_gettime(time.CLOCK_MONOTONIC) % 1000), file=sys.stderr)
     t0 = time.time()
@@ -279,6 +291,16 @@ def main():
     if os.environ.get("SINA_HIP_TRACE_ALLOC"):
         print("[bench] %.3f timed region ends" % (time.clock_gettime(time.CLOCK_MONOTONIC) % 1000), file=sys.stderr)
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    if tt0 is not None and rank == 0:
+        tt1, tck = thread_times(), os.sysconf("SC_CLK_TCK")
+        rows = sorted(((tt1[t][0] - tt0[t][0] + tt1[t][1] - tt0[t][1], t) for t in tt1 if t in tt0), reverse=True)
+        for tot, t in rows[:20]:
+            print("timed region: thread tid %-8s user %6.2f s  kernel %6.2f s  minor faults %8d%s" % (
+                t, (tt1[t][0] - tt0[t][0]) / tck, (tt1[t][1] - tt0[t][1]) / tck, tt1[t][2] - tt0[t][2],
+                "  (main)" if int(t) == os.getpid() else ""), file=sys.stderr)
+        print("timed region: whole process user %.2f s kernel %.2f s over %.2f s (threads that started and ended "
+              "inside it are in the 'thread: ... (whole run)' lines)" % (
+                  ru1.ru_utime - ru0.ru_utime, ru1.ru_stime - ru0.ru_stime, elapsed), file=sys.stderr)
     host_cores = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / elapsed
     host_cores_sys = (ru1.ru_stime - ru0.ru_stime) / elapsed
     host_minor_faults = (ru1.ru_minflt - ru0.ru_minflt) / elapsed
@@ -354,9 +376,15 @@ def main():
                 f = open("/proc/self/task/%s/stat" % tid).read()
                 comm = f[f.index("(") + 1:f.rindex(")")]
                 rest = f[f.rindex(")") + 2:].split()
-                rows.append(((int(rest[11]) + int(rest[12])) / tck, int(rest[11]) / tck, int(rest[12]) / tck, comm, tid))
-            for tot, u, k, comm, tid in sorted(rows, reverse=True)[:24]:
-                print("thread %-18s tid %-8s user %7.2f s  kernel %7.2f s" % (comm, tid, u, k), file=sys.stderr)
+                sw = {}
+                for ln in open("/proc/self/task/%s/status" % tid):
+                    if "ctxt_switches" in ln:
+                        sw[ln.split(":")[0]] = int(ln.split(":")[1])
+                rows.append(((int(rest[11]) + int(rest[12])) / tck, int(rest[11]) / tck, int(rest[12]) / tck, comm, tid,
+                             int(rest[7]), sw.get("voluntary_ctxt_switches", 0), sw.get("nonvoluntary_ctxt_switches", 0)))
+            for tot, u, k, comm, tid, minflt, vol, invol in sorted(rows, reverse=True)[:24]:
+                print("thread %-18s tid %-8s user %7.2f s  kernel %7.2f s  minor faults %8d  ctx switches %8d vol %6d invol"
+                      % (comm, tid, u, k, minflt, vol, invol), file=sys.stderr)
         except Exception as e:  # noqa: BLE001
             print("thread times unavailable: %s" % e, file=sys.stderr)
     if rank == 0:

@@ -7,3 +7,6 @@ import os
 # the time no DP kernel resident).  The runtime reads this once, when it starts: set here, at package
 # import, and again by libsina_hip.so's load-time constructor for non-Python hosts (csrc/api.hip).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# the runtime's pool of completion signals (default 64) runs dry with four batches in flight: its helper thread then
+# spends 0.8 of a core creating and waiting for signals (csrc/api.hip, sina_hip_runtime_defaults)
+os.environ.setdefault("ROC_SIGNAL_POOL_SIZE", "1024")

@@ -434,8 +434,17 @@ static int finish_ctx(sina_hip_ctx *c) {  // streams + events of a new context
 
 // Runs when the library is loaded, i.e. normally before the HIP runtime has started: the pipeline's
 // streams need more hardware queues than the runtime's default of four (see sina_amd/__init__.py).
+// ROC_SIGNAL_POOL_SIZE: the runtime recycles completion signals out of a pool (default 64); four batches in
+// flight, each with a dozen copies, kernels and events on several streams, run it dry, and from then on the
+// runtime's helper thread creates and waits for interrupt signals one ioctl at a time -- 0.8 of a core in
+// kernel mode at 125 k sequences/s (bench.py under SINA_HOST_PROFILE=1: "timed region: thread ..." lines;
+// tools/ubench/bench_env_matrix.sh).  With 256 the thread is idle for 16S (3.2 -> 2.5 busy cores, same rate);
+// the V4 shape (365 k sequences/s) needs 1024 for that (7.9 -> 6.8).
 // An explicit setting in the environment wins.
-__attribute__((constructor)) static void sina_hip_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+__attribute__((constructor)) static void sina_hip_runtime_defaults() {
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    setenv("ROC_SIGNAL_POOL_SIZE", "1024", 0);
+}
 
 int sina_hip_init(int device, sina_hip_ctx **ctx) {
     if (!ctx) SH_FAIL("init: null ctx pointer");

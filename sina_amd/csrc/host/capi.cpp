@@ -610,7 +610,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
             std::vector<std::thread> th;
             for (uint32_t i = 0; i < n_find; i++)
                 th.emplace_back([&] {
-                    struct cpu_report { ~cpu_report() { host_profile_add_cpu("thread: finder (whole run)", host_thread_cpu_seconds()); } } rep;
+                    struct cpu_report { ~cpu_report() { host_profile_thread_exit("thread: finder (whole run)"); } } rep;
                     try {
                         item it;
                         while (take(it)) {
@@ -626,7 +626,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                 });
             for (uint32_t i = 0; i < n_align; i++)
                 th.emplace_back([&] {
-                    struct cpu_report { ~cpu_report() { host_profile_add_cpu("thread: aligner (whole run)", host_thread_cpu_seconds()); } } rep;
+                    struct cpu_report { ~cpu_report() { host_profile_thread_exit("thread: aligner (whole run)"); } } rep;
                     try {
                         item it;
                         while (found.pop(it)) {
@@ -642,7 +642,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                 });
             for (uint32_t i = 0; i < n_sink; i++)
                 th.emplace_back([&] {
-                    struct cpu_report { ~cpu_report() { host_profile_add_cpu("thread: sink (whole run)", host_thread_cpu_seconds()); } } rep;
+                    struct cpu_report { ~cpu_report() { host_profile_thread_exit("thread: sink (whole run)"); } } rep;
                     try {
                         item it;
                         while (aligned.pop(it)) {

@@ -3,6 +3,7 @@
 // lifting goes through the C ABI (include/sina_hip.h).  No CPU fallback: if the
 // HIP library reports an error, the stage throws.
 #include "stages.h"
+#include <sys/resource.h>
 #include "id_order.h"
 
 #include <algorithm>
@@ -52,6 +53,28 @@ double thread_cpu_s() {
     clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
+// user + kernel CPU seconds, kernel seconds alone and minor page faults of the calling thread so far
+struct thread_use {
+    double cpu = 0, sys = 0, faults = 0;
+};
+thread_use thread_use_now() {
+    thread_use u;
+    if (!prof().on) return u;
+    rusage ru;
+    if (getrusage(RUSAGE_THREAD, &ru) != 0) return u;
+    u.sys = (double)ru.ru_stime.tv_sec + 1e-6 * (double)ru.ru_stime.tv_usec;
+    u.cpu = thread_cpu_s();
+    u.faults = (double)ru.ru_minflt;
+    return u;
+}
+void add_cpu(const char *phase, double s);
+void add_use(const char *phase, const thread_use &since) {
+    const thread_use now = thread_use_now();
+    add_cpu(phase, now.cpu - since.cpu);
+    const std::string ph(phase);
+    add_cpu((ph + " (kernel mode)").c_str(), now.sys - since.sys);
+    add_cpu((ph + " (k page faults)").c_str(), 1e-3 * (now.faults - since.faults));
+}
 void add_cpu(const char *phase, double s) {  // CPU seconds spent under a phase, by whichever thread
     prof_state &p = prof();
     if (!p.on) return;
@@ -63,15 +86,15 @@ void add_cpu(const char *phase, double s) {  // CPU seconds spent under a phase,
 struct scoped_phase {
     const char *name;
     const char *outer;
-    double cpu0;
+    thread_use use0;
     std::chrono::steady_clock::time_point t0;
-    explicit scoped_phase(const char *n) : name(n), outer(tl_phase), cpu0(thread_cpu_s()), t0(std::chrono::steady_clock::now()) {
+    explicit scoped_phase(const char *n) : name(n), outer(tl_phase), use0(thread_use_now()), t0(std::chrono::steady_clock::now()) {
         tl_phase = n;
     }
     ~scoped_phase() {
         tl_phase = outer;
         prof_state &p = prof();
-        if (p.on) add_cpu(name, thread_cpu_s() - cpu0);
+        if (p.on) add_use(name, use0);
         if (!p.on && !p.trace_path) return;
         const auto t1 = std::chrono::steady_clock::now();
         const double s = std::chrono::duration<double>(t1 - t0).count();
@@ -119,6 +142,17 @@ uint64_t host_tick(const char *what, uint64_t since) {
     return now;
 }
 double host_thread_cpu_seconds() { return thread_cpu_s(); }
+void host_profile_thread_exit(const char *who) {
+    if (!prof().on) return;
+    rusage ru;
+    if (getrusage(RUSAGE_THREAD, &ru) != 0) return;
+    const std::string w(who);
+    add_cpu(w.c_str(), thread_cpu_s());
+    add_cpu((w + " kernel-mode").c_str(), (double)ru.ru_stime.tv_sec + 1e-6 * (double)ru.ru_stime.tv_usec);
+    add_cpu((w + " k-minor-faults").c_str(), 1e-3 * (double)ru.ru_minflt);
+    add_cpu((w + " k-voluntary-switches").c_str(), 1e-3 * (double)ru.ru_nvcsw);
+    add_cpu((w + " k-involuntary-switches").c_str(), 1e-3 * (double)ru.ru_nivcsw);
+}
 host_phase::host_phase(const char *n) : impl(new scoped_phase(n)) {}
 host_phase::~host_phase() { delete static_cast<scoped_phase *>(impl); }
 
@@ -245,13 +279,13 @@ private:
     }
     void work_on(job &j) {
         const bool helper = tl_phase != j.phase;  // (the posting thread's own time is in its scoped_phase)
-        const double c0 = (helper && prof().on) ? thread_cpu_s() : 0;
+        const thread_use c0 = (helper && prof().on) ? thread_use_now() : thread_use();
         struct at_exit {
             bool on;
             const char *ph;
-            double c0;
+            thread_use c0;
             ~at_exit() {
-                if (on) add_cpu(ph, thread_cpu_s() - c0);
+                if (on) add_use(ph, c0);
             }
         } acc{helper && prof().on, j.phase, c0};
         for (;;) {

@@ -533,6 +533,9 @@ void host_profile_add_cpu(const char *what, double seconds);  // (no-op unless S
 uint64_t host_tsc();
 uint64_t host_tick(const char *what, uint64_t since);
 double host_thread_cpu_seconds();
+// a stage driver's thread ends: its CPU seconds, kernel-mode seconds, page faults and context switches
+// (thousands) go into the profile under "<who> ..." (no-op unless SINA_HOST_PROFILE is set)
+void host_profile_thread_exit(const char *who);
 class host_phase {                           // a named phase of the calling thread (profile / SINA_HOST_TRACE)
 public:
     explicit host_phase(const char *name);
