@@ -168,24 +168,50 @@ public:
     // name, width and attributes of `o` WITHOUT its bases (the aligner's working copy: its bases are
     // written once, when the alignment is known -- copying the query's first would be 6 KB for nothing)
     struct meta_only {};
-    annotated_cseq(const annotated_cseq &o, meta_only) : attributes(o.attributes) {
+    annotated_cseq(const annotated_cseq &o, meta_only) {
         setName(o.getName());
         setWidth(o.getWidth());
+        assign_attrs(o.attributes);
     }
     void copy_meta(const annotated_cseq &o) {  // the same into an existing (recycled) object
         clearSequence();
         setName(o.getName());
         setWidth(o.getWidth());
-        attributes = o.attributes;
+        assign_attrs(o.attributes);
     }
-    void clear_all() {  // back to the default-constructed state, keeping the heap blocks
+    // Back to the default-constructed state, keeping the heap blocks -- the base list's and those of the
+    // attribute strings (family list, date ...: half a dozen blocks per sequence that one pool thread
+    // allocated and another one frees; with a dozen threads doing so the allocator's arena locks were 8 us
+    // per query of the V4 shape).  The strings wait in `spare` for the object's next life.
+    void clear_all() {
         clearSequence();
         setName(std::string());
+        retire_strings();
         attributes.clear();
     }
 
-    template <typename T> void set_attr(std::string_view key, T val) { slot(key) = variant(std::move(val)); }
-    void set_attr(std::string_view key, const char *val) { slot(key) = variant(std::string(val)); }
+    template <typename T> void set_attr(std::string_view key, T val) {
+        if constexpr (std::is_same<T, std::string>::value) string_slot(key).assign(val);
+        else slot(key) = variant(std::move(val));
+    }
+    void set_attr(std::string_view key, const std::string &val) { string_slot(key).assign(val); }
+    void set_attr(std::string_view key, const char *val) { string_slot(key).assign(val); }
+    void set_attr(std::string_view key, std::string_view val) { string_slot(key).assign(val); }
+    // the string value of `key`, EMPTY, to be written in place (made a string attribute if it is none yet);
+    // its heap block is a recycled one where the object has any
+    std::string &string_slot(std::string_view key) {
+        variant &v = slot(key);
+        if (std::string *s = std::get_if<std::string>(&v)) {
+            if (s->capacity() <= 15 && !spare.empty()) {  // (a fresh slot holds an empty, block-less string)
+                *s = std::move(spare.back());
+                spare.pop_back();
+            }
+            s->clear();
+            return *s;
+        }
+        v = variant(fresh_string());
+        return std::get<std::string>(v);
+    }
     bool has_attr(std::string_view key) const { return find(key) != nullptr; }
     template <typename T> T get_attr(std::string_view attr) const { return get_attr<T>(attr, T()); }
     template <typename T> T get_attr(std::string_view attr, T dflt) const {
@@ -202,6 +228,34 @@ private:
         return nullptr;
     }
     variant &slot(std::string_view key);  // the value of `key`, inserted in key order if new (cseq.cpp)
+    std::string fresh_string() {
+        if (spare.empty()) return std::string();
+        std::string s = std::move(spare.back());
+        spare.pop_back();
+        return s;
+    }
+    void retire_strings() {
+        for (attr &a : attributes)
+            if (std::string *s = std::get_if<std::string>(&a.second))
+                if (s->capacity() > 15 && spare.size() < 16) {
+                    s->clear();
+                    spare.push_back(std::move(*s));
+                }
+    }
+    void assign_attrs(const attr_list &from) {  // attributes = from, into recycled string blocks
+        retire_strings();
+        attributes.clear();
+        attributes.reserve(from.size());
+        for (const attr &a : from) {
+            if (const std::string *s = std::get_if<std::string>(&a.second)) {
+                std::string mine = fresh_string();
+                mine.assign(*s);
+                attributes.push_back(attr{a.name, variant(std::move(mine))});
+            } else {
+                attributes.push_back(a);
+            }
+        }
+    }
     template <typename T, typename S> static T convert(const S &s) {
         if constexpr (std::is_same<T, S>::value) {
             return s;
@@ -219,6 +273,7 @@ private:
         }
     }
     attr_list attributes;
+    std::vector<std::string> spare;  // emptied strings of earlier lives, with their heap blocks
 };
 
 typedef annotated_cseq cseq;

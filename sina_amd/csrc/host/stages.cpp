@@ -1020,7 +1020,7 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
         auto &vc = *t.alignment_reference;
         cseq &c = *t.input_sequence;
         uint64_t tk = host_tsc();
-        std::string fam;
+        std::string &fam = c.string_slot(fn::family);  // (written in place, into the sequence's recycled block)
         char buf[64];
         fam.reserve(vc.size() * 24);
         for (auto &r : vc) {  // "<acc>.<start>:<score> " per relative (famfinder.cpp:462-470)
@@ -1053,8 +1053,6 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
             fam += buf;
         }
         tk = host_tick("ff.post: family string", tk);
-        c.set_attr(fn::family, fam);
-        tk = host_tick("ff.post: set family attr", tk);
         if (o.fs_req_gaps != 0) {  // :472-480
             auto too_few_gaps = [&](search::result_item &it) {
                 return 0 == it.sequence->size() ||
@@ -1312,7 +1310,7 @@ aligner::~aligner() = default;
 aligner::aligner(const aligner &) = default;
 aligner &aligner::operator=(const aligner &) = default;
 
-static std::string make_datetime() {  // src/align.cpp:287-299 (formatted once per second and thread)
+static const std::string &make_datetime() {  // src/align.cpp:287-299 (formatted once per second and thread)
     thread_local time_t last = (time_t)-1;
     thread_local std::string text;
     const time_t t = time(nullptr);

@@ -95,7 +95,7 @@ private:
 template <typename T> struct object_cache {
     static T *take() {
         auto &f = mine().free;
-        if (f.empty()) return new T();
+        if (f.empty() && !from_depot(f)) return new T();
         T *o = f.back();
         f.pop_back();
         return o;
@@ -103,25 +103,57 @@ template <typename T> struct object_cache {
     static void give(T *o) {
         if (o == nullptr) return;
         auto &f = mine().free;
-        if (f.size() >= kKeep) {
-            delete o;
-            return;
-        }
         reset(*o);
         f.push_back(o);
+        if (f.size() >= kLocalMax) to_depot(f);
     }
 
 private:
-    static constexpr size_t kKeep = 8192;  // per thread
+    // Threads that only hand out (the finder's driver thread building trays) and threads that only take back
+    // (the sink's) exchange whole chunks through a depot: one lock per kChunk objects.
+    static constexpr size_t kChunk = 128, kLocalMax = 4 * kChunk, kDepotChunks = 1024;
     struct list {
         std::vector<T *> free;
         ~list() {
             for (T *o : free) delete o;
         }
     };
+    struct depot_t {
+        std::mutex mu;
+        std::vector<std::vector<T *>> chunks;
+        ~depot_t() {
+            for (auto &c : chunks)
+                for (T *o : c) delete o;
+        }
+    };
     static list &mine() {
         thread_local list l;
         return l;
+    }
+    static depot_t &depot() {
+        static depot_t d;
+        return d;
+    }
+    static bool from_depot(std::vector<T *> &f) {
+        depot_t &d = depot();
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (d.chunks.empty()) return false;
+        f.swap(d.chunks.back());
+        d.chunks.pop_back();
+        return !f.empty();
+    }
+    static void to_depot(std::vector<T *> &f) {
+        std::vector<T *> chunk(f.end() - (std::ptrdiff_t)kChunk, f.end());
+        f.resize(f.size() - kChunk);
+        depot_t &d = depot();
+        {
+            std::lock_guard<std::mutex> lk(d.mu);
+            if (d.chunks.size() < kDepotChunks) {
+                d.chunks.push_back(std::move(chunk));
+                return;
+            }
+        }
+        for (T *o : chunk) delete o;
     }
     static void reset(cseq &c) { c.clear_all(); }
     template <typename V> static void reset(std::vector<V> &v) { v.clear(); }
