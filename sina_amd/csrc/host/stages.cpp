@@ -24,6 +24,31 @@ static void hip_check(int rc, const char *what) {
     if (rc != 0) throw std::runtime_error(std::string(what) + ": " + sina_hip_last_error());
 }
 
+// The big per-batch arrays of a stage call (packed queries, aligned columns coming back: tens of MB): a
+// std::vector of that size is a fresh mmap every batch -- zero-filled by the kernel page by page, then
+// zero-filled again by the constructor -- 46 MB and 11 000 page faults per 6144-query batch.  One grow-only,
+// uninitialised block per calling thread and use instead.
+template <typename T> struct batch_scratch {
+    T *p = nullptr;
+    size_t cap = 0;
+    T *get(size_t n) {
+        if (n > cap) {
+            free(p);
+            cap = n + n / 4 + 1024;
+            p = static_cast<T *>(malloc(cap * sizeof(T)));
+            if (!p) {
+                cap = 0;
+                throw std::bad_alloc();
+            }
+        }
+        return p;
+    }
+    ~batch_scratch() { free(p); }
+    batch_scratch() = default;
+    batch_scratch(const batch_scratch &) = delete;
+    batch_scratch &operator=(const batch_scratch &) = delete;
+};
+
 // ================================================================ phase profiler (SINA_HOST_PROFILE=1)
 
 namespace {
@@ -671,7 +696,8 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
     st.ensure_index(pimpl->k, pimpl->nofast);
     std::vector<uint64_t> qoff(queries.size() + 1, 0);
     for (size_t i = 0; i < queries.size(); i++) qoff[i + 1] = qoff[i] + queries[i]->size();
-    std::vector<uint8_t> qmask(qoff.back() ? qoff.back() : 1);
+    thread_local batch_scratch<uint8_t> qmask_buf;
+    uint8_t *const qmask = qmask_buf.get(qoff.back() + 1);
     parallel_for(queries.size(), [&](size_t i) {
         const auto &b = queries[i]->getAlignedBases();
         for (size_t x = 0; x < b.size(); x++) qmask[qoff[i] + x] = (uint8_t)(b[x].raw >> 24);
@@ -679,12 +705,14 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
     auto dev = st.worker_device(reference_store::dev_search);
     sina_hip_ctx *ctx = dev.get();
     if (max <= 4096) {
-        std::vector<uint32_t> ids((size_t)queries.size() * max), cnt(queries.size());
-        std::vector<float> sc((size_t)queries.size() * max);
+        thread_local batch_scratch<uint32_t> ids_buf;
+        thread_local batch_scratch<float> sc_buf;
+        uint32_t *const ids = ids_buf.get((size_t)queries.size() * max);
+        float *const sc = sc_buf.get((size_t)queries.size() * max);
+        std::vector<uint32_t> cnt(queries.size());
         {
             scoped_phase ph("ff.kmer_topk(C-ABI)");
-            hip_check(sina_hip_kmer_topk(ctx, qmask.data(), qoff.data(), (uint32_t)queries.size(), max, ids.data(),
-                                         sc.data(), cnt.data()),
+            hip_check(sina_hip_kmer_topk(ctx, qmask, qoff.data(), (uint32_t)queries.size(), max, ids, sc, cnt.data()),
                       "kmer_topk");
         }
         parallel_for(queries.size(), [&](size_t i) {
@@ -700,7 +728,7 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
         using pair = std::pair<int16_t, int>;
         std::vector<pair> ranks(n);
         for (size_t i = 0; i < queries.size(); i++) {
-            hip_check(sina_hip_kmer_scores(ctx, qmask.data() + qoff[i], (uint32_t)(qoff[i + 1] - qoff[i]),
+            hip_check(sina_hip_kmer_scores(ctx, qmask + qoff[i], (uint32_t)(qoff[i + 1] - qoff[i]),
                                            scores.data()),
                       "kmer_scores");
             for (unsigned r = 0; r < n; r++) ranks[r] = pair(scores[r], (int)r);
@@ -1518,15 +1546,17 @@ void aligner::operator()(std::vector<tray> &batch) {
         ph.reset(), ph.reset(new scoped_phase("al.pack_queries"));  // (the old phase ends first: the new one names the pool jobs)
         std::vector<uint64_t> qoff(nq + 1, 0);
         for (size_t x = 0; x < nq; x++) qoff[x + 1] = qoff[x] + jobs[idx[x]].t->input_sequence->size();
-        std::vector<uint8_t> qmask(qoff.back() ? qoff.back() : 1);
+        thread_local batch_scratch<uint8_t> qmask_buf;
+        thread_local batch_scratch<uint32_t> out_pos_buf;
+        uint8_t *const qmask = qmask_buf.get(qoff.back() + 1);
         parallel_for(nq, [&](size_t x) {  // (the DP looks at the four base bits only: case does not matter)
             const uint32_t *b = jobs[idx[x]].t->input_sequence->packed();
             const size_t nb = jobs[idx[x]].t->input_sequence->size();
-            uint8_t *dst = qmask.data() + qoff[x];
+            uint8_t *dst = qmask + qoff[x];
             for (size_t y = 0; y < nb; y++) dst[y] = (uint8_t)(b[y] >> 24);
         });
         std::vector<sina_hip_align_out> out(nq);
-        std::vector<uint32_t> out_pos(qoff.back() ? qoff.back() : 1);
+        uint32_t *const out_pos = out_pos_buf.get(qoff.back() + 1);  // (a query's columns are read up to its n_ab only)
         auto dev = store->worker_device(reference_store::dev_align);
         sina_hip_ctx *ctx = dev.get();
         uint32_t width = 0;
@@ -1540,8 +1570,8 @@ void aligner::operator()(std::vector<tray> &batch) {
                     fids[foff[x] + y] = store->id_of(jobs[idx[x]].family[y]);
             width = store->getAlignmentWidth();
             ph.reset(), ph.reset(new scoped_phase("al.align_families(C-ABI)"));  // (the old phase ends first: the new one names the pool jobs)
-            hip_check(sina_hip_align_families(ctx, fids.data(), foff.data(), (uint32_t)nq, qmask.data(), qoff.data(),
-                                              &p, out.data(), out_pos.data()),
+            hip_check(sina_hip_align_families(ctx, fids.data(), foff.data(), (uint32_t)nq, qmask, qoff.data(),
+                                              &p, out.data(), out_pos),
                       "align_families");
         } else {
             std::vector<host_graph> gs(nq);
@@ -1591,7 +1621,7 @@ void aligner::operator()(std::vector<tray> &batch) {
             gb.node_score16 = o.fs_no_graph ? nscore.data() : nullptr;
             gb.self_score16 = o.fs_no_graph ? self16 : nullptr;
             ph.reset(), ph.reset(new scoped_phase("al.align_graphs(C-ABI)"));  // (the old phase ends first: the new one names the pool jobs)
-            hip_check(sina_hip_align_graphs(ctx, &gb, qmask.data(), qoff.data(), &p, out.data(), out_pos.data()),
+            hip_check(sina_hip_align_graphs(ctx, &gb, qmask, qoff.data(), &p, out.data(), out_pos),
                       "align_graphs");
         }
 
@@ -1605,7 +1635,7 @@ void aligner::operator()(std::vector<tray> &batch) {
             if (r.status != 0) throw std::runtime_error("device alignment failed for " + c.getName());
             uint64_t tk = host_tsc();
             const uint32_t L = (uint32_t)t.input_sequence->size();
-            const uint32_t *pos = out_pos.data() + qoff[x];
+            const uint32_t *pos = out_pos + qoff[x];
             if (r.assembled) {
                 // the device did the container steps (append rule, setWidth, reverse) and a NAST fix-up
                 // in which every insertion fitted its gap: the finished bases, and the fix-up's log line
