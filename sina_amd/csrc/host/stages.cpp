@@ -372,7 +372,7 @@ unsigned host_threads() { return pool::get().size(); }
 tray::tray(const tray &o)
     : seqno(o.seqno), input_sequence(o.input_sequence), aligned_sequence(o.aligned_sequence),
       alignment_reference(o.alignment_reference), search_result(o.search_result), astats(o.astats),
-      family_scores_kmer_k(o.family_scores_kmer_k) {
+      family_scores_kmer_k(o.family_scores_kmer_k), query_kmer_count(o.query_kmer_count) {
     log.str(o.log.str());
     log.seekp(0, std::ios_base::end);
 }
@@ -386,6 +386,7 @@ tray &tray::operator=(const tray &o) {
     log.seekp(0, std::ios_base::end);
     astats = o.astats;
     family_scores_kmer_k = o.family_scores_kmer_k;
+    query_kmer_count = o.query_kmer_count;
     return *this;
 }
 alignment_stats *alignment_stats::shared_default() {
@@ -685,7 +686,7 @@ void kmer_search::find(const cseq &query, result_vector &results, unsigned int m
 
 // src/kmer_search.cpp:366-420 for a batch of queries
 void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vector<result_vector> &results,
-                             unsigned int max) {
+                             unsigned int max, std::vector<uint32_t> *kmer_counts) {
     reference_store &st = *pimpl->store;
     const unsigned n = st.size();
     // (the callers' vectors are kept -- famfinder hands in recycled ones -- and only emptied)
@@ -698,9 +699,22 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
     for (size_t i = 0; i < queries.size(); i++) qoff[i + 1] = qoff[i] + queries[i]->size();
     thread_local batch_scratch<uint8_t> qmask_buf;
     uint8_t *const qmask = qmask_buf.get(qoff.back() + 1);
+    if (kmer_counts) kmer_counts->assign(queries.size(), 0);
+    const unsigned kk = pimpl->k;
+    const bool count_all = pimpl->nofast;
     parallel_for(queries.size(), [&](size_t i) {
         const auto &b = queries[i]->getAlignedBases();
-        for (size_t x = 0; x < b.size(); x++) qmask[qoff[i] + x] = (uint8_t)(b[x].raw >> 24);
+        uint8_t *dst = qmask + qoff[i];
+        for (size_t x = 0; x < b.size(); x++) dst[x] = (uint8_t)(b[x].raw >> 24);
+        if (kmer_counts) {  // windows of k unambiguous bases ending before the last base (kmer.h:188-201)
+            unsigned run = 0, n = 0;
+            for (size_t e = 0; e + 1 < b.size(); e++) {
+                const unsigned m = dst[e] & 0xfu;
+                run = (m & (m - 1)) == 0 && m != 0 ? run + 1 : 0;
+                if (run >= kk && (count_all || (dst[e + 1 - kk] & 0xfu) == 1u)) n++;
+            }
+            (*kmer_counts)[i] = n;
+        }
     });
     auto dev = st.worker_device(reference_store::dev_search);
     sina_hip_ctx *ctx = dev.get();
@@ -1006,6 +1020,7 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
         t->alignment_reference = object_cache<search::result_vector>::take();
         // (what the scores below are: raw k-mer counts of this engine -- the aligner's containment pre-filter asks)
         t->family_scores_kmer_k = o.engine == ENGINE_SINA_KMER ? (o.fs_no_fast ? -(int)o.fs_kmer_len : (int)o.fs_kmer_len) : 0;
+        t->query_kmer_count = -1;
         todo.push_back(t);
     }
     size_t max_results = (size_t)o.fs_max + 1;
@@ -1015,10 +1030,13 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
         for (tray *t : todo) qs.push_back(t->input_sequence);
         std::vector<search::result_vector> found(todo.size());
         for (size_t i = 0; i < todo.size(); i++) found[i].swap(*todo[i]->alignment_reference);  // (their heap blocks, recycled)
+        std::vector<uint32_t> nk;
         {
             scoped_phase ph_find("ff.find_batch");
-            index->find_batch(qs, found, (unsigned)std::min<size_t>(max_results, isize));
+            index->find_batch(qs, found, (unsigned)std::min<size_t>(max_results, isize),
+                              o.engine == ENGINE_SINA_KMER ? &nk : nullptr);
         }
+        for (size_t i = 0; i < nk.size(); i++) todo[i]->query_kmer_count = (int)nk[i];
         std::vector<char> done(todo.size(), 0);
         scoped_phase ph_match("ff.match_pass");
         parallel_for(todo.size(), [&](size_t i) {
@@ -1443,7 +1461,9 @@ void aligner::operator()(std::vector<tray> &batch) {
         // A family member can only contain the query's bases if it has every one of the query's
         // k-mers, i.e. if its k-mer score (what famfinder ranked it by) is the query's k-mer count --
         // which spares the string search for all but exact relatives.
-        const float all_kmers = t.family_scores_kmer_k != 0 ? (float)query_kmer_count(*t.input_sequence, t.family_scores_kmer_k) : -1.f;
+        const float all_kmers = t.family_scores_kmer_k == 0 ? -1.f
+                                : (float)(t.query_kmer_count >= 0 ? (unsigned)t.query_kmer_count
+                                                                  : query_kmer_count(*t.input_sequence, t.family_scores_kmer_k));
         auto lacks_query = [&](search::result_item &item) {
             if (item.score < all_kmers) return true;
             std::string tmp;

@@ -173,6 +173,8 @@ public:
     // engine (value: k, negative with --fs-kmer-no-fast); 0 = unknown.  The aligner's containment
     // pre-filter (a member with fewer k-mers than the query cannot contain it) is only valid then.
     int family_scores_kmer_k{0};
+    // with it: the query's own k-mer count under that k / filter, or -1 = not counted
+    int query_kmer_count{-1};
 
     tray() = default;
     tray(const tray &o);
@@ -301,8 +303,10 @@ public:
                  bool) override;
     void find(const cseq &query, result_vector &results, unsigned int max) override;
     // one launch for many queries; results[i] gets min(max, size()) items
+    // (kmer_counts, optional: the number of k-mers of every query, with multiplicity -- what a reference
+    // holding all of them scores; counted in the pass that packs the queries for the device)
     void find_batch(const std::vector<const cseq *> &queries, std::vector<result_vector> &results,
-                    unsigned int max);
+                    unsigned int max, std::vector<uint32_t> *kmer_counts = nullptr);
     unsigned int size() const override;
     ~kmer_search() override;
 

@@ -40,6 +40,33 @@ __global__ void __launch_bounds__(256) k(float *out, float a, float b, int n_ite
             if constexpr (OP == 13) asm volatile("v_mov_b32 %0, %1" : "=v"(x[i]) : "v"(c));
             if constexpr (OP == 14) asm volatile("v_bfe_u32 %0, %0, 1, 4" : "+v"(u[i]));
             if constexpr (OP == 15) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1\n\tv_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(x[i]) : "v"(c) : "s20", "s21");
+            // integer / packed 16-bit candidates for a fixed-point DP (round 3)
+            if constexpr (OP == 30) asm volatile("v_min_i32 %0, %0, %1" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 31) asm volatile("v_min_u32 %0, %0, %1" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 32) asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(c), "v"(a));
+            if constexpr (OP == 33) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 34) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 35) asm volatile("v_pk_mad_i16 %0, %0, %1, %2" : "+v"(u[i]) : "v"(c), "v"(a));
+            if constexpr (OP == 36) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 37) asm volatile("v_pk_ashrrev_i16 %0, 15, %0" : "+v"(u[i]));
+            if constexpr (OP == 38) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(u[i]) : "v"(c), "v"(a));
+            if constexpr (OP == 39) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(c), "v"(a));
+            if constexpr (OP == 40) asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 41) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(c), "v"(a));
+            if constexpr (OP == 42) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(c), "v"(a));
+            if constexpr (OP == 43) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 44) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(u[i]));
+            if constexpr (OP == 45) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 46) asm volatile("v_cmp_lt_i32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(c) : "vcc");
+            if constexpr (OP == 47) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 48) asm volatile("v_max_i32 %0, %0, %1" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 49) asm volatile("v_or_b32 %0, %0, %1" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 50) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 51) asm volatile("v_min_i16 %0, %0, %1" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 52) asm volatile("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 53) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(u[i]));
+            if constexpr (OP == 54) asm volatile("v_min_i32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(u[i]) : "v"(c));
+            if constexpr (OP == 55) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(u[i]) : "v"(c));
         }
     }
     float s = 0;
@@ -136,6 +163,32 @@ int main() {
     run<7>("v_mov_b32_dpp wave_shr:1", 1, d_out);
     run<12>("v_add_f32_dpp wave_shr:1", 1, d_out);
     run<8>("v_pk_add_f32", 1, d_out);
+    run<30>("v_min_i32", 1, d_out);
+    run<31>("v_min_u32", 1, d_out);
+    run<48>("v_max_i32", 1, d_out);
+    run<32>("v_min3_i32", 1, d_out);
+    run<51>("v_min_i16", 1, d_out);
+    run<46>("v_cmp_lt_i32+v_cndmask", 2, d_out);
+    run<33>("v_pk_add_i16", 1, d_out);
+    run<52>("v_pk_add_i16 clamp", 1, d_out);
+    run<36>("v_pk_sub_i16", 1, d_out);
+    run<34>("v_pk_min_i16", 1, d_out);
+    run<47>("v_pk_min_u16", 1, d_out);
+    run<45>("v_pk_max_i16", 1, d_out);
+    run<35>("v_pk_mad_i16", 1, d_out);
+    run<55>("v_pk_mul_lo_u16", 1, d_out);
+    run<37>("v_pk_ashrrev_i16", 1, d_out);
+    run<38>("v_bfi_b32", 1, d_out);
+    run<39>("v_perm_b32", 1, d_out);
+    run<40>("v_alignbit_b32", 1, d_out);
+    run<41>("v_and_or_b32", 1, d_out);
+    run<42>("v_add3_u32", 1, d_out);
+    run<43>("v_sub_u32", 1, d_out);
+    run<44>("v_lshlrev_b32", 1, d_out);
+    run<49>("v_or_b32", 1, d_out);
+    run<50>("v_xor_b32", 1, d_out);
+    run<53>("v_mov_b32_dpp row_shr:1", 1, d_out);
+    run<54>("v_min_i32_dpp row_shr:1", 1, d_out);
     runlat<0>("v_add_f32", 1, d_out);
     runlat<2>("v_min3_f32", 1, d_out);
     runlat<3>("v_cmp+v_cndmask", 2, d_out);
