@@ -742,6 +742,28 @@ int sina_host_build_graph(const char *key, const uint32_t *ids, uint32_t F, floa
     }
 }
 
+// the family as a profile (--fs-no-graph): columns and the match-term table the aligner hands to the device
+// (build_family_profile, stages.cpp) -- for CPU-only tests against the oracle's pseq restatement
+int sina_host_build_profile(const char *key, const uint32_t *ids, uint32_t F, float match, float mismatch, float gap,
+                            float gap_ext, uint32_t *n_nodes, uint32_t *pos, float *score16, float *self16,
+                            uint32_t cap_nodes) {
+    try {
+        auto st = reference_store::get(key);
+        std::vector<const cseq *> fam;
+        for (uint32_t i = 0; i < F; i++) fam.push_back(&st->getCseq(ids[i]));
+        host_graph g;
+        build_family_profile(fam, match, mismatch, gap, gap_ext, &g);
+        *n_nodes = (uint32_t)g.pos.size();
+        if (g.pos.size() > cap_nodes) throw std::runtime_error("profile buffers too small");
+        std::copy(g.pos.begin(), g.pos.end(), pos);
+        std::copy(g.score16.begin(), g.score16.end(), score16);
+        profile_self_scores(match, mismatch, gap, gap_ext, self16);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
 // cseq_comparator on two aligned strings, for CPU-only tests against the reference's KAT table
 // (src/unit_tests/cseq_comparator_test.cpp); also returns the six counters
 int sina_host_compare(const char *a_aligned, const char *b_aligned, int iupac, int dist, int cover, int filter_lc,

@@ -61,6 +61,8 @@ def load_host():
                                       C.POINTER(C.c_uint64)]
     H.sina_host_sidx_store.argtypes = [C.c_char_p, C.c_uint, C.c_int, C.c_uint32, capi.u32p, capi.u32p, C.c_uint64]
     H.sina_host_store_open.argtypes = [C.c_char_p, C.c_int]
+    H.sina_host_build_profile.argtypes = [C.c_char_p, capi.u32p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          capi.u32p, capi.u32p, capi.f32p, capi.f32p, C.c_uint32]
     H.sina_host_store_open_arb_order.argtypes = [C.c_char_p, C.c_int]
     H.sina_host_reference_order.restype = C.c_uint32
     H.sina_host_reference_order.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, capi.u32p, capi.u64p, capi.u64p]
@@ -147,6 +149,19 @@ class Store:
     def add_filter(self, name, weights):
         w = np.ascontiguousarray(weights, np.float32)
         _chk(self.H.sina_host_add_filter(self.key.encode(), name.encode(), w.ctypes.data_as(capi.f32p), len(w)))
+
+    def build_profile(self, ids, match, mismatch, gap, gap_ext, cap=200000):
+        """--fs-no-graph: (columns, match-term table [n, 16], self table [16]) of a family as the aligner builds them."""
+        ids = np.ascontiguousarray(ids, np.uint32)
+        nn = C.c_uint32()
+        pos = np.zeros(cap, np.uint32)
+        sc = np.zeros(16 * cap, np.float32)
+        own = np.zeros(16, np.float32)
+        _chk(self.H.sina_host_build_profile(self.key.encode(), ids.ctypes.data_as(capi.u32p), len(ids), match, mismatch,
+                                            gap, gap_ext, C.byref(nn), pos.ctypes.data_as(capi.u32p),
+                                            sc.ctypes.data_as(capi.f32p), own.ctypes.data_as(capi.f32p), cap))
+        n = nn.value
+        return pos[:n].copy(), sc[:16 * n].reshape(n, 16).copy(), own
 
     def build_graph(self, ids, fs_weight=1.0):
         ids = np.ascontiguousarray(ids, np.uint32)

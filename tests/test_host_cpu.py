@@ -120,6 +120,31 @@ def test_host_family_graph_equals_oracle(oracle):
         st.close()
 
 
+def test_host_family_profile_equals_oracle(oracle):
+    """--fs-no-graph on the host (build_family_profile, stages.cpp): the columns and the per-node match terms the
+    aligner hands to the device against the oracle's pseq + base_profile::comp, bit for bit."""
+    refs = synth.make_refs(80, length=300, width=3000, seed=43, amb_rate=0.03, lower_rate=0.03, long_del_prob=0.3)
+    cs = util.cseqs_from_refs(refs)
+    st = pipeline.Store(":mem:hostprofile", refs)
+    rng = np.random.default_rng(2)
+    try:
+        for ms, mms, gp, gpe in [(-2.0, 1.0, 5.0, 2.0), (-3.0, 2.0, 4.0, 1.5), (-1.5, 0.5, 6.0, 0.5)]:
+            for _ in range(5):
+                ids = rng.choice(refs.n, size=int(rng.integers(1, 41)), replace=False).astype(np.uint32)
+                pos, sc, own = st.build_profile(ids, ms, mms, gp, gpe)
+                o = oracle.pseq_build([cs[i] for i in ids])
+                assert len(pos) == o["n"] and (pos == o["pos"]).all()
+                want = np.array([[oracle.profile_comp(o["prof"][m], code, ms, mms, gp, gpe) for code in range(1, 16)]
+                                 for m in range(0, o["n"], max(1, o["n"] // 40))], np.float32)
+                got = sc[::max(1, o["n"] // 40), 1:]
+                assert (util.f32_bits(got) == util.f32_bits(want)).all()
+                assert np.isinf(sc[:, 0]).all()          # (code 0: no query base has it)
+                assert (util.f32_bits(own[1:]) == util.f32_bits(np.array(
+                    [oracle.profile_comp(None, code, ms, mms, gp, gpe) for code in range(1, 16)], np.float32))).all()
+    finally:
+        st.close()
+
+
 def test_option_names_and_validation():
     H = pipeline.load_host()
     H.sina_host_reset_options()
@@ -127,6 +152,9 @@ def test_option_names_and_validation():
     assert H.sina_host_set_option(b"aligner", b"overhang", b"edge") == 0
     assert H.sina_host_set_option(b"aligner", b"overhang", b"sideways") != 0
     assert H.sina_host_set_option(b"famfinder", b"no-such-option", b"1") != 0
+    assert H.sina_host_set_option(b"aligner", b"fs-no-graph", b"1") == 0      # the family as a profile: on this path
+    assert H.sina_host_set_option(b"aligner", b"use-subst-matrix", b"1") != 0  # needs the ARB database: refused
+    assert b"accelerated path" in H.sina_host_last_error()
     H.sina_host_reset_options()
     assert not H.sina_host_pipeline_create()          # no --db: "Must have reference database"
     assert b"reference database" in H.sina_host_last_error()
