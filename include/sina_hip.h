@@ -167,6 +167,10 @@ typedef struct sina_hip_align_params {
                              * are plain (see sina_hip_align_out::assembled); 0 (default): columns only */
 } sina_hip_align_params;
 void sina_hip_align_params_default(sina_hip_align_params *p);
+/* The aligned columns of the context's last sina_hip_align_graphs / sina_hip_align_families call, laid out like
+ * that call's out_pos with qoff[0] taken as 0 (query q's entries start at qoff[q] - qoff[0]).  Host memory owned
+ * by the context; valid until the next align call on this context (or its destruction). */
+const uint32_t *sina_hip_staged_out_pos(sina_hip_ctx *ctx);
 
 /* Longest query (bases) any entry point takes: k-mer search, family alignment, graph alignment.
  * (The k-mer count kernel keeps a query's k-mer cursors in LDS beside its 64 KiB score tile: 9 bytes
@@ -232,6 +236,8 @@ typedef struct sina_hip_align_out {
  *                the column handed to the i-th cseq::append() call of
  *                backtrack() (i.e. in reverse query order, tail overhang first) --
  *                or, with p->assemble and out[q].assembled, the finished alignment.
+ *                May be NULL: the columns then stay where the device copied them, in the context's
+ *                pinned staging buffer -- see sina_hip_staged_out_pos (spares a 6 KB copy per 16S query).
  */
 int sina_hip_align_graphs(sina_hip_ctx *ctx, const sina_hip_graph_batch *g, const uint8_t *qmask,
                           const uint64_t *qoff, const sina_hip_align_params *p,

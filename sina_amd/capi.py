@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "sina_hip_sync",
     "sina_hip_upload_refs", "sina_hip_build_index", "sina_hip_download_index", "sina_hip_upload_index", "sina_hip_store_view_get",
     "sina_hip_store_alloc_like", "sina_hip_kmer_topk", "sina_hip_kmer_scores", "sina_hip_compare",
-    "sina_hip_align_params_default", "sina_hip_align_graphs", "sina_hip_align_families",
+    "sina_hip_align_params_default", "sina_hip_staged_out_pos", "sina_hip_align_graphs", "sina_hip_align_families",
     "sina_hip_debug_mesh", "sina_hip_debug_family_graph", "sina_hip_get_stats",
 ]
 
@@ -93,6 +93,8 @@ def load():
     L.sina_hip_destroy.argtypes = [vp]
     L.sina_hip_destroy.restype = None
     L.sina_hip_sync.argtypes = [vp]
+    L.sina_hip_staged_out_pos.restype = C.POINTER(C.c_uint32)
+    L.sina_hip_staged_out_pos.argtypes = [vp]
     L.sina_hip_upload_refs.argtypes = [vp, u32p, u64p, C.c_uint32, C.c_uint32]
     L.sina_hip_build_index.argtypes = [vp, C.c_uint, C.c_int]
     L.sina_hip_upload_index.argtypes = [vp, C.c_uint, C.c_int, u32p, u32p, C.c_uint64]

@@ -241,12 +241,14 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         fprintf(stderr, "[sina_hip] backtrack kernel done\n");
     }
     SH_CHECK(hipEventRecord(c->ev[2], s));
-    if (c->h_out.reserve(sizeof(sina_hip_align_out) * bq) || c->h_out_pos.reserve(4 * std::max<uint64_t>(nqm, 1))) return 1;
+    // (h_out_pos was sized for the whole call by the entry point; this range's columns go to their place in it)
+    if (c->h_out.reserve(sizeof(sina_hip_align_out) * bq)) return 1;
+    unsigned char *staged_pos = static_cast<unsigned char *>(c->h_out_pos.p) + 4 * c->out_pos_base;
     SH_CHECK(hipMemcpyAsync(c->h_out.p, c->out.p, sizeof(sina_hip_align_out) * bq, hipMemcpyDeviceToHost, s));
-    SH_CHECK(hipMemcpyAsync(c->h_out_pos.p, c->out_pos.p, 4 * nqm, hipMemcpyDeviceToHost, s));
+    SH_CHECK(hipMemcpyAsync(staged_pos, c->out_pos.p, 4 * nqm, hipMemcpyDeviceToHost, s));
     SH_CHECK(wait_stream(c, s));
     memcpy(out, c->h_out.p, sizeof(sina_hip_align_out) * bq);
-    memcpy(out_pos, c->h_out_pos.p, 4 * nqm);
+    if (out_pos) memcpy(out_pos, staged_pos, 4 * nqm);
     float ms = 0;
     SH_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     std::lock_guard<std::mutex> slk(c->st->stats_mu);
@@ -285,10 +287,11 @@ static bool weighted_scheme(const sina_hip_align_params *p) { return p->weights 
 static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, const uint8_t *qmask,
                              const uint64_t *qoff, const sina_hip_align_params *p, sina_hip_align_out *out,
                              uint32_t *out_pos, float *dbg_value_host, uint32_t *dbg_vm, uint32_t *dbg_vs) {
-    if (!c || !g || !qmask || !qoff || !p || !out || !out_pos) SH_FAIL("align_graphs: null argument");
+    if (!c || !g || !qmask || !qoff || !p || !out) SH_FAIL("align_graphs: null argument");
     const uint32_t nq = g->nq;
     if (nq == 0) return 0;
     SH_CHECK(hipSetDevice(c->device));
+    if (c->h_out_pos.reserve(4 * std::max<uint64_t>(qoff[nq] - qoff[0], 1))) return 1;
     const bool forbid = p->insertion == SINA_INSERTION_FORBID;
     if (forbid && !g->succ_minpos) SH_FAIL("align_graphs: insertion=forbid needs succ_minpos");
     uint32_t maxL = 0;
@@ -344,8 +347,9 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
             SH_CHECK(hipMemcpyAsync(c->prof16.p, g->node_score16 + 16 * nbase, 64 * nn, hipMemcpyHostToDevice, s));
             SH_CHECK(hipMemcpyAsync(c->self16.p, g->self_score16, 64, hipMemcpyHostToDevice, s));
         }
+        c->out_pos_base = qbase - qoff[0];
         if (run_dp_device(c, pl, hp.qd.data(), bq, nn, hp.tb_cells, hp.spill_rows, hp.cells, nqm, p, g->width, out + q0,
-                          out_pos + qbase, dbg_value_host != nullptr))
+                          out_pos ? out_pos + qbase : nullptr, dbg_value_host != nullptr))
             return 1;
         if (dbg_vm) {  // single-query debug: unpack the planes
             const QDesc &d = hp.qd[0];
@@ -510,6 +514,10 @@ int sina_hip_sync(sina_hip_ctx *c) {
     SH_CHECK(hipStreamSynchronize(c->stream_dp));
     if (c->st->heavy) SH_CHECK(hipStreamSynchronize(c->st->heavy));
     return 0;
+}
+
+const uint32_t *sina_hip_staged_out_pos(sina_hip_ctx *c) {
+    return c ? static_cast<const uint32_t *>(c->h_out_pos.p) : nullptr;
 }
 
 void sina_hip_align_params_default(sina_hip_align_params *p) {

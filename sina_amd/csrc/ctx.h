@@ -78,6 +78,9 @@ struct sina_hip_ctx {
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes, g_wtab;
     sina_hip::DevBuf s_qab, s_qoff, s_cand, s_coff, s_out;  // search-stage comparison
     sina_hip::HostBuf h_out, h_out_pos;  // pinned staging for the DP results
+    // h_out_pos holds the aligned columns of a whole align call (laid out like the caller's out_pos): a launch
+    // range writes at out_pos_base, callers that pass no out_pos read them here (sina_hip_staged_out_pos)
+    uint64_t out_pos_base = 0;
     sina_hip::HostBuf h_stage[12];       // pinned staging of the per-batch uploads / downloads (sina_hip::upload)
     float wtab_fs_weight = NAN;  // fs_weight the device weight table was computed for
 

@@ -706,7 +706,7 @@ extern "C" {
 int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t *fam_off, uint32_t nq,
                             const uint8_t *qmask, const uint64_t *qoff, const sina_hip_align_params *p,
                             sina_hip_align_out *out, uint32_t *out_pos) {
-    if (!c || !fam_ids || !fam_off || !qmask || !qoff || !p || !out || !out_pos)
+    if (!c || !fam_ids || !fam_off || !qmask || !qoff || !p || !out)
         SH_FAIL("align_families: null argument");
     std::lock_guard<std::mutex> lk(c->mu);
     sina_hip_hint_guard hints(c);
@@ -726,6 +726,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
     if (plan_dp(c, maxL, &pl)) return 1;
     const int Lp = pl.geom.Lp();
     if (upload_weights(c, p)) return 1;
+    if (c->h_out_pos.reserve(4 * std::max<uint64_t>(qoff[nq] - qoff[0], 1))) return 1;
 
     const uint64_t tb_budget_cells = tb_plane_budget(c) / tb_cell_bytes(p->insertion == SINA_INSERTION_FORBID);
     // queries per DAG build: two rounds of DP wave slots (one DP wave per query); the DP launches
@@ -779,8 +780,9 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
             if (upload(c, 5, c->qd.p, qd.data(), sizeof(QDesc) * rq, s) || upload(c, 6, c->qmask.p, qmask + qbase, nqm, s))
                 return 1;
             c->profile_batch = false;  // (device-built DAGs: never a profile)
+            c->out_pos_base = qbase - qoff[0];
             if (run_dp_device(c, pl, qd.data(), rq, (uint64_t)bq * bg.ncap, tbc, sprows, cells, nqm, p, c->st->width,
-                              out + q0 + r0, out_pos + qbase, false))
+                              out + q0 + r0, out_pos ? out_pos + qbase : nullptr, false))
                 return 1;
             r0 = r1;
         }

@@ -1567,7 +1567,6 @@ void aligner::operator()(std::vector<tray> &batch) {
         std::vector<uint64_t> qoff(nq + 1, 0);
         for (size_t x = 0; x < nq; x++) qoff[x + 1] = qoff[x] + jobs[idx[x]].t->input_sequence->size();
         thread_local batch_scratch<uint8_t> qmask_buf;
-        thread_local batch_scratch<uint32_t> out_pos_buf;
         uint8_t *const qmask = qmask_buf.get(qoff.back() + 1);
         parallel_for(nq, [&](size_t x) {  // (the DP looks at the four base bits only: case does not matter)
             const uint32_t *b = jobs[idx[x]].t->input_sequence->packed();
@@ -1576,7 +1575,9 @@ void aligner::operator()(std::vector<tray> &batch) {
             for (size_t y = 0; y < nb; y++) dst[y] = (uint8_t)(b[y] >> 24);
         });
         std::vector<sina_hip_align_out> out(nq);
-        uint32_t *const out_pos = out_pos_buf.get(qoff.back() + 1);  // (a query's columns are read up to its n_ab only)
+        // (the aligned columns are read where the device copied them, in the context's pinned staging buffer:
+        // sina_hip_staged_out_pos -- the context stays leased until the alignments below are finished)
+        uint32_t *const out_pos = nullptr;
         auto dev = store->worker_device(reference_store::dev_align);
         sina_hip_ctx *ctx = dev.get();
         uint32_t width = 0;
@@ -1645,6 +1646,7 @@ void aligner::operator()(std::vector<tray> &batch) {
                       "align_graphs");
         }
 
+        const uint32_t *const staged_pos = sina_hip_staged_out_pos(ctx);
         // cseq container steps of backtrack() (src/mesh.h:603-736) + do_align attrs (:507-509)
         ph.reset(), ph.reset(new scoped_phase("al.finish(NAST,log)"));  // (the old phase ends first: the new one names the pool jobs)
         parallel_for(nq, [&](size_t x) {
@@ -1655,7 +1657,7 @@ void aligner::operator()(std::vector<tray> &batch) {
             if (r.status != 0) throw std::runtime_error("device alignment failed for " + c.getName());
             uint64_t tk = host_tsc();
             const uint32_t L = (uint32_t)t.input_sequence->size();
-            const uint32_t *pos = out_pos + qoff[x];
+            const uint32_t *pos = staged_pos + qoff[x];
             if (r.assembled) {
                 // the device did the container steps (append rule, setWidth, reverse) and a NAST fix-up
                 // in which every insertion fitted its gap: the finished bases, and the fix-up's log line
