@@ -282,12 +282,16 @@ def main():
     tt0 = thread_times() if os.environ.get("SINA_HOST_PROFILE") else None
     if os.environ.get("SINA_HIP_TRACE_ALLOC"):
         print("[bench] %.3f timed region starts" % (time.clock_gettime(time.CLOCK_MONOTONIC) % 1000), file=sys.stderr)
+    if os.environ.get("SINA_HOST_TRACE"):
+        pipeline.load_host().sina_host_profile_mark(0)
     t0 = time.time()
     timing = run_steps(a.warmup, a.steps)
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
     elapsed = time.time() - t0
+    if os.environ.get("SINA_HOST_TRACE"):
+        pipeline.load_host().sina_host_profile_mark(1)
     if os.environ.get("SINA_HIP_TRACE_ALLOC"):
         print("[bench] %.3f timed region ends" % (time.clock_gettime(time.CLOCK_MONOTONIC) % 1000), file=sys.stderr)
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
@@ -365,6 +369,8 @@ def main():
     except Exception:
         pass
     verify_failed = False
+    if rank == 0 and os.environ.get("SINA_HOST_TRACE") and not os.environ.get("SINA_HOST_PROFILE"):
+        pl.profile()  # (writes the trace file)
     if rank == 0 and os.environ.get("SINA_HOST_PROFILE"):
         print(pl.profile(), file=sys.stderr)
         # CPU time of every thread of this process so far (the stage driver's threads are gone by now;

@@ -80,16 +80,41 @@ struct base_arena {
         cap = 0;
     }
     ~base_arena() { release(); }
+    base_arena() = default;
+    base_arena(const base_arena &) = delete;
+    base_arena &operator=(const base_arena &) = delete;
+    base_arena(base_arena &&o) noexcept : p(o.p), cap(o.cap) {
+        o.p = nullptr;
+        o.cap = 0;
+    }
+    base_arena &operator=(base_arena &&o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p;
+            cap = o.cap;
+            o.p = nullptr;
+            o.cap = 0;
+        }
+        return *this;
+    }
 };
 
 struct pipeline {
-    base_arena bases;
     famfinder ff;
     aligner al;
     std::unique_ptr<search_filter> sf;  // only with sina_host_pipeline_create_search()
     std::shared_ptr<reference_store> search_store;
     double sf_s = 0;
-    std::vector<result> results;
+    // The results of a run, batch by batch: chunk b holds the results of queries [b * chunk_q, (b + 1) * chunk_q)
+    // and the arena their aligned bases live in.  A chunk is sized and reset by the sink when its batch arrives
+    // (and kept between runs) -- sizing everything before the first batch was 17 ms of every run's start.
+    struct result_chunk {
+        std::vector<result> results;
+        base_arena bases;
+    };
+    std::vector<result_chunk> chunks;
+    uint32_t chunk_q = 1, n_results = 0;
+    result &result_of(uint32_t q) { return chunks[q / chunk_q].results[q % chunk_q]; }
     double wall_s = 0, ff_s = 0, al_s = 0;
     // A batch's trays (6144 objects with a stringstream each) travel from the source to the sink and come
     // back here, emptied, for the next batch -- and the next run: constructing and destroying them per batch
@@ -432,20 +457,29 @@ void sina_host_pipeline_destroy(void *p) { delete (pipeline *)p; }
 // Feeds nq unaligned queries (iupac masks) through famfinder -> aligner in batches
 // of `batch`, with `inflight` batches being worked on concurrently (host stages of
 // one batch overlap GPU work of another).
+// marks of the bench in the SINA_HOST_TRACE file: 0 = timed region starts, 1 = ends
+void sina_host_profile_mark(int which) { host_profile_mark(which == 0 ? "MARK:timed-start" : "MARK:timed-end"); }
+
 int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff, uint32_t nq, uint32_t batch,
                            uint32_t inflight) {
     pipeline *p = (pipeline *)pp;
     try {
-        p->results.resize(nq);
-        parallel_for(nq, [&](size_t i) { p->results[i].reset(); });
-        aligned_base *const base_block = p->bases.reserve(nq ? (size_t)qoff[nq] : 0);
+        host_profile_mark("MARK:run-entered");
         if (batch == 0) batch = nq ? nq : 1;
+        if (p->chunk_q != batch) p->chunks.clear();  // (chunks follow the batch size)
+        p->chunk_q = batch;
+        p->n_results = nq;
+        const size_t n_chunks = ((size_t)nq + batch - 1) / batch;
+        if (p->chunks.size() < n_chunks) p->chunks.resize(n_chunks);
+        for (size_t b = 0; b < n_chunks; b++)  // (a batch that fails early leaves its chunk in this state: "not aligned")
+            if (p->chunks[b].results.size() != std::min<size_t>(batch, nq - b * batch)) p->chunks[b].results.clear();
         if (inflight == 0) inflight = 1;
         std::atomic<uint32_t> next{0};
         std::atomic<uint64_t> ff_ns{0}, al_ns{0}, sf_ns{0};
         std::exception_ptr err;
         std::mutex err_mu;
         const auto t0 = std::chrono::steady_clock::now();
+        host_profile_mark("MARK:run-threads-start");
         // One batch travelling through the stages (what a tray is in SINA's TBB flow graph, times `batch`).
         struct item {
             uint32_t b0 = 0, b1 = 0;
@@ -501,10 +535,15 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
             host_phase hp("drv.extract");
             const uint32_t b0 = it.b0;
             std::vector<tray> &trays = it.trays;
+            pipeline::result_chunk &chunk = p->chunks[b0 / batch];
+            chunk.results.resize(it.b1 - it.b0);
+            aligned_base *const base_block = chunk.bases.reserve((size_t)(qoff[it.b1] - qoff[b0]));
+            const uint64_t base0 = qoff[b0];
             parallel_for(it.b1 - it.b0, [&](size_t i) {  // (what SINA's writer stage does per sequence)
                 const uint32_t q = b0 + (uint32_t)i;
                 tray &t = trays[i];
-                result &r = p->results[q];
+                result &r = chunk.results[i];
+                r.reset();
                 uint64_t tk = host_tsc();
                 r.log = t.log.str();
                 r.family = t.input_sequence->get_attr<std::string>(fn::family);
@@ -527,8 +566,8 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                     // (copied: the sequence keeps its heap block for its next life; a result has no more
                     // bases than its query -- a copied alignment exactly as many)
                     r.n_ab = std::min<uint32_t>(c.size(), (uint32_t)(qoff[q + 1] - qoff[q]));
-                    r.ab = base_block + qoff[q];
-                    memcpy((void *)(base_block + qoff[q]), c.packed(), sizeof(aligned_base) * (size_t)r.n_ab);
+                    r.ab = base_block + (qoff[q] - base0);
+                    memcpy((void *)(base_block + (qoff[q] - base0)), c.packed(), sizeof(aligned_base) * (size_t)r.n_ab);
                 }
                 if (t.search_result) {
                     r.searched = true;
@@ -686,11 +725,21 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
     }
 }
 
+namespace {
+const result &result_at(void *pp, uint32_t q) {
+    static const result none;  // (out of range, or a batch that never reached the sink: "not aligned")
+    pipeline *p = (pipeline *)pp;
+    if (q >= p->n_results) return none;
+    const auto &chunk = p->chunks[q / p->chunk_q].results;
+    return (q % p->chunk_q) < chunk.size() ? chunk[q % p->chunk_q] : none;
+}
+}  // namespace
+
 int sina_host_result(void *pp, uint32_t q, int *status, int *head, int *tail, int *qual, uint32_t *width,
                      uint32_t *n_bases) {
     pipeline *p = (pipeline *)pp;
-    if (q >= p->results.size()) return 1;
-    const result &r = p->results[q];
+    if (q >= p->n_results) return 1;
+    const result &r = result_at(pp, q);
     *status = r.status;
     *head = r.head;
     *tail = r.tail;
@@ -700,14 +749,14 @@ int sina_host_result(void *pp, uint32_t q, int *status, int *head, int *tail, in
     return 0;
 }
 const uint32_t *sina_host_result_bases(void *pp, uint32_t q) {
-    return reinterpret_cast<const uint32_t *>(((pipeline *)pp)->results[q].ab);
+    return reinterpret_cast<const uint32_t *>(result_at(pp, q).ab);
 }
-const char *sina_host_result_log(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].log.c_str(); }
-const char *sina_host_result_family(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].family.c_str(); }
+const char *sina_host_result_log(void *pp, uint32_t q) { return result_at(pp, q).log.c_str(); }
+const char *sina_host_result_family(void *pp, uint32_t q) { return result_at(pp, q).family.c_str(); }
 // search stage: number of results (-1: stage did not run for this query), ids/scores best first,
 // string attributes it set on the sequence (nearest_slv, lca_<field>, copy_<acc>_<field>; "" if absent)
 int sina_host_result_search(void *pp, uint32_t q, uint32_t *ids, float *scores, uint32_t cap) {
-    const result &r = ((pipeline *)pp)->results[q];
+    const result &r = result_at(pp, q);
     if (!r.searched) return -1;
     for (size_t i = 0; i < r.sr_ids.size() && i < cap; i++) {
         ids[i] = r.sr_ids[i];
@@ -716,12 +765,12 @@ int sina_host_result_search(void *pp, uint32_t q, uint32_t *ids, float *scores, 
     return (int)r.sr_ids.size();
 }
 const char *sina_host_result_attr(void *pp, uint32_t q, const char *name) {
-    const result &r = ((pipeline *)pp)->results[q];
+    const result &r = result_at(pp, q);
     const auto it = r.attrs.find(name);
     return it == r.attrs.end() ? "" : it->second.c_str();
 }
 double sina_host_search_seconds(void *pp) { return ((pipeline *)pp)->sf_s; }
-float sina_host_result_idty(void *pp, uint32_t q) { return ((pipeline *)pp)->results[q].idty; }
+float sina_host_result_idty(void *pp, uint32_t q) { return result_at(pp, q).idty; }
 void sina_host_timings(void *pp, double *wall_s, double *famfinder_s, double *aligner_s) {
     pipeline *p = (pipeline *)pp;
     *wall_s = p->wall_s;

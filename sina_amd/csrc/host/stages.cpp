@@ -137,6 +137,13 @@ struct scoped_phase {
 }  // namespace
 
 void host_profile_add_cpu(const char *what, double seconds) { add_cpu(what, seconds); }
+void host_profile_mark(const char *what) {  // a zero-length event in the SINA_HOST_TRACE file
+    prof_state &p = prof();
+    if (!p.trace_path) return;
+    const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - p.origin).count();
+    std::lock_guard<std::mutex> lk(p.mu);
+    p.events.push_back({0, what, t, t});
+}
 
 namespace {
 struct tick_slot {
@@ -223,6 +230,7 @@ std::string host_profile_dump(bool reset) {
             fclose(f);
         }
     }
+    if (reset) p.events.clear();
     return out;
 }
 

@@ -562,6 +562,7 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn);
 void set_host_threads(unsigned n);
 unsigned host_threads();
 std::string host_profile_dump(bool reset);  // per-phase wall time when SINA_HOST_PROFILE is set
+void host_profile_mark(const char *what);  // (`what` must outlive the process: a literal)
 void host_profile_add_cpu(const char *what, double seconds);  // (no-op unless SINA_HOST_PROFILE is set)
 // Fine-grained timers for per-query code (SINA_HOST_PROFILE=1): time-stamp-counter deltas summed in
 // per-slot atomics -- no system call and no lock per sample, unlike host_profile_add_cpu.
