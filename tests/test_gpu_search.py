@@ -237,6 +237,40 @@ def test_fasta_database_keeps_its_index_in_a_sidx_file(oracle, tmp_path):
     assert origin3 == "built"
 
 
+def test_fasta_database_in_arb_id_order(oracle, tmp_path):
+    """SURVEY 8f-2, second half: a database opened with the reference's id order (the walk of its
+    unordered_map<string, ..., boost::hash<string>>, host/id_order.cpp) numbers, indexes and reports its sequences
+    in that order: the .sidx it writes is the oracle's for the permuted references, names included, and the
+    families are the oracle's over the permuted references (ties between equal k-mer scores go to the larger id)."""
+    import os
+    refs = synth.make_refs(300, length=300, width=2600, seed=481, amb_rate=0.01)
+    names = ["Acc%05d" % (7919 * i % 100000) for i in range(refs.n)]
+    db = str(tmp_path / "arbdb.fasta")
+    with open(db, "w") as f:
+        for i in range(refs.n):
+            f.write(">%s\n%s\n" % (names[i], synth.aligned_string(refs.seq(i), refs.width)))
+    order, _, _ = pipeline.reference_order(names)
+    assert sorted(order.tolist()) == list(range(refs.n)) and order.tolist() != list(range(refs.n))
+    cs = [oracle.Cseq.from_packed(names[j], refs.seq(int(j)), refs.width) for j in order]
+    idx = oracle.Index(cs, k=10)
+    qs = synth.make_queries(refs, 16, seed=482)
+    st = pipeline.Store.open(db, id_order="arb")
+    assert [st.name(i) for i in range(refs.n)] == [names[j] for j in order]
+    pl = pipeline.Pipeline(st, famfinder={"fs-min-len": 100, "fs-full-len": 250})
+    pl.run(qs.mask, qs.off)
+    for q in range(qs.n):
+        ids, sc, _ = idx.famfinder(util.query_cseq(qs, q, upper=False), oracle.ff_opts(fs_min_len=100, fs_full_len=250))
+        assert pl.result(q)["family"] == "".join("%s.0:%.2f " % (names[order[i]], s) for i, s in zip(ids, sc))
+    assert st.index_origin() == "built"
+    pl.close()
+    st.close()
+    want = str(tmp_path / "want.sidx")
+    idx.write_sidx(want, names=[names[j] for j in order])
+    a, b = open(want, "rb").read(), open(str(tmp_path / "arbdb.sidx"), "rb").read()
+    keep = lambda x: x[:10] + x[12:18] + x[24:]
+    assert keep(a) == keep(b)
+
+
 def test_fasta_pipeline_and_show_dist_metrics(oracle, tmp_path):
     """FASTA in -> famfinder -> aligner -> FASTA out with --show-dist, run the way the
     reference's accuracy test does (tests/accuracy_kmer.test: the database's own sequences, --realign
