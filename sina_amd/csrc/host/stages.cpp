@@ -693,6 +693,38 @@ void kmer_search::find(const cseq &query, result_vector &results, unsigned int m
 }
 
 // src/kmer_search.cpp:366-420 for a batch of queries
+// Number of k-mers of a query with multiplicity (kmer.h:188-201): windows of k bases with exactly one base bit
+// each, ending before the last base; with the "fast" prefix filter only those starting with A.  Counted as
+// (candidate starts) - (starts whose window holds an ambiguous base): both loops over the bytes vectorise, the
+// per-window work is done for the few ambiguous bases only (a running-length loop was 2.7 us per 16S query).
+static unsigned count_query_kmers(const uint8_t *m, size_t n, unsigned k, bool count_all) {
+    if (n < (size_t)k + 1) return 0;
+    const size_t last_start = n - 1 - k;  // window [i, i + k), i + k - 1 <= n - 2
+    unsigned total = 0;
+    if (count_all) total = (unsigned)(last_start + 1);
+    else
+        for (size_t i = 0; i <= last_start; i++) total += (m[i] & 0xfu) == 1u;
+    long covered_to = -1;  // starts up to here are already taken off
+    for (size_t blk = 0; blk + 1 < n; blk += 64) {
+        const size_t end = std::min(n - 1, blk + 64);
+        unsigned bad = 0;
+        for (size_t p = blk; p < end; p++) {
+            const unsigned x = m[p] & 0xfu;
+            bad += (x == 0u) | ((x & (x - 1u)) != 0u);
+        }
+        if (bad == 0) continue;
+        for (size_t p = blk; p < end; p++) {
+            const unsigned x = m[p] & 0xfu;
+            if (x != 0u && (x & (x - 1u)) == 0u) continue;
+            const long lo = std::max<long>(std::max<long>((long)p - (long)k + 1, covered_to + 1), 0);
+            const long hi = std::min<long>((long)p, (long)last_start);
+            for (long i = lo; i <= hi; i++) total -= count_all ? 1u : (unsigned)((m[i] & 0xfu) == 1u);
+            if (hi > covered_to) covered_to = hi;
+        }
+    }
+    return total;
+}
+
 void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vector<result_vector> &results,
                              unsigned int max, std::vector<uint32_t> *kmer_counts) {
     reference_store &st = *pimpl->store;
@@ -714,15 +746,7 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
         const auto &b = queries[i]->getAlignedBases();
         uint8_t *dst = qmask + qoff[i];
         for (size_t x = 0; x < b.size(); x++) dst[x] = (uint8_t)(b[x].raw >> 24);
-        if (kmer_counts) {  // windows of k unambiguous bases ending before the last base (kmer.h:188-201)
-            unsigned run = 0, n = 0;
-            for (size_t e = 0; e + 1 < b.size(); e++) {
-                const unsigned m = dst[e] & 0xfu;
-                run = (m & (m - 1)) == 0 && m != 0 ? run + 1 : 0;
-                if (run >= kk && (count_all || (dst[e + 1 - kk] & 0xfu) == 1u)) n++;
-            }
-            (*kmer_counts)[i] = n;
-        }
+        if (kmer_counts) (*kmer_counts)[i] = count_query_kmers(dst, b.size(), kk, count_all);
     });
     auto dev = st.worker_device(reference_store::dev_search);
     sina_hip_ctx *ctx = dev.get();
