@@ -545,8 +545,9 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                 result &r = chunk.results[i];
                 r.reset();
                 uint64_t tk = host_tsc();
-                r.log = t.log.str();
-                r.family = t.input_sequence->get_attr<std::string>(fn::family);
+                r.log.assign(t.log.view());  // (no temporary: the result's string keeps its block between runs)
+                if (const std::string *fam = t.input_sequence->string_attr(fn::family)) r.family.assign(*fam);
+                else r.family = t.input_sequence->get_attr<std::string>(fn::family);
                 if (t.input_sequence->has_attr(fn::turn)) r.attrs[fn::turn] = t.input_sequence->get_attr<std::string>(fn::turn);
                 tk = host_tick("extract: log + family + turn", tk);
                 if (t.aligned_sequence) {

@@ -213,6 +213,11 @@ public:
         return std::get<std::string>(v);
     }
     bool has_attr(std::string_view key) const { return find(key) != nullptr; }
+    // the value of a string attribute in place (nullptr: absent or not a string) -- get_attr<std::string> copies
+    const std::string *string_attr(std::string_view key) const {
+        const variant *v = find(key);
+        return v ? std::get_if<std::string>(v) : nullptr;
+    }
     template <typename T> T get_attr(std::string_view attr) const { return get_attr<T>(attr, T()); }
     template <typename T> T get_attr(std::string_view attr, T dflt) const {
         const variant *v = find(attr);
