@@ -39,17 +39,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=6144, help="queries per step and rank")
+    ap.add_argument("--batch", type=int, default=9216, help="queries per step and rank")
     ap.add_argument("--refs", type=int, default=100000)
     ap.add_argument("--length", type=int, default=1500)
     ap.add_argument("--width", type=int, default=50000)
     ap.add_argument("--window", type=int, default=0, help="cut queries to this many bases (V4: 250)")
     ap.add_argument("--inflight", type=int, default=4, help="batches worked on concurrently per rank")
-    ap.add_argument("--sub-batch", type=int, default=6144,
+    ap.add_argument("--sub-batch", type=int, default=9216,
                     help="queries per GPU launch inside a step (one DP wave per query; an MI355X has 3072 wave slots "
-                         "at three waves per SIMD: 6144 = two rounds, the second filling the slots as the first "
-                         "round's shorter queries end -- 34.2 instead of 2 x 17.6 ms of DP per 6144 queries; the "
-                         "trace-back planes come from the device's pool of two, csrc/ctx.h)")
+                         "at three waves per SIMD: 9216 = three rounds.  Every DP launch ends with ~4.4 ms in which its "
+                         "last waves finish on a draining device -- tools/perf_dp.py: 3072 / 6144 / 9216 / 12288 queries "
+                         "in 23.4 / 42.3 / 61.6 / 80.4 ms = 595 / 660 / 680 / 694 Gcell/s -- so longer launches are "
+                         "faster per query; the trace-back planes (66 GB each at 9216 16S queries) come from the "
+                         "device's pool of two, csrc/ctx.h)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="CPU baseline: queries per thread and thread count (0 = 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=8,

@@ -729,10 +729,13 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
     if (c->h_out_pos.reserve(4 * std::max<uint64_t>(qoff[nq] - qoff[0], 1))) return 1;
 
     const uint64_t tb_budget_cells = tb_plane_budget(c) / tb_cell_bytes(p->insertion == SINA_INSERTION_FORBID);
-    // queries per DAG build: two rounds of DP wave slots (one DP wave per query); the DP launches
-    // below are whole rounds of them where the trace-back budget cuts a chunk
+    // queries per DAG build and DP launch: up to three rounds of DP wave slots (one DP wave per query) -- a DP
+    // launch ends with ~4.4 ms of draining device whatever its size, so a third round makes it 3 % faster per
+    // query than two (a fourth adds 2 % and another 22 GB per trace-back plane; SINA_HIP_DP_ROUNDS); the DP
+    // launches below are whole rounds where the trace-back budget cuts a chunk
     const uint32_t slots = dp_wave_slots(c, pl.geom.B);
-    const uint32_t chunk_q = 2 * slots;
+    static const uint32_t rounds = getenv("SINA_HIP_DP_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("SINA_HIP_DP_ROUNDS"))) : 3u;
+    const uint32_t chunk_q = rounds * slots;
     BuiltGraphs bg;
     for (uint32_t q0 = 0; q0 < nq; q0 += chunk_q) {
         const uint32_t bq = std::min(chunk_q, nq - q0);
