@@ -158,6 +158,7 @@ __device__ __forceinline__ void store_cells(T *__restrict__ dst, const T (&src)[
 // Profiling builds only (make PROFILE=1: per-phase s_memtime totals summed over all waves + ablation
 // switches; make PROFILE=2: the ablation switches alone, without the timers' own cost).
 __device__ unsigned long long g_dp_prof[32];
+__device__ unsigned long long g_dp_span[2 * 16384];  // start / end (100 MHz wall clock) of every query's wave: the launch's drain
 __device__ int g_dp_abl;  // ablation mask (timing experiments only, results are WRONG when set)
 #define SH_ABL(bit) (abl_ & (bit))
 #if SINA_DP_PROFILE == 1
@@ -1007,6 +1008,9 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     bool all_any = false;
 
     SH_PROF_DECL
+#ifdef SH_PROF_TIMERS
+    if (lane == 0 && blockIdx.x < 16384) g_dp_span[2 * blockIdx.x] = wall_clock64();
+#endif
     // trace-back tags (16-bit cells, common.h)
     constexpr uint32_t kXL = kTb16XLast, kExtXL = kTb16Ext | kTb16XLast;
     const float gpv = opaque_v(gp), gpev = opaque_v(gpe);  // gap costs as select operands
@@ -1426,6 +1430,9 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     }
     }  // strips
     SH_PROF_FLUSH
+#ifdef SH_PROF_TIMERS
+    if (lane == 0 && blockIdx.x < 16384) g_dp_span[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 
     const float v1min = __shfl(lc_min, lane_last);
     const float v_snk0 = __shfl(lc_snk0, lane_last);
@@ -1897,6 +1904,15 @@ int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a,
 extern "C" int sina_hip_debug_dp_ablate(int mask) {
     SH_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dp_abl), &mask, sizeof mask));
     return 0;
+}
+extern "C" int sina_hip_debug_dp_spans(unsigned long long *out, unsigned n_queries) {
+#if SINA_DP_PROFILE == 1
+    SH_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dp_span), sizeof(unsigned long long) * 2 * (n_queries < 16384u ? n_queries : 16384u)));
+    return 0;
+#else
+    (void)out; (void)n_queries;
+    return 1;
+#endif
 }
 extern "C" int sina_hip_debug_dp_profile(unsigned long long *out32, int reset) {
     SH_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_dp_prof), sizeof(unsigned long long) * 32));

@@ -54,3 +54,22 @@ if prof:
         rows, a[9] / rows, a[10] / rows, a[11] / rows))
     print("rerun iterations/row histogram [0,1,2,3,4,5-8,9-16,17-32,33+]:",
           " ".join("%.3f" % (a[16 + i] / rows) for i in range(9)))
+# ... and the launch's drain: when the waves of the last launch started and ended (100 MHz clock)
+if prof and hasattr(lib, "sina_hip_debug_dp_spans") and nq <= 16384:
+    sp = (ctypes.c_ulonglong * (2 * nq))()
+    if lib.sina_hip_debug_dp_spans(sp, nq) == 0:
+        t = np.array(sp, dtype=np.float64).reshape(nq, 2) / 100e3  # ms
+        t0 = t[:, 0].min()
+        start, end = t[:, 0] - t0, t[:, 1] - t0
+        span = end.max()
+        cells = np.array(sorted((g["n"] * len(m) for g, m in zip(graphs, qms)), reverse=True), dtype=np.float64)  # launch order: largest first
+        dur = end - start
+        print("launch %.2f ms; waves started: first %.2f .. last %.2f ms; ended: 1%% %.2f  50%% %.2f  90%% %.2f  99%% %.2f  last %.2f ms" % (
+            span, start.min(), start.max(), *np.percentile(end, [1, 50, 90, 99]), end.max()))
+        for back in (8, 6, 4, 3, 2, 1, 0.5):
+            print("  resident waves %.1f ms before the end: %d" % (back, int(((start <= span - back) & (end > span - back)).sum())))
+        rate = cells / dur  # cells per ms of a wave
+        print("  cells per wave-ms: median %.0f, 5%% %.0f, 95%% %.0f; of the last 3072 waves to start: median %.0f" % (
+            np.median(rate), *np.percentile(rate, [5, 95]), np.median(rate[np.argsort(start)[-3072:]])))
+        lastq = np.argsort(end)[-10:]
+        print("  the ten waves that end last: launch index", lastq.tolist(), "durations", np.round(dur[lastq], 2).tolist(), "started", np.round(start[lastq], 2).tolist())
