@@ -224,7 +224,11 @@ __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballo
 // (tools/perf_dp.py on the profiling build).  A wave that is behind catches up instead, the SIMD's waves end
 // together: 3072 / 9216 queries in 21.8 / 58.1 instead of 23.4 / 61.4 ms (597 -> 641, 683 -> 721 Gcell/s).
 // Results do not depend on it.  (Tried: quarters 3 2 1 0 -- 623 / 710; the reverse -- no change; high priority
-// for the first eighths only -- 607 / 688; updates every 32 or 512 rows -- the same.)
+// for the first eighths only -- 607 / 688; updates every 32 or 512 rows -- the same; a priority that merely
+// ROTATES with the row count, unrelated to progress -- 655 / 703-722, i.e. as good: what the scheduler's default
+// lacks is waves of a SIMD taking turns at being preferred, and the steady state gains as much as the drain
+// (19.0 -> 18.2 ms per round of 3072 queries); a STATIC priority by hardware wave slot -- 597 / 656, worse
+// than none.)
 __device__ __forceinline__ void issue_priority_by_progress(uint32_t rows_done, uint32_t rows_total) {
 #ifndef SINA_DP_NO_PRIO
     const uint32_t r8 = (8u * rows_done) / rows_total;
