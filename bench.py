@@ -464,7 +464,9 @@ def main():
                         "x this run's cells; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave-instruction "
                         "(MI355X_MICROARCH.md).  At three waves per SIMD the instruction classes of this kernel "
                         "issue at 3.5 (add / select / logic) and 5.5 (compare / min / DPP) cycles per wave-instruction "
-                        "(profiles/r02_valu_issue_rates.txt): 0.35 at the 2-cycle rate is a VALU that is ~85 % busy",
+                        "(profiles/r03_valu_issue_rates.txt): at those measured rates the kernel's mix would need ~1.5 ns "
+                        "per wave-instruction and SIMD, it takes ~2.4 -- the rest is dependency stalls and scalar work that "
+                        "three waves per SIMD do not hide (DESIGN.md 3.1, 8)",
             },
             "kernels_ms_per_step_isolated": {
                 "kmer_count_kernel": iso["kmer_count_ms"],
