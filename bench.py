@@ -191,8 +191,28 @@ def verify_against_oracle(world, qs, picked):
     return len(picked), len(picked) - len(diffs), diffs[:4]
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher's environment: start the N ranks ourselves, as
+    children of `torch.distributed.run` (one process per GPU, rendezvous on 127.0.0.1), hand their one
+    JSON line through and leave with their exit code.  Decided before anything touches a GPU: this
+    parent process never does (the reference's counterpart is `--threads`, src/sina.cpp:241-243,450)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(a))
     import torch
     from sina_amd import dist as sdist
     from sina_amd import pipeline, synth
@@ -207,6 +227,8 @@ def main():
         tdist.init_process_group(backend="nccl", rank=0, world_size=1)
         dist = tdist
     if world != a.gpus:
+        # (a launcher's WORLD_SIZE that disagrees with --gpus: the line below says n_gpus = WORLD_SIZE, the
+        # ranks that exist -- never the number that was asked for)
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():

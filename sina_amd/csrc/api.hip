@@ -170,6 +170,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     if (c->order.reserve(4 * (size_t)bq)) return 1;
     if (upload(c, 0, c->order.p, order.data(), 4 * (size_t)bq, s)) return 1;
     DpArgs a;
+    a.dry = DryArgs{nullptr, nullptr, 0};
     a.qd = c->qd.as<QDesc>();
     a.order = c->order.as<uint32_t>();
     a.rec = c->rec.as<uint4>();
@@ -206,6 +207,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         SH_CHECK(hipStreamWaitEvent(s, c->ev[8], 0));
         heavy_launch hl(c, s);
         SH_CHECK(hipEventRecord(c->ev[0], hl.stream()));
+        a.dry = hl.dry();
         if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, hl.stream())) return 1;
         SH_CHECK(hipEventRecord(c->ev[1], hl.stream()));
         if (hl.done()) return 1;
@@ -444,8 +446,12 @@ static int finish_ctx(sina_hip_ctx *c) {  // streams + events of a new context
 // kernel mode at 125 k sequences/s (bench.py under SINA_HOST_PROFILE=1: "timed region: thread ..." lines;
 // tools/ubench/bench_env_matrix.sh).  With 256 the thread is idle for 16S (3.2 -> 2.5 busy cores, same rate);
 // the V4 shape (365 k sequences/s) needs 1024 for that (7.9 -> 6.8).
-// An explicit setting in the environment wins.
+// An explicit setting in the environment wins, and a host that wants its process environment left alone
+// altogether sets SINA_HIP_NO_RUNTIME_DEFAULTS (to anything but "0") before it loads the library: nothing is
+// touched then -- the pipeline still works, with the costs described above.
 __attribute__((constructor)) static void sina_hip_runtime_defaults() {
+    const char *off = getenv("SINA_HIP_NO_RUNTIME_DEFAULTS");
+    if (off && *off && !(off[0] == '0' && off[1] == 0)) return;
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
     setenv("ROC_SIGNAL_POOL_SIZE", "1024", 0);
 }
@@ -461,7 +467,17 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
     c->st = new sina_hip_store();
     c->owns_store = true;
     memset(&c->st->stats, 0, sizeof(c->st->stats));
-    if (finish_ctx(c) || hipStreamCreateWithFlags(&c->st->heavy, hipStreamNonBlocking) != hipSuccess) {
+    // (the FIFO of device-filling kernels: two streams taking turns + the "queue has run dry" words, ctx.h)
+    auto make_heavy = [](sina_hip_store *st) {
+        if (hipStreamCreateWithFlags(&st->heavy, hipStreamNonBlocking) != hipSuccess) return 1;
+        if (hipStreamCreateWithFlags(&st->heavy2, hipStreamNonBlocking) != hipSuccess) return 1;
+        for (auto &e : st->heavy_done)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 1;
+        const size_t bytes = 4 * (1 + (size_t)sina_hip_store::kDryCounters);
+        if (hipMalloc(reinterpret_cast<void **>(&st->dry_mem), bytes) != hipSuccess) return 1;
+        return hipMemset(st->dry_mem, 0, bytes) != hipSuccess ? 1 : 0;
+    };
+    if (finish_ctx(c) || make_heavy(c->st)) {
         const std::string why = sina_hip_last_error();
         discard_ctx(c);
         set_error(why.empty() ? "init: could not create the context's streams" : why);
@@ -513,6 +529,7 @@ int sina_hip_sync(sina_hip_ctx *c) {
     SH_CHECK(hipStreamSynchronize(c->stream));
     SH_CHECK(hipStreamSynchronize(c->stream_dp));
     if (c->st->heavy) SH_CHECK(hipStreamSynchronize(c->st->heavy));
+    if (c->st->heavy2) SH_CHECK(hipStreamSynchronize(c->st->heavy2));
     return 0;
 }
 

@@ -107,6 +107,25 @@ struct HostBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// "My last workgroup has been dispatched": what a device-filling kernel tells the launch queued behind it
+// (ctx.h, heavy_launch).  Every workgroup counts itself in when it starts; the one that completes the grid
+// clears the counter for its next user and raises the flag word to this launch's sequence number, which a
+// hipStreamWaitValue32 on the other heavy stream is waiting for.  counter == nullptr: nobody is listening.
+struct DryArgs {
+    uint32_t *counter, *flag;
+    uint32_t seq;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ void dry_signal(const DryArgs &d, uint32_t n_workgroups, bool one_thread) {
+    if (d.counter != nullptr && one_thread) {
+        if (atomicAdd(d.counter, 1u) == n_workgroups - 1u) {
+            __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(d.flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+#endif
+
 // ---------------------------------------------------------------- mesh DP
 
 // Per-query descriptor of one DP problem inside a batch.
@@ -232,6 +251,7 @@ struct DpArgs {
     uint32_t n_weights;
     float ms, mms, gp, gpe;     // scheme ctor args: -match, -mismatch, gap, gapext
     const float *prof16;        // --fs-no-graph: match term per node and query mask [16 * node + mask], else nullptr
+    DryArgs dry;                // (heavy_launch::dry(): tells the next launch when this one's queue has run dry)
 };
 
 struct BtArgs {

@@ -37,6 +37,18 @@ struct sina_hip_store {
     // stream, in the order the host threads reach them: see sina_hip::heavy_launch below.
     hipStream_t heavy = nullptr;
     std::mutex heavy_mu;
+    // Round 4: the FIFO is kept on TWO streams taking turns, so that a kernel can start when the kernel
+    // queued before it has DISPATCHED its last workgroup ("its queue has run dry") instead of when it has
+    // ended -- see sina_hip::heavy_launch.  dry_mem: [0] the flag word (sequence number of the last launch
+    // that ran dry), [1 + seq % kDryCounters] that launch's count of started workgroups.
+    hipStream_t heavy2 = nullptr;
+    hipEvent_t heavy_done[2] = {nullptr, nullptr};  // end of the last launch queued on heavy / heavy2
+    uint32_t *dry_mem = nullptr;
+    static constexpr uint32_t kDryCounters = 64;
+    uint32_t heavy_seq = 0;          // launches queued so far (guarded by heavy_mu, like the three below)
+    int heavy_turn = 0;              // the stream the next launch goes to
+    bool heavy_prev_dry = false;     // the last launch signals "dry" (flag word reaches heavy_seq) ...
+    bool heavy_prev_any = false;     // ... there has been one at all
     // largest capacity any context has needed for each scratch buffer so far: a new fork reserves
     // these at once (hipMalloc / hipFree synchronise the device; never in steady state)
     size_t cap_hint[64] = {};  // (indexed like sina_hip_ctx::scratch(): kNumScratch entries)
@@ -125,6 +137,10 @@ struct sina_hip_ctx {
         for (auto &h : h_stage) h.release();
         if (owns_store && st) {
             if (st->heavy) (void)hipStreamDestroy(st->heavy);
+            if (st->heavy2) (void)hipStreamDestroy(st->heavy2);
+            for (auto &e : st->heavy_done)
+                if (e) (void)hipEventDestroy(e);
+            if (st->dry_mem) (void)hipFree(st->dry_mem);
             st->ref_ab.release();
             st->ref_off.release();
             st->idx_off.release();
@@ -293,20 +309,67 @@ inline int download(sina_hip_ctx *c, int slot, const void *src, size_t bytes, hi
     SH_CHECK(hipMemcpyAsync(c->h_stage[slot].p, src, bytes, hipMemcpyDeviceToHost, s));
     return 0;
 }
+// What a device-filling kernel needs to tell the queue that its last workgroup has been dispatched:
+// every workgroup calls dry_signal() (common.h) first thing.
+// (declared in common.h: struct DryArgs { uint32_t *counter, *flag; uint32_t seq; })
+//
+// Round 4 -- chained launches.  A DP launch ends with its last waves finishing on a device that empties SIMD
+// by SIMD (4.4 ms of a 48 ms launch), and until round 3 the next kernel of the FIFO waited
+// for the very last of them.  Now the FIFO alternates between two streams, and a launch waits
+//   * for what its own context queued before it (event, as before),
+//   * for the END of the launch two places ahead (stream order: same stream),
+//   * for the launch right ahead of it only to have RUN DRY -- hipStreamWaitValue32 on a flag word that
+//     launch's last-started workgroup writes (tools/ubench/chain.hip: the follower starts 0.3 ms after the
+//     flag, i.e. as soon as a slot is free) -- if that launch signals it (DP, DAG build), else for its end.
+// So at most two device-filling kernels are resident, and only while the older one has nothing left to
+// dispatch: the newer one gets exactly the slots the drain leaves empty.  Nothing runs beside a kernel
+// that still has workgroups waiting (what round 1 measured as mutual stretching).  Every wait refers to
+// work queued EARLIER, so hardware queues shared between streams cannot dead-lock (see done()).
+// SINA_HIP_CHAIN=0: one stream, every launch waits for the end of the one before (round 3).
+inline bool chain_kernels() {
+    static const bool on = [] {
+        const char *v = getenv("SINA_HIP_CHAIN");
+        return !(v && *v == '0');
+    }();
+    return on;
+}
 struct heavy_launch {
     sina_hip_ctx *c;
     hipStream_t own, hs;
     std::unique_lock<std::mutex> lk;
     bool failed = false;
+    int turn = 0;
+    bool signals_dry = false;
     // `own`: the context stream whose queued work (uploads) the kernel depends on
     heavy_launch(sina_hip_ctx *c_, hipStream_t own_) : c(c_), own(own_), hs(own_) {
         if (!serialize_kernels() || !c->st->heavy) return;
-        hs = c->st->heavy;
+        sina_hip_store *st = c->st;
         failed = hipEventRecord(c->ev[10], own) != hipSuccess;
-        lk = std::unique_lock<std::mutex>(c->st->heavy_mu);
+        lk = std::unique_lock<std::mutex>(st->heavy_mu);
+        const bool chain = chain_kernels() && st->heavy2 && st->dry_mem;
+        turn = chain ? st->heavy_turn : 0;
+        hs = turn ? st->heavy2 : st->heavy;
         failed = failed || hipStreamWaitEvent(hs, c->ev[10], 0) != hipSuccess;
+        if (chain && st->heavy_prev_any) {
+            if (st->heavy_prev_dry)
+                failed = failed || hipStreamWaitValue32(hs, st->dry_mem, st->heavy_seq, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess;
+            else
+                failed = failed || hipStreamWaitEvent(hs, st->heavy_done[turn ^ 1], 0) != hipSuccess;
+        }
+        if (chain) ++st->heavy_seq;
     }
     hipStream_t stream() const { return hs; }
+    // for the LAST kernel of the launch, if it can tell when its last workgroup starts
+    DryArgs dry() {
+        DryArgs d{nullptr, nullptr, 0};
+        sina_hip_store *st = c->st;
+        if (!lk.owns_lock() || !chain_kernels() || !st->heavy2 || !st->dry_mem) return d;
+        d.flag = st->dry_mem;
+        d.counter = st->dry_mem + 1 + st->heavy_seq % sina_hip_store::kDryCounters;
+        d.seq = st->heavy_seq;
+        signals_dry = true;
+        return d;
+    }
     // After the launches: the HOST waits for them.  (Never let a context stream wait for the heavy
     // stream on the GPU side: streams share hardware queues once there are more streams than queues,
     // a queue blocked on the heavy stream would hold up another context's uploads that an EARLIER
@@ -315,7 +378,16 @@ struct heavy_launch {
     int done() {
         if (hs == own) return failed ? 1 : 0;
         failed = failed || hipEventRecord(c->ev[11], hs) != hipSuccess;
-        if (lk.owns_lock()) lk.unlock();
+        if (lk.owns_lock()) {
+            sina_hip_store *st = c->st;
+            if (chain_kernels() && st->heavy2 && st->dry_mem) {
+                failed = failed || hipEventRecord(st->heavy_done[turn], hs) != hipSuccess;
+                st->heavy_prev_dry = signals_dry && !failed;
+                st->heavy_prev_any = true;
+                st->heavy_turn = turn ^ 1;
+            }
+            lk.unlock();
+        }
         failed = failed || wait_event(c->ev[11]) != hipSuccess;
         if (failed) set_error("heavy_launch: event hand-over failed");
         return failed ? 1 : 0;

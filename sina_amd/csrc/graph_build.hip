@@ -82,6 +82,7 @@ struct GraphArgs {
     uint32_t member_off;       // LDS offset of the per-member arrays (behind the tile tables), entries each
     uint32_t member_cap;
     int W;                     // DP ring depth: edges longer than this need a spill row
+    DryArgs dry;               // (ctx.h, heavy_launch: tells the launch queued behind when the last workgroup has started)
 };
 
 // exclusive scan of in[0..n) into out[0..n) (may alias if same type); returns the total.
@@ -130,6 +131,7 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
     uint32_t *s_carry = s_curn + a.member_cap, *s_carryn = s_carry + a.member_cap;  // node of member j's last base before the tile
     __shared__ uint32_t s_tmp[kGT / 64 + 8];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    dry_signal(a.dry, gridDim.x, tid == 0);
     const uint32_t nwords = (a.width + 31) / 32;
     const uint64_t f0 = a.fam_off[q];
     const uint32_t F = (uint32_t)(a.fam_off[q + 1] - f0);
@@ -671,6 +673,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         {
             heavy_launch hl(c, s);  // (a device-filling kernel: ctx.h)
             SH_CHECK(hipEventRecord(c->ev[6], hl.stream()));
+            ga.dry = hl.dry();
             hipLaunchKernelGGL(family_graph_kernel, dim3(bq), dim3(kGT), glds, hl.stream(), ga);
             SH_CHECK(hipGetLastError());
             SH_CHECK(hipEventRecord(c->ev[7], hl.stream()));

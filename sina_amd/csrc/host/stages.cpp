@@ -18,6 +18,7 @@
 #include <sys/stat.h>
 #include <chrono>
 #include <map>
+#include <unordered_map>
 
 namespace sina {
 
@@ -612,10 +613,43 @@ void reference_store::ensure_index(unsigned k, bool nofast) {
             std::vector<std::string> names;
             std::vector<uint32_t> offsets, ids;
             if (sidx_load(idxpath, k, nofast, &names, &offsets, &ids) && names.size() == seqs.size()) {
-                hip_check(sina_hip_upload_index(c, k, nofast ? 1 : 0, offsets.data(), ids.data(), ids.size()),
-                          "upload_index");
-                loaded = true;
-                idx_origin = "loaded " + idxpath;
+                // The file's posting ids count ITS name list (the reference resolves ids through the names it
+                // stored: kmer_search.cpp try_load + getCseq(sequence_names[id])).  This store may number the
+                // same database differently -- file order vs the ARB walk order of a stock-SINA .sidx
+                // (reference_store::open(path, arb_id_order)) -- so: same names in the same order -> take the
+                // lists as they are; the same names in another order -> renumber every list through a
+                // name -> id table and re-sort it; anything else -> not this database's index, rebuild.
+                bool same_order = true;
+                for (size_t i = 0; i < seqs.size() && same_order; i++) same_order = names[i] == seqs[i].getName();
+                bool usable = same_order;
+                if (!same_order) {
+                    std::unordered_map<std::string, uint32_t> id_of;
+                    id_of.reserve(seqs.size() * 2);
+                    for (size_t i = 0; i < seqs.size(); i++) id_of.emplace(seqs[i].getName(), (uint32_t)i);
+                    std::vector<uint32_t> remap(names.size());
+                    std::vector<char> hit(seqs.size(), 0);
+                    usable = id_of.size() == seqs.size();
+                    for (size_t i = 0; i < names.size() && usable; i++) {
+                        auto it = id_of.find(names[i]);
+                        usable = it != id_of.end() && !hit[it->second];
+                        if (usable) {
+                            remap[i] = it->second;
+                            hit[it->second] = 1;
+                        }
+                    }
+                    if (usable) {
+                        for (auto &id : ids) id = remap[id];
+                        parallel_for(offsets.size() - 1, [&](size_t km) {
+                            if (offsets[km + 1] - offsets[km] > 1) std::sort(ids.begin() + offsets[km], ids.begin() + offsets[km + 1]);
+                        });
+                    }
+                }
+                if (usable) {
+                    hip_check(sina_hip_upload_index(c, k, nofast ? 1 : 0, offsets.data(), ids.data(), ids.size()),
+                              "upload_index");
+                    loaded = true;
+                    idx_origin = std::string(same_order ? "loaded " : "loaded (ids renumbered by name) ") + idxpath;
+                }
             }
         }
     }

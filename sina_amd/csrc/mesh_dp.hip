@@ -249,12 +249,13 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
                const uint8_t *__restrict__ qmaskv, const float *__restrict__ weights, uint32_t n_weights,
                void *__restrict__ tbv, float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev,
                uint64_t edge_stride, uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp,
-               float gpe, const float *__restrict__ prof16v) {
+               float gpe, const float *__restrict__ prof16v, DryArgs dry) {
     static_assert(B % 4 == 0, "16-byte accesses per array");
     constexpr int kStrip = 64 * B;  // columns per strip
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int lane = threadIdx.x;
+    dry_signal(dry, gridDim.x, lane == 0);  // (the launch queued behind this one may start once the last of us has: ctx.h)
     // workgroups are dispatched in blockIdx order: the launch lists the queries by decreasing work
     // (longest first), so that a launch of more workgroups than the GPU holds at once ends evenly
     const uint32_t qi = orderv[blockIdx.x];
@@ -1001,11 +1002,12 @@ __global__ void __launch_bounds__(64, (B <= 4 ? 4 : (B <= 8 ? SINA_DP_SIMPLE_WAV
 mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ orderv, const uint4 *__restrict__ recv,
                       const uint32_t *__restrict__ predv, const uint8_t *__restrict__ qmaskv, void *__restrict__ tbv,
                       float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev, uint64_t edge_stride,
-                      uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe) {
+                      uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe, DryArgs dry) {
     static_assert(B % 4 == 0, "16-byte accesses per array");
     constexpr int kStrip = 64 * B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
+    dry_signal(dry, gridDim.x, lane == 0);  // (the launch queued behind this one may start once the last of us has: ctx.h)
     const uint32_t qi = orderv[blockIdx.x];
     const QDesc d = qdv[qi];
     const uint32_t N = uniform(d.N), L = uniform(d.L);
@@ -1820,7 +1822,7 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
         if (allow_full_lds(reinterpret_cast<const void *>(kfn))) return 1;                               \
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.node_pos, a.succ_minpos, \
                            a.qmask, a.weights, a.n_weights, a.tb, a.dbg_value, a.spill, a.edge, a.edge_stride, \
-                           n_strips, a.res, a.ms, a.mms, a.gp, a.gpe, a.prof16);                         \
+                           n_strips, a.res, a.ms, a.mms, a.gp, a.gpe, a.prof16, a.dry);                  \
     } while (0)
     // the simple scheme with gap_open >= gap_extend in a launch below the initial value (every BASELINE
     // configuration): the specialised kernel; SINA_HIP_DP_GENERIC=1 keeps the generic one (parity tests)
@@ -1829,7 +1831,7 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
         auto kfn = a.dbg_value ? mesh_dp_simple_kernel<B, true> : mesh_dp_simple_kernel<B, false>;
         if (allow_full_lds(reinterpret_cast<const void *>(kfn))) return 1;
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.qmask, a.tb, a.dbg_value, a.spill,
-                           a.edge, a.edge_stride, n_strips, a.res, a.ms, a.mms, a.gp, a.gpe);
+                           a.edge, a.edge_stride, n_strips, a.res, a.ms, a.mms, a.gp, a.gpe, a.dry);
     } else if (!weighted && !forbid && a.below_init) SH_LAUNCH(false, false, true);
     else if (!weighted && !forbid) SH_LAUNCH(false, false, false);
     else if (weighted && !forbid) SH_LAUNCH(true, false, false);
@@ -1842,19 +1844,22 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
 
 }  // namespace
 
-// The dynamic-LDS ceiling of a kernel is a process-wide attribute: raised ONCE per kernel to all of a
-// CU's 160 KB (a per-launch size would race between contexts launching from different host threads).
+// The dynamic-LDS ceiling of a kernel is raised ONCE per kernel and device to all of a CU's 160 KB (a
+// per-launch size would race between contexts launching from different host threads; the attribute belongs
+// to the current device's function object, so a process with contexts on several devices sets it on each).
 int allow_full_lds(const void *kernel) {
     static std::mutex mu;
-    static std::vector<const void *> done;
+    static std::vector<std::pair<int, const void *>> done;
+    int dev = 0;
+    SH_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    for (const void *k : done)
-        if (k == kernel) return 0;
+    for (const auto &k : done)
+        if (k.first == dev && k.second == kernel) return 0;
     hipFuncAttributes fa;
     SH_CHECK(hipFuncGetAttributes(&fa, kernel));  // (the ceiling is what the kernel's static LDS leaves of the 160 KB)
     const int room = 160 * 1024 - (int)fa.sharedSizeBytes;
     SH_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, room));
-    done.push_back(kernel);
+    done.emplace_back(dev, kernel);
     return 0;
 }
 

@@ -271,6 +271,63 @@ def test_fasta_database_in_arb_id_order(oracle, tmp_path):
     assert keep(a) == keep(b)
 
 
+def test_sidx_written_under_one_id_order_is_renumbered_under_the_other(oracle, tmp_path):
+    """A <db>.sidx holds ids that count ITS OWN name list (the reference resolves them through those names,
+    kmer_search.cpp try_load).  The same database opened first in file order (index built + cached), then in
+    ARB order, must not take the cached posting ids at face value: they are renumbered by name (or the cache is
+    rebuilt) and the families are those of an index built for that order -- and the other way round; a cache
+    whose names are not this database's is rebuilt."""
+    import os
+    refs = synth.make_refs(280, length=300, width=2600, seed=491, amb_rate=0.01)
+    names = ["Acc%05d" % (104729 * i % 100000) for i in range(refs.n)]
+    db = str(tmp_path / "both.fasta")
+    with open(db, "w") as f:
+        for i in range(refs.n):
+            f.write(">%s\n%s\n" % (names[i], synth.aligned_string(refs.seq(i), refs.width)))
+    order, _, _ = pipeline.reference_order(names)
+    qs = synth.make_queries(refs, 12, seed=492)
+    ffo = {"fs-min-len": 100, "fs-full-len": 250}
+
+    def run(id_order):
+        st = pipeline.Store.open(db, id_order=id_order) if id_order else pipeline.Store.open(db)
+        pl = pipeline.Pipeline(st, famfinder=ffo)
+        pl.run(qs.mask, qs.off)
+        fam = [pl.result(q)["family"] for q in range(qs.n)]
+        origin = st.index_origin()
+        pl.close()
+        st.close()
+        return fam, origin
+
+    def want(perm):
+        cs = [oracle.Cseq.from_packed(names[j], refs.seq(int(j)), refs.width) for j in perm]
+        idx = oracle.Index(cs, k=10)
+        out = []
+        for q in range(qs.n):
+            ids, sc, _ = idx.famfinder(util.query_cseq(qs, q, upper=False), oracle.ff_opts(fs_min_len=100, fs_full_len=250))
+            out.append("".join("%s.0:%.2f " % (names[perm[i]], s) for i, s in zip(ids, sc)))
+        return out
+
+    sidx = str(tmp_path / "both.sidx")
+    want_file, want_arb = want(list(range(refs.n))), want([int(j) for j in order])
+    fam, origin = run(None)
+    assert origin == "built" and fam == want_file
+    fam, origin = run("arb")                     # the cache is in file order
+    assert origin == "loaded (ids renumbered by name) " + sidx and fam == want_arb
+    os.remove(sidx)
+    fam, origin = run("arb")
+    assert origin == "built" and fam == want_arb
+    fam, origin = run(None)                      # the cache is in ARB order now
+    assert origin == "loaded (ids renumbered by name) " + sidx and fam == want_file
+    fam, origin = run("arb")
+    assert origin == "loaded " + sidx and fam == want_arb
+    # a cache of the right size whose names belong to another database: rebuilt
+    blob = open(sidx, "rb").read()
+    at = blob.index(names[int(order[0])].encode())
+    open(sidx, "wb").write(blob[:at] + b"Zzz" + blob[at + 3:])
+    fam, origin = run("arb")
+    assert origin == "built" and fam == want_arb
+
+
 def test_fasta_pipeline_and_show_dist_metrics(oracle, tmp_path):
     """FASTA in -> famfinder -> aligner -> FASTA out with --show-dist, run the way the
     reference's accuracy test does (tests/accuracy_kmer.test: the database's own sequences, --realign

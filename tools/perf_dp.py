@@ -8,7 +8,19 @@ import pickle
 nq=int(sys.argv[1]) if len(sys.argv)>1 else 256
 refs=synth.make_refs(2000, length=1500, width=50000, seed=2)
 t=time.time()
-cache="/tmp/perf_dp_prep_%d.pkl" % nq   # (the oracle-side preparation, reused by later runs on the same box)
+# the oracle-side preparation, reused by later runs of the same session: kept in a directory of this user's own
+# (mode 0700; not a fixed name in a world-writable /tmp) and keyed by everything it is computed from -- the
+# generator, the oracle and the helpers -- so that a stale file is never taken for the current workload
+import hashlib
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h=hashlib.sha1(("refs=2000,1500,50000,2;queries=%d,3" % nq).encode())
+for _f in ("sina_amd/synth.py","tests/util.py","oracle/pyoracle.py","oracle/sina_oracle.c","oracle/sina_oracle.h"):
+    _h.update(open(os.path.join(ROOT,_f),"rb").read())
+import tempfile
+_dir=os.path.join(tempfile.gettempdir(),"sina_amd_cache_%d" % os.getuid())
+os.makedirs(_dir,mode=0o700,exist_ok=True)
+if os.stat(_dir).st_uid!=os.getuid() or (os.stat(_dir).st_mode&0o077): raise SystemExit("%s is not a private directory of this user" % _dir)
+cache=os.path.join(_dir,"perf_dp_prep_%d_%s.pkl" % (nq,_h.hexdigest()[:12]))
 if os.path.exists(cache):
     graphs,qms=pickle.load(open(cache,"rb"))
 else:
