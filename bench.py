@@ -362,7 +362,13 @@ def main():
         per_rank = [[float(x) for x in t.cpu()] for t in every]
         elapsed = sdist.reduce_max(elapsed, dist, device)
         n_aligned = int(sdist.reduce_sum(n_aligned, dist, device))
-    dp_ms = s1["dp_ms"] - s0["dp_ms"]
+    # DP launches are chained (csrc/ctx.h, heavy_launch): a launch starts when the launch before it has dispatched
+    # its last workgroup, so consecutive DP launches overlap while the older one drains.  dp_busy_ms = the time
+    # during which a DP kernel was resident (sum of the launches' start-to-end durations minus their overlaps):
+    # the denominator of the kernel's throughput.  dp_ms_sum = the plain sum of start-to-end durations, what a
+    # kernel trace's "average duration" multiplies out to; it counts every overlap twice.
+    dp_ms_sum = s1["dp_ms"] - s0["dp_ms"]
+    dp_ms = s1["dp_busy_ms"] - s0["dp_busy_ms"]
     dp_cells = s1["dp_cells"] - s0["dp_cells"]
     dp_launches = s1["dp_launches"] - s0["dp_launches"]
     achieved = DP_BYTES_PER_CELL * dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
@@ -460,11 +466,19 @@ def main():
                 "algorithmic_bytes_per_launch": DP_BYTES_PER_CELL * dp_cells / dp_launches if dp_launches else 0,
                 "cells_per_launch": dp_cells / dp_launches if dp_launches else 0,
                 "ms_per_launch": dp_ms / dp_launches if dp_launches else 0,
+                "ms_per_launch_start_to_end": dp_ms_sum / dp_launches if dp_launches else 0,
+                "frac_by_start_to_end": (DP_BYTES_PER_CELL * dp_cells / (dp_ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                         if dp_ms_sum > 0 else 0.0),
                 "gcells_per_s": dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0,
                 "note": "contractual accounting (SURVEY 8d): 8 algorithmic bytes per mesh cell against the HBM peak; "
                         "the kernel writes 2 B per cell and is bound by VALU issue, see roofline_valu.  Timed "
-                        "region: HIP events on the store's FIFO stream, where every device-filling kernel of "
-                        "every batch runs alone; `isolated` = one extra untimed step with a single batch in flight",
+                        "region: HIP events around every launch on the FIFO streams it runs on.  Launches are chained: "
+                        "a DP launch starts when the one before it has DISPATCHED its last workgroup, so two DP "
+                        "launches share the device while the older one drains; ms_per_launch / achieved / frac "
+                        "count that shared time once (time with a DP kernel resident / launches), "
+                        "ms_per_launch_start_to_end / frac_by_start_to_end count it in both launches (what a kernel "
+                        "trace's average duration gives; tools/kt_union.py on the committed trace gives both); "
+                        "`isolated` = one extra untimed step with a single batch in flight, nothing overlapping",
                 "isolated": {
                     "achieved": DP_BYTES_PER_CELL * iso["dp_cells"] / (iso["dp_ms"] * 1e-3) / 1e9,
                     "frac": DP_BYTES_PER_CELL * iso["dp_cells"] / (iso["dp_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -510,6 +524,7 @@ def main():
                 "kmer_select_kernel": (s1["kmer_select_ms"] - s0["kmer_select_ms"]) / a.steps,
                 "graph_kernel": (s1["graph_ms"] - s0["graph_ms"]) / a.steps,
                 "mesh_dp_kernel": dp_ms / a.steps,
+                "mesh_dp_kernel_start_to_end": dp_ms_sum / a.steps,
                 "backtrack_kernel": (s1["backtrack_ms"] - s0["backtrack_ms"]) / a.steps,
             },
         }

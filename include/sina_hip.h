@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SINA_HIP_ABI_VERSION 2
+#define SINA_HIP_ABI_VERSION 3  /* 3: sina_hip_stats grew dp_busy_ms */
 
 typedef struct sina_hip_ctx sina_hip_ctx;
 
@@ -284,6 +284,9 @@ typedef struct sina_hip_stats {
     uint32_t compare_launches;
     uint32_t n_dense_lists;  /* gauge, not cumulative: posting lists the index currently also holds as
                                 reference bitmaps (0 until the first search after an index change) */
+    double dp_busy_ms;       /* time during which a DP kernel was resident: dp_ms minus the time a launch shared
+                                the device with the launch before it (a DP launch starts when its predecessor
+                                has dispatched its last workgroup, not when it has ended)                     */
 } sina_hip_stats;
 int sina_hip_get_stats(sina_hip_ctx *ctx, sina_hip_stats *s);
 

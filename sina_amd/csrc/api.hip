@@ -197,6 +197,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         a.below_init = (!weighted && !forbid && dp_below_init(max_n, a.gp, a.gpe)) ? 1 : 0;
     }
 
+    uint64_t dp_no = ~0ull;  // this launch's number among the store's DP launches
     {
         // the DP kernel: on the store's heavy stream, behind the uploads queued on c->stream; the
         // backtrack walk and the result copies then follow it on the context's low-priority stream
@@ -205,11 +206,15 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         SH_CHECK(hipEventRecord(c->ev[8], s));
         s = c->stream_dp;
         SH_CHECK(hipStreamWaitEvent(s, c->ev[8], 0));
-        heavy_launch hl(c, s);
+        heavy_launch hl(c, s, kHeavyDp);
         SH_CHECK(hipEventRecord(c->ev[0], hl.stream()));
         a.dry = hl.dry();
         if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, hl.stream())) return 1;
         SH_CHECK(hipEventRecord(c->ev[1], hl.stream()));
+        if (hl.lk.owns_lock() && c->st->dp_end[0]) {  // (under the queue's lock: launch order = dp_seq order)
+            dp_no = c->st->dp_seq++;
+            SH_CHECK(hipEventRecord(c->st->dp_end[dp_no % 8], hl.stream()));
+        }
         if (hl.done()) return 1;
         if (getenv("SINA_HIP_DEBUG_SYNC")) fprintf(stderr, "[sina_hip] DP kernel done: %u queries, geometry %dx%d, weighted %d forbid %d\n", bq, pl.geom.T, pl.geom.B, (int)weighted, (int)forbid);
         if (token.owns_lock()) SH_CHECK(wait_event(c->ev[1]));
@@ -253,8 +258,17 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     if (out_pos) memcpy(out_pos, staged_pos, 4 * nqm);
     float ms = 0;
     SH_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    // ... of which this launch shared the device with the DP launch before it (chained launches, ctx.h)
+    float shared = 0;
+    if (dp_no != ~0ull && dp_no > 0) {
+        float to_prev_end = 0;
+        const hipError_t e = hipEventElapsedTime(&to_prev_end, c->ev[0], c->st->dp_end[(dp_no - 1) % 8]);
+        if (e == hipSuccess) shared = std::min(ms, std::max(0.f, to_prev_end));
+        else (void)hipGetLastError();  // (the launch before has not ended yet: cannot happen behind a chain; counted as no overlap)
+    }
     std::lock_guard<std::mutex> slk(c->st->stats_mu);
     c->st->stats.dp_ms += ms;
+    c->st->stats.dp_busy_ms += ms - shared;
     SH_CHECK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
     c->st->stats.backtrack_ms += ms;
     c->st->stats.dp_cells += cells;
@@ -473,6 +487,8 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
         if (hipStreamCreateWithFlags(&st->heavy2, hipStreamNonBlocking) != hipSuccess) return 1;
         for (auto &e : st->heavy_done)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 1;
+        for (auto &e : st->dp_end)
+            if (hipEventCreate(&e) != hipSuccess) return 1;
         const size_t bytes = 4 * (1 + (size_t)sina_hip_store::kDryCounters);
         if (hipMalloc(reinterpret_cast<void **>(&st->dry_mem), bytes) != hipSuccess) return 1;
         return hipMemset(st->dry_mem, 0, bytes) != hipSuccess ? 1 : 0;

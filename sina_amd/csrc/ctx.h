@@ -45,10 +45,26 @@ struct sina_hip_store {
     hipEvent_t heavy_done[2] = {nullptr, nullptr};  // end of the last launch queued on heavy / heavy2
     uint32_t *dry_mem = nullptr;
     static constexpr uint32_t kDryCounters = 64;
-    uint32_t heavy_seq = 0;          // launches queued so far (guarded by heavy_mu, like the three below)
+    uint32_t heavy_seq = 0;          // launches queued so far (guarded by heavy_mu, like everything below)
     int heavy_turn = 0;              // the stream the next launch goes to
     bool heavy_prev_dry = false;     // the last launch signals "dry" (flag word reaches heavy_seq) ...
     bool heavy_prev_any = false;     // ... there has been one at all
+    // admission (heavy_launch): launches handed to the GPU and not yet known to have ended, the kind of the
+    // last one handed over, and who is waiting to be
+    std::condition_variable heavy_cv;
+    int heavy_outstanding = 0;
+    int heavy_last_kind = -1;
+    uint64_t heavy_ticket = 0;
+    struct heavy_waiter {
+        uint64_t ticket;
+        int kind;
+    };
+    std::vector<heavy_waiter> heavy_waiting;
+    // DP launches overlap now (the next one starts in the drain of the one before): stats.dp_busy_ms is the time
+    // during which ANY DP kernel was resident -- the sum of the launches' durations minus their overlaps, which
+    // are measured against the end event of the launch before (a ring: launch k records dp_end[k % 8])
+    hipEvent_t dp_end[8] = {};
+    uint64_t dp_seq = 0;
     // largest capacity any context has needed for each scratch buffer so far: a new fork reserves
     // these at once (hipMalloc / hipFree synchronise the device; never in steady state)
     size_t cap_hint[64] = {};  // (indexed like sina_hip_ctx::scratch(): kNumScratch entries)
@@ -141,6 +157,8 @@ struct sina_hip_ctx {
             for (auto &e : st->heavy_done)
                 if (e) (void)hipEventDestroy(e);
             if (st->dry_mem) (void)hipFree(st->dry_mem);
+            for (auto &e : st->dp_end)
+                if (e) (void)hipEventDestroy(e);
             st->ref_ab.release();
             st->ref_off.release();
             st->idx_off.release();
@@ -333,20 +351,69 @@ inline bool chain_kernels() {
     }();
     return on;
 }
+// Which launch goes next.  Until round 4 the FIFO was the order in which host threads arrived.  With chained
+// launches the order matters: the best filler of a DP launch's drain is the NEXT DP launch (a DP wave needs
+// exactly what a retiring DP wave frees: one wave slot, 168 VGPRs, 12 KB of LDS; a DAG-build workgroup needs a
+// quarter of a CU, a k-mer count workgroup half of one).  So at most kHeavyDepth launches are handed to the GPU
+// ahead of time (one running, one queued behind it -- enough to never leave the device idle: every launch here
+// runs for milliseconds), the other callers wait on the host, and when a place frees up the waiter to take it
+// is: after a DP launch another DP launch if one is waiting (else a DAG build, else the oldest waiter); after
+// anything else the oldest waiter.  Bursts of DP launches are bounded by the batches in flight, and by the
+// trace-back planes (a DP launch asks for its plane BEFORE it queues here).
+enum heavy_kind { kHeavyKmer = 0, kHeavyGraph = 1, kHeavyDp = 2 };
+constexpr int kHeavyDepth = 2;
+inline bool heavy_reorder() {
+    static const bool on = [] {
+        const char *v = getenv("SINA_HIP_DP_BURST");
+        return !(v && *v == '0');
+    }();
+    return on;
+}
 struct heavy_launch {
     sina_hip_ctx *c;
     hipStream_t own, hs;
     std::unique_lock<std::mutex> lk;
     bool failed = false;
     int turn = 0;
+    int kind = 0;
     bool signals_dry = false;
+    bool admitted = false;
     // `own`: the context stream whose queued work (uploads) the kernel depends on
-    heavy_launch(sina_hip_ctx *c_, hipStream_t own_) : c(c_), own(own_), hs(own_) {
+    heavy_launch(sina_hip_ctx *c_, hipStream_t own_, int kind_ = kHeavyKmer) : c(c_), own(own_), hs(own_), kind(kind_) {
         if (!serialize_kernels() || !c->st->heavy) return;
         sina_hip_store *st = c->st;
         failed = hipEventRecord(c->ev[10], own) != hipSuccess;
         lk = std::unique_lock<std::mutex>(st->heavy_mu);
         const bool chain = chain_kernels() && st->heavy2 && st->dry_mem;
+        if (chain) {
+            const uint64_t me = st->heavy_ticket++;
+            st->heavy_waiting.push_back({me, kind});
+            st->heavy_cv.wait(lk, [&] {
+                if (st->heavy_outstanding >= kHeavyDepth) return false;
+                // whose turn is it?
+                const sina_hip_store::heavy_waiter *pick = nullptr;
+                auto oldest_of = [&](int k) {
+                    const sina_hip_store::heavy_waiter *o = nullptr;
+                    for (const auto &w : st->heavy_waiting)
+                        if ((k < 0 || w.kind == k) && (!o || w.ticket < o->ticket)) o = &w;
+                    return o;
+                };
+                if (heavy_reorder() && st->heavy_last_kind == kHeavyDp) {
+                    pick = oldest_of(kHeavyDp);
+                    if (!pick) pick = oldest_of(kHeavyGraph);
+                }
+                if (!pick) pick = oldest_of(-1);
+                return pick && pick->ticket == me;
+            });
+            for (size_t i = 0; i < st->heavy_waiting.size(); i++)
+                if (st->heavy_waiting[i].ticket == me) {
+                    st->heavy_waiting.erase(st->heavy_waiting.begin() + (std::ptrdiff_t)i);
+                    break;
+                }
+            ++st->heavy_outstanding;
+            st->heavy_last_kind = kind;
+            admitted = true;
+        }
         turn = chain ? st->heavy_turn : 0;
         hs = turn ? st->heavy2 : st->heavy;
         failed = failed || hipStreamWaitEvent(hs, c->ev[10], 0) != hipSuccess;
@@ -387,11 +454,24 @@ struct heavy_launch {
                 st->heavy_turn = turn ^ 1;
             }
             lk.unlock();
+            c->st->heavy_cv.notify_all();
         }
         failed = failed || wait_event(c->ev[11]) != hipSuccess;
+        leave();
         if (failed) set_error("heavy_launch: event hand-over failed");
         return failed ? 1 : 0;
     }
+    // the launch has ended (or was never made): its place goes to a waiter
+    void leave() {
+        if (!admitted) return;
+        admitted = false;
+        sina_hip_store *st = c->st;
+        if (!lk.owns_lock()) lk = std::unique_lock<std::mutex>(st->heavy_mu);
+        --st->heavy_outstanding;
+        lk.unlock();
+        st->heavy_cv.notify_all();
+    }
+    ~heavy_launch() { leave(); }
 };
 }  // namespace sina_hip
 

@@ -671,7 +671,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         if (allow_full_lds(reinterpret_cast<const void *>(family_graph_kernel))) return 1;
         bg->sizes.resize(4 * (size_t)bq);
         {
-            heavy_launch hl(c, s);  // (a device-filling kernel: ctx.h)
+            heavy_launch hl(c, s, kHeavyGraph);  // (a device-filling kernel: ctx.h)
             SH_CHECK(hipEventRecord(c->ev[6], hl.stream()));
             ga.dry = hl.dry();
             hipLaunchKernelGGL(family_graph_kernel, dim3(bq), dim3(kGT), glds, hl.stream(), ga);

@@ -111,7 +111,9 @@ struct pipeline {
     struct result_chunk {
         std::vector<result> results;
         base_arena bases;
+        uint64_t run = 0;  // the run (pipeline::run_no) whose sink filled it: an older one's results are not this run's
     };
+    uint64_t run_no = 0;
     std::vector<result_chunk> chunks;
     uint32_t chunk_q = 1, n_results = 0;
     result &result_of(uint32_t q) { return chunks[q / chunk_q].results[q % chunk_q]; }
@@ -133,6 +135,73 @@ struct pipeline {
         if (spare_trays.size() < 16) spare_trays.push_back(std::move(v));
     }
 };
+// The sink's work for one tray (what SINA's writer stage does per sequence): log, family, attributes and the
+// aligned bases go into the result record -- the bases into `dst`, room for as many as the query has (a DP
+// alignment has exactly the query's bases, a copied one its reference's: never more than the query, which the
+// copy short-cut requires to be contained in it) -- and the tray gives its objects back.
+void extract_tray(pipeline *p, tray &t, result &r, aligned_base *dst, uint32_t query_bases) {
+    r.reset();
+    uint64_t tk = host_tsc();
+    r.log.assign(t.log.view());  // (no temporary: the result's string keeps its block between runs)
+    if (const std::string *fam = t.input_sequence->string_attr(fn::family)) r.family.assign(*fam);
+    else r.family = t.input_sequence->get_attr<std::string>(fn::family);
+    if (t.input_sequence->has_attr(fn::turn)) r.attrs[fn::turn] = t.input_sequence->get_attr<std::string>(fn::turn);
+    tk = host_tick("extract: log + family + turn", tk);
+    if (t.aligned_sequence) {
+        cseq &c = *t.aligned_sequence;
+        r.qual = c.get_attr<int>(fn::qual);
+        r.head = c.get_attr<int>(fn::head);
+        r.tail = c.get_attr<int>(fn::tail);
+        r.width = c.getWidth();
+        r.status = (r.log.find("copied alignment from") != std::string::npos) ? 1 : 0;
+        for (const auto &kv : c.get_attrs()) {
+            const std::string &k = kv.key();
+            if (k == search_filter::fn_nearest || k.compare(0, 4, "lca_") == 0 || k.compare(0, 5, "copy_") == 0)
+                r.attrs[k] = c.get_attr<std::string>(k);
+        }
+        r.idty = c.has_attr(fn::idty) ? c.get_attr<float>(fn::idty) : -1.f;
+        // (copied: the sequence keeps its heap block for its next life)
+        if (c.size() > query_bases)
+            throw std::logic_error("result of " + t.input_sequence->getName() + " has " + std::to_string(c.size()) +
+                                   " bases, its query " + std::to_string(query_bases));
+        r.n_ab = (uint32_t)c.size();
+        r.ab = dst;
+        memcpy((void *)dst, c.packed(), sizeof(aligned_base) * (size_t)r.n_ab);
+    }
+    if (t.search_result) {
+        r.searched = true;
+        for (const auto &sr : *t.search_result) {
+            r.sr_ids.push_back(p->search_store->id_of(sr.sequence));
+            r.sr_scores.push_back(sr.score);
+        }
+    }
+    tk = host_tick("extract: aligned attrs + bases", tk);
+    t.destroy();
+    host_tick("extract: tray.destroy", tk);
+}
+
+// An unaligned query as the reader stage would hand it over: base i in column i.
+void fill_query_tray(tray &t, uint32_t q, const uint8_t *qmask, const uint64_t *qoff) {
+    uint64_t tk = host_tsc();
+    t.seqno = q;
+    // (trays are reused from batch to batch: a fresh log -- destroy() frees the sequences but leaves the
+    // text, and the previous occupant's would lead this one's)
+    t.log.str(std::string());
+    t.log.clear();
+    const std::string name = "query" + std::to_string(q);
+    t.input_sequence = object_cache<cseq>::take();
+    t.input_sequence->setName(name);
+    tk = host_tick("build: log reset + new cseq", tk);
+    // (written in one piece, not by per-base appends)
+    std::vector<aligned_base> &ab = t.input_sequence->mutableAlignedBases();
+    const uint32_t n_bases = (uint32_t)(qoff[q + 1] - qoff[q]);
+    ab.resize(n_bases);
+    uint32_t *raw = reinterpret_cast<uint32_t *>(ab.data());
+    const uint8_t *m = qmask + qoff[q];
+    for (uint32_t x = 0; x < n_bases; x++) raw[x] = x | ((uint32_t)m[x] << 24);
+    t.input_sequence->setWidth(n_bases);
+    host_tick("build: bases", tk);
+}
 }  // namespace
 
 extern "C" {
@@ -471,8 +540,9 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
         p->n_results = nq;
         const size_t n_chunks = ((size_t)nq + batch - 1) / batch;
         if (p->chunks.size() < n_chunks) p->chunks.resize(n_chunks);
-        for (size_t b = 0; b < n_chunks; b++)  // (a batch that fails early leaves its chunk in this state: "not aligned")
-            if (p->chunks[b].results.size() != std::min<size_t>(batch, nq - b * batch)) p->chunks[b].results.clear();
+        // (a chunk keeps its records -- their heap blocks -- between runs, but not their meaning: only a chunk
+        // the sink of THIS run has filled is served by result_at(); a batch that fails early leaves "not aligned")
+        ++p->run_no;
         if (inflight == 0) inflight = 1;
         std::atomic<uint32_t> next{0};
         std::atomic<uint64_t> ff_ns{0}, al_ns{0}, sf_ns{0};
@@ -491,27 +561,7 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
             {
                 host_phase hp("drv.build_trays");
                 parallel_for(it.b1 - it.b0, [&](size_t i) {  // (what SINA's reader stage does per sequence)
-                    const uint32_t q = it.b0 + (uint32_t)i;
-                    tray &t = it.trays[i];
-                    uint64_t tk = host_tsc();
-                    t.seqno = q;
-                    // (the item's trays are reused from batch to batch: a fresh log -- destroy() frees the
-                    // sequences but leaves the text, and the previous occupant's would lead this one's)
-                    t.log.str(std::string());
-                    t.log.clear();
-                    const std::string name = "query" + std::to_string(q);
-                    t.input_sequence = object_cache<cseq>::take();
-                    t.input_sequence->setName(name);
-                    tk = host_tick("build: log reset + new cseq", tk);
-                    // (an unaligned query: base i in column i -- written in one piece, not by per-base appends)
-                    std::vector<aligned_base> &ab = t.input_sequence->mutableAlignedBases();
-                    const uint32_t n_bases = (uint32_t)(qoff[q + 1] - qoff[q]);
-                    ab.resize(n_bases);
-                    uint32_t *raw = reinterpret_cast<uint32_t *>(ab.data());
-                    const uint8_t *m = qmask + qoff[q];
-                    for (uint32_t x = 0; x < n_bases; x++) raw[x] = x | ((uint32_t)m[x] << 24);
-                    t.input_sequence->setWidth(n_bases);
-                    host_tick("build: bases", tk);
+                    fill_query_tray(it.trays[i], it.b0 + (uint32_t)i, qmask, qoff);
                 });
             }
             const auto a = std::chrono::steady_clock::now();
@@ -539,47 +589,10 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
             chunk.results.resize(it.b1 - it.b0);
             aligned_base *const base_block = chunk.bases.reserve((size_t)(qoff[it.b1] - qoff[b0]));
             const uint64_t base0 = qoff[b0];
+            chunk.run = p->run_no;
             parallel_for(it.b1 - it.b0, [&](size_t i) {  // (what SINA's writer stage does per sequence)
                 const uint32_t q = b0 + (uint32_t)i;
-                tray &t = trays[i];
-                result &r = chunk.results[i];
-                r.reset();
-                uint64_t tk = host_tsc();
-                r.log.assign(t.log.view());  // (no temporary: the result's string keeps its block between runs)
-                if (const std::string *fam = t.input_sequence->string_attr(fn::family)) r.family.assign(*fam);
-                else r.family = t.input_sequence->get_attr<std::string>(fn::family);
-                if (t.input_sequence->has_attr(fn::turn)) r.attrs[fn::turn] = t.input_sequence->get_attr<std::string>(fn::turn);
-                tk = host_tick("extract: log + family + turn", tk);
-                if (t.aligned_sequence) {
-                    cseq &c = *t.aligned_sequence;
-                    r.qual = c.get_attr<int>(fn::qual);
-                    r.head = c.get_attr<int>(fn::head);
-                    r.tail = c.get_attr<int>(fn::tail);
-                    r.width = c.getWidth();
-                    r.status = (r.log.find("copied alignment from") != std::string::npos) ? 1 : 0;
-                    for (const auto &kv : c.get_attrs()) {
-                        const std::string &k = kv.key();
-                        if (k == search_filter::fn_nearest || k.compare(0, 4, "lca_") == 0 ||
-                            k.compare(0, 5, "copy_") == 0)
-                            r.attrs[k] = c.get_attr<std::string>(k);
-                    }
-                    r.idty = c.has_attr(fn::idty) ? c.get_attr<float>(fn::idty) : -1.f;
-                    // (copied: the sequence keeps its heap block for its next life; a result has no more
-                    // bases than its query -- a copied alignment exactly as many)
-                    r.n_ab = std::min<uint32_t>(c.size(), (uint32_t)(qoff[q + 1] - qoff[q]));
-                    r.ab = base_block + (qoff[q] - base0);
-                    memcpy((void *)(base_block + (qoff[q] - base0)), c.packed(), sizeof(aligned_base) * (size_t)r.n_ab);
-                }
-                if (t.search_result) {
-                    r.searched = true;
-                    for (const auto &sr : *t.search_result) {
-                        r.sr_ids.push_back(p->search_store->id_of(sr.sequence));
-                        r.sr_scores.push_back(sr.score);
-                    }
-                }
-                tk = host_tick("extract: aligned attrs + bases", tk);
-                t.destroy();
-                host_tick("extract: tray.destroy", tk);
+                extract_tray(p, trays[i], chunk.results[i], base_block + (qoff[q] - base0), (uint32_t)(qoff[q + 1] - qoff[q]));
             });
         };
         auto take = [&](item &it) -> bool {
@@ -726,13 +739,96 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
     }
 }
 
+// The boundary as INTEGRATION.md binds it (src/sina.cpp:497-519): `n_threads` callers -- TBB workers of
+// unlimited-concurrency function_nodes in SINA -- each push ONE tray at a time through
+// batched<famfinder> -> batched<aligner> (-> batched<search_filter> for a search pipeline), and the shim
+// groups whoever is waiting into one GPU batch.  Results land where sina_host_pipeline_run puts them.
+// poison_q >= 0: that query's family gets a member that is not of the store before the aligner sees it -- the
+// device rejects the batch it travels in, the stage throws (std::runtime_error) and every
+// caller of that batch gets the exception: failed[q] = 1 for those, the first message in err / err_cap.
+int sina_host_pipeline_run_single_trays(void *pp, const uint8_t *qmask, const uint64_t *qoff, uint32_t nq,
+                                        uint32_t n_threads, uint32_t max_batch, uint32_t linger_us, int32_t poison_q,
+                                        uint8_t *failed, char *err, uint32_t err_cap) {
+    pipeline *p = (pipeline *)pp;
+    try {
+        if (n_threads == 0) n_threads = 1;
+        ++p->run_no;
+        p->chunk_q = nq ? nq : 1;
+        p->n_results = nq;
+        p->chunks.clear();
+        p->chunks.resize(1);
+        pipeline::result_chunk &chunk = p->chunks[0];
+        chunk.results.resize(nq);
+        chunk.run = p->run_no;
+        aligned_base *const base_block = chunk.bases.reserve((size_t)(nq ? qoff[nq] - qoff[0] : 1));
+        if (failed) memset(failed, 0, nq);
+        if (err && err_cap) err[0] = 0;
+        batched<famfinder> bff(p->ff, max_batch, linger_us);
+        batched<aligner> bal(p->al, max_batch, linger_us);
+        std::unique_ptr<batched<search_filter>> bsf;
+        if (p->sf) bsf.reset(new batched<search_filter>(*p->sf, max_batch, linger_us));
+        // (a sequence of the store's width that is not one of the store's: what a stale tray would carry)
+        cseq foreign("not-in-this-store");
+        if (poison_q >= 0) {
+            const auto store = reference_store::get(aligner::opts->database);
+            foreign.append("ACGU");
+            foreign.setWidth(store->getAlignmentWidth());
+        }
+        std::atomic<uint32_t> next{0};
+        std::mutex err_mu;
+        std::exception_ptr fatal;
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> th;
+        for (uint32_t w = 0; w < n_threads; w++)
+            th.emplace_back([&] {
+                for (;;) {
+                    const uint32_t q = next.fetch_add(1);
+                    if (q >= nq) return;
+                    try {
+                        tray t;
+                        fill_query_tray(t, q, qmask, qoff);
+                        t = bff(std::move(t));
+                        if ((int32_t)q == poison_q && t.alignment_reference && !t.alignment_reference->empty())
+                            t.alignment_reference->back().sequence = &foreign;
+                        tray keep = t;  // (the pointers: a stage that throws hands nothing back)
+                        try {
+                            t = bal(std::move(t));
+                            if (bsf) t = (*bsf)(std::move(t));
+                        } catch (const std::exception &e) {
+                            if (failed) failed[q] = 1;
+                            {
+                                std::lock_guard<std::mutex> lk(err_mu);
+                                if (err && err_cap && err[0] == 0) snprintf(err, err_cap, "%s", e.what());
+                            }
+                            keep.destroy();
+                            continue;
+                        }
+                        extract_tray(p, t, chunk.results[q], base_block + (qoff[q] - qoff[0]), (uint32_t)(qoff[q + 1] - qoff[q]));
+                    } catch (...) {
+                        std::lock_guard<std::mutex> lk(err_mu);
+                        if (!fatal) fatal = std::current_exception();
+                        next.store(nq);
+                        return;
+                    }
+                }
+            });
+        for (auto &t : th) t.join();
+        p->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (fatal) std::rethrow_exception(fatal);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
 namespace {
 const result &result_at(void *pp, uint32_t q) {
     static const result none;  // (out of range, or a batch that never reached the sink: "not aligned")
     pipeline *p = (pipeline *)pp;
     if (q >= p->n_results) return none;
-    const auto &chunk = p->chunks[q / p->chunk_q].results;
-    return (q % p->chunk_q) < chunk.size() ? chunk[q % p->chunk_q] : none;
+    const auto &chunk = p->chunks[q / p->chunk_q];
+    if (chunk.run != p->run_no) return none;
+    return (q % p->chunk_q) < chunk.results.size() ? chunk.results[q % p->chunk_q] : none;
 }
 }  // namespace
 

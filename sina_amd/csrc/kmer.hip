@@ -685,7 +685,7 @@ static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint6
     ca.dense_words = c->st->dense_words;
     const size_t clds = (size_t)kTileRefs * 2 + (size_t)ca.kmax * 9 + 64;
     if (allow_full_lds(reinterpret_cast<const void *>(kmer_count_kernel))) return 1;
-    heavy_launch hl(c, s);  // (count + select: device-filling kernels, ctx.h)
+    heavy_launch hl(c, s, kHeavyKmer);  // (count + select: device-filling kernels, ctx.h)
     const hipStream_t hs = hl.stream();
     SH_CHECK(hipEventRecord(c->ev[3], hs));
     hipLaunchKernelGGL(kmer_count_kernel, dim3(nq), dim3(kCountThreads), clds, hs, ca);

@@ -34,6 +34,8 @@ def load_host():
     H.sina_host_pipeline_destroy.argtypes = [vp]
     H.sina_host_pipeline_destroy.restype = None
     H.sina_host_pipeline_run.argtypes = [vp, capi.u8p, capi.u64p, C.c_uint32, C.c_uint32, C.c_uint32]
+    H.sina_host_pipeline_run_single_trays.argtypes = [vp, capi.u8p, capi.u64p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                      C.c_uint32, C.c_int32, capi.u8p, C.c_char_p, C.c_uint32]
     H.sina_host_result.argtypes = [vp, C.c_uint32] + [C.POINTER(C.c_int)] * 4 + [capi.u32p, capi.u32p]
     H.sina_host_result_bases.restype = capi.u32p
     H.sina_host_result_bases.argtypes = [vp, C.c_uint32]
@@ -248,6 +250,22 @@ class Pipeline:
         _chk(self.H.sina_host_pipeline_run(self.h, qmask.ctypes.data_as(capi.u8p), qoff.ctypes.data_as(capi.u64p),
                                            self.nq, batch, inflight))
         return self.timings()
+
+    def run_single_trays(self, qmask, qoff, threads=32, max_batch=1024, linger_us=300, poison=-1):
+        """The boundary as INTEGRATION.md binds it: `threads` concurrent callers push ONE tray at a time through
+        sina::batched<famfinder> -> batched<aligner> (-> batched<search_filter>), as SINA's TBB nodes would
+        (src/sina.cpp:497-519).  poison: index of a query whose family gets a sequence that is not of the store
+        before the aligner sees it (the stage throws for the batch it travels in).
+        Returns (failed flags per query, first exception text)."""
+        qmask = np.ascontiguousarray(qmask, np.uint8)
+        qoff = np.ascontiguousarray(qoff, np.uint64)
+        self.nq = len(qoff) - 1
+        failed = np.zeros(max(self.nq, 1), np.uint8)
+        err = C.create_string_buffer(512)
+        _chk(self.H.sina_host_pipeline_run_single_trays(self.h, qmask.ctypes.data_as(capi.u8p),
+                                                        qoff.ctypes.data_as(capi.u64p), self.nq, threads, max_batch,
+                                                        linger_us, poison, failed.ctypes.data_as(capi.u8p), err, 512))
+        return failed[:self.nq].astype(bool), err.value.decode()
 
     def profile(self, reset=True):
         """Per-phase host wall times (needs SINA_HOST_PROFILE=1 in the environment)."""

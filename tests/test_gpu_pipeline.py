@@ -337,16 +337,90 @@ def test_single_tray_batching_shim(oracle, world):
     pl.close()
 
 
+def test_batched_stage_shim_under_32_concurrent_single_tray_callers(oracle, world):
+    """INTEGRATION.md section 1 as it is bound: sina::batched<famfinder> -> batched<aligner>, called with ONE
+    tray per call from 40 threads at once (SINA's unlimited-concurrency function_nodes, src/sina.cpp:497-519).
+    Every caller gets its own tray back, equal to the oracle's, whatever batches the shim happened to form."""
+    refs, cs, idx, st = world
+    qs = synth.make_queries(refs, 150, seed=58, ins=0.01, dele=0.01, lower_rate=0.03)
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    pl = pipeline.Pipeline(st, famfinder=ff)
+    failed, err = pl.run_single_trays(qs.mask, qs.off, threads=40, max_batch=64, linger_us=500)
+    assert not failed.any() and err == ""
+    n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250))
+    assert n_dp >= 130
+    # ... a second run on the same pipeline object with other queries, small batches (max_batch 4: full batches
+    # go at once, the rest after the linger), and nothing of the first run's results shows through
+    qs2 = synth.make_queries(refs, 37, seed=59)
+    failed, err = pl.run_single_trays(qs2.mask, qs2.off, threads=33, max_batch=4, linger_us=200)
+    assert not failed.any()
+    _check(oracle, refs, qs2, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250))
+    assert pl.result(40)["status"] == 2 and pl.result(40)["log"] == ""   # (beyond this run: "none")
+    pl.close()
+
+
+def test_batched_stage_shim_hands_a_stage_exception_to_the_callers_of_that_batch(oracle, world):
+    """One tray reaches the aligner with a family member that is not of the reference store (a stale pointer):
+    the device call rejects its batch, the stage throws std::runtime_error, and the shim hands that exception to
+    every caller whose tray travelled in the batch -- nobody hangs, nobody gets another caller's tray, and the
+    trays of all other batches are the oracle's."""
+    refs, cs, idx, st = world
+    qs = synth.make_queries(refs, 96, seed=60)
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    pl = pipeline.Pipeline(st, famfinder=ff)
+    wants = [_oracle_run(oracle, cs, idx, qs, qi, dict(fs_min_len=100, fs_full_len=250)) for qi in range(qs.n)]
+    poison = next(qi for qi in range(40, qs.n) if wants[qi]["status"] == 0)   # (one that goes through the DP)
+    failed, err = pl.run_single_trays(qs.mask, qs.off, threads=32, max_batch=8, linger_us=300, poison=poison)
+    assert failed[poison] and "reference id out of range" in err
+    assert 1 <= failed.sum() <= 8                      # its batch, no more than max_batch callers
+    ok = 0
+    for qi in range(qs.n):
+        got, want = pl.result(qi), wants[qi]
+        if failed[qi]:
+            assert got["status"] == 2 and got["log"] == ""
+            continue
+        assert got["status"] == want["status"]
+        if want["status"] != 2:
+            assert (got["packed"] == want["packed"]).all()
+            if want["status"] == 0:
+                assert got["log"] == want["log"]
+            ok += 1
+    assert ok >= 80
+    # the pipeline (store, contexts, shim) is as good as new afterwards
+    failed, err = pl.run_single_trays(qs.mask, qs.off, threads=32, max_batch=64, linger_us=300)
+    assert not failed.any()
+    _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250))
+    pl.close()
+
+
+def test_batched_stage_shim_serves_a_lone_caller_after_the_linger(oracle, world):
+    """A single caller is not kept waiting for a batch to fill: it is served one linger period after it arrived
+    (twice per tray: famfinder and aligner)."""
+    import time
+    refs, cs, idx, st = world
+    qs = synth.make_queries(refs, 3, seed=62)
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    pl = pipeline.Pipeline(st, famfinder=ff)
+    pl.run_single_trays(qs.mask, qs.off, threads=1, max_batch=1024, linger_us=100)       # (warm: contexts, scratch)
+    t0 = time.time()
+    failed, _ = pl.run_single_trays(qs.mask, qs.off, threads=1, max_batch=1024, linger_us=100000)
+    dt = time.time() - t0
+    assert not failed.any()
+    assert 3 * 2 * 0.1 <= dt < 3 * 2 * 0.1 + 1.5, dt
+    _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250))
+    pl.close()
+
+
 @pytest.mark.parametrize("shape", ["v4_amplicon", "lsu_23s"])
 def test_baseline_config_shapes(oracle, shape):
     """BASELINE.json configs[2] (250 bp V4 amplicons vs full-length 16S references) and configs[4]
     (23S-like ~3000 bp, width 150k): the short-query and the long-query / wide-graph DP shapes."""
     if shape == "v4_amplicon":
         refs = synth.make_refs(300, length=1500, width=50000, seed=81)
-        qs = synth.make_queries(refs, 10, seed=82, window=(1.0 / 3.0, 250))
+        qs = synth.make_queries(refs, 32, seed=82, window=(1.0 / 3.0, 250))
     else:
         refs = synth.make_refs(120, length=3000, width=150000, seed=83)
-        qs = synth.make_queries(refs, 2, seed=84)
+        qs = synth.make_queries(refs, 32, seed=84)
     cs = util.cseqs_from_refs(refs)
     idx = oracle.Index(cs, k=10)
     st = pipeline.Store(":mem:gpu-shape-" + shape, refs)

@@ -272,16 +272,26 @@ def test_v4_amplicons_vs_40k_references(oracle):
     (two reference tiles, bitmaps active): family, alignment, head / tail / quality and log text equal
     the oracle's."""
     refs = synth.make_refs(40000, length=1500, width=50000, seed=31)
-    qs = synth.make_queries(refs, 8, seed=32, window=(1.0 / 3.0, 250))
-    _pipeline_equals_oracle(oracle, refs, qs, ":mem:v4-40k", min_dp=7)
+    qs = synth.make_queries(refs, 32, seed=32, window=(1.0 / 3.0, 250))
+    _pipeline_equals_oracle(oracle, refs, qs, ":mem:v4-40k", min_dp=28)
 
 
 def test_23s_vs_33k_references(oracle):
     """configs[4] shape: ~3000-base queries, alignment width 150 000, 33 000 references (two tiles):
     the 256x12 DP geometry and the wide DAG build against the oracle."""
     refs = synth.make_refs(33000, length=3000, width=150000, seed=41)
-    qs = synth.make_queries(refs, 2, seed=42)
-    _pipeline_equals_oracle(oracle, refs, qs, ":mem:23s-33k", min_dp=2)
+    qs = synth.make_queries(refs, 8, seed=42)
+    _pipeline_equals_oracle(oracle, refs, qs, ":mem:23s-33k", min_dp=8)
+
+
+def test_16s_full_length_vs_100k_references(oracle):
+    """configs[1] itself, end to end: 32 full-length 16S queries against the bench's 100 000-sequence reference
+    (synthetic SILVA-NR-like clade model, width 50 000, seed 2 -- what bench.py builds): four reference tiles,
+    dense bitmaps, the three-strip 8-column DP geometry, device DAG build, backtrack, device-side assembly.
+    Family, aligned columns + case bits, head / tail / quality and the full log text equal the oracle's."""
+    refs = synth.make_refs(100000, length=1500, width=50000, seed=2)
+    qs = synth.make_queries(refs, 32, seed=3)
+    _pipeline_equals_oracle(oracle, refs, qs, ":mem:16s-100k", min_dp=30)
 
 
 def test_turn_orientations_equal_oracle(oracle):
