@@ -352,22 +352,29 @@ inline bool chain_kernels() {
     return on;
 }
 // Which launch goes next.  Until round 4 the FIFO was the order in which host threads arrived.  With chained
-// launches the order matters: the best filler of a DP launch's drain is the NEXT DP launch (a DP wave needs
-// exactly what a retiring DP wave frees: one wave slot, 168 VGPRs, 12 KB of LDS; a DAG-build workgroup needs a
-// quarter of a CU, a k-mer count workgroup half of one).  So at most kHeavyDepth launches are handed to the GPU
-// ahead of time (one running, one queued behind it -- enough to never leave the device idle: every launch here
+// launches the order matters, because of what runs in a DP launch's last milliseconds and right behind it:
+//   * the launch behind it fills the slots its drain leaves empty -- but starts its own waves staggered by as
+//     much, and ends with a drain that wide (a DP wave runs three 16 ms queries back to back: nothing evens a
+//     5 ms stagger out).  A DAG build or a k-mer search, made of thousands of short workgroups, absorbs that;
+//     a DP launch hands it on to whatever follows it;
+//   * the finished launch's backtrack walk starts on its context's own stream the moment it ends and runs beside
+//     whatever is resident then: it stretches a DAG build by 1.8 ms and a DP launch by 8 (its waves take the LDS
+//     of retiring DP waves).
+// Kernel trace of a run that PREFERRED a DP launch behind a DP launch (profiles/r04_burst_trace.txt): two DP
+// launches back to back took 102 ms, 2 x 48.3 alone.  So at most kHeavyDepth launches are handed to the GPU
+// ahead of time (one running, one queued behind it -- enough to never leave the device idle: every launch
 // runs for milliseconds), the other callers wait on the host, and when a place frees up the waiter to take it
-// is: after a DP launch another DP launch if one is waiting (else a DAG build, else the oldest waiter); after
-// anything else the oldest waiter.  Bursts of DP launches are bounded by the batches in flight, and by the
-// trace-back planes (a DP launch asks for its plane BEFORE it queues here).
+// is: behind a DP launch the oldest waiting DAG build, else the oldest k-mer search, and only if neither is
+// waiting another DP launch; behind anything else the oldest waiter.
+// SINA_HIP_DP_BURST: 0 = arrival order, 1 = DP behind DP preferred (the experiment above), default -1.
 enum heavy_kind { kHeavyKmer = 0, kHeavyGraph = 1, kHeavyDp = 2 };
 constexpr int kHeavyDepth = 2;
-inline bool heavy_reorder() {
-    static const bool on = [] {
+inline int heavy_order_policy() {
+    static const int mode = [] {
         const char *v = getenv("SINA_HIP_DP_BURST");
-        return !(v && *v == '0');
+        return v && *v ? atoi(v) : -1;
     }();
-    return on;
+    return mode;
 }
 struct heavy_launch {
     sina_hip_ctx *c;
@@ -398,9 +405,12 @@ struct heavy_launch {
                         if ((k < 0 || w.kind == k) && (!o || w.ticket < o->ticket)) o = &w;
                     return o;
                 };
-                if (heavy_reorder() && st->heavy_last_kind == kHeavyDp) {
+                if (st->heavy_last_kind == kHeavyDp && heavy_order_policy() > 0) {
                     pick = oldest_of(kHeavyDp);
                     if (!pick) pick = oldest_of(kHeavyGraph);
+                } else if (st->heavy_last_kind == kHeavyDp && heavy_order_policy() < 0) {
+                    pick = oldest_of(kHeavyGraph);
+                    if (!pick) pick = oldest_of(kHeavyKmer);
                 }
                 if (!pick) pick = oldest_of(-1);
                 return pick && pick->ticket == me;

@@ -82,6 +82,7 @@ struct GraphArgs {
     uint32_t member_off;       // LDS offset of the per-member arrays (behind the tile tables), entries each
     uint32_t member_cap;
     int W;                     // DP ring depth: edges longer than this need a spill row
+    int want_smin;             // succ_min is read by somebody (--insertion=forbid, the debug entry): else it is not touched at all
     DryArgs dry;               // (ctx.h, heavy_launch: tells the launch queued behind when the last workgroup has started)
 };
 
@@ -231,10 +232,8 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
     uint32_t *smin = a.succ_min + (size_t)q * a.ncap;
     uint32_t *last = a.far_mark + (size_t)q * a.ncap;
     uint32_t *pred = a.pred + a.pred_off[q];
-    for (uint32_t i = tid; i < a.ncap; i += kGT) {
-        smin[i] = 0xFFFFFFFFu;
-        last[i] = 0;
-    }
+    // (smin / last of a node are initialised by the tile that creates it, right before the first successor can
+    // touch them: clearing all ncap entries up front wrote four times what a 16S DAG uses)
     const float *wt = a.wtab + (size_t)F * (kMaxFam + 1);
     uint32_t N = 0, E = 0;  // running totals (uniform)
     GP(1)
@@ -350,6 +349,11 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
         __syncthreads();
         for (uint32_t c = tid; c < tc; c += kGT)  // (cl8 is dead: its LDS becomes the node -> column map)
             for (uint32_t k = 0; k < nn[c]; k++) ncolT[nbaseT[c] + k] = (uint8_t)c;
+        for (uint32_t ln = tid; ln < tn; ln += kGT)  // this tile's nodes: no successor seen yet
+            if (N + ln < a.ncap) {
+                last[N + ln] = 0;
+                if (a.want_smin) smin[N + ln] = 0xFFFFFFFFu;
+            }
         __syncthreads();
         GP(6)
         // 5. node records + sorted unique predecessor lists: one thread per NODE of the tile (a column
@@ -417,7 +421,7 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
                         if (pa != 0xFFFFFFFFu) {
                             pred[seg + np] = pa;
                             np++;
-                            atomicMin(&smin[pa], pos);
+                            if (a.want_smin) atomicMin(&smin[pa], pos);
                             atomicMax(&last[pa], node);
                         }
                     }
@@ -432,7 +436,7 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
                         for (uint32_t y = np; y > x; y--) pred[seg + y] = pred[seg + y - 1];
                         pred[seg + x] = pa;
                         np++;
-                        atomicMin(&smin[pa], pos);
+                        if (a.want_smin) atomicMin(&smin[pa], pos);
                         atomicMax(&last[pa], node);
                     }
                 }
@@ -465,15 +469,22 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
         return;
     }
     GP(8)
-    // 6. sinks, successor minimum, fence flag
+    // 6. sinks, successor minimum, fence flag -- and, in the same pass over the rows, the slot allocator's
+    // row codes (step 7) when they fit the tile tables' space
+    const uint32_t seg_len = dp_slot_segment(N);
+    const uint32_t n_seg = (N + seg_len - 1) / seg_len;
+    uint32_t *codeL = reinterpret_cast<uint32_t *>(tile);
+    const bool in_lds = (size_t)N * 4 <= a.tile_bytes;
     for (uint32_t i = tid; i < N; i += kGT) {
         uint32_t z = rec[i].z;
-        if (smin[i] == 0xFFFFFFFFu) {
+        const uint32_t l = last[i];
+        if (l == 0) {  // (a successor's id is greater than its predecessor's: never 0)
             z |= kRecSink;
-            smin[i] = 1000000u;  // "no successor" sentinel of mesh.h:480
+            if (a.want_smin) smin[i] = 1000000u;  // "no successor" sentinel of mesh.h:480
         }
-        if (last[i] > i && last[i] - i > (uint32_t)kFarLds) z |= kRecFence;
+        if (l > i && l - i > (uint32_t)kFarLds) z |= kRecFence;
         rec[i].z = z;
+        if (in_lds) codeL[i] = l | ((z & kRecSink) ? (1u << 30) : 0u) | ((z & kRecFence) ? (1u << 31) : 0u);
     }
     __syncthreads();
     GP(9)
@@ -483,19 +494,8 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
     // per segment: a row whose last successor lies in a later segment is kept in a spill row (three
     // or so per boundary), every segment starts with all slots free.  Spill rows are numbered in row
     // order (per-segment counts, prefix sum).  tests/util.py row_store_model states the same rule.
-    const uint32_t seg_len = dp_slot_segment(N);
-    const uint32_t n_seg = (N + seg_len - 1) / seg_len;
     // (the lanes walk their segments row by row: from LDS when the rows fit the tile tables' space --
     // a dependent global load per row was most of this step's time)
-    uint32_t *codeL = reinterpret_cast<uint32_t *>(tile);
-    const bool in_lds = (size_t)N * 4 <= a.tile_bytes;
-    if (in_lds) {
-        for (uint32_t i = tid; i < N; i += kGT) {
-            const uint32_t z = rec[i].z;
-            codeL[i] = last[i] | ((z & kRecSink) ? (1u << 30) : 0u) | ((z & kRecFence) ? (1u << 31) : 0u);
-        }
-        __syncthreads();
-    }
     if (tid < n_seg) {
         uint32_t fa[8];  // last successor of the row in slot x (0: empty)
 #pragma unroll
@@ -601,7 +601,7 @@ struct BuiltGraphs {
 // Builds the DAGs of bq families (fam_off is absolute, first family = q0) into the context's
 // rec / node_pos / succ_minpos / pred buffers; grows the per-query caps and retries on overflow.
 int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t *fam_off, uint32_t q0,
-                        uint32_t bq, float fs_weight, int W, BuiltGraphs *bg) {
+                        uint32_t bq, float fs_weight, int W, BuiltGraphs *bg, bool want_smin) {
     hipStream_t s = c->stream;
     if (ensure_ref_off_host(c)) return 1;  // (a store that arrived by broadcast reads it back once)
     // weight table: the reference's expression (mseq.cpp:113) evaluated on the host
@@ -668,6 +668,7 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         ga.member_off = (uint32_t)((glds_tables + 7) & ~(size_t)7);
         ga.member_cap = (uint32_t)graph_member_cap(max_f);
         ga.W = W;
+        ga.want_smin = want_smin ? 1 : 0;
         if (allow_full_lds(reinterpret_cast<const void *>(family_graph_kernel))) return 1;
         bg->sizes.resize(4 * (size_t)bq);
         {
@@ -742,7 +743,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
     BuiltGraphs bg;
     for (uint32_t q0 = 0; q0 < nq; q0 += chunk_q) {
         const uint32_t bq = std::min(chunk_q, nq - q0);
-        if (build_family_graphs(c, fam_ids, fam_off, q0, bq, p->fs_weight, pl.W, &bg)) return 1;
+        if (build_family_graphs(c, fam_ids, fam_off, q0, bq, p->fs_weight, pl.W, &bg, p->insertion == SINA_INSERTION_FORBID)) return 1;
         // DP in sub-ranges that fit the trace-back budget
         uint32_t r0 = 0;
         while (r0 < bq) {
@@ -819,7 +820,7 @@ int sina_hip_debug_family_graph(sina_hip_ctx *c, const uint32_t *fam_ids, uint32
     SH_CHECK(hipSetDevice(c->device));
     const uint64_t foff[2] = {0, F};
     BuiltGraphs bg;
-    if (build_family_graphs(c, fam_ids, foff, 0, 1, fs_weight, (int)ring_depth, &bg)) return 1;
+    if (build_family_graphs(c, fam_ids, foff, 0, 1, fs_weight, (int)ring_depth, &bg, true)) return 1;
     const uint32_t N = bg.sizes[0];
     std::vector<uint4> rec(N);
     std::vector<uint32_t> pr(bg.sizes[1] + 8);

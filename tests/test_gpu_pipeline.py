@@ -355,7 +355,8 @@ def test_batched_stage_shim_under_32_concurrent_single_tray_callers(oracle, worl
     failed, err = pl.run_single_trays(qs2.mask, qs2.off, threads=33, max_batch=4, linger_us=200)
     assert not failed.any()
     _check(oracle, refs, qs2, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250))
-    assert pl.result(40)["status"] == 2 and pl.result(40)["log"] == ""   # (beyond this run: "none")
+    with pytest.raises(pipeline.HostError):          # (beyond this run's 37 results: nothing of the first run's)
+        pl.result(40)
     pl.close()
 
 
