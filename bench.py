@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--verify", type=int, default=8,
                     help="queries of the timed run re-done by the oracle afterwards and compared (0 = none; "
                          "skipped together with the CPU baseline, whose oracle index it shares)")
+    ap.add_argument("--dup-rate", type=float, default=0.0,
+                    help="fraction of every step's queries that repeat another query of the same step (amplicon-like "
+                         "input; identical queries of a batch are searched and aligned once).  Default 0: the headline "
+                         "workload has no repeats")
     ap.add_argument("--host-graph", action="store_true", help="build family DAGs on the host")
     ap.add_argument("--host-threads", type=int, default=0, help="threads of the host-side loop pool (0 = default)")
     return ap.parse_args()
@@ -248,6 +252,8 @@ def main():
     n_q = a.batch * (a.steps + a.warmup + 1) + prime_n
     window = (1.0 / 3.0, a.window) if a.window else None
     qs = synth.make_queries(refs, n_q, seed=3 + 1000 * rank, window=window)
+    if a.dup_rate > 0:
+        qs = synth.with_repeats(qs, a.dup_rate, a.batch, seed=17 + rank)
 
     # ---- resident state: references + index in HBM, stages constructed
     # (ranks other than 0 do not upload: the references arrive with the index, by broadcast)
@@ -445,7 +451,7 @@ def main():
                                 ("configs[3] shape: full-length 16S, large reference" if a.refs >= 400000 else
                                  "configs[1]: full-length 16S")),
                                a.length, (", cut to %d" % a.window) if a.window else "", a.refs, a.width),
-                "refs": a.refs, "length": a.length, "width": a.width, "window": a.window,
+                "refs": a.refs, "length": a.length, "width": a.width, "window": a.window, "dup_rate": a.dup_rate,
                 "queries_per_step_per_gpu": a.batch,
                 "queries_per_launch": a.sub_batch,
                 "inflight_batches": a.inflight,

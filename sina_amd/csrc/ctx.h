@@ -47,7 +47,8 @@ struct sina_hip_store {
     static constexpr uint32_t kDryCounters = 64;
     uint32_t heavy_seq = 0;          // launches queued so far (guarded by heavy_mu, like everything below)
     int heavy_turn = 0;              // the stream the next launch goes to
-    bool heavy_prev_dry = false;     // the last launch signals "dry" (flag word reaches heavy_seq) ...
+    bool heavy_prev_dry = false;     // the last launch signals "dry" (flag word reaches heavy_prev_seq) ...
+    uint32_t heavy_prev_seq = 0;     // (its number: NOT heavy_seq -- a launch that failed half-way took a number too)
     bool heavy_prev_any = false;     // ... there has been one at all
     // admission (heavy_launch): launches handed to the GPU and not yet known to have ended, the kind of the
     // last one handed over, and who is waiting to be
@@ -385,6 +386,7 @@ struct heavy_launch {
     int kind = 0;
     bool signals_dry = false;
     bool admitted = false;
+    uint32_t my_seq = 0;
     // `own`: the context stream whose queued work (uploads) the kernel depends on
     heavy_launch(sina_hip_ctx *c_, hipStream_t own_, int kind_ = kHeavyKmer) : c(c_), own(own_), hs(own_), kind(kind_) {
         if (!serialize_kernels() || !c->st->heavy) return;
@@ -429,11 +431,11 @@ struct heavy_launch {
         failed = failed || hipStreamWaitEvent(hs, c->ev[10], 0) != hipSuccess;
         if (chain && st->heavy_prev_any) {
             if (st->heavy_prev_dry)
-                failed = failed || hipStreamWaitValue32(hs, st->dry_mem, st->heavy_seq, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess;
+                failed = failed || hipStreamWaitValue32(hs, st->dry_mem, st->heavy_prev_seq, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess;
             else
                 failed = failed || hipStreamWaitEvent(hs, st->heavy_done[turn ^ 1], 0) != hipSuccess;
         }
-        if (chain) ++st->heavy_seq;
+        if (chain) my_seq = ++st->heavy_seq;
     }
     hipStream_t stream() const { return hs; }
     // for the LAST kernel of the launch, if it can tell when its last workgroup starts
@@ -442,8 +444,8 @@ struct heavy_launch {
         sina_hip_store *st = c->st;
         if (!lk.owns_lock() || !chain_kernels() || !st->heavy2 || !st->dry_mem) return d;
         d.flag = st->dry_mem;
-        d.counter = st->dry_mem + 1 + st->heavy_seq % sina_hip_store::kDryCounters;
-        d.seq = st->heavy_seq;
+        d.counter = st->dry_mem + 1 + my_seq % sina_hip_store::kDryCounters;
+        d.seq = my_seq;
         signals_dry = true;
         return d;
     }
@@ -460,6 +462,7 @@ struct heavy_launch {
             if (chain_kernels() && st->heavy2 && st->dry_mem) {
                 failed = failed || hipEventRecord(st->heavy_done[turn], hs) != hipSuccess;
                 st->heavy_prev_dry = signals_dry && !failed;
+                st->heavy_prev_seq = my_seq;
                 st->heavy_prev_any = true;
                 st->heavy_turn = turn ^ 1;
             }

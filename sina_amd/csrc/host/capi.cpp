@@ -205,6 +205,7 @@ void fill_query_tray(tray &t, uint32_t q, const uint8_t *qmask, const uint64_t *
 }  // namespace
 
 extern "C" {
+static void tune_allocator();
 
 const char *sina_host_last_error(void) { return g_err.c_str(); }
 
@@ -274,54 +275,199 @@ int sina_host_store_build_index(const char *key, unsigned k, int nofast) {
 // [-> search_filter] -> log printer -> FASTA writer, in batches of `batch` sequences.  The stage
 // options are whatever sina_host_set_option set.  summary: n_read, n_aligned, n_written, n_skipped,
 // then avg_sps, avg_cpm, avg_idty (as Log::printer prints them at exit).
-int sina_host_run_fasta(const char *in_path, const char *out_path, const char *log_path, int do_search,
-                        int show_dist, uint32_t batch, double *summary7) {
-    try {
+//
+// sina_host_run_fasta_serial: one batch at a time, stage after stage, tray after tray (rounds 1-3: parity runs).
+// sina_host_run_fasta: the same stages as CONCURRENT nodes, as SINA's flow graph has them (src/sina.cpp:452-586:
+// a serial source, the stages, serial ordered sinks): a reader thread cuts and parses the next batch while the
+// batch before it is searched (famfinder thread) and the one before that aligned (aligner thread); the sink
+// takes the batches in input order, renders the trays' log reports and composes their FASTA records on the loop
+// pool, and only the hand-over of the finished text -- running totals, csv rows, the write itself -- stays
+// serial.  Output, log and summary are byte for byte those of the serial driver.
+namespace {
+struct fasta_run {
+    famfinder ff;
+    aligner al;
+    std::unique_ptr<search_filter> sf;
+    std::unique_ptr<rw_fasta::reader> rd;
+    std::unique_ptr<rw_fasta::writer> wr;
+    std::unique_ptr<log_printer> lp;
+    std::ofstream logf;
+    std::ostringstream devnull;
+    bool log_to_file = false;
+    int n_read = 0, n_aligned = 0;
+    std::ostream &log() { return log_to_file ? static_cast<std::ostream &>(logf) : devnull; }
+    fasta_run(const char *in_path, const char *out_path, const char *log_path, int do_search, int show_dist) {
         famfinder::validate_options();
         aligner::validate_options();
         if (do_search) search_filter::validate_options();
-        famfinder ff;
-        aligner al;
-        std::unique_ptr<search_filter> sf;
         if (do_search) sf.reset(new search_filter());
-        rw_fasta::reader rd(in_path);
-        rw_fasta::writer wr(out_path);
-        log_printer lp(show_dist != 0);
-        std::ofstream logf;
-        if (log_path && *log_path) logf.open(log_path);
-        std::ostringstream sink;
-        std::ostream &log = logf.is_open() ? static_cast<std::ostream &>(logf) : sink;
-        if (batch == 0) batch = 1024;
-        int n_read = 0, n_aligned = 0;
-        for (;;) {
-            std::vector<tray> trays;
-            while (trays.size() < batch) {
-                tray t;
-                if (!rd(t)) break;
-                trays.push_back(t);
-            }
-            if (trays.empty()) break;
-            n_read += (int)trays.size();
-            ff(trays);
-            al(trays);
-            if (sf) (*sf)(trays);
-            for (auto &t : trays) {  // serial, in input order (Log::printer and the writer are serial nodes)
-                if (t.aligned_sequence) n_aligned++;
-                t = lp(t, log);
-                t = wr(t);
-                t.destroy();
-                sink.str("");
-            }
+        rd.reset(new rw_fasta::reader(in_path));
+        wr.reset(new rw_fasta::writer(out_path));
+        lp.reset(new log_printer(show_dist != 0));
+        if (log_path && *log_path) {
+            logf.open(log_path);
+            log_to_file = logf.is_open();
         }
-        wr.flush();
-        const log_printer::summary sm = lp.totals();
+    }
+    bool read_batch(std::vector<tray> &trays, uint32_t batch) {
+        trays.clear();
+        while (trays.size() < batch) {
+            tray t;
+            if (!(*rd)(t)) break;
+            trays.push_back(t);
+        }
+        return !trays.empty();
+    }
+    void finish(double *summary7) {
+        wr->flush();
+        const log_printer::summary sm = lp->totals();
         summary7[0] = n_read;
         summary7[1] = n_aligned;
-        summary7[2] = wr.written();
-        summary7[3] = rd.skipped();
+        summary7[2] = wr->written();
+        summary7[3] = rd->skipped();
         summary7[4] = sm.avg_sps;
         summary7[5] = sm.avg_cpm;
         summary7[6] = sm.avg_idty;
+    }
+};
+}  // namespace
+
+int sina_host_run_fasta_serial(const char *in_path, const char *out_path, const char *log_path, int do_search,
+                               int show_dist, uint32_t batch, double *summary7) {
+    try {
+        fasta_run r(in_path, out_path, log_path, do_search, show_dist);
+        if (batch == 0) batch = 1024;
+        std::vector<tray> trays;
+        while (r.read_batch(trays, batch)) {
+            r.n_read += (int)trays.size();
+            r.ff(trays);
+            r.al(trays);
+            if (r.sf) (*r.sf)(trays);
+            for (auto &t : trays) {  // serial, in input order (Log::printer and the writer are serial nodes)
+                if (t.aligned_sequence) r.n_aligned++;
+                t = (*r.lp)(t, r.log());
+                t = (*r.wr)(t);
+                t.destroy();
+                r.devnull.str("");
+            }
+        }
+        r.finish(summary7);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+int sina_host_run_fasta(const char *in_path, const char *out_path, const char *log_path, int do_search,
+                        int show_dist, uint32_t batch, double *summary7) {
+    try {
+        fasta_run r(in_path, out_path, log_path, do_search, show_dist);
+        if (batch == 0) batch = 1024;
+        tune_allocator();
+        // bounded hand-over between the nodes; batches stay in input order (one thread per node: FIFO)
+        struct chan {
+            std::mutex mu;
+            std::condition_variable cv;
+            std::deque<std::vector<tray>> q;
+            bool closed = false, abort = false;
+            void push(std::vector<tray> &&b) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return q.size() < 2 || abort; });
+                if (abort) {
+                    for (auto &t : b) t.destroy();
+                    return;
+                }
+                q.push_back(std::move(b));
+                cv.notify_all();
+            }
+            bool pop(std::vector<tray> &b) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !q.empty() || closed || abort; });
+                if (abort || q.empty()) return false;
+                b = std::move(q.front());
+                q.pop_front();
+                cv.notify_all();
+                return true;
+            }
+            void close() {
+                std::lock_guard<std::mutex> lk(mu);
+                closed = true;
+                cv.notify_all();
+            }
+            void stop() {
+                std::lock_guard<std::mutex> lk(mu);
+                abort = true;
+                for (auto &b : q)
+                    for (auto &t : b) t.destroy();
+                q.clear();
+                cv.notify_all();
+            }
+        };
+        chan read_q, found_q, aligned_q;
+        std::exception_ptr err;
+        std::mutex err_mu;
+        auto on_error = [&] {
+            { std::lock_guard<std::mutex> lk(err_mu); if (!err) err = std::current_exception(); }
+            read_q.stop();
+            found_q.stop();
+            aligned_q.stop();
+        };
+        std::thread reader([&] {
+            try {
+                std::vector<tray> trays;
+                while (r.read_batch(trays, batch)) {
+                    r.n_read += (int)trays.size();
+                    read_q.push(std::move(trays));
+                    trays = std::vector<tray>();
+                }
+            } catch (...) { on_error(); }
+            read_q.close();
+        });
+        std::thread finder([&] {
+            try {
+                std::vector<tray> trays;
+                while (read_q.pop(trays)) {
+                    r.ff(trays);
+                    found_q.push(std::move(trays));
+                    trays = std::vector<tray>();
+                }
+            } catch (...) { on_error(); }
+            found_q.close();
+        });
+        std::thread align([&] {
+            try {
+                std::vector<tray> trays;
+                while (found_q.pop(trays)) {
+                    r.al(trays);
+                    if (r.sf) (*r.sf)(trays);
+                    aligned_q.push(std::move(trays));
+                    trays = std::vector<tray>();
+                }
+            } catch (...) { on_error(); }
+            aligned_q.close();
+        });
+        try {  // the sink: this thread
+            std::vector<tray> trays;
+            std::vector<log_printer::report> reports;
+            while (aligned_q.pop(trays)) {
+                reports.resize(trays.size());
+                parallel_for(trays.size(), [&](size_t i) { r.lp->render(trays[i], reports[i]); });
+                r.wr->precompose(trays);  // (after render: the reports' attributes are part of the records' meta data)
+                for (size_t i = 0; i < trays.size(); i++) {
+                    tray &t = trays[i];
+                    if (t.aligned_sequence) r.n_aligned++;
+                    r.lp->commit(reports[i], r.log());
+                    t = (*r.wr)(t);
+                    r.devnull.str("");
+                }
+                parallel_for(trays.size(), [&](size_t i) { trays[i].destroy(); });
+            }
+        } catch (...) { on_error(); }
+        reader.join();
+        finder.join();
+        align.join();
+        if (err) std::rethrow_exception(err);
+        r.finish(summary7);
         return 0;
     } catch (const std::exception &e) {
         return fail(e);
@@ -472,6 +618,7 @@ int sina_host_set_option(const char *stage, const char *name, const char *value)
         else if (!strcmp(stage, "search")) search_filter::set_option(name, value);
         else if (!strcmp(stage, "fasta")) rw_fasta::set_option(name, value);
         else if (!strcmp(stage, "host") && !strcmp(name, "threads")) set_host_threads((unsigned)atoi(value));
+        else if (!strcmp(stage, "host") && !strcmp(name, "dedup")) set_batch_dedup(atoi(value) != 0);
         else throw std::logic_error(std::string("unknown stage ") + stage);
         return 0;
     } catch (const std::exception &e) {

@@ -22,6 +22,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string_view>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -469,6 +470,10 @@ struct rw_fasta::writer::priv_data {
     int count = 0, excluded = 0;
     std::unordered_set<std::string> relatives_written;
     unsigned long copy_relatives = 0;
+    // records composed ahead of time (precompose): the text of a batch's aligned sequences, by sequence object
+    std::vector<std::string> pre_text;
+    std::unordered_map<const cseq *, size_t> pre_of;
+    void compose(const cseq &c, std::string &rec) const;  // the FASTA record of one sequence (no shared state)
     void write(const cseq &c);
 };
 
@@ -540,7 +545,39 @@ tray rw_fasta::writer::operator()(tray t) {  // :394-435
 
 // One sequence = one buffer: ">name[ full name][ meta]\n[meta lines]sequence lines", pushed to the sink
 // in a single call (and its csv row to the side file).
-void rw_fasta::writer::priv_data::write(const cseq &c) {
+// The sequence line itself: a 50 000-column alignment row holds ~1500 bases -- the row is one memset to the
+// gap character and a scatter of the bases, then the leading and trailing gaps become dots (getAligned()
+// appends run by run through a std::string; same bytes).
+static void aligned_line(const cseq &c, bool nodots, bool dna, std::string &out) {
+    const size_t at = out.size();
+    const uint32_t width = c.getWidth();
+    const auto &bases = c.getAlignedBases();
+    bool plain = true;  // columns strictly ascending and inside the alignment (what every finished sequence is)
+    uint32_t prev = 0;
+    for (size_t i = 0; i < bases.size() && plain; i++) {
+        const uint32_t pos = bases[i].getPosition();
+        plain = pos < width && (i == 0 || pos > prev);
+        prev = pos;
+    }
+    if (!plain) {  // (the general way, whatever it makes of such a sequence)
+        out += c.getAligned(nodots, dna);
+        return;
+    }
+    out.append(width, '-');
+    char *row = out.data() + at;
+    for (const auto &b : bases) row[b.getPosition()] = (char)(dna ? b.getBase().iupac_dna() : b.getBase().iupac_rna());
+    if (!nodots) {
+        if (bases.empty()) {
+            memset(row, '.', width);
+        } else {
+            memset(row, '.', bases.front().getPosition());
+            const uint32_t last = bases.back().getPosition();
+            memset(row + last + 1, '.', width - last - 1);
+        }
+    }
+}
+
+void rw_fasta::writer::priv_data::compose(const cseq &c, std::string &rec) const {
     const options &o = fa_opts();
     const auto &attrs = c.get_attrs();
     rec.clear();
@@ -550,24 +587,53 @@ void rw_fasta::writer::priv_data::write(const cseq &c) {
     style->on_header_line(rec, attrs);
     rec.push_back('\n');
     style->below_header(rec, attrs);
-    if (out_csv) {
-        rows.clear();
-        style->side_file(rows, c, attrs, count == 0);
-        out_csv->push(rows.data(), rows.size());
+    if (o.line_length <= 0) {  // the whole row on one line
+        rec.reserve(rec.size() + c.getWidth() + 2);
+        aligned_line(c, !o.out_dots, o.out_dna, rec);
+        rec.push_back('\n');
+        return;
     }
-    const std::string seq = c.getAligned(!o.out_dots, o.out_dna);
-    const size_t per_line = o.line_length > 0 ? (size_t)o.line_length : seq.size();
-    rec.reserve(rec.size() + seq.size() + (per_line ? seq.size() / per_line : 0) + 2);
+    std::string seq;
+    aligned_line(c, !o.out_dots, o.out_dna, seq);
+    const size_t per_line = (size_t)o.line_length;
+    rec.reserve(rec.size() + seq.size() + seq.size() / per_line + 2);
     size_t at = 0;
-    do {  // (an empty sequence still gets its empty line -- unless lines are wrapped)
+    while (at < seq.size()) {  // (an empty sequence gets no line at all when lines are wrapped)
         const size_t n = std::min(per_line, seq.size() - at);
         rec.append(seq, at, n);
         rec.push_back('\n');
         at += n;
-    } while (at < seq.size());
-    if (o.line_length > 0 && seq.empty()) rec.pop_back();
-    out->push(rec.data(), rec.size());
+    }
+}
+
+void rw_fasta::writer::priv_data::write(const cseq &c) {
+    if (out_csv) {
+        rows.clear();
+        style->side_file(rows, c, c.get_attrs(), count == 0);
+        out_csv->push(rows.data(), rows.size());
+    }
+    const auto pre = pre_of.find(&c);
+    if (pre != pre_of.end()) {
+        const std::string &text = pre_text[pre->second];
+        out->push(text.data(), text.size());
+    } else {
+        compose(c, rec);
+        out->push(rec.data(), rec.size());
+    }
     count++;
+}
+
+// The records of a batch's aligned sequences, composed on the loop pool ahead of the (serial, ordered) calls of
+// operator(): what is left for those is the hand-over to the sink.  Same bytes either way; the text is dropped
+// with the next precompose().  (Sequences operator() then decides not to write just go unused.)
+void rw_fasta::writer::precompose(const std::vector<tray> &batch) {
+    priv_data &d = *data;
+    d.pre_of.clear();
+    std::vector<const cseq *> todo;
+    for (const tray &t : batch)
+        if (t.aligned_sequence != nullptr && d.pre_of.emplace(t.aligned_sequence, todo.size()).second) todo.push_back(t.aligned_sequence);
+    if (d.pre_text.size() < todo.size()) d.pre_text.resize(todo.size());
+    parallel_for(todo.size(), [&](size_t i) { d.compose(*todo[i], d.pre_text[i]); });
 }
 
 // ---------------------------------------------------------------- Log::printer (--show-dist)
@@ -577,7 +643,6 @@ struct log_printer::priv_data {
     // data for computing alignment quality based on a reference (src/log.cpp:262-266)
     double total_sps = 0, total_cpm = 0, total_idty = 0, total_bps = 0;
     bool show_dist = false;
-    void show(cseq &orig, cseq &aligned, search::result_vector &ref, std::ostream &log);
 };
 log_printer::log_printer(bool show_dist) : data(new priv_data) { data->show_dist = show_dist; }
 log_printer::log_printer(const log_printer &) = default;
@@ -591,25 +656,26 @@ log_printer::~log_printer() = default;
 //   orig_closest_idty  identity of the input alignment with its closest relative,
 //   closest_idty       identity of the new alignment with that same relative,
 // and cpm, the loss against the closest relative: orig_closest_idty - closest_idty.
-void log_printer::priv_data::show(cseq &orig, cseq &aligned, search::result_vector &ref, std::ostream &log) {
+static void show_dist_report(cseq &orig, cseq &aligned, search::result_vector &ref, log_printer::report &out) {
     auto report = [&](const char *what, float v) {
         char line[96];
         snprintf(line, sizeof line, "%s: %.6f\n", what, (double)v);
-        log << line;
+        out.text += line;
     };
     auto identity = [](const cseq &a, const cseq &b, CMP_IUPAC_TYPE rule) {
         return cseq_comparator(rule, CMP_DIST_NONE, CMP_COVER_QUERY, false)(a, b);
     };
     if (orig.getWidth() != aligned.getWidth()) {
-        log << "Cannot show dist - " << orig.getName() << " and " << aligned.getName() << " have lengths "
-            << orig.getWidth() << " and " << aligned.getWidth() << "\n";
+        out.text += "Cannot show dist - " + orig.getName() + " and " + aligned.getName() + " have lengths " +
+                    std::to_string(orig.getWidth()) + " and " + std::to_string(aligned.getWidth()) + "\n";
         return;
     }
     const float sps = identity(orig, aligned, CMP_IUPAC_EXACT);
     report("orig_idty", sps);
-    total_sps += sps;
+    out.has_sps = true;
+    out.sps = sps;
     if (ref.empty()) {
-        log << "reference / search result empty?\n";
+        out.text += "reference / search result empty?\n";
         return;
     }
     // the closest relative of the input alignment: the last of the relatives sorted by identity
@@ -620,24 +686,29 @@ void log_printer::priv_data::show(cseq &orig, cseq &aligned, search::result_vect
     std::sort(by_identity.begin(), by_identity.end());
     const search::result_item &closest = by_identity.back();
     const float before = closest.score, after = identity(aligned, *closest.sequence, CMP_IUPAC_OPTIMISTIC);
-    total_idty += before;
     report("orig_closest_idty", before);
     report("closest_idty", after);
     report("cpm", before - after);
-    total_cpm += before - after;
+    out.has_closest = true;
+    out.idty = before;
+    out.cpm = before - after;
 }
 
-tray log_printer::operator()(tray t, std::ostream &log) {  // src/log.cpp:364-430
+// The report of one tray (src/log.cpp:364-430), as text + the figures the totals take: everything that does not
+// depend on the trays before it, so that a batch's reports can be rendered side by side.
+void log_printer::render(tray &t, report &out) const {
     if (t.input_sequence == nullptr) throw std::runtime_error("Received broken tray in log printer");
-    log << "sequence_number: " << t.seqno << "\n";
-    log << "sequence_identifier: " << t.input_sequence->getName() << "\n";
+    out = report();
+    std::string &log = out.text;
+    log += "sequence_number: " + std::to_string(t.seqno) + "\n";
+    log += "sequence_identifier: " + t.input_sequence->getName() + "\n";
     if (t.aligned_sequence == nullptr) {
-        log << fn::align_log << ": " << t.log.str() << "\n";
-        log << fn::fullname << ": " << t.input_sequence->get_attr<std::string>(fn::fullname) << "\n";
-        log << "alignment failed!\n";
-        return t;
+        log += std::string(fn::align_log) + ": " + t.log.str() + "\n";
+        log += std::string(fn::fullname) + ": " + t.input_sequence->get_attr<std::string>(fn::fullname) + "\n";
+        log += "alignment failed!\n";
+        return;
     }
-    ++data->sequence_num;
+    out.aligned = true;
     cseq &aligned = *t.aligned_sequence;
     // (helix pairing comes from the ARB database: no pairs, bp score 0)
     aligned.set_attr("align_bp_score_slv", 0);
@@ -650,11 +721,36 @@ tray log_printer::operator()(tray t, std::ostream &log) {  // src/log.cpp:364-43
         aligned.set_attr("align_startpos_slv", 0);
         aligned.set_attr("align_stoppos_slv", 0);
     }
-    for (auto &ap : aligned.get_attrs()) log << ap.key() << ": " << attr_to_string(ap.second) << "\n";
-    search::result_vector ref;
-    if (t.search_result != nullptr) ref = *t.search_result;
-    else if (t.alignment_reference != nullptr) ref = *t.alignment_reference;
-    if (data->show_dist) data->show(*t.input_sequence, aligned, ref, log);
+    for (auto &ap : aligned.get_attrs()) {
+        log += ap.key();
+        log += ": ";
+        log += attr_to_string(ap.second);
+        log += "\n";
+    }
+    if (data->show_dist) {
+        search::result_vector ref;
+        if (t.search_result != nullptr) ref = *t.search_result;
+        else if (t.alignment_reference != nullptr) ref = *t.alignment_reference;
+        show_dist_report(*t.input_sequence, aligned, ref, out);
+    }
+}
+
+// ... and what does: the count and the running totals, in tray order (the sums are doubles: their order shows)
+void log_printer::commit(const report &r, std::ostream &log) {
+    log << r.text;
+    if (!r.aligned) return;
+    ++data->sequence_num;
+    if (r.has_sps) data->total_sps += r.sps;
+    if (r.has_closest) {
+        data->total_idty += r.idty;
+        data->total_cpm += r.cpm;
+    }
+}
+
+tray log_printer::operator()(tray t, std::ostream &log) {
+    report r;
+    render(t, r);
+    commit(r, log);
     return t;
 }
 

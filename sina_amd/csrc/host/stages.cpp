@@ -760,6 +760,70 @@ static unsigned count_query_kmers(const uint8_t *m, size_t n, unsigned k, bool c
     return total;
 }
 
+// Batch-level memoisation of repeated queries.  The reference's kmer_search::find keeps the scored list of the
+// base strings it has just seen (src/kmer_search.cpp:105,377-378,419: a cache of 32 keyed by getBases()) -- real
+// amplicon runs are dominated by repeats.  A GPU batch is thousands of queries wide, so the analogue is inside the
+// batch: items with the same key bytes (and, for the aligner, the same family) go to the device ONCE, and every
+// item reads the slot of its first occurrence.  rep[i] = index of the first item equal to item i; returns the
+// number of distinct items.  set_batch_dedup(false) / SINA_HOST_DEDUP=0 switch it off (tests compare both ways).
+static std::atomic<int> g_dedup{-1};  // -1: ask the environment (SINA_HOST_DEDUP=0 switches it off)
+void set_batch_dedup(bool on) { g_dedup.store(on ? 1 : 0); }
+static bool dedup_enabled() {
+    const int v = g_dedup.load(std::memory_order_relaxed);
+    if (v >= 0) return v != 0;
+    static const bool from_env = [] {
+        const char *e = getenv("SINA_HOST_DEDUP");
+        return !(e && *e == '0');
+    }();
+    return from_env;
+}
+template <class Hash, class Equal>
+static size_t group_equal_items(size_t n, Hash &&hash_of, Equal &&equal, std::vector<uint32_t> &rep) {
+    rep.resize(n);
+    if (!dedup_enabled() || n < 2) {
+        for (size_t i = 0; i < n; i++) rep[i] = (uint32_t)i;
+        return n;
+    }
+    std::vector<uint64_t> h(n);
+    parallel_for(n, [&](size_t i) { h[i] = hash_of(i); });
+    // open addressing over the first occurrences (a batch is a few thousand items)
+    size_t cap = 16;
+    while (cap < 2 * n) cap <<= 1;
+    std::vector<uint32_t> slot(cap, 0xFFFFFFFFu);
+    size_t distinct = 0;
+    for (size_t i = 0; i < n; i++) {
+        size_t at = (size_t)(h[i] * 0x9E3779B97F4A7C15ull >> 20) & (cap - 1);
+        for (;;) {
+            const uint32_t j = slot[at];
+            if (j == 0xFFFFFFFFu) {
+                slot[at] = (uint32_t)i;
+                rep[i] = (uint32_t)i;
+                distinct++;
+                break;
+            }
+            if (h[j] == h[i] && equal(j, i)) {
+                rep[i] = j;
+                break;
+            }
+            at = (at + 1) & (cap - 1);
+        }
+    }
+    return distinct;
+}
+static uint64_t hash_bytes(const void *p, size_t n, uint64_t seed) {  // (FNV-1a over 8-byte words + tail)
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    uint64_t h = 0xcbf29ce484222325ull ^ seed;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, b + i, 8);
+        h = (h ^ w) * 0x100000001b3ull;
+        h ^= h >> 29;
+    }
+    for (; i < n; i++) h = (h ^ b[i]) * 0x100000001b3ull;
+    return h ^ (h >> 32);
+}
+
 void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vector<result_vector> &results,
                              unsigned int max, std::vector<uint32_t> *kmer_counts) {
     reference_store &st = *pimpl->store;
@@ -786,20 +850,55 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
     auto dev = st.worker_device(reference_store::dev_search);
     sina_hip_ctx *ctx = dev.get();
     if (max <= 4096) {
+        // repeated queries (same bases, same case: the packed mask bytes) are searched once
+        std::vector<uint32_t> rep;
+        const size_t nu = group_equal_items(
+            queries.size(),
+            [&](size_t i) { return hash_bytes(qmask + qoff[i], qoff[i + 1] - qoff[i], qoff[i + 1] - qoff[i]); },
+            [&](size_t a, size_t b) {
+                return qoff[a + 1] - qoff[a] == qoff[b + 1] - qoff[b] &&
+                       memcmp(qmask + qoff[a], qmask + qoff[b], qoff[a + 1] - qoff[a]) == 0;
+            },
+            rep);
+        std::vector<uint32_t> slot_of(queries.size());
+        const uint8_t *dev_mask = qmask;
+        const uint64_t *dev_off = qoff.data();
+        std::vector<uint64_t> uoff;
+        thread_local batch_scratch<uint8_t> umask_buf;
+        if (nu == queries.size()) {
+            for (size_t i = 0; i < queries.size(); i++) slot_of[i] = (uint32_t)i;
+        } else {  // the distinct queries, packed again for the device
+            uoff.assign(nu + 1, 0);
+            std::vector<uint32_t> firsts;
+            firsts.reserve(nu);
+            for (size_t i = 0; i < queries.size(); i++) {
+                if (rep[i] == i) {
+                    slot_of[i] = (uint32_t)firsts.size();
+                    uoff[firsts.size() + 1] = uoff[firsts.size()] + (qoff[i + 1] - qoff[i]);
+                    firsts.push_back((uint32_t)i);
+                } else {
+                    slot_of[i] = slot_of[rep[i]];
+                }
+            }
+            uint8_t *const um = umask_buf.get(uoff.back() + 1);
+            parallel_for(nu, [&](size_t u) { memcpy(um + uoff[u], qmask + qoff[firsts[u]], uoff[u + 1] - uoff[u]); });
+            dev_mask = um;
+            dev_off = uoff.data();
+        }
         thread_local batch_scratch<uint32_t> ids_buf;
         thread_local batch_scratch<float> sc_buf;
-        uint32_t *const ids = ids_buf.get((size_t)queries.size() * max);
-        float *const sc = sc_buf.get((size_t)queries.size() * max);
-        std::vector<uint32_t> cnt(queries.size());
+        uint32_t *const ids = ids_buf.get(nu * max);
+        float *const sc = sc_buf.get(nu * max);
+        std::vector<uint32_t> cnt(nu);
         {
             scoped_phase ph("ff.kmer_topk(C-ABI)");
-            hip_check(sina_hip_kmer_topk(ctx, qmask, qoff.data(), (uint32_t)queries.size(), max, ids, sc, cnt.data()),
-                      "kmer_topk");
+            hip_check(sina_hip_kmer_topk(ctx, dev_mask, dev_off, (uint32_t)nu, max, ids, sc, cnt.data()), "kmer_topk");
         }
         parallel_for(queries.size(), [&](size_t i) {
-            results[i].reserve(cnt[i]);
-            for (uint32_t x = 0; x < cnt[i]; x++)
-                results[i].emplace_back(sc[i * max + x], &st.getCseq(ids[i * max + x]));
+            const size_t u = slot_of[i];
+            results[i].reserve(cnt[u]);
+            for (uint32_t x = 0; x < cnt[u]; x++)
+                results[i].emplace_back(sc[u * max + x], &st.getCseq(ids[u * max + x]));
         });
     } else {
         // rare escalation (famfinder asks for >4096 candidates): the GPU still does the
@@ -1654,7 +1753,49 @@ void aligner::operator()(std::vector<tray> &batch) {
             uint8_t *dst = qmask + qoff[x];
             for (size_t y = 0; y < nb; y++) dst[y] = (uint8_t)(b[y] >> 24);
         });
-        std::vector<sina_hip_align_out> out(nq);
+        // Repeated queries -- the same bases in the same case against the same ordered family: amplicon runs are
+        // full of them -- are aligned ONCE (one DAG, one DP, one walk); every tray then finishes from the device
+        // results of its first occurrence, with its own name, log and attributes (group_equal_items above).
+        std::vector<uint32_t> rep;
+        const size_t dnq = group_equal_items(
+            nq,
+            [&](size_t x) {
+                const auto &fam = jobs[idx[x]].family;
+                return hash_bytes(qmask + qoff[x], qoff[x + 1] - qoff[x], hash_bytes(fam.data(), fam.size() * sizeof(fam[0]), fam.size()));
+            },
+            [&](size_t a, size_t b) {
+                return qoff[a + 1] - qoff[a] == qoff[b + 1] - qoff[b] && jobs[idx[a]].family == jobs[idx[b]].family &&
+                       memcmp(qmask + qoff[a], qmask + qoff[b], qoff[a + 1] - qoff[a]) == 0;
+            },
+            rep);
+        std::vector<uint32_t> slot_of(nq);       // device slot of group member x
+        std::vector<size_t> uidx;                // job of device slot u
+        std::vector<uint64_t> dqoff_store;
+        const uint8_t *dqmask = qmask;
+        thread_local batch_scratch<uint8_t> dqmask_buf;
+        if (dnq == nq) {
+            for (size_t x = 0; x < nq; x++) slot_of[x] = (uint32_t)x;
+        } else {
+            uidx.reserve(dnq);
+            dqoff_store.assign(dnq + 1, 0);
+            std::vector<uint32_t> first_x;
+            first_x.reserve(dnq);
+            for (size_t x = 0; x < nq; x++) {
+                if (rep[x] == x) {
+                    slot_of[x] = (uint32_t)uidx.size();
+                    dqoff_store[uidx.size() + 1] = dqoff_store[uidx.size()] + (qoff[x + 1] - qoff[x]);
+                    uidx.push_back(idx[x]);
+                    first_x.push_back((uint32_t)x);
+                } else {
+                    slot_of[x] = slot_of[rep[x]];
+                }
+            }
+            uint8_t *const um = dqmask_buf.get(dqoff_store.back() + 1);
+            parallel_for(dnq, [&](size_t u) { memcpy(um + dqoff_store[u], qmask + qoff[first_x[u]], dqoff_store[u + 1] - dqoff_store[u]); });
+            dqmask = um;
+        }
+        const std::vector<uint64_t> &dqoff = dnq == nq ? qoff : dqoff_store;
+        std::vector<sina_hip_align_out> out(dnq);
         // (the aligned columns are read where the device copied them, in the context's pinned staging buffer:
         // sina_hip_staged_out_pos -- the context stays leased until the alignments below are finished)
         uint32_t *const out_pos = nullptr;
@@ -1662,6 +1803,12 @@ void aligner::operator()(std::vector<tray> &batch) {
         sina_hip_ctx *ctx = dev.get();
         uint32_t width = 0;
 
+        {   // ---- the device's share, over the DISTINCT queries of the group (the names below shadow the group's)
+        const std::vector<size_t> &group_idx = idx;
+        const std::vector<size_t> &idx = dnq == group_idx.size() ? group_idx : uidx;
+        const size_t nq = dnq;
+        const std::vector<uint64_t> &qoff = dqoff;
+        const uint8_t *const qmask = dqmask;
         if (graph_on_device) {
             std::vector<uint64_t> foff(nq + 1, 0);
             for (size_t x = 0; x < nq; x++) foff[x + 1] = foff[x] + jobs[idx[x]].family.size();
@@ -1725,6 +1872,7 @@ void aligner::operator()(std::vector<tray> &batch) {
             hip_check(sina_hip_align_graphs(ctx, &gb, qmask, qoff.data(), &p, out.data(), out_pos),
                       "align_graphs");
         }
+        }   // ---- (end of the device's share)
 
         const uint32_t *const staged_pos = sina_hip_staged_out_pos(ctx);
         // cseq container steps of backtrack() (src/mesh.h:603-736) + do_align attrs (:507-509)
@@ -1733,11 +1881,11 @@ void aligner::operator()(std::vector<tray> &batch) {
             dp_job &jb = jobs[idx[x]];
             tray &t = *jb.t;
             cseq &c = *jb.c;
-            const sina_hip_align_out &r = out[x];
+            const sina_hip_align_out &r = out[slot_of[x]];
             if (r.status != 0) throw std::runtime_error("device alignment failed for " + c.getName());
             uint64_t tk = host_tsc();
             const uint32_t L = (uint32_t)t.input_sequence->size();
-            const uint32_t *pos = staged_pos + qoff[x];
+            const uint32_t *pos = staged_pos + dqoff[slot_of[x]];
             if (r.assembled) {
                 // the device did the container steps (append rule, setWidth, reverse) and a NAST fix-up
                 // in which every insertion fitted its gap: the finished bases, and the fix-up's log line

@@ -462,6 +462,9 @@ public:
         writer &operator=(const writer &);
         ~writer();
         tray operator()(tray t);
+        // composes the records of a batch's aligned sequences on the loop pool, ahead of the ordered operator()
+        // calls for those trays (which then only hand the text to the sink); same bytes either way
+        void precompose(const std::vector<tray> &batch);
         int written() const;
         int excluded() const;
         void flush();
@@ -480,11 +483,19 @@ public:
         int sequences = 0;
         double avg_sps = 0, avg_cpm = 0, avg_idty = 0, avg_bps = 0;
     };
+    // one tray's report: its text, and what the running totals take from it
+    struct report {
+        std::string text;
+        bool aligned = false, has_sps = false, has_closest = false;
+        float sps = 0, idty = 0, cpm = 0;
+    };
     explicit log_printer(bool show_dist);
     log_printer(const log_printer &);
     log_printer &operator=(const log_printer &);
     ~log_printer();
-    tray operator()(tray t, std::ostream &log);  // serial stage: call in sequence order
+    tray operator()(tray t, std::ostream &log);  // serial stage: call in sequence order (= render + commit)
+    void render(tray &t, report &out) const;      // any thread, any order (sets the aligned sequence's attributes)
+    void commit(const report &r, std::ostream &log);  // in sequence order
     summary totals() const;
 };
 
@@ -537,8 +548,14 @@ private:
                 // linger briefly so that concurrent callers end up in the same launch
                 cv.wait_for(lk, std::chrono::microseconds(linger_us),
                             [this] { return stop || pending.size() >= max_batch; });
+                // (at most max_batch callers per launch, first come first served: the rest is the next batch)
                 std::vector<std::pair<tray, std::promise<tray>>> work;
-                work.swap(pending);
+                if (pending.size() <= max_batch) {
+                    work.swap(pending);
+                } else {
+                    work.assign(std::make_move_iterator(pending.begin()), std::make_move_iterator(pending.begin() + (std::ptrdiff_t)max_batch));
+                    pending.erase(pending.begin(), pending.begin() + (std::ptrdiff_t)max_batch);
+                }
                 lk.unlock();
                 std::vector<tray> batch;
                 batch.reserve(work.size());
@@ -560,6 +577,9 @@ private:
 // parallel for over [0, n) on a process-wide pool (stands in for TBB's workers)
 void parallel_for(size_t n, const std::function<void(size_t)> &fn);
 void set_host_threads(unsigned n);
+// identical queries of a batch go to the device once (k-mer search; DAG + DP when the family is the same too):
+// on by default; off = every tray's query is searched and aligned on its own
+void set_batch_dedup(bool on);
 unsigned host_threads();
 std::string host_profile_dump(bool reset);  // per-phase wall time when SINA_HOST_PROFILE is set
 void host_profile_mark(const char *what);  // (`what` must outlive the process: a literal)

@@ -73,6 +73,7 @@ def load_host():
     H.sina_host_store_expect_broadcast.argtypes = [C.c_char_p]
     H.sina_host_run_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint32,
                                       C.POINTER(C.c_double)]
+    H.sina_host_run_fasta_serial.argtypes = H.sina_host_run_fasta.argtypes
     H.sina_host_fasta_roundtrip.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     H.sina_host_store_index_origin.restype = C.c_char_p
     H.sina_host_store_index_origin.argtypes = [C.c_char_p]
@@ -215,10 +216,11 @@ class Pipeline:
     """famfinder + aligner (+ search_filter when `search` is given, as `sina --search`) over one Store.
     Options use SINA's command-line names."""
 
-    def __init__(self, store, famfinder=None, aligner=None, host_threads=None, search=None):
+    def __init__(self, store, famfinder=None, aligner=None, host_threads=None, search=None, dedup=True):
         self.H = load_host()
         self.store = store
         self.H.sina_host_reset_options()
+        self._set("host", "dedup", bool(dedup))  # repeated queries of a batch go to the device once
         self._set("famfinder", "db", store.key)
         self._set("aligner", "db", store.key)
         for k, v in (famfinder or {}).items():
@@ -353,7 +355,7 @@ def _set_options(H, stage, opts):
 
 
 def run_fasta(store, in_path, out_path, famfinder=None, aligner=None, search=None, fasta=None, show_dist=False,
-              log_path="", batch=1024):
+              log_path="", batch=1024, serial=False):
     """`sina -i in_path -o out_path --db <store> [--search] [--show-dist]`: FASTA in, aligned FASTA out, through
     the stage mirror.  Returns dict(read, aligned, written, skipped, avg_sps, avg_cpm, avg_idty)."""
     H = load_host()
@@ -364,8 +366,10 @@ def run_fasta(store, in_path, out_path, famfinder=None, aligner=None, search=Non
         _set_options(H, "search", dict({"search-db": store.key}, **search))
     _set_options(H, "fasta", fasta)
     out = (C.c_double * 7)()
-    _chk(H.sina_host_run_fasta(in_path.encode(), out_path.encode(), log_path.encode(), int(search is not None),
-                               int(show_dist), batch, out))
+    # (serial=True: one batch at a time, stage after stage -- the parity driver; default: the stages as concurrent
+    # nodes with an ordered, parallel-composing sink; same output byte for byte)
+    run = H.sina_host_run_fasta_serial if serial else H.sina_host_run_fasta
+    _chk(run(in_path.encode(), out_path.encode(), log_path.encode(), int(search is not None), int(show_dist), batch, out))
     return dict(read=int(out[0]), aligned=int(out[1]), written=int(out[2]), skipped=int(out[3]), avg_sps=out[4],
                 avg_cpm=out[5], avg_idty=out[6])
 

@@ -158,6 +158,35 @@ def make_queries(refs, n_queries, seed=2, sub=0.03, dele=0.005, ins=0.003, windo
     return QuerySet(mask=np.ascontiguousarray(out_m), off=off, src=src)
 
 
+def pick_queries(qs, pick):
+    """The queries qs[i] for i in pick, in that order (repeats allowed), as a QuerySet of their own."""
+    pick = np.asarray(pick, dtype=np.int64)
+    lens = (qs.off[pick + 1] - qs.off[pick]).astype(np.int64)
+    off = np.zeros(len(pick) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    gi = np.arange(int(off[-1]), dtype=np.int64) - np.repeat(off[:-1], lens) + np.repeat(qs.off[pick], lens)
+    return QuerySet(mask=np.ascontiguousarray(qs.mask[gi]), off=off, src=qs.src[pick])
+
+
+def with_repeats(qs, dup_rate, block, seed=9):
+    """Amplicon-like repetition: inside every block of `block` consecutive queries, a fraction dup_rate of the
+    queries is replaced by copies of other queries of the same block (chosen among those that stay)."""
+    if dup_rate <= 0:
+        return qs
+    rng = np.random.default_rng(seed)
+    pick = np.arange(qs.n, dtype=np.int64)
+    for b0 in range(0, qs.n, block):
+        b1 = min(qs.n, b0 + block)
+        n = b1 - b0
+        n_dup = min(n - 1, int(round(dup_rate * n)))
+        if n_dup <= 0:
+            continue
+        order = rng.permutation(n)
+        dups, keep = order[:n_dup], order[n_dup:]
+        pick[b0 + dups] = b0 + rng.choice(keep, size=n_dup, replace=True)
+    return pick_queries(qs, pick)
+
+
 def aligned_string(ab, width, dna=False):
     """Render a packed aligned sequence as a gapped string ('-' for gaps)."""
     chars = b".AGRCMSVUWKDYHBN.agrcmsvuwkdyhbn" if not dna else b".AGRCMSVTWKDYHBN.agrcmsvtwkdyhbn"

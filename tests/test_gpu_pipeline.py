@@ -337,6 +337,43 @@ def test_single_tray_batching_shim(oracle, world):
     pl.close()
 
 
+@pytest.mark.parametrize("al,oal", [({}, {}), ({"lowercase": "original", "overhang": "edge"}, dict(lowercase=1, overhang=2)),
+                                    ({"device-graph": False, "insertion": "forbid"}, dict(insertion=1))])
+def test_repeated_queries_go_to_the_device_once(oracle, world, al, oal):
+    """Batch-level memoisation (the device-side analogue of kmer_search's cache of the base strings it has just
+    seen, src/kmer_search.cpp:105,377-378,419): 60 queries of which only 24 are distinct -- same bases, same case.
+    The trays equal the oracle's and those of a run with the memoisation switched off, field by field, and the
+    device has searched and aligned 24 where the other run searched and aligned 60."""
+    refs, cs, idx, st = world
+    base = synth.make_queries(refs, 24, seed=63, ins=0.01, dele=0.01, lower_rate=0.05, window=(0.2, 200))
+    rng = np.random.default_rng(64)
+    pick = np.concatenate([np.arange(24), rng.integers(0, 24, size=36)])
+    rng.shuffle(pick)
+    qs = synth.pick_queries(base, pick)
+    ff = {"fs-min-len": 100, "fs-full-len": 250}
+    runs = {}
+    for dedup in (True, False):
+        pl = pipeline.Pipeline(st, famfinder=ff, aligner=al, dedup=dedup)
+        s0 = st.stats()
+        pl.run(qs.mask, qs.off, batch=60, inflight=1)
+        s1 = st.stats()
+        runs[dedup] = ([pl.result(q) for q in range(qs.n)], s1["dp_cells"] - s0["dp_cells"], s1["postings"] - s0["postings"])
+        n_dp, _ = _check(oracle, refs, qs, pl, cs, idx, ff=dict(fs_min_len=100, fs_full_len=250), al=oal)
+        assert n_dp >= 50
+        pl.close()
+    for a, b in zip(runs[True][0], runs[False][0]):
+        assert a["status"] == b["status"] and a["family"] == b["family"] and a["log"] == b["log"]
+        assert (a["packed"] == b["packed"]).all() and (a["head"], a["tail"], a["qual"]) == (b["head"], b["tail"], b["qual"])
+    # the device's share: the 24 distinct queries' cells and postings -- what a run over just those costs
+    pl = pipeline.Pipeline(st, famfinder=ff, aligner=al, dedup=False)
+    s0 = st.stats()
+    pl.run(base.mask, base.off, batch=24, inflight=1)
+    s1 = st.stats()
+    pl.close()
+    assert runs[True][1] == s1["dp_cells"] - s0["dp_cells"] and runs[True][2] == s1["postings"] - s0["postings"]
+    assert runs[False][1] > 2 * runs[True][1] and runs[False][2] > 2 * runs[True][2]
+
+
 def test_batched_stage_shim_under_32_concurrent_single_tray_callers(oracle, world):
     """INTEGRATION.md section 1 as it is bound: sina::batched<famfinder> -> batched<aligner>, called with ONE
     tray per call from 40 threads at once (SINA's unlimited-concurrency function_nodes, src/sina.cpp:497-519).

@@ -371,3 +371,45 @@ def test_fasta_pipeline_and_show_dist_metrics(oracle, tmp_path):
     assert got["avg_sps"] == tot_sps / n and got["avg_cpm"] == tot_cpm / n and got["avg_idty"] == tot_idty / n
     assert got["avg_sps"] > 0.97   # (the reference's own accuracy test asks for > 0.996 on real rRNA)
     st.close()
+
+
+@pytest.mark.parametrize("fasta,search", [({}, None), ({"fasta-write-dots": True, "line-length": 70, "meta-fmt": "comment"}, {}),
+                                          ({"meta-fmt": "csv", "fasta-write-dna": True}, None)])
+def test_fasta_driver_with_concurrent_stages_writes_the_serial_drivers_bytes(oracle, tmp_path, fasta, search):
+    """SURVEY 8f-3 at speed: the FASTA driver runs reader, famfinder, aligner (+ search) and the sink as concurrent
+    nodes (src/sina.cpp:452-586) -- the sink renders the log reports and composes the records of a batch on the loop
+    pool and hands the text over in input order.  Output file, csv side file, log and summary are byte for byte
+    those of the one-batch-at-a-time driver (the aligned_slv time stamp aside); batches of 16 make 20 hand-overs."""
+    import os
+    refs = synth.make_refs(400, length=320, width=3200, seed=495, amb_rate=0.01, lower_rate=0.02)
+    st = pipeline.Store(":mem:gpu-fasta-conc", refs)
+    qs = synth.make_queries(refs, 310, seed=496, ins=0.01, dele=0.01, lower_rate=0.03)
+    src = str(tmp_path / "in.fasta")
+    with open(src, "w") as f:
+        for i in range(qs.n):
+            text = synth.bases_string(qs.seq(i))
+            if i == 17:
+                text = text[:40] + "!" + text[41:]          # a record the reader drops
+            if i == 23:
+                text = "ACGU"                               # one without relatives
+            f.write(">q%d sample %d\n%s\n" % (i, i % 7, text))
+    ffo = {"fs-min-len": 100, "fs-full-len": 250}
+    if search is not None:
+        search = {"search-min-sim": 0.5, "search-kmer-candidates": 50}
+    outs = {}
+    for serial in (True, False):
+        tag = "serial" if serial else "conc"
+        dst, logp = str(tmp_path / (tag + ".fasta")), str(tmp_path / (tag + ".log"))
+        got = pipeline.run_fasta(st, src, dst, famfinder=ffo, search=search, fasta=fasta, show_dist=False, batch=16,
+                                 log_path=logp, serial=serial)
+        strip = lambda text: "\n".join(l for l in text.splitlines() if "aligned_slv" not in l)
+        csv = str(tmp_path / (tag + ".csv"))
+        outs[tag] = (got, strip(open(dst).read()), strip(open(logp).read()),
+                     strip(open(csv).read()) if os.path.exists(csv) else None)
+    assert outs["serial"][0] == outs["conc"][0]
+    assert outs["serial"][0]["read"] == qs.n - 1 and outs["serial"][0]["skipped"] == 1
+    assert outs["serial"][0]["written"] >= qs.n - 12
+    assert outs["serial"][1] == outs["conc"][1]
+    assert outs["serial"][2] == outs["conc"][2]
+    assert outs["serial"][3] == outs["conc"][3] and (outs["serial"][3] is not None) == (fasta.get("meta-fmt") == "csv")
+    st.close()
