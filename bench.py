@@ -61,6 +61,12 @@ def parse():
                     help="fraction of every step's queries that repeat another query of the same step (amplicon-like "
                          "input; identical queries of a batch are searched and aligned once).  Default 0: the headline "
                          "workload has no repeats")
+    ap.add_argument("--confined-cpus", type=int, default=2,
+                    help="N = 1 only: after the timed region the same number of steps runs once more with every thread of "
+                         "the process confined to this many CPUs (an 8-rank node inside a 16-CPU quota leaves a rank two) "
+                         "and --confined-threads loop-pool threads; the line reports confined_rate_frac = that rate / "
+                         "the timed region's.  0 = skip")
+    ap.add_argument("--confined-threads", type=int, default=3)
     ap.add_argument("--host-graph", action="store_true", help="build family DAGs on the host")
     ap.add_argument("--host-threads", type=int, default=0, help="threads of the host-side loop pool (0 = default)")
     return ap.parse_args()
@@ -359,6 +365,42 @@ def main():
     s2 = store.stats()
     iso = {k: s2[k] - s1[k] for k in s1}
 
+    # ---- the host budget of an 8-rank node, proven on this one GPU: the same steps once more with the whole
+    # process (loop pool, stage driver threads, the HIP runtime's helpers) on --confined-cpus CPUs
+    confined = None
+    if world == 1 and a.confined_cpus > 0 and hasattr(os, "sched_setaffinity"):
+        def all_tasks():
+            return [int(t) for t in os.listdir("/proc/self/task")]
+        allowed = sorted(os.sched_getaffinity(0))
+        cpus = set(allowed[:a.confined_cpus])
+        before = {}
+        for tid in all_tasks():
+            try:
+                before[tid] = os.sched_getaffinity(tid)
+                os.sched_setaffinity(tid, cpus)
+            except OSError:
+                pass
+        pl._set("host", "threads", a.confined_threads)
+        try:
+            run_steps(a.warmup, min(2, a.steps))  # (the pool's new threads, the caches on the new CPUs)
+            ru_a = resource.getrusage(resource.RUSAGE_SELF)
+            t_c = time.time()
+            run_steps(a.warmup, a.steps)
+            torch.cuda.synchronize(device)
+            dt_c = time.time() - t_c
+            ru_b = resource.getrusage(resource.RUSAGE_SELF)
+            n_c = sum(1 for q in range(n_done) if pl.result(q)["status"] in (0, 1))
+            confined = {"cpus": len(cpus), "pool_threads": a.confined_threads, "sequences_per_s": n_c / dt_c,
+                        "host_cores_busy": ((ru_b.ru_utime - ru_a.ru_utime) + (ru_b.ru_stime - ru_a.ru_stime)) / dt_c,
+                        "rate_frac": (n_c / dt_c) / (n_aligned / elapsed)}
+        finally:
+            for tid in all_tasks():
+                try:
+                    os.sched_setaffinity(tid, before.get(tid, set(allowed)))
+                except OSError:
+                    pass
+            pl._set("host", "threads", host_threads or 12)
+
     per_rank = None
     if dist is not None:
         # per rank: its own rate and host load (the job's rate below is total work / slowest rank's time)
@@ -517,6 +559,8 @@ def main():
                 "mesh_dp_kernel": iso["dp_ms"],
                 "backtrack_kernel": iso["backtrack_ms"],
             },
+            "confined_rate_frac": confined["rate_frac"] if confined else None,  # rate on --confined-cpus CPUs / rate above
+            "confined": confined,
             "host_cores_busy": host_cores,  # CPU seconds per wall second of this rank in the timed region
             "host_cpus_pinned": pinned,     # logical CPUs this rank's host threads are confined to (None: not pinned)
             "host_pool_threads": host_threads,  # None: the library's default (12)

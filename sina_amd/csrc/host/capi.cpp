@@ -53,7 +53,26 @@ struct result {
     bool searched = false;          // search stage ran and produced a result vector
     std::vector<uint32_t> sr_ids;   // search results, best first
     std::vector<float> sr_scores;
-    std::map<std::string, std::string> attrs;  // nearest_slv, lca_*, copy_*
+    // turn, nearest_slv, lca_*, copy_*: a handful per query.  A flat list whose strings keep their blocks from
+    // one query to the next (a std::map was two heap blocks per attribute and query, freed by reset())
+    struct attr_list {
+        std::vector<std::pair<std::string, std::string>> v;
+        size_t n = 0;
+        void clear() { n = 0; }
+        std::string &operator[](std::string_view key) {
+            for (size_t i = 0; i < n; i++)
+                if (v[i].first == key) return v[i].second;
+            if (n == v.size()) v.emplace_back();
+            v[n].first.assign(key);
+            v[n].second.clear();
+            return v[n++].second;
+        }
+        const std::string *find(std::string_view key) const {
+            for (size_t i = 0; i < n; i++)
+                if (v[i].first == key) return &v[i].second;
+            return nullptr;
+        }
+    } attrs;
 };
 
 // Where the aligned bases of a run's results live: one block for the whole run (a query's result has
@@ -145,7 +164,8 @@ void extract_tray(pipeline *p, tray &t, result &r, aligned_base *dst, uint32_t q
     r.log.assign(t.log.view());  // (no temporary: the result's string keeps its block between runs)
     if (const std::string *fam = t.input_sequence->string_attr(fn::family)) r.family.assign(*fam);
     else r.family = t.input_sequence->get_attr<std::string>(fn::family);
-    if (t.input_sequence->has_attr(fn::turn)) r.attrs[fn::turn] = t.input_sequence->get_attr<std::string>(fn::turn);
+    if (const std::string *turn = t.input_sequence->string_attr(fn::turn)) r.attrs[fn::turn].assign(*turn);
+    else if (t.input_sequence->has_attr(fn::turn)) r.attrs[fn::turn] = t.input_sequence->get_attr<std::string>(fn::turn);
     tk = host_tick("extract: log + family + turn", tk);
     if (t.aligned_sequence) {
         cseq &c = *t.aligned_sequence;
@@ -196,9 +216,7 @@ void fill_query_tray(tray &t, uint32_t q, const uint8_t *qmask, const uint64_t *
     std::vector<aligned_base> &ab = t.input_sequence->mutableAlignedBases();
     const uint32_t n_bases = (uint32_t)(qoff[q + 1] - qoff[q]);
     ab.resize(n_bases);
-    uint32_t *raw = reinterpret_cast<uint32_t *>(ab.data());
-    const uint8_t *m = qmask + qoff[q];
-    for (uint32_t x = 0; x < n_bases; x++) raw[x] = x | ((uint32_t)m[x] << 24);
+    packed_of_masks(reinterpret_cast<uint32_t *>(ab.data()), qmask + qoff[q], n_bases);
     t.input_sequence->setWidth(n_bases);
     host_tick("build: bases", tk);
 }
@@ -1010,8 +1028,8 @@ int sina_host_result_search(void *pp, uint32_t q, uint32_t *ids, float *scores, 
 }
 const char *sina_host_result_attr(void *pp, uint32_t q, const char *name) {
     const result &r = result_at(pp, q);
-    const auto it = r.attrs.find(name);
-    return it == r.attrs.end() ? "" : it->second.c_str();
+    const std::string *v = r.attrs.find(name);
+    return v ? v->c_str() : "";
 }
 double sina_host_search_seconds(void *pp) { return ((pipeline *)pp)->sf_s; }
 float sina_host_result_idty(void *pp, uint32_t q) { return result_at(pp, q).idty; }

@@ -844,7 +844,8 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
     parallel_for(queries.size(), [&](size_t i) {
         const auto &b = queries[i]->getAlignedBases();
         uint8_t *dst = qmask + qoff[i];
-        for (size_t x = 0; x < b.size(); x++) dst[x] = (uint8_t)(b[x].raw >> 24);
+        static_assert(sizeof(aligned_base) == 4, "packed words");
+        masks_of_packed(dst, reinterpret_cast<const uint32_t *>(b.data()), b.size());
         if (kmer_counts) (*kmer_counts)[i] = count_query_kmers(dst, b.size(), kk, count_all);
     });
     auto dev = st.worker_device(reference_store::dev_search);
@@ -1243,39 +1244,50 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
         cseq &c = *t.input_sequence;
         uint64_t tk = host_tsc();
         std::string &fam = c.string_slot(fn::family);  // (written in place, into the sequence's recycled block)
-        char buf[64];
-        fam.reserve(vc.size() * 24);
+        // "<acc>.<start>:<score> " per relative (famfinder.cpp:462-470), ":%.2f " for the score.  The text is
+        // sized first and then written through a pointer: forty relatives were eighty checked appends.
         // (the members' labels are 40 random reads into a 100 000-entry table: ask for all of them first)
         for (auto &r : vc)
             if (arb->owns(r.sequence)) __builtin_prefetch(&arb->family_label(arb->id_of(r.sequence)));
-        for (auto &r : vc) {  // "<acc>.<start>:<score> " per relative (famfinder.cpp:462-470)
-            // (":%.2f " -- the scores are k-mer counts, whole numbers: digits + ".00" without printf)
+        bool plain = true;  // every relative is of the store and has a whole-number score (k-mer counts are)
+        size_t total = 0;
+        for (auto &r : vc) {
             const float sc = r.score;
-            if (sc >= 0.f && sc < 16777216.f && sc == (float)(uint32_t)sc) {
-                char *w = buf + sizeof(buf);
-                *--w = 0;
-                *--w = ' ';
-                *--w = '0';
-                *--w = '0';
-                *--w = '.';
-                uint32_t v = (uint32_t)sc;
-                do {
-                    *--w = (char)('0' + v % 10);
-                    v /= 10;
-                } while (v);
-                *--w = ':';
-                memmove(buf, w, (size_t)(buf + sizeof(buf) - w));
-            } else {
-                snprintf(buf, sizeof(buf), ":%.2f ", (double)sc);
+            if (!(arb->owns(r.sequence) && sc >= 0.f && sc < 16777216.f && sc == (float)(uint32_t)sc)) {
+                plain = false;
+                break;
             }
-            if (arb->owns(r.sequence)) {
-                fam += arb->family_label(arb->id_of(r.sequence));  // (the "<acc>.<start>" part, cached per reference)
-            } else {
-                arb->loadKey(*r.sequence, fn::acc);
-                arb->loadKey(*r.sequence, fn::start);
-                fam += r.sequence->get_attr<std::string>(fn::acc) + "." + r.sequence->get_attr<std::string>(fn::start, "0");
+            const uint32_t v = (uint32_t)sc;
+            const size_t digits = v < 10 ? 1 : v < 100 ? 2 : v < 1000 ? 3 : v < 10000 ? 4 : v < 100000 ? 5 : v < 1000000 ? 6 : v < 10000000 ? 7 : 8;
+            total += arb->family_label(arb->id_of(r.sequence)).size() + 1 + digits + 4;
+        }
+        if (plain) {
+            fam.resize(total);
+            char *w = fam.data();
+            for (auto &r : vc) {
+                const std::string &label = arb->family_label(arb->id_of(r.sequence));
+                memcpy(w, label.data(), label.size());
+                w += label.size();
+                *w++ = ':';
+                w = std::to_chars(w, w + 10, (uint32_t)r.score).ptr;
+                memcpy(w, ".00 ", 4);
+                w += 4;
             }
-            fam += buf;
+        } else {
+            char buf[64];
+            fam.clear();
+            fam.reserve(vc.size() * 24);
+            for (auto &r : vc) {
+                snprintf(buf, sizeof(buf), ":%.2f ", (double)r.score);
+                if (arb->owns(r.sequence)) {
+                    fam += arb->family_label(arb->id_of(r.sequence));  // (the "<acc>.<start>" part, cached per reference)
+                } else {
+                    arb->loadKey(*r.sequence, fn::acc);
+                    arb->loadKey(*r.sequence, fn::start);
+                    fam += r.sequence->get_attr<std::string>(fn::acc) + "." + r.sequence->get_attr<std::string>(fn::start, "0");
+                }
+                fam += buf;
+            }
         }
         tk = host_tick("ff.post: family string", tk);
         if (o.fs_req_gaps != 0) {  // :472-480
@@ -1751,7 +1763,7 @@ void aligner::operator()(std::vector<tray> &batch) {
             const uint32_t *b = jobs[idx[x]].t->input_sequence->packed();
             const size_t nb = jobs[idx[x]].t->input_sequence->size();
             uint8_t *dst = qmask + qoff[x];
-            for (size_t y = 0; y < nb; y++) dst[y] = (uint8_t)(b[y] >> 24);
+            masks_of_packed(dst, b, nb);
         });
         // Repeated queries -- the same bases in the same case against the same ordered family: amplicon runs are
         // full of them -- are aligned ONCE (one DAG, one DP, one walk); every tray then finishes from the device
