@@ -66,9 +66,12 @@ def parse():
                          "the process confined to this many CPUs (an 8-rank node inside a 16-CPU quota leaves a rank two) "
                          "and --confined-threads loop-pool threads; the line reports confined_rate_frac = that rate / "
                          "the timed region's.  0 = skip")
-    ap.add_argument("--confined-threads", type=int, default=3)
+    ap.add_argument("--confined-threads", type=int, default=2)
     ap.add_argument("--host-graph", action="store_true", help="build family DAGs on the host")
-    ap.add_argument("--host-threads", type=int, default=0, help="threads of the host-side loop pool (0 = default)")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="threads of the host-side loop pool (0 = default: 6 for a single rank -- measured on one MI355X: "
+                         "3 threads 140.1 k seq/s at 1.56 busy cores, 4: 141.8 k / 1.67, 6: 143.1 k / 1.69, 12: 143.9 k / "
+                         "1.97, profiles/r04_host_threads.txt; with several ranks inside one CPU quota: 1.5 x the rank's share)")
     return ap.parse_args()
 
 
@@ -276,6 +279,8 @@ def main():
     # several ranks inside one CPU quota, no more threads than the rank's share can run (measured on one
     # GPU: 6 threads 128.8 k seq/s at 3.3 busy cores, 12 threads 131.1 k at 3.8)
     host_threads = a.host_threads or None
+    if host_threads is None and world == 1:
+        host_threads = 6
     if host_threads is None and world > 1:
         quota = cpu_quota()
         share = (quota if quota else (os.cpu_count() or 16)) / float(world)
@@ -399,7 +404,7 @@ def main():
                     os.sched_setaffinity(tid, before.get(tid, set(allowed)))
                 except OSError:
                     pass
-            pl._set("host", "threads", host_threads or 12)
+            pl._set("host", "threads", host_threads or 12)  # (12: the library's own default)
 
     per_rank = None
     if dist is not None:
@@ -563,7 +568,7 @@ def main():
             "confined": confined,
             "host_cores_busy": host_cores,  # CPU seconds per wall second of this rank in the timed region
             "host_cpus_pinned": pinned,     # logical CPUs this rank's host threads are confined to (None: not pinned)
-            "host_pool_threads": host_threads,  # None: the library's default (12)
+            "host_pool_threads": host_threads,
             "host_cores_busy_kernel_mode": host_cores_sys,
             "host_minor_faults_per_s": host_minor_faults,
             "host_context_switches_per_s": host_ctx_switches,
