@@ -427,26 +427,26 @@ def main():
     achieved = DP_BYTES_PER_CELL * dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
 
     # HBM bytes per DP launch from the PMC passes of this same command (tools/prof_bench.sh ->
-    # profiles/r03_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), and the DP kernel's VALU
-    # wave-instructions per cell from its SQ pass (tools/prof_dp_pmc.sh -> profiles/r03_dp_valu.json);
+    # profiles/r04_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), and the DP kernel's VALU
+    # wave-instructions per cell from its SQ pass (tools/prof_dp_pmc.sh -> profiles/r04_dp_valu.json);
     # both only if they were recorded on this kernel source revision, else null
     dp_kernel_name = "mesh_dp_simple_kernel"  # (SINA defaults: simple scheme, gap_open >= gap_extend; mesh_dp.hip)
     dp_traffic, traffic_note = None, "no PMC profile recorded for this kernel source + configuration"
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
         meta = tj.get("_meta", {})
         if (meta.get("kernel_source_rev") == kernel_source_rev() and meta.get("batch") == a.batch and
                 meta.get("sub_batch") == a.sub_batch and meta.get("refs") == a.refs and
                 meta.get("length") == a.length and meta.get("window") == a.window):
             dp_traffic = tj[dp_kernel_name]["hbm_bytes"]
             traffic_note = ("HBM bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from the separate "
-                            "--pmc passes of this same command recorded in profiles/r03_traffic.json (same kernel "
+                            "--pmc passes of this same command recorded in profiles/r04_traffic.json (same kernel "
                             "source revision and configuration as this run; not measured by this run)")
     except Exception:
         pass
     valu_per_cell = None
     try:
-        vj = json.load(open(os.path.join(ROOT, "profiles", "r03_dp_valu.json")))
+        vj = json.load(open(os.path.join(ROOT, "profiles", "r04_dp_valu.json")))
         if vj.get("kernel_source_rev") == kernel_source_rev():
             valu_per_cell = float(vj["valu_wave_instructions_per_cell"])
     except Exception:
@@ -540,7 +540,7 @@ def main():
                 },
             },
             # what actually binds the kernel: VALU wave-instructions (SQ_INSTS_VALU of the same kernel source,
-            # profiles/r03_dp_sq_counters.txt) at the guide's 2 cycles per wave-instruction and SIMD
+            # profiles/r04_dp_sq_counters.txt) at the guide's 2 cycles per wave-instruction and SIMD
             "roofline_valu": None if valu_per_cell is None or dp_ms <= 0 else {
                 "kernel": dp_kernel_name,
                 "bound": "valu",
