@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SINA_HIP_ABI_VERSION 3  /* 3: sina_hip_stats grew dp_busy_ms */
+#define SINA_HIP_ABI_VERSION 3  /* 3: sina_hip_stats grew dp_busy_ms, dags_built, dags_used */
 
 typedef struct sina_hip_ctx sina_hip_ctx;
 
@@ -287,6 +287,8 @@ typedef struct sina_hip_stats {
     double dp_busy_ms;       /* time during which a DP kernel was resident: dp_ms minus the time a launch shared
                                 the device with the launch before it (a DP launch starts when its predecessor
                                 has dispatched its last workgroup, not when it has ended)                     */
+    uint64_t dags_built;     /* family DAGs built on the device ...                                             */
+    uint64_t dags_used;      /* ... and queries aligned against them (queries with the same ordered family share one) */
 } sina_hip_stats;
 int sina_hip_get_stats(sina_hip_ctx *ctx, sina_hip_stats *s);
 

@@ -70,7 +70,8 @@ class Stats(C.Structure):
                 ("kmer_count_ms", C.c_double), ("kmer_select_ms", C.c_double), ("dp_cells", C.c_uint64),
                 ("postings", C.c_uint64), ("dp_launches", C.c_uint32), ("kmer_launches", C.c_uint32),
                 ("compare_ms", C.c_double), ("compare_bases", C.c_uint64), ("compare_launches", C.c_uint32),
-                ("n_dense_lists", C.c_uint32), ("dp_busy_ms", C.c_double)]
+                ("n_dense_lists", C.c_uint32), ("dp_busy_ms", C.c_double), ("dags_built", C.c_uint64),
+                ("dags_used", C.c_uint64)]
 
 
 _lib = None

@@ -489,6 +489,16 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 1;
         for (auto &e : st->dp_end)
             if (hipEventCreate(&e) != hipSuccess) return 1;
+        // (chained launches need hipStreamWaitValue32: a device without it keeps dry_mem == nullptr and every launch
+        // waits for the end of the one before, as until round 3)
+        int can_wait_value = 0;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            can_wait_value = 0;
+        }
+        if (!can_wait_value) return 0;
         const size_t bytes = 4 * (1 + (size_t)sina_hip_store::kDryCounters);
         if (hipMalloc(reinterpret_cast<void **>(&st->dry_mem), bytes) != hipSuccess) return 1;
         return hipMemset(st->dry_mem, 0, bytes) != hipSuccess ? 1 : 0;

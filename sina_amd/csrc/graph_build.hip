@@ -741,9 +741,77 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
     static const uint32_t rounds = getenv("SINA_HIP_DP_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("SINA_HIP_DP_ROUNDS"))) : 3u;
     const uint32_t chunk_q = rounds * slots;
     BuiltGraphs bg;
+    std::vector<uint32_t> dag_of;      // per query of the chunk: which of the chunk's distinct DAGs is its family's
+    std::vector<uint32_t> ufam_ids;    // the distinct families, concatenated
+    std::vector<uint64_t> ufam_off;
     for (uint32_t q0 = 0; q0 < nq; q0 += chunk_q) {
         const uint32_t bq = std::min(chunk_q, nq - q0);
-        if (build_family_graphs(c, fam_ids, fam_off, q0, bq, p->fs_weight, pl.W, &bg, p->insertion == SINA_INSERTION_FORBID)) return 1;
+        // Queries with the same ORDERED family share one DAG (node order, weights, predecessor lists and the DP's
+        // row-slot assignment depend on nothing else): amplicons of one region against one reference clade.  The
+        // DAG is built once per distinct family of the chunk; every query keeps its own trace-back cells, spill
+        // rows and edge records.  (SINA_HIP_SHARE_DAGS=0: one build per query.)
+        static const bool share = !(getenv("SINA_HIP_SHARE_DAGS") && getenv("SINA_HIP_SHARE_DAGS")[0] == '0');
+        dag_of.assign(bq, 0);
+        uint32_t n_dags = bq;
+        const uint32_t *b_ids = fam_ids;
+        const uint64_t *b_off = fam_off;
+        uint32_t b_q0 = q0;
+        if (share && bq > 1) {
+            auto fam_hash = [&](uint32_t q) {
+                uint64_t h = 0xcbf29ce484222325ull ^ (fam_off[q + 1] - fam_off[q]);
+                for (uint64_t x = fam_off[q]; x < fam_off[q + 1]; x++) {
+                    h = (h ^ fam_ids[x]) * 0x100000001b3ull;
+                    h ^= h >> 31;
+                }
+                return h;
+            };
+            size_t cap = 16;
+            while (cap < 2 * (size_t)bq) cap <<= 1;
+            std::vector<uint32_t> slot(cap, 0xFFFFFFFFu), first;  // first[u] = first query (in the chunk) of DAG u
+            std::vector<uint64_t> hq(bq);
+            for (uint32_t q = 0; q < bq; q++) {
+                hq[q] = fam_hash(q0 + q);
+                size_t at = (size_t)(hq[q] >> 17) & (cap - 1);
+                for (;;) {
+                    const uint32_t u = slot[at];
+                    if (u == 0xFFFFFFFFu) {
+                        slot[at] = (uint32_t)first.size();
+                        dag_of[q] = (uint32_t)first.size();
+                        first.push_back(q);
+                        break;
+                    }
+                    const uint32_t f = first[u];
+                    const uint64_t la = fam_off[q0 + q + 1] - fam_off[q0 + q], lb = fam_off[q0 + f + 1] - fam_off[q0 + f];
+                    if (hq[f] == hq[q] && la == lb && memcmp(fam_ids + fam_off[q0 + q], fam_ids + fam_off[q0 + f], 4 * la) == 0) {
+                        dag_of[q] = u;
+                        break;
+                    }
+                    at = (at + 1) & (cap - 1);
+                }
+            }
+            n_dags = (uint32_t)first.size();
+            if (n_dags < bq) {  // the distinct families, packed for the build
+                ufam_off.assign((size_t)n_dags + 1, 0);
+                for (uint32_t u = 0; u < n_dags; u++)
+                    ufam_off[u + 1] = ufam_off[u] + (fam_off[q0 + first[u] + 1] - fam_off[q0 + first[u]]);
+                ufam_ids.resize(ufam_off[n_dags]);
+                for (uint32_t u = 0; u < n_dags; u++)
+                    memcpy(ufam_ids.data() + ufam_off[u], fam_ids + fam_off[q0 + first[u]], 4 * (ufam_off[u + 1] - ufam_off[u]));
+                b_ids = ufam_ids.data();
+                b_off = ufam_off.data();
+                b_q0 = 0;
+            } else {
+                for (uint32_t q = 0; q < bq; q++) dag_of[q] = q;
+            }
+        } else {
+            for (uint32_t q = 0; q < bq; q++) dag_of[q] = q;
+        }
+        if (build_family_graphs(c, b_ids, b_off, b_q0, n_dags, p->fs_weight, pl.W, &bg, p->insertion == SINA_INSERTION_FORBID)) return 1;
+        {
+            std::lock_guard<std::mutex> slk(c->st->stats_mu);
+            c->st->stats.dags_built += n_dags;
+            c->st->stats.dags_used += bq;
+        }
         // DP in sub-ranges that fit the trace-back budget
         uint32_t r0 = 0;
         while (r0 < bq) {
@@ -752,17 +820,18 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
             uint32_t erec_cursor = 0;
             std::vector<QDesc> qd;
             while (r1 < bq) {
-                const uint32_t N = bg.sizes[4 * r1];
+                const uint32_t u = dag_of[r1];  // (this query's DAG among the chunk's distinct ones)
+                const uint32_t N = bg.sizes[4 * u];
                 if (r1 > r0 && tbc + (uint64_t)N * Lp > tb_budget_cells) break;
                 QDesc d;
-                d.node_off = (uint64_t)r1 * bg.ncap;
-                d.edge_off = bg.pred_off[r1];
+                d.node_off = (uint64_t)u * bg.ncap;
+                d.edge_off = bg.pred_off[u];
                 d.q_off = qoff[q0 + r1] - qoff[q0 + r0];
                 d.tb_off = tbc;
                 d.spill_off = sprows;
                 d.N = N;
                 d.L = (uint32_t)(qoff[q0 + r1 + 1] - qoff[q0 + r1]);
-                d.n_spill = bg.sizes[4 * r1 + 2];
+                d.n_spill = bg.sizes[4 * u + 2];
                 d.erec_off = erec_cursor;
                 erec_cursor += dp_edge_entries(N);
                 qd.push_back(d);
@@ -788,7 +857,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
                 return 1;
             c->profile_batch = false;  // (device-built DAGs: never a profile)
             c->out_pos_base = qbase - qoff[0];
-            if (run_dp_device(c, pl, qd.data(), rq, (uint64_t)bq * bg.ncap, tbc, sprows, cells, nqm, p, c->st->width,
+            if (run_dp_device(c, pl, qd.data(), rq, (uint64_t)n_dags * bg.ncap, tbc, sprows, cells, nqm, p, c->st->width,
                               out + q0 + r0, out_pos ? out_pos + qbase : nullptr, false))
                 return 1;
             r0 = r1;

@@ -33,3 +33,40 @@ def test_bench_line_and_rank_confined_to_two_cpus():
     assert c["cpus"] == 2 and j["confined_rate_frac"] == c["rate_frac"]
     assert c["host_cores_busy"] <= 2.05
     assert c["rate_frac"] >= 0.8, c
+
+
+_CHILD = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+from sina_amd import pipeline, synth
+refs = synth.make_refs(500, length=320, width=3200, seed=51, amb_rate=0.01, lower_rate=0.02)
+qs = synth.make_queries(refs, 240, seed=77, ins=0.01, dele=0.01, lower_rate=0.03)
+st = pipeline.Store(":mem:order-policy", refs)
+pl = pipeline.Pipeline(st, famfinder={"fs-min-len": 100, "fs-full-len": 250})
+h = hashlib.sha1()
+for rep in range(2):
+    pl.run(qs.mask, qs.off, batch=30, inflight=4)
+    for q in range(qs.n):
+        r = pl.result(q)
+        h.update(r["packed"].tobytes()); h.update(r["log"].encode()); h.update(r["family"].encode())
+        h.update(("%%d %%d %%d %%d" %% (r["status"], r["head"], r["tail"], r["qual"])).encode())
+pl.close(); st.close()
+print("RESULT", h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize("env", [{"SINA_HIP_CHAIN": "0"}, {"SINA_HIP_DP_BURST": "0"}, {"SINA_HIP_DP_BURST": "1"},
+                                 {"SINA_HIP_NO_RUNTIME_DEFAULTS": "1"}])
+def test_launch_order_settings_do_not_change_results(env):
+    """Chained launches (a kernel starts when its predecessor's queue has run dry), the order the admission queue
+    hands launches over in, and the opt-out of the library's load-time environment defaults are scheduling only:
+    eight batches in flight twice over give the same trays bit for bit under every setting."""
+    def run(extra):
+        e = dict(os.environ)
+        for k in ("SINA_HIP_CHAIN", "SINA_HIP_DP_BURST", "SINA_HIP_NO_RUNTIME_DEFAULTS"):
+            e.pop(k, None)
+        e.update(extra)
+        p = subprocess.run([sys.executable, "-c", _CHILD % ROOT], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0]
+    assert run(env) == run({})

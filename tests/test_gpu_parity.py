@@ -257,6 +257,49 @@ def test_align_families_equals_align_graphs(oracle, gpu_ctx, small):
         assert (o1 == o2).all() and (p1 == p2).all()
 
 
+def test_queries_with_the_same_ordered_family_share_one_dag(oracle, gpu_ctx, small):
+    """sina_hip_align_families builds ONE DAG per distinct ordered family of a launch and aligns every query that
+    names it against that DAG (own trace-back cells, spill rows, edge records).  Eighteen queries over three
+    families, interleaved, plus the same members in another ORDER (a different DAG: node order follows the family
+    order): results equal those of per-query graphs handed over by the host (sina_hip_align_graphs, no sharing),
+    plain and with --insertion=forbid (the kernel then also keeps succ_min), and the device built 4 DAGs for 20."""
+    refs, qs, cs, idx = small
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    base = []
+    for qi in range(qs.n):
+        q, fam, ids = _family(oracle, refs, cs, idx, qs, qi)
+        if len(ids) >= 5:
+            base.append((fam, ids.astype(np.uint32)))
+        if len(base) == 3:
+            break
+    assert len(base) == 3
+    fams, graphs, qms = [], [], []
+    for qi in range(18):
+        fam, ids = base[qi % 3]
+        fams.append(ids)
+        graphs.append(util.graph_dict(fam))
+        qms.append((util.query_cseq(qs, (5 * qi) % qs.n).packed() >> 24).astype(np.uint8))
+    for qi in (18, 19):  # family 0 with two members swapped: same set, another DAG
+        fam, ids = base[0]
+        perm = list(range(len(ids)))
+        perm[0], perm[1] = perm[1], perm[0]
+        fams.append(ids[perm])
+        graphs.append(util.graph_dict([fam[i] for i in perm]))
+        qms.append((util.query_cseq(qs, (5 * qi) % qs.n).packed() >> 24).astype(np.uint8))
+    qoff = np.zeros(len(qms) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(m) for m in qms])
+    foff = np.zeros(len(fams) + 1, np.uint64)
+    foff[1:] = np.cumsum([len(f) for f in fams])
+    for ins in (0, 1):
+        p = gpu_ctx.params(insertion=ins)
+        o1, p1 = gpu_ctx.align_graphs(gpu_ctx.graph_batch(graphs, refs.width), np.concatenate(qms), qoff, p)
+        s0 = gpu_ctx.stats()
+        o2, p2 = gpu_ctx.align_families(np.concatenate(fams), foff, np.concatenate(qms), qoff, p)
+        s1 = gpu_ctx.stats()
+        assert (o1 == o2).all() and (p1 == p2).all()
+        assert s1["dags_used"] - s0["dags_used"] == 20 and s1["dags_built"] - s0["dags_built"] == 4
+
+
 def test_mesh_planes_equal_reference_parts_hashes(oracle, gpu_ctx):
     """The DP kernel against planes the REFERENCE's scoring schemes and dag<T> produced (oracle/_ref cell
     loop, tests/golden/make_ref_vectors.py): value / value_midx / value_sidx of 25 families -- 1..41
