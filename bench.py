@@ -566,6 +566,8 @@ def main():
             },
             "confined_rate_frac": confined["rate_frac"] if confined else None,  # rate on --confined-cpus CPUs / rate above
             "confined": confined,
+            # family DAGs the device built per query aligned by DP (queries with the same ordered family share one)
+            "family_dags_built_per_query": ((s1["dags_built"] - s0["dags_built"]) / max(1, s1["dags_used"] - s0["dags_used"])),
             "host_cores_busy": host_cores,  # CPU seconds per wall second of this rank in the timed region
             "host_cpus_pinned": pinned,     # logical CPUs this rank's host threads are confined to (None: not pinned)
             "host_pool_threads": host_threads,
