@@ -32,14 +32,11 @@
 namespace sina_hip {
 namespace {
 
-#ifndef SINA_KMER_LANE_HEADS
-#define SINA_KMER_LANE_HEADS 1  // list heads one per lane, whole waves only for lists with more in a tile (kmer_count_kernel, phase A / B)
-#endif
 constexpr int kCountThreads = 1024;
 constexpr int kTileRefs = 32768;            // refs per LDS histogram tile (64 KiB)
 constexpr int kWide = 2;                    // 1 KiB loads a wave of the count kernel keeps in flight
 constexpr int kMaxQueryLen = (int)SINA_HIP_MAX_QUERY_LEN;  // k-mer list capacity in LDS: 64 KiB tile + 9 B per base <= 160 KiB
-static_assert((size_t)kTileRefs * 2 + ((size_t)kMaxQueryLen + 63) / 64 * 64 * 9 + ((size_t)kMaxQueryLen + 63) / 64 * 8 + 64 <= 160 * 1024, "LDS of the count kernel");
+static_assert((size_t)kTileRefs * 2 + ((size_t)kMaxQueryLen + 63) / 64 * 64 * 9 + 64 <= 160 * 1024, "LDS of the count kernel");
 constexpr int kSelThreads = 256;
 constexpr int kSelMax = 4096;               // candidates sortable in LDS
 
@@ -165,7 +162,6 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
     uint32_t *cur = hist + kTileRefs / 2;                                // [kmax]
     uint32_t *end = cur + a.kmax;                                        // [kmax]
     uint8_t *qb = reinterpret_cast<uint8_t *>(end + a.kmax);             // [kmax] query masks
-    uint32_t *longm = reinterpret_cast<uint32_t *>(qb + a.kmax);         // [kmax / 32] lists with more left in the tile than a lane takes
     // bitmap numbers of the query's dense k-mers: from the top of cur[] downwards (cursor slots grow
     // from the bottom; together they are at most kmax k-mers) -- a third array would cost the second
     // workgroup per CU
@@ -209,61 +205,12 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
         const uint32_t tile_hi = min(tile_lo + (uint32_t)kTileRefs, a.n_refs);
         for (uint32_t i = tid; i < kTileRefs / 2; i += kCountThreads) hist[i] = 0;
         if (tid == 0) next_kmer = 0;
-#if SINA_KMER_LANE_HEADS
-        for (uint32_t i = tid; i < (nk + 31u) / 32u; i += kCountThreads) longm[i] = 0;
-#endif
         __syncthreads();
-#if SINA_KMER_LANE_HEADS
-        // Phase A -- the heads of all lists, one list per LANE.  A query's ~1300 short lists (97 % of its k-mers,
-        // 3 % of its postings) have half a dozen postings in a tile: a wave per list paid a load round trip per
-        // list and tile for them, 80 in a row per wave.  Here every lane reads the next (up to) 2 x 4 postings of
-        // its own list, counts those below the tile end and moves its cursor; a list with more left in the tile
-        // than that is marked and streamed by a whole wave in phase B.
-        for (uint32_t i = tid; i < nk; i += kCountThreads) {
-            uint32_t c = cur[i];
-            const uint32_t e = end[i];
-            bool more = false;
-            for (int round = 0; round < 2 && c < e; round++) {
-                uint32_t id[4];
-                const uint32_t *src = a.idx_ids + c;
-#pragma unroll
-                for (int v = 0; v < 4; v++) id[v] = (c + (uint32_t)v < e) ? src[v] : 0xFFFFFFFFu;
-                uint32_t took = 0;
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    if (id[v] < tile_hi) {  // (ascending: a prefix)
-                        const uint32_t r = id[v] - tile_lo;
-                        atomicAdd(&hist[r >> 1], 1u << (16 * (r & 1)));
-                        took++;
-                    }
-                }
-                c += took;
-                more = took == 4u && c < e;
-                if (took < 4u) break;
-            }
-            cur[i] = c;
-            if (more && a.idx_ids[c] < tile_hi) atomicOr(&longm[i >> 5], 1u << (i & 31));
-        }
-        __syncthreads();
-#endif
         for (uint32_t guard = 0; guard < (1u << 22); guard++) {
             uint32_t i = 0;
-#if SINA_KMER_LANE_HEADS
-            // Phase B -- a wave per marked list (a word of marks per grab)
-            uint32_t wsel = 0;
-            if (lane == 0) wsel = atomicAdd(&next_kmer, 1u);
-            wsel = __builtin_amdgcn_readfirstlane(wsel);
-            if (wsel >= (nk + 31u) / 32u) break;
-            uint32_t marks = longm[wsel];
-            marks = __builtin_amdgcn_readfirstlane(marks);
-            for (; marks != 0; marks &= marks - 1) {
-            i = wsel * 32u + (uint32_t)__builtin_ctz(marks);
-#else
             if (lane == 0) i = atomicAdd(&next_kmer, 1u);
             i = __builtin_amdgcn_readfirstlane(i);
             if (i >= nk) break;
-            {
-#endif
             uint32_t c = cur[i];
             const uint32_t e = end[i];
             // kWide x 1 KiB in flight per wave: every lane reads four consecutive postings per load
@@ -303,7 +250,6 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
                 if (cnt < 256u * kWide) break;
             }
             if (lane == 0) cur[i] = c;
-            }  // (a marked list / the one list of this grab)
         }
         __syncthreads();
         // Dense k-mers: thread t owns the 32 references of bitmap word t of this tile and counts, for
@@ -737,7 +683,7 @@ static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint6
     ca.dense_id = c->st->n_dense ? c->st->dense_id.as<uint32_t>() : nullptr;
     ca.dense_bits = c->st->dense_bits.as<uint32_t>();
     ca.dense_words = c->st->dense_words;
-    const size_t clds = (size_t)kTileRefs * 2 + (size_t)ca.kmax * 9 + (size_t)ca.kmax / 8 + 64;  // tile | cursors, ends, masks | marks
+    const size_t clds = (size_t)kTileRefs * 2 + (size_t)ca.kmax * 9 + 64;
     if (allow_full_lds(reinterpret_cast<const void *>(kmer_count_kernel))) return 1;
     heavy_launch hl(c, s, kHeavyKmer);  // (count + select: device-filling kernels, ctx.h)
     const hipStream_t hs = hl.stream();
