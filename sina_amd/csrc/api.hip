@@ -284,6 +284,13 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
 int make_streams(sina_hip_ctx *c) {
     int least = 0, greatest = 0;
     SH_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // (SINA_HIP_STREAM_PRIO=0, experiments: both streams at the default priority)
+    static const bool flat = getenv("SINA_HIP_STREAM_PRIO") && getenv("SINA_HIP_STREAM_PRIO")[0] == '0';
+    if (flat) {
+        SH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        SH_CHECK(hipStreamCreateWithFlags(&c->stream_dp, hipStreamNonBlocking));
+        return 0;
+    }
     SH_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
     SH_CHECK(hipStreamCreateWithPriority(&c->stream_dp, hipStreamNonBlocking, least));
     return 0;

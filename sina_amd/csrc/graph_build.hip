@@ -674,7 +674,9 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         {
             heavy_launch hl(c, s, kHeavyGraph);  // (a device-filling kernel: ctx.h)
             SH_CHECK(hipEventRecord(c->ev[6], hl.stream()));
-            ga.dry = hl.dry();
+            // (SINA_HIP_GRAPH_DRY=0, experiments: the launch behind a DAG build waits for its END)
+            static const bool graph_dry = !(getenv("SINA_HIP_GRAPH_DRY") && getenv("SINA_HIP_GRAPH_DRY")[0] == '0');
+            ga.dry = graph_dry ? hl.dry() : DryArgs{nullptr, nullptr, 0};
             hipLaunchKernelGGL(family_graph_kernel, dim3(bq), dim3(kGT), glds, hl.stream(), ga);
             SH_CHECK(hipGetLastError());
             SH_CHECK(hipEventRecord(c->ev[7], hl.stream()));
