@@ -197,28 +197,6 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         a.below_init = (!weighted && !forbid && dp_below_init(max_n, a.gp, a.gpe)) ? 1 : 0;
     }
 
-    uint64_t dp_no = ~0ull;  // this launch's number among the store's DP launches
-    {
-        // the DP kernel: on the store's heavy stream, behind the uploads queued on c->stream; the
-        // backtrack walk and the result copies then follow it on the context's low-priority stream
-        std::unique_lock<std::mutex> token(c->st->dp_token, std::defer_lock);
-        if (!serialize_kernels()) token.lock();  // (then: one DP kernel at a time by this token)
-        SH_CHECK(hipEventRecord(c->ev[8], s));
-        s = c->stream_dp;
-        SH_CHECK(hipStreamWaitEvent(s, c->ev[8], 0));
-        heavy_launch hl(c, s, kHeavyDp);
-        SH_CHECK(hipEventRecord(c->ev[0], hl.stream()));
-        a.dry = hl.dry();
-        if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, hl.stream())) return 1;
-        SH_CHECK(hipEventRecord(c->ev[1], hl.stream()));
-        if (hl.lk.owns_lock() && c->st->dp_end[0]) {  // (under the queue's lock: launch order = dp_seq order)
-            dp_no = c->st->dp_seq++;
-            SH_CHECK(hipEventRecord(c->st->dp_end[dp_no % 8], hl.stream()));
-        }
-        if (hl.done()) return 1;
-        if (getenv("SINA_HIP_DEBUG_SYNC")) fprintf(stderr, "[sina_hip] DP kernel done: %u queries, geometry %dx%d, weighted %d forbid %d\n", bq, pl.geom.T, pl.geom.B, (int)weighted, (int)forbid);
-        if (token.owns_lock()) SH_CHECK(wait_event(c->ev[1]));
-    }
     BtArgs b;
     b.qd = a.qd;
     b.rec = a.rec;
@@ -241,13 +219,54 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     b.self16 = c->profile_batch ? c->self16.as<float>() : nullptr;
     b.asm_cap = 0;
     for (uint32_t q = 0; q < bq; q++) b.asm_cap = std::max<uint32_t>(b.asm_cap, qd_host[q].L);
-    if (launch_backtrack(b, s)) return 1;
-    if (p->assemble && launch_assemble(b, s)) return 1;
-    if (getenv("SINA_HIP_DEBUG_SYNC")) {
-        SH_CHECK(hipStreamSynchronize(s));
-        fprintf(stderr, "[sina_hip] backtrack kernel done\n");
+    uint64_t dp_no = ~0ull;  // this launch's number among the store's DP launches
+    // Where the walk runs.  Until round 4: on the context's own stream, launched by the host once it had seen the
+    // DP kernel end -- beside whatever device-filling kernel was resident by then.  A kernel trace of round 4
+    // showed that "by then" can be late: a walk whose hardware queue shares a dispatch pipe with the FIFO's queue
+    // is not dispatched before the resident kernel has handed out its last workgroup, starts 5 ms late, runs
+    // beside the NEXT DP launch instead of the DAG build behind its own, takes 17 ms there instead of 3 and
+    // stretches that launch by 10 (profiles/r04_bt_delay.txt).  With chained launches the walk and the assembly
+    // are queued right behind their DP kernel on the same FIFO stream: they start the moment it ends, run beside
+    // the launch that started in its drain (the other FIFO stream), and the launch after that -- often the next DP
+    // launch -- is ordered behind them by the stream itself.  SINA_HIP_BT_ON_FIFO=0: the context's stream.
+    static const bool bt_fifo_wanted = !(getenv("SINA_HIP_BT_ON_FIFO") && getenv("SINA_HIP_BT_ON_FIFO")[0] == '0');
+    bool bt_done = false;
+    {
+        // the DP kernel: on the store's heavy stream, behind the uploads queued on c->stream; the
+        // backtrack walk and the result copies then follow it on the context's low-priority stream
+        std::unique_lock<std::mutex> token(c->st->dp_token, std::defer_lock);
+        if (!serialize_kernels()) token.lock();  // (then: one DP kernel at a time by this token)
+        SH_CHECK(hipEventRecord(c->ev[8], s));
+        s = c->stream_dp;
+        SH_CHECK(hipStreamWaitEvent(s, c->ev[8], 0));
+        heavy_launch hl(c, s, kHeavyDp);
+        SH_CHECK(hipEventRecord(c->ev[0], hl.stream()));
+        a.dry = hl.dry();
+        if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, hl.stream())) return 1;
+        SH_CHECK(hipEventRecord(c->ev[1], hl.stream()));
+        if (hl.lk.owns_lock() && c->st->dp_end[0]) {  // (under the queue's lock: launch order = dp_seq order)
+            dp_no = c->st->dp_seq++;
+            SH_CHECK(hipEventRecord(c->st->dp_end[dp_no % 8], hl.stream()));
+        }
+        if (hl.chained && bt_fifo_wanted) {
+            if (launch_backtrack(b, hl.stream())) return 1;
+            if (p->assemble && launch_assemble(b, hl.stream())) return 1;
+            SH_CHECK(hipEventRecord(c->ev[2], hl.stream()));
+            bt_done = true;
+        }
+        if (hl.done()) return 1;
+        if (getenv("SINA_HIP_DEBUG_SYNC")) fprintf(stderr, "[sina_hip] DP kernel done: %u queries, geometry %dx%d, weighted %d forbid %d\n", bq, pl.geom.T, pl.geom.B, (int)weighted, (int)forbid);
+        if (token.owns_lock()) SH_CHECK(wait_event(c->ev[1]));
     }
-    SH_CHECK(hipEventRecord(c->ev[2], s));
+    if (!bt_done) {
+        if (launch_backtrack(b, s)) return 1;
+        if (p->assemble && launch_assemble(b, s)) return 1;
+        if (getenv("SINA_HIP_DEBUG_SYNC")) {
+            SH_CHECK(hipStreamSynchronize(s));
+            fprintf(stderr, "[sina_hip] backtrack kernel done\n");
+        }
+        SH_CHECK(hipEventRecord(c->ev[2], s));
+    }
     // (h_out_pos was sized for the whole call by the entry point; this range's columns go to their place in it)
     if (c->h_out.reserve(sizeof(sina_hip_align_out) * bq)) return 1;
     unsigned char *staged_pos = static_cast<unsigned char *>(c->h_out_pos.p) + 4 * c->out_pos_base;

@@ -386,6 +386,7 @@ struct heavy_launch {
     int kind = 0;
     bool signals_dry = false;
     bool admitted = false;
+    bool chained = false;  // this launch went through the two-stream FIFO (else: the single heavy stream, or the context's own)
     uint32_t my_seq = 0;
     // `own`: the context stream whose queued work (uploads) the kernel depends on
     heavy_launch(sina_hip_ctx *c_, hipStream_t own_, int kind_ = kHeavyKmer) : c(c_), own(own_), hs(own_), kind(kind_) {
@@ -394,6 +395,7 @@ struct heavy_launch {
         failed = hipEventRecord(c->ev[10], own) != hipSuccess;
         lk = std::unique_lock<std::mutex>(st->heavy_mu);
         const bool chain = chain_kernels() && st->heavy2 && st->dry_mem;
+        chained = chain;
         if (chain) {
             const uint64_t me = st->heavy_ticket++;
             st->heavy_waiting.push_back({me, kind});
