@@ -295,21 +295,23 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     return 0;
 }
 
-// A DP kernel holds every CU's LDS for ~20 ms, and the kernels that prepare the NEXT DP launch (DAG
-// build, k-mer search of other contexts) only get workgroup slots as DP workgroups retire: a 3 ms DAG
-// build took up to 19 ms beside a DP kernel and the next DP launch waited for it.  The DP kernel and
-// backtrack therefore run on a lowest-priority stream, everything else on a highest-priority one:
-// a retiring DP workgroup's slot goes to the preparing kernels first.
+// The two streams of a context: uploads, k-mer searches' copies ... on `stream`; DP hand-over, result copies (and, with
+// SINA_HIP_CHAIN=0 / SINA_HIP_BT_ON_FIFO=0, the backtrack walk) on `stream_dp`.  Both at the DEFAULT priority since round 4.
+// Rounds 1-3 created `stream` at the highest and `stream_dp` at the lowest priority (round 1: kernels of different
+// batches overlapped freely and a DAG build starved beside a DP kernel).  Since the device-filling kernels go through
+// the store's FIFO that no longer decides anything -- except that a lowest-priority walk is not dispatched while a
+// default-priority kernel still has workgroups to hand out: with one more stream in the process the walk started
+// 5 ms late in half of the launches, ran beside the next DP launch and took 16 ms instead of 7
+// (profiles/r04_bt_delay.txt).  SINA_HIP_STREAM_PRIO=1 restores the priorities.
 int make_streams(sina_hip_ctx *c) {
-    int least = 0, greatest = 0;
-    SH_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    // (SINA_HIP_STREAM_PRIO=0, experiments: both streams at the default priority)
-    static const bool flat = getenv("SINA_HIP_STREAM_PRIO") && getenv("SINA_HIP_STREAM_PRIO")[0] == '0';
-    if (flat) {
+    static const bool prio = getenv("SINA_HIP_STREAM_PRIO") && getenv("SINA_HIP_STREAM_PRIO")[0] == '1';
+    if (!prio) {
         SH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         SH_CHECK(hipStreamCreateWithFlags(&c->stream_dp, hipStreamNonBlocking));
         return 0;
     }
+    int least = 0, greatest = 0;
+    SH_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     SH_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
     SH_CHECK(hipStreamCreateWithPriority(&c->stream_dp, hipStreamNonBlocking, least));
     return 0;
