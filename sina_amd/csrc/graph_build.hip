@@ -674,8 +674,11 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         {
             heavy_launch hl(c, s, kHeavyGraph);  // (a device-filling kernel: ctx.h)
             SH_CHECK(hipEventRecord(c->ev[6], hl.stream()));
-            // (SINA_HIP_GRAPH_DRY=0, experiments: the launch behind a DAG build waits for its END)
-            static const bool graph_dry = !(getenv("SINA_HIP_GRAPH_DRY") && getenv("SINA_HIP_GRAPH_DRY")[0] == '0');
+            // The launch behind a DAG build waits for its END: the build's own drain is a millisecond, and a DP launch
+            // that starts in it begins with a stagger it carries to its own end (measured: 142.1 k sequences/s with
+            // the signal, 143.1 k without, DP 49.5 against 48.3 ms per launch; profiles/r04_chain_ab.txt).
+            // SINA_HIP_GRAPH_DRY=1 (experiments): the build tells its follower when its queue has run dry, like a DP launch.
+            static const bool graph_dry = getenv("SINA_HIP_GRAPH_DRY") && getenv("SINA_HIP_GRAPH_DRY")[0] == '1';
             ga.dry = graph_dry ? hl.dry() : DryArgs{nullptr, nullptr, 0};
             hipLaunchKernelGGL(family_graph_kernel, dim3(bq), dim3(kGT), glds, hl.stream(), ga);
             SH_CHECK(hipGetLastError());

@@ -228,17 +228,15 @@ __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballo
 // ROTATES with the row count, unrelated to progress -- 655 / 703-722, i.e. as good: what the scheduler's default
 // lacks is waves of a SIMD taking turns at being preferred, and the steady state gains as much as the drain
 // (19.0 -> 18.2 ms per round of 3072 queries); a STATIC priority by hardware wave slot -- 597 / 656, worse
-// than none.)
-#ifndef SINA_DP_PRIO_FLOOR
-#define SINA_DP_PRIO_FLOOR 0  // priority of a wave's last eighth (experiment: 1 = above the other kernels' waves, which run at 0)
-#endif
+// than none.  Round 4, chained launches: a floor of 1 for the last eighth, above the waves of the kernel that fills the
+// drain -- 142.1 k sequences/s against 142.1 k: nothing.)
 __device__ __forceinline__ void issue_priority_by_progress(uint32_t rows_done, uint32_t rows_total) {
 #ifndef SINA_DP_NO_PRIO
     const uint32_t r8 = (8u * rows_done) / rows_total;
     if (r8 < 3u) __builtin_amdgcn_s_setprio(3);
     else if (r8 < 5u) __builtin_amdgcn_s_setprio(2);
     else if (r8 < 7u) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(SINA_DP_PRIO_FLOOR);
+    else __builtin_amdgcn_s_setprio(0);
 #else
     (void)rows_done;
     (void)rows_total;
