@@ -56,14 +56,17 @@ print("RESULT", h.hexdigest())
 
 
 @pytest.mark.parametrize("env", [{"SINA_HIP_CHAIN": "0"}, {"SINA_HIP_DP_BURST": "0"}, {"SINA_HIP_DP_BURST": "1"},
-                                 {"SINA_HIP_NO_RUNTIME_DEFAULTS": "1"}])
+                                 {"SINA_HIP_NO_RUNTIME_DEFAULTS": "1"}, {"SINA_HIP_BT_ON_FIFO": "0", "SINA_HIP_STREAM_PRIO": "1"},
+                                 {"SINA_HIP_GRAPH_DRY": "1", "SINA_HIP_SHARE_DAGS": "0"}])
 def test_launch_order_settings_do_not_change_results(env):
-    """Chained launches (a kernel starts when its predecessor's queue has run dry), the order the admission queue
-    hands launches over in, and the opt-out of the library's load-time environment defaults are scheduling only:
+    """Chained launches (the kernel behind a DP launch starts when that launch's queue has run dry), the order the
+    admission queue hands launches over in, where the backtrack walk is queued, stream priorities, DAG sharing and
+    the opt-out of the library's load-time environment defaults are scheduling / bookkeeping only:
     eight batches in flight twice over give the same trays bit for bit under every setting."""
     def run(extra):
         e = dict(os.environ)
-        for k in ("SINA_HIP_CHAIN", "SINA_HIP_DP_BURST", "SINA_HIP_NO_RUNTIME_DEFAULTS"):
+        for k in ("SINA_HIP_CHAIN", "SINA_HIP_DP_BURST", "SINA_HIP_NO_RUNTIME_DEFAULTS", "SINA_HIP_BT_ON_FIFO",
+                  "SINA_HIP_STREAM_PRIO", "SINA_HIP_GRAPH_DRY", "SINA_HIP_SHARE_DAGS"):
             e.pop(k, None)
         e.update(extra)
         p = subprocess.run([sys.executable, "-c", _CHILD % ROOT], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
