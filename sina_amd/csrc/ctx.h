@@ -192,6 +192,20 @@ inline uint64_t tb_plane_budget(sina_hip_ctx *c) {
         }
         if (tp.budget < ((uint64_t)1 << 28)) tp.budget = (uint64_t)1 << 28;
     }
+    // ... and never more than the device can give NOW: what is free plus what this pool already holds (a plane that
+    // has to grow is freed first).  Two stores on one device, or two ranks sharing a GPU, each decided their budget
+    // when most of the memory was free; the one that comes second splits its launches to what is left instead of
+    // failing in hipMalloc.  (SINA_HIP_TB_GB still wins: an explicit size is taken as given.)
+    if (!(getenv("SINA_HIP_TB_GB") && atof(getenv("SINA_HIP_TB_GB")) > 0)) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            uint64_t held = 0;
+            for (int i = 0; i < tp.n; i++) held += tp.plane[i].cap;
+            const uint64_t now = (uint64_t)((double)(free_b + held) * 0.84 / tp.n);
+            return std::max<uint64_t>((uint64_t)1 << 28, std::min<uint64_t>(tp.budget, now));
+        }
+        (void)hipGetLastError();
+    }
     return tp.budget;
 }
 // a free plane of at least `bytes` (waits for one; grows it -- rarely: sizes repeat -- up to the budget)

@@ -12,11 +12,28 @@ def short(n):
     return n[:24]
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in rows)
 hv = [x for x in iv if x[2] in HEAVY]
-dp = [x for x in hv if x[2] == "mesh_dp_"]
-# steady part: skip the set-up launches
-t0, t1 = dp[len(dp) // 3][0], dp[-3][1]
+# the timed region: the run's longest stretch without a gap of more than 25 ms between device-filling kernels
+# (tools/kt_union.py picks the same window), from its second DP launch to its last
+runs, cur, reach = [], [hv[0]], hv[0][1]
+for x in hv[1:]:
+    if x[0] - reach > 25e6:
+        runs.append(cur)
+        cur = []
+    cur.append(x)
+    reach = max(reach, x[1])
+runs.append(cur)
+best = max(runs, key=lambda r: sum(1 for x in r if x[2] == "mesh_dp_"))
+dp = [x for x in best if x[2] == "mesh_dp_"]
+t0, t1 = dp[1][0], dp[-1][1]
 hv = [x for x in hv if x[0] >= t0 and x[1] <= t1]
-busy = sum(e - s for s, e, _ in hv)
+busy, reach = 0, None   # (union: chained kernels overlap)
+for s0, e0, _ in sorted(hv):
+    if reach is None or s0 > reach:
+        busy += e0 - s0
+        reach = e0
+    elif e0 > reach:
+        busy += e0 - reach
+        reach = e0
 print("window %.1f ms: heavy kernels busy %.1f ms (%.1f %%)" % ((t1 - t0) / 1e6, busy / 1e6, 100.0 * busy / (t1 - t0)))
 import collections
 tot = collections.Counter(); cnt = collections.Counter()
@@ -26,8 +43,10 @@ for n in HEAVY:
     if cnt[n]:
         print("  %-22s %4d launches  avg %7.2f ms  total %8.1f ms (%.1f %%)" % (n, cnt[n], tot[n] / cnt[n] / 1e6, tot[n] / 1e6, 100.0 * tot[n] / (t1 - t0)))
 gaps = collections.Counter(); gcnt = collections.Counter()
+reach = None
 for (s0, e0, n0), (s1, e1, n1) in zip(hv, hv[1:]):
-    g = s1 - e0
+    reach = e0 if reach is None else max(reach, e0)
+    g = s1 - reach
     if g > 20000:
         gaps[n0 + " -> " + n1] += g; gcnt[n0 + " -> " + n1] += 1
 print("idle between heavy kernels (> 20 us), by neighbours:")
