@@ -196,7 +196,11 @@ inline uint64_t tb_plane_budget(sina_hip_ctx *c) {
     // has to grow is freed first).  Two stores on one device, or two ranks sharing a GPU, each decided their budget
     // when most of the memory was free; the one that comes second splits its launches to what is left instead of
     // failing in hipMalloc.  (SINA_HIP_TB_GB still wins: an explicit size is taken as given.)
-    if (!(getenv("SINA_HIP_TB_GB") && atof(getenv("SINA_HIP_TB_GB")) > 0)) {
+    // (asked only while the pool is still being built: once every plane exists launches repeat their sizes, and
+    // hipMemGetInfo is not a call to make per batch)
+    bool building = false;
+    for (int i = 0; i < tp.n; i++) building = building || tp.plane[i].cap == 0;
+    if (building && !(getenv("SINA_HIP_TB_GB") && atof(getenv("SINA_HIP_TB_GB")) > 0)) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             uint64_t held = 0;
