@@ -45,6 +45,12 @@ int sina_hip_init(int device, sina_hip_ctx **ctx);
  * store (upload_refs / build_index / upload_index fail on it); destroy forks before the parent,
  * and do not change the parent's store while forks are in use. */
 int sina_hip_fork(sina_hip_ctx *parent, sina_hip_ctx **ctx);
+/* Brings the scratch buffers ONE kind of call uses (0: k-mer search, 1: alignment, 2: search-stage comparison) to the
+ * largest sizes any context of the store has needed for them so far: device allocations stall every stream of the
+ * device, so a host that runs a pipeline makes its worker contexts, and warms them, before the run -- not in it
+ * (the reference sizes its per-thread state the same way: one famfinder / aligner copy per worker, made before the
+ * flow graph starts, src/sina.cpp:497-519).  No-op where nothing is known yet or the buffers are big enough. */
+int sina_hip_prewarm(sina_hip_ctx *ctx, int kind);
 void sina_hip_destroy(sina_hip_ctx *ctx);
 /* Blocks until all work queued on the context's stream has finished. */
 int sina_hip_sync(sina_hip_ctx *ctx);

@@ -22,7 +22,7 @@ i16p = C.POINTER(C.c_int16)
 
 # every extern "C" symbol include/sina_hip.h declares
 ABI_SYMBOLS = [
-    "sina_hip_abi_version", "sina_hip_last_error", "sina_hip_init", "sina_hip_fork", "sina_hip_destroy",
+    "sina_hip_abi_version", "sina_hip_last_error", "sina_hip_init", "sina_hip_fork", "sina_hip_prewarm", "sina_hip_destroy",
     "sina_hip_sync",
     "sina_hip_upload_refs", "sina_hip_build_index", "sina_hip_download_index", "sina_hip_upload_index", "sina_hip_store_view_get",
     "sina_hip_store_alloc_like", "sina_hip_kmer_topk", "sina_hip_kmer_scores", "sina_hip_compare",
@@ -91,6 +91,7 @@ def load():
     L.sina_hip_last_error.restype = C.c_char_p
     L.sina_hip_init.argtypes = [C.c_int, C.POINTER(vp)]
     L.sina_hip_fork.argtypes = [vp, C.POINTER(vp)]
+    L.sina_hip_prewarm.argtypes = [vp, C.c_int]
     L.sina_hip_destroy.argtypes = [vp]
     L.sina_hip_destroy.restype = None
     L.sina_hip_sync.argtypes = [vp]

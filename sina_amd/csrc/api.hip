@@ -537,6 +537,7 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
         set_error(why.empty() ? "init: could not create the context's streams" : why);
         return 1;
     }
+    c->bind_hints();
     c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 0) * 1024;
     if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 1) {
         (void)hipGetLastError();
@@ -555,7 +556,8 @@ int sina_hip_fork(sina_hip_ctx *parent, sina_hip_ctx **ctx) {
     c->owns_store = false;
     c->lds_budget = parent->lds_budget;
     c->n_cu = parent->n_cu;
-    if (finish_ctx(c) || c->adopt_hints()) {
+    c->bind_hints();
+    if (finish_ctx(c)) {
         const std::string why = sina_hip_last_error();
         discard_ctx(c);
         set_error(why);
@@ -563,6 +565,13 @@ int sina_hip_fork(sina_hip_ctx *parent, sina_hip_ctx **ctx) {
     }
     *ctx = c;
     return 0;
+}
+
+int sina_hip_prewarm(sina_hip_ctx *c, int kind) {
+    if (!c || kind < 0 || kind > 2) SH_FAIL("prewarm: null ctx or unknown kind");
+    std::lock_guard<std::mutex> lk(c->mu);
+    SH_CHECK(hipSetDevice(c->device));
+    return c->prewarm(kind);
 }
 
 void sina_hip_destroy(sina_hip_ctx *c) {

@@ -37,6 +37,10 @@ void set_error(const std::string &msg);
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    // the largest capacity any context of the store has needed for THIS buffer so far (sina_hip_store::cap_hint;
+    // nullptr: none): a buffer that has to grow goes there at once -- a context allocates only what its kind of
+    // call uses, and each of those once
+    const size_t *hint = nullptr;
     // (hipFree / hipMalloc synchronise the whole device and stall every other context's stream:
     // grow in big steps so that batch-to-batch size jitter never reallocates in steady state)
     int reserve(size_t bytes) {
@@ -45,6 +49,7 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
         size_t want = bytes + bytes / 4 + 4096;
+        if (hint && *hint > want) want = *hint;
         trace_alloc(want);
         SH_CHECK(hipMalloc(&p, want));
         cap = want;

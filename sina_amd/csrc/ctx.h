@@ -132,16 +132,29 @@ struct sina_hip_ctx {
         for (int i = 0; i < kNumScratch; i++)
             if (all[i]->cap > st->cap_hint[i]) st->cap_hint[i] = all[i]->cap;
     }
-    int adopt_hints() {  // new fork: size everything like the biggest context so far
+    // Every scratch buffer knows where the store keeps the largest capacity any context needed for it: a buffer
+    // that grows goes there in one step (DevBuf::reserve).  Until round 4 a new fork allocated ALL its buffers at
+    // those sizes at once -- a context that only ever searches carried 10 GB of aligner scratch, and a fork made
+    // in the middle of a run cost a dozen hipMallocs (13 GB; usually a millisecond, sometimes 250: one default
+    // bench run in four lost a third of its rate to it).
+    void bind_hints() {
         sina_hip::DevBuf *all[kNumScratch];
         scratch(all);
-        size_t want[kNumScratch];
-        {
-            std::lock_guard<std::mutex> lk(st->stats_mu);
-            for (int i = 0; i < kNumScratch; i++) want[i] = st->cap_hint[i];
+        for (int i = 0; i < kNumScratch; i++) all[i]->hint = &st->cap_hint[i];
+    }
+    // What one KIND of call uses, brought to the hinted sizes now (sina_hip_prewarm): 0 k-mer search,
+    // 1 alignment (DAG build, DP, walk), 2 search-stage comparison.
+    int prewarm(int kind) {
+        sina_hip::DevBuf *search[] = {&k_qoff, &k_scores, &k_out_ids, &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2, &qmask};
+        sina_hip::DevBuf *align[] = {&qd, &order, &rec, &node_pos, &pred, &succ_minpos, &qmask, &spill, &edge, &res, &weights, &out,
+                                     &out_pos, &g_fam_ids, &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab};
+        sina_hip::DevBuf *compare[] = {&s_qab, &s_qoff, &s_cand, &s_coff, &s_out};
+        sina_hip::DevBuf **list = kind == 0 ? search : (kind == 1 ? align : compare);
+        const size_t n = kind == 0 ? sizeof search / sizeof *search : (kind == 1 ? sizeof align / sizeof *align : sizeof compare / sizeof *compare);
+        for (size_t i = 0; i < n; i++) {
+            const size_t want = list[i]->hint ? *list[i]->hint : 0;
+            if (want > list[i]->cap && list[i]->reserve_exact(want)) return 1;
         }
-        for (int i = 0; i < kNumScratch; i++)
-            if (want[i] > all[i]->cap && all[i]->reserve_exact(want[i])) return 1;
         return 0;
     }
     void free_all() {

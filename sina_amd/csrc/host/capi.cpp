@@ -835,6 +835,17 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
             const char *nf_env = getenv("SINA_HOST_FINDERS");
             const uint32_t n_find = nf_env ? (uint32_t)std::max(1, atoi(nf_env)) : (inflight >= 4 ? 3 : (inflight >= 3 ? 2 : 1));
             const uint32_t n_align = inflight, n_sink = 1;
+            try {  // the contexts the threads below will lease, made and warmed before any of them starts
+                const auto store = reference_store::get(aligner::opts->database);
+                store->reserve_workers(reference_store::dev_search, n_find + (p->sf && p->search_store == store ? n_align : 0));
+                store->reserve_workers(reference_store::dev_align, n_align);
+                if (p->sf && p->search_store) {
+                    if (p->search_store != store) p->search_store->reserve_workers(reference_store::dev_search, n_align);
+                    p->search_store->reserve_workers(reference_store::dev_compare, n_align);
+                }
+            } catch (const std::exception &) {
+                // (no store registered under the aligner's name, or no room to warm: the stages will say so themselves)
+            }
             found.cap = n_find;
             found.producers = (int)n_find;
             aligned.producers = (int)n_align;

@@ -511,12 +511,23 @@ reference_store::lease reference_store::worker_device(device_role role) {
     sina_hip_ctx *c = nullptr;
     auto &pool = idle_forks[role];
     if (!pool.empty()) {
-        c = pool.back();
-        pool.pop_back();
+        c = pool.front();  // (round robin: every context of the kind sees batches -- and grows -- early)
+        pool.erase(pool.begin());
     } else {
         hip_check(sina_hip_fork(root, &c), "sina_hip_fork");
     }
     return lease(this, c, role);
+}
+void reference_store::reserve_workers(device_role role, unsigned n) {
+    sina_hip_ctx *root = device();
+    std::lock_guard<std::mutex> lk(gpu_mu);
+    auto &pool = idle_forks[role];
+    while (pool.size() < n) {
+        sina_hip_ctx *c = nullptr;
+        hip_check(sina_hip_fork(root, &c), "sina_hip_fork");
+        pool.push_back(c);
+    }
+    for (sina_hip_ctx *c : pool) hip_check(sina_hip_prewarm(c, (int)role), "sina_hip_prewarm");
 }
 reference_store::lease::~lease() {
     if (!c) return;

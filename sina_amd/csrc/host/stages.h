@@ -262,6 +262,9 @@ public:
         int role;
     };
     lease worker_device(device_role role);
+    // at least `n` contexts of that kind exist and are warm (sina_hip_prewarm) -- called by a driver BEFORE it starts
+    // the threads that will lease them: a context made, or grown, in the middle of a run stalls the device
+    void reserve_workers(device_role role, unsigned n);
 
 private:
     reference_store() = default;
