@@ -61,7 +61,6 @@ struct sina_hip_store {
         int kind;
     };
     std::vector<heavy_waiter> heavy_waiting;
-    double heavy_wait_ms[3] = {0, 0, 0};  // per kind: how long callers waited for their launch lately (moving average)
     // DP launches overlap now (the next one starts in the drain of the one before): stats.dp_busy_ms is the time
     // during which ANY DP kernel was resident -- the sum of the launches' durations minus their overlaps, which
     // are measured against the end event of the launch before (a ring: launch k records dp_end[k % 8])
@@ -338,21 +337,6 @@ inline hipError_t wait_event(hipEvent_t ev) {
         if (ns < 1000000) ns += ns / 2;
     }
 }
-// The same for a launch whose duration is roughly known (the store remembers, per kind of launch, how long its
-// callers waited lately): one long sleep for most of it, then the polling above.  A DP launch used to cost its
-// waiting thread ~50 wake-ups, seven such threads 16 000 context switches a second -- on a rank squeezed onto
-// two CPUs (bench.py's confined leg) every one of them preempts a thread that has work.
-inline hipError_t wait_event_about(hipEvent_t ev, double expect_ms) {
-    static const bool adapt = !(getenv("SINA_HIP_WAIT_ADAPT") && getenv("SINA_HIP_WAIT_ADAPT")[0] == '0');
-    if (adapt && expect_ms > 2.0) {
-        const hipError_t e = hipEventQuery(ev);
-        if (e != hipErrorNotReady) return e;
-        const long ns = (long)(expect_ms * 0.7 * 1e6);
-        timespec ts{ns / 1000000000L, ns % 1000000000L};
-        nanosleep(&ts, nullptr);
-    }
-    return wait_event(ev);
-}
 inline hipError_t wait_stream(sina_hip_ctx *c, hipStream_t s) {
     const hipError_t e = hipEventRecord(c->ev[9], s);
     return e != hipSuccess ? e : wait_event(c->ev[9]);
@@ -433,7 +417,6 @@ struct heavy_launch {
     int kind = 0;
     bool signals_dry = false;
     bool admitted = false;
-    double waited_ms = -1;
     bool chained = false;  // this launch went through the two-stream FIFO (else: the single heavy stream, or the context's own)
     uint32_t my_seq = 0;
     // `own`: the context stream whose queued work (uploads) the kernel depends on
@@ -519,15 +502,7 @@ struct heavy_launch {
             lk.unlock();
             c->st->heavy_cv.notify_all();
         }
-        {
-            double expect = 0;
-            if (admitted && kind >= 0 && kind < 3) expect = c->st->heavy_wait_ms[kind];  // (a racy read of a hint)
-            timespec t0, t1;
-            clock_gettime(CLOCK_MONOTONIC, &t0);
-            failed = failed || wait_event_about(c->ev[11], expect) != hipSuccess;
-            clock_gettime(CLOCK_MONOTONIC, &t1);
-            waited_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
-        }
+        failed = failed || wait_event(c->ev[11]) != hipSuccess;
         leave();
         if (failed) set_error("heavy_launch: event hand-over failed");
         return failed ? 1 : 0;
@@ -539,11 +514,6 @@ struct heavy_launch {
         sina_hip_store *st = c->st;
         if (!lk.owns_lock()) lk = std::unique_lock<std::mutex>(st->heavy_mu);
         --st->heavy_outstanding;
-        if (kind >= 0 && kind < 3 && waited_ms >= 0) {
-            double &avg = st->heavy_wait_ms[kind];
-            // (follows shorter waits at once -- a sleep that overshoots delays this batch's next step --, longer ones slowly)
-            avg = (avg == 0 || waited_ms < avg) ? waited_ms : 0.75 * avg + 0.25 * waited_ms;
-        }
         lk.unlock();
         st->heavy_cv.notify_all();
     }
