@@ -415,3 +415,27 @@ def test_fasta_driver_with_concurrent_stages_writes_the_serial_drivers_bytes(ora
     assert outs["serial"][2] == outs["conc"][2]
     assert outs["serial"][3] == outs["conc"][3] and (outs["serial"][3] is not None) == (fasta.get("meta-fmt") == "csv")
     st.close()
+
+
+def test_fasta_driver_stops_cleanly_when_its_source_fails_in_mid_run(oracle, tmp_path):
+    """The concurrent FASTA driver with an input that breaks off (a truncated gzip file: the reader thread throws
+    after it has handed over several batches): the error reaches the caller, no thread is left waiting on a queue,
+    and the store and its contexts serve the next run as if nothing had happened."""
+    import gzip
+    refs = synth.make_refs(300, length=320, width=3200, seed=497)
+    st = pipeline.Store(":mem:gpu-fasta-broken", refs)
+    qs = synth.make_queries(refs, 400, seed=498)
+    good, bad = str(tmp_path / "in.fasta.gz"), str(tmp_path / "broken.fasta.gz")
+    with gzip.open(good, "wt", compresslevel=1) as f:
+        for i in range(qs.n):
+            f.write(">q%d\n%s\n" % (i, synth.bases_string(qs.seq(i))))
+    whole = open(good, "rb").read()
+    open(bad, "wb").write(whole[:(2 * len(whole)) // 3])
+    ffo = {"fs-min-len": 100, "fs-full-len": 250}
+    with pytest.raises(pipeline.HostError):
+        pipeline.run_fasta(st, bad, str(tmp_path / "out1.fasta"), famfinder=ffo, batch=16)
+    got = pipeline.run_fasta(st, good, str(tmp_path / "out2.fasta"), famfinder=ffo, batch=16)
+    ser = pipeline.run_fasta(st, good, str(tmp_path / "out3.fasta"), famfinder=ffo, batch=16, serial=True)
+    assert got == ser and got["read"] == qs.n and got["written"] >= qs.n - 10
+    assert open(str(tmp_path / "out2.fasta")).read() == open(str(tmp_path / "out3.fasta")).read()
+    st.close()
