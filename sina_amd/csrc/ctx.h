@@ -376,10 +376,17 @@ inline int download(sina_hip_ctx *c, int slot, const void *src, size_t bytes, hi
 // that still has workgroups waiting (what round 1 measured as mutual stretching).  Every wait refers to
 // work queued EARLIER, so hardware queues shared between streams cannot dead-lock (see done()).
 // SINA_HIP_CHAIN=0: one stream, every launch waits for the end of the one before (round 3).
+// Under a profiler that collects hardware counters (rocprofv3 --pmc: ROCPROF_COUNTER_COLLECTION in the environment)
+// chaining is off unless SINA_HIP_CHAIN=1 insists: counter collection runs ONE kernel at a time across all queues, in
+// the order the tool intercepts them -- the runtime's wait-value poller of a follower can be let in before the DP
+// launch it waits for (that launch still being held by its own upload event), and then nothing ever runs again (one
+// of three PMC passes hung this way in round 4).  Per-kernel counters do not depend on what a kernel was chained to.
 inline bool chain_kernels() {
     static const bool on = [] {
         const char *v = getenv("SINA_HIP_CHAIN");
-        return !(v && *v == '0');
+        if (v && *v) return *v != '0';
+        const char *pmc = getenv("ROCPROF_COUNTER_COLLECTION");
+        return !(pmc && *pmc && *pmc != '0');
     }();
     return on;
 }

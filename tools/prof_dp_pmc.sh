@@ -16,7 +16,7 @@ GRPS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
 [ -n "$QUICK" ] && GRPS=("${GRPS[@]:0:2}")
 for grp in "${GRPS[@]}"; do
   i=$((i+1))
-  rocprofv3 --output-format csv --pmc $grp -d $OUT/p$i -o pmc -- python3 tools/perf_dp.py $NQ > $OUT/run$i.log 2>&1
+  timeout 400 rocprofv3 --output-format csv --pmc $grp -d $OUT/p$i -o pmc -- python3 tools/perf_dp.py $NQ > $OUT/run$i.log 2>&1
 done
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
