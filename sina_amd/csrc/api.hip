@@ -219,8 +219,6 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     b.self16 = c->profile_batch ? c->self16.as<float>() : nullptr;
     b.asm_cap = 0;
     for (uint32_t q = 0; q < bq; q++) b.asm_cap = std::max<uint32_t>(b.asm_cap, qd_host[q].L);
-    b.wait_ready = 0;
-    b.order = nullptr;
     uint64_t dp_no = ~0ull;  // this launch's number among the store's DP launches
     // Where the walk runs.  Until round 4: on the context's own stream, launched by the host once it had seen the
     // DP kernel end -- beside whatever device-filling kernel was resident by then.  A kernel trace of round 4
@@ -232,11 +230,6 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     // the launch that started in its drain (the other FIFO stream), and the launch after that -- often the next DP
     // launch -- is ordered behind them by the stream itself.  SINA_HIP_BT_ON_FIFO=0: the context's stream.
     static const bool bt_fifo_wanted = !(getenv("SINA_HIP_BT_ON_FIFO") && getenv("SINA_HIP_BT_ON_FIFO")[0] == '0');
-    // SINA_HIP_BT_AT_DRY=1 (experiment): the walk is let go when its DP launch has DISPATCHED its last workgroup -- on the
-    // context's stream, behind a wait for the launch's "dry" flag -- and every walk waits for its own query's result
-    // record (kDpResultPending until the DP wave publishes it): the walks of the queries that are done fill the slots
-    // the launch's drain leaves empty
-    static const bool bt_at_dry = getenv("SINA_HIP_BT_AT_DRY") && getenv("SINA_HIP_BT_AT_DRY")[0] == '1';
     bool bt_done = false;
     {
         // the DP kernel: on the store's heavy stream, behind the uploads queued on c->stream; the
@@ -247,7 +240,6 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         s = c->stream_dp;
         SH_CHECK(hipStreamWaitEvent(s, c->ev[8], 0));
         heavy_launch hl(c, s, kHeavyDp);
-        if (hl.chained && bt_at_dry) SH_CHECK(hipMemsetAsync(c->res.p, 0x7f, sizeof(DpResult) * bq, hl.stream()));
         SH_CHECK(hipEventRecord(c->ev[0], hl.stream()));
         a.dry = hl.dry();
         if (launch_mesh_dp(pl.geom, weighted, forbid, a, bq, pl.lds, hl.stream())) return 1;
@@ -256,15 +248,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
             dp_no = c->st->dp_seq++;
             SH_CHECK(hipEventRecord(c->st->dp_end[dp_no % 8], hl.stream()));
         }
-        if (hl.chained && bt_at_dry && a.dry.flag != nullptr) {
-            SH_CHECK(hipStreamWaitValue32(s, a.dry.flag, a.dry.seq, hipStreamWaitValueGte, 0xffffffffu));
-            b.wait_ready = 1;
-            b.order = a.order;
-            if (launch_backtrack(b, s)) return 1;
-            if (p->assemble && launch_assemble(b, s)) return 1;
-            SH_CHECK(hipEventRecord(c->ev[2], s));
-            bt_done = true;
-        } else if (hl.chained && bt_fifo_wanted) {
+        if (hl.chained && bt_fifo_wanted) {
             if (launch_backtrack(b, hl.stream())) return 1;
             if (p->assemble && launch_assemble(b, hl.stream())) return 1;
             SH_CHECK(hipEventRecord(c->ev[2], hl.stream()));

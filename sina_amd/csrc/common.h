@@ -228,22 +228,6 @@ struct DpResult {
     float raw;
     int32_t status;
 };
-// A result nobody has written yet (run_dp_device fills the launch's records with 0x7f bytes before the DP kernel):
-// the backtrack walk of a launch that started in its DP launch's drain waits for its query's record to change.
-constexpr int32_t kDpResultPending = 0x7f7f7f7f;
-#ifdef __HIPCC__
-// The DP wave's last act: its trace-back cells, spill rows and the record itself become visible to waves of OTHER
-// kernels on the device (agent-scope release: on gfx950 the L2 of this XCD is written back first), then the status.
-__device__ __forceinline__ void wave_release_to_device() {  // (every lane: the cells are the whole wave's stores)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-}
-__device__ __forceinline__ void publish_result(DpResult *dst, const DpResult &r) {
-    dst->end_m = r.end_m;
-    dst->end_s = r.end_s;
-    dst->raw = r.raw;
-    __hip_atomic_store(&dst->status, r.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-#endif
 
 // Every cell is at most its deletion candidate from any predecessor, value[p][s] + gap_open, and rows
 // without predecessors start at 1: no value exceeds 1 + N * gap_open (the float sums stay within
@@ -295,8 +279,6 @@ struct BtArgs {
     int lowercase;
     uint32_t asm_cap;  // bases of the launch's longest query (the kernel's LDS follows it)
     const float *self16;  // --fs-no-graph: comp(base, base) per iupac mask (sum_weight's term), else nullptr
-    int wait_ready;       // the DP launch may still be running: wait for the query's DpResult (kDpResultPending until then)
-    const uint32_t *order;  // (then also: workgroup -> query in the DP launch's own order, the queries that finish first first)
 };
 
 // Picks the (threads, cells per thread) geometry for the longest query of a batch.

@@ -939,7 +939,6 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
     const float v1min = __shfl(lc_min, lane_last);
     const float v_snk0 = __shfl(lc_snk0, lane_last);
     const uint32_t v1arg = __shfl(lc_arg, lane_last);
-    wave_release_to_device();
     if (lane == 0) {
         DpResult r;
         r.status = 0;
@@ -960,7 +959,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         r.end_m = em;
         r.end_s = es;
         r.raw = ev;
-        publish_result(&resv[qi], r);
+        resv[qi] = r;
     }
 }
 
@@ -1468,7 +1467,6 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     const float v1min = __shfl(lc_min, lane_last);
     const float v_snk0 = __shfl(lc_snk0, lane_last);
     const uint32_t v1arg = __shfl(lc_arg, lane_last);
-    wave_release_to_device();
     if (lane == 0) {
         DpResult r;
         r.status = 0;
@@ -1487,7 +1485,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         r.end_m = em;
         r.end_s = es;
         r.raw = ev;
-        publish_result(&resv[qi], r);
+        resv[qi] = r;
     }
 }
 
@@ -1506,16 +1504,9 @@ __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
     __shared__ __attribute__((aligned(16))) cell_t w_cell[kBtRows][kBtCols];
     __shared__ uint4 w_rec[kBtRows];   // row records, .w replaced by the node's column
     __shared__ uint4 w_pred[kBtRows];  // first four predecessor entries of the row
-    if (blockIdx.x >= a.nq) return;
-    const uint32_t q = a.wait_ready ? a.order[blockIdx.x] : blockIdx.x;
+    const uint32_t q = blockIdx.x;
     const uint32_t lane = threadIdx.x;
-    if (a.wait_ready) {
-        // started in the DP launch's drain (run_dp_device): the query's DP wave is running or done -- every workgroup
-        // of that launch had been dispatched before this kernel was let go -- so the wait ends; what the wave wrote
-        // is visible once its status is (agent-scope acquire)
-        while (__hip_atomic_load(&a.res[q].status, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == kDpResultPending)
-            __builtin_amdgcn_s_sleep(64);
-    }
+    if (q >= a.nq) return;
     const QDesc d = a.qd[q];
     const uint32_t L = d.L, N = d.N;
     const uint32_t Lp = a.Lp;
