@@ -1497,16 +1497,6 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
 // inside the window costs LDS latency; a refill (two round trips, every ~30 steps) is paid by 64
 // lanes at once.  LAZY: 16-bit cells (type code + predecessor ordinal) instead of 32-bit ones.
 constexpr int kBtRows = 64, kBtCols = 32;
-#ifndef SINA_BT_SCALAR
-#define SINA_BT_SCALAR 1  // the walk's loaded values through v_readfirstlane: its logic on the scalar unit (0: as until round 3)
-#endif
-template <typename T> __device__ __forceinline__ T bt_u(T x) {
-#if SINA_BT_SCALAR
-    return uniform(x);
-#else
-    return x;
-#endif
-}
 template <bool LAZY>
 __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
     using cell_t = typename std::conditional<LAZY, uint16_t, uint32_t>::type;
@@ -1518,17 +1508,14 @@ __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
     const uint32_t lane = threadIdx.x;
     if (q >= a.nq) return;
     const QDesc d = a.qd[q];
-    const uint32_t L = bt_u(d.L), N = bt_u(d.N);
+    const uint32_t L = d.L, N = d.N;
     const uint32_t Lp = a.Lp;
-    const cell_t *tb = reinterpret_cast<const cell_t *>(a.tb) + bt_u(d.tb_off);
-    const uint4 *rec = a.rec + bt_u(d.node_off);
-    const uint32_t *node_pos = a.node_pos + bt_u(d.node_off);
-    const uint32_t *pred = a.pred + bt_u(d.edge_off);
-    uint32_t *out = a.out_pos + bt_u(d.q_off);
-    DpResult r = a.res[q];
-    r.end_m = bt_u(r.end_m);
-    r.end_s = bt_u(r.end_s);
-    r.status = (int32_t)bt_u((uint32_t)r.status);
+    const cell_t *tb = reinterpret_cast<const cell_t *>(a.tb) + d.tb_off;
+    const uint4 *rec = a.rec + d.node_off;
+    const uint32_t *node_pos = a.node_pos + d.node_off;
+    const uint32_t *pred = a.pred + d.edge_off;
+    uint32_t *out = a.out_pos + d.q_off;
+    const DpResult r = a.res[q];
     sina_hip_align_out o;
     o.status = r.status;
     o.end_m = r.end_m;
@@ -1570,32 +1557,23 @@ __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
         __syncthreads();
     };
     auto in_rows = [&](uint32_t row) -> bool { return row - wr0 < (uint32_t)kBtRows; };
-    // (Everything the walk reads is the same in every lane -- one logical thread -- but what comes out of LDS or
-    // memory sits in vector registers, and the compiler then runs the whole walk, its compares and its branches, on
-    // the vector unit under an exec mask: 633 VALU instructions of 64 lanes each for scalar work, 9216 walks at once.
-    // Handing every loaded value over through v_readfirstlane puts rows, columns, cells and records into SGPRs and
-    // the walk's logic on the scalar unit.)
     auto cell_at = [&](uint32_t row, uint32_t col) -> uint32_t {
         if (!(in_rows(row) && col - wc0 < (uint32_t)kBtCols)) refill(row, col);
-        return bt_u((uint32_t)w_cell[row - wr0][col - wc0]);
+        return (uint32_t)w_cell[row - wr0][col - wc0];
     };
     // row record / column / predecessor entry e of a row (through the window if the row is in it)
     auto rec_at = [&](uint32_t row) -> uint4 {  // (.w = the node's column)
-        uint4 rx;
-        if (in_rows(row)) {
-            rx = w_rec[row - wr0];
-        } else {
-            rx = rec[row];
-            rx.w = node_pos[row];
-        }
-        return uint4{bt_u(rx.x), bt_u(rx.y), bt_u(rx.z), bt_u(rx.w)};
+        if (in_rows(row)) return w_rec[row - wr0];
+        uint4 rx = rec[row];
+        rx.w = node_pos[row];
+        return rx;
     };
     auto pred_at = [&](uint32_t row, uint32_t pb, uint32_t e) -> uint32_t {
         if (e < 4 && in_rows(row)) {
             const uint4 pe = w_pred[row - wr0];
-            return bt_u((e == 0 ? pe.x : (e == 1 ? pe.y : (e == 2 ? pe.z : pe.w))) & 0xffffu);
+            return (e == 0 ? pe.x : (e == 1 ? pe.y : (e == 2 ? pe.z : pe.w))) & 0xffffu;
         }
-        return bt_u(pred[pb + e] & 0xffffu);
+        return pred[pb + e] & 0xffffu;
     };
     const uint32_t width = a.width;
     uint32_t m = r.end_m, s = r.end_s;
