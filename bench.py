@@ -211,6 +211,14 @@ def self_launch(a):
     parent process never does (the reference's counterpart is `--threads`, src/sina.cpp:241-243,450)."""
     import socket
     import subprocess
+    try:  # (counting devices does not start the HIP runtime; a node with fewer GPUs than asked for is said so here)
+        import torch
+        have = torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        have = None
+    if have is not None and have < a.gpus:
+        print("bench.py --gpus %d: this node shows %d GPU(s)" % (a.gpus, have), file=sys.stderr)
+        return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]

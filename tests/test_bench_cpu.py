@@ -18,7 +18,9 @@ def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
         seen["cmd"], seen["env"] = cmd, env
         return 7
 
+    import torch
     monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.delenv("RANK", raising=False)
@@ -50,3 +52,25 @@ def test_bench_under_a_launcher_does_not_spawn():
                         "bench.main()"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "needs a GPU" in p.stderr and "spawned" not in p.stderr
+
+
+def test_bench_gpus_n_on_a_node_with_fewer_gpus_says_so(monkeypatch, capsys):
+    """More ranks than the node has GPUs: a clear message and a non-zero exit before anything is spawned."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import torch
+
+    def no_spawn(*a, **k):
+        raise AssertionError("spawned")
+
+    monkeypatch.setattr(subprocess, "call", no_spawn)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    try:
+        bench.main()
+        raise AssertionError("should have left")
+    except SystemExit as e:
+        assert e.code == 2
+    assert "shows 1 GPU" in capsys.readouterr().err
