@@ -54,7 +54,7 @@ def parse():
                          "device's pool of two, csrc/ctx.h)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="CPU baseline: queries per thread and thread count (0 = 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", type=int, default=8,
+    ap.add_argument("--verify", type=int, default=64,
                     help="queries of the timed run re-done by the oracle afterwards and compared (0 = none; "
                          "skipped together with the CPU baseline, whose oracle index it shares)")
     ap.add_argument("--dup-rate", type=float, default=0.0,

@@ -294,6 +294,19 @@ def test_16s_full_length_vs_100k_references(oracle):
     _pipeline_equals_oracle(oracle, refs, qs, ":mem:16s-100k", min_dp=30)
 
 
+def test_16s_full_length_vs_500k_references(oracle):
+    """configs[3] at its real shape: full-length 16S queries against 500 000 full-length references
+    (width 50 000, seed 4 -- what `bench.py --refs 500000` builds): 16 reference tiles of 32 768 in the k-mer
+    count kernel, full-length posting lists with the dense bitmaps active, the select kernel's tie order at
+    the tile seams (kmer_search.cpp:405-412, greater<pair<int16, int>>), then DAG build, DP, walk and
+    assembly.  Family, aligned columns + case bits, head / tail / quality and the full log text equal the
+    oracle's at the FULL reference count."""
+    refs = synth.make_refs(500000, length=1500, width=50000, seed=4)
+    assert (refs.n + 32767) // 32768 == 16
+    qs = synth.make_queries(refs, 16, seed=5)
+    _pipeline_equals_oracle(oracle, refs, qs, ":mem:16s-500k", min_dp=15)
+
+
 def test_turn_orientations_equal_oracle(oracle):
     """--turn none / revcomp / all (famfinder.cpp:312-378; the shape of the reference's own
     famfinder_test.cpp:89-116): queries handed in reversed, complemented, or both are recognised by
