@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SINA_HIP_ABI_VERSION 3  /* 3: sina_hip_stats grew dp_busy_ms, dags_built, dags_used */
+#define SINA_HIP_ABI_VERSION 4  /* 4: sina_hip_stats grew the row-skip counters (dp_rows ... dp_prune_rho); sina_hip_debug_dp_info, _rgain */
 
 typedef struct sina_hip_ctx sina_hip_ctx;
 
@@ -264,6 +264,21 @@ int sina_hip_debug_mesh(sina_hip_ctx *ctx, const sina_hip_graph_batch *g, const 
                         uint32_t qlen, const sina_hip_align_params *p, uint32_t *tb_vm,
                         uint32_t *tb_vs, float *value);
 
+/* Test hooks for the certified row skip: what the DP kernel reported for query q of the context's LAST launch
+ * (attempts 0: that launch swept everything), and the first n entries of the per-node bound R(m) the last launch /
+ * the last sina_hip_debug_family_graph left on the device (units of 1/64; entry i belongs to node i of the launch's
+ * first DAG).  prune_step = the largest gain of one match step the launch assumed, same units. */
+typedef struct sina_hip_dp_info {
+    uint32_t end_m, end_s;
+    float raw;
+    int32_t status;
+    uint32_t rows_swept, cells_swept, attempts;
+    float gain0, ubound;
+    uint32_t prune_step;
+} sina_hip_dp_info;
+int sina_hip_debug_dp_info(sina_hip_ctx *ctx, uint32_t q, sina_hip_dp_info *out);
+int sina_hip_debug_rgain(sina_hip_ctx *ctx, uint32_t n, uint32_t *out);
+
 /* Test hook: the DAG the GPU builds for ONE family (ids into the uploaded store, in family
  * order), in compact CSR form, for comparison with mseq (src/mseq.cpp:47-118).
  * ring_depth is the number of LDS row slots the DP kernel will have; spill_idx reports where each
@@ -295,6 +310,18 @@ typedef struct sina_hip_stats {
                                 has dispatched its last workgroup, not when it has ended)                     */
     uint64_t dags_built;     /* family DAGs built on the device ...                                             */
     uint64_t dags_used;      /* ... and queries aligned against them (queries with the same ordered family share one) */
+    /* Certified row skip of the DP kernel (the reference fills every cell, src/mesh.h:512-528; here a row of a
+     * 512-column strip whose every input provably exceeds what any path ending at the optimum can hold is not
+     * swept -- the end cell, its value and the whole trace-back path are certified identical, or the query is
+     * swept again): dp_cells above stays the NOMINAL N*L. */
+    uint64_t dp_rows;            /* (row, strip) pairs of the launches, nominal                                  */
+    uint64_t dp_rows_swept;      /* ... actually swept, second and third attempts included                       */
+    uint64_t dp_cells_swept;     /* cells actually computed (= dp_cells where nothing was skipped)               */
+    uint64_t dp_queries_pruned;  /* queries that went through the skipping kernel ...                            */
+    uint64_t dp_second_attempts; /* ... whose first bound failed its certificate (swept again under the bound the
+                                    first attempt found) ...                                                      */
+    uint64_t dp_full_sweeps;     /* ... and whose second did too (swept in full)                                 */
+    double dp_prune_rho;         /* gauge: the guess (optimum / bound on the whole gain) the next launch starts with */
 } sina_hip_stats;
 int sina_hip_get_stats(sina_hip_ctx *ctx, sina_hip_stats *s);
 

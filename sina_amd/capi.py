@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "sina_hip_upload_refs", "sina_hip_build_index", "sina_hip_download_index", "sina_hip_upload_index", "sina_hip_store_view_get",
     "sina_hip_store_alloc_like", "sina_hip_kmer_topk", "sina_hip_kmer_scores", "sina_hip_compare",
     "sina_hip_align_params_default", "sina_hip_staged_out_pos", "sina_hip_align_graphs", "sina_hip_align_families",
-    "sina_hip_debug_mesh", "sina_hip_debug_family_graph", "sina_hip_get_stats",
+    "sina_hip_debug_mesh", "sina_hip_debug_family_graph", "sina_hip_debug_dp_info", "sina_hip_debug_rgain", "sina_hip_get_stats",
 ]
 
 
@@ -71,7 +71,15 @@ class Stats(C.Structure):
                 ("postings", C.c_uint64), ("dp_launches", C.c_uint32), ("kmer_launches", C.c_uint32),
                 ("compare_ms", C.c_double), ("compare_bases", C.c_uint64), ("compare_launches", C.c_uint32),
                 ("n_dense_lists", C.c_uint32), ("dp_busy_ms", C.c_double), ("dags_built", C.c_uint64),
-                ("dags_used", C.c_uint64)]
+                ("dags_used", C.c_uint64), ("dp_rows", C.c_uint64), ("dp_rows_swept", C.c_uint64),
+                ("dp_cells_swept", C.c_uint64), ("dp_queries_pruned", C.c_uint64), ("dp_second_attempts", C.c_uint64),
+                ("dp_full_sweeps", C.c_uint64), ("dp_prune_rho", C.c_double)]
+
+
+class DpInfo(C.Structure):
+    _fields_ = [("end_m", C.c_uint32), ("end_s", C.c_uint32), ("raw", C.c_float), ("status", C.c_int32),
+                ("rows_swept", C.c_uint32), ("cells_swept", C.c_uint32), ("attempts", C.c_uint32),
+                ("gain0", C.c_float), ("ubound", C.c_float), ("prune_step", C.c_uint32)]
 
 
 _lib = None
@@ -117,6 +125,8 @@ def load():
     L.sina_hip_debug_family_graph.argtypes = [vp, u32p, C.c_uint32, C.c_float, C.c_uint32, u32p, u32p, u32p, u8p,
                                               f32p, u32p, u32p, u32p, u8p, u32p, C.c_uint32, C.c_uint32]
     L.sina_hip_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.sina_hip_debug_dp_info.argtypes = [vp, C.c_uint32, C.POINTER(DpInfo)]
+    L.sina_hip_debug_rgain.argtypes = [vp, C.c_uint32, u32p]
     _lib = L
     return L
 
@@ -301,7 +311,10 @@ class Context:
                                                    out.ctypes.data_as(C.POINTER(AlignOut)), _ptr(pos, u32p)))
         return out, pos
 
-    def debug_mesh(self, gb, qmask, params=None, want_value=True):
+    def debug_mesh(self, gb, qmask, params=None, want_value=True, prune=False):
+        """DP planes of ONE query.  prune=False (default): every row of every strip is swept, the planes are
+        the reference's cell for cell; prune=True: the production launch with its certified row skip -- cells the
+        kernel proved irrelevant hold whatever it left there (see dp_info / rgain for the bound it used)."""
         params = params or self.params()
         qmask = _c(qmask, np.uint8)
         n = int(gb._keep["node_off"][1])
@@ -309,9 +322,19 @@ class Context:
         vm = np.zeros((n, L), np.uint32)
         vs = np.zeros((n, L), np.uint32)
         val = np.zeros((n, L), np.float32) if want_value else None
-        self._check(self.L.sina_hip_debug_mesh(self.h, C.byref(gb), _ptr(qmask, u8p), L, C.byref(params),
-                                               _ptr(vm, u32p), _ptr(vs, u32p),
-                                               _ptr(val, f32p) if want_value else None))
+        old = os.environ.get("SINA_HIP_DP_PRUNE")  # (read by the library per launch)
+        if not prune:
+            os.environ["SINA_HIP_DP_PRUNE"] = "0"
+        try:
+            self._check(self.L.sina_hip_debug_mesh(self.h, C.byref(gb), _ptr(qmask, u8p), L, C.byref(params),
+                                                   _ptr(vm, u32p), _ptr(vs, u32p),
+                                                   _ptr(val, f32p) if want_value else None))
+        finally:
+            if not prune:
+                if old is None:
+                    os.environ.pop("SINA_HIP_DP_PRUNE", None)
+                else:
+                    os.environ["SINA_HIP_DP_PRUNE"] = old
         return vm, vs, val
 
     def debug_family_graph(self, fam_ids, fs_weight=1.0, ring_depth=4):
@@ -334,6 +357,18 @@ class Context:
         n, e = nn.value, ne.value
         return dict(n=n, pos=pos[:n].copy(), mask=mask[:n].copy(), weight=w[:n].copy(), pred_off=poff[:n + 1].copy(),
                     pred=pred[:e].copy(), succ_minpos=smin[:n].copy(), sink=sink[:n].copy(), spill=spill[:n].copy())
+
+    def dp_info(self, q=0):
+        """What the DP kernel reported for query q of this context's last launch (row-skip test hook)."""
+        d = DpInfo()
+        self._check(self.L.sina_hip_debug_dp_info(self.h, q, C.byref(d)))
+        return {f[0]: getattr(d, f[0]) for f in DpInfo._fields_}
+
+    def rgain(self, n):
+        """First n entries of the per-node row-skip bound the last launch / debug_family_graph left on the device."""
+        out = np.zeros(max(n, 1), np.uint32)
+        self._check(self.L.sina_hip_debug_rgain(self.h, n, _ptr(out, u32p)))
+        return out[:n]
 
     def stats(self):
         s = Stats()

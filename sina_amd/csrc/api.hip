@@ -32,22 +32,48 @@ int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl) {
     return 0;
 }
 
+// SINA_HIP_DP_PRUNE=0 switches the DP kernel's certified row skip off (every row of every strip is swept);
+// SINA_HIP_DP_PRUNE_RHO=<x> fixes the launches' guess of optimum / bound (tests: 2 = too bold for any query, every
+// query takes the second attempt; 0.01 = nearly no bound).  Read per launch.
+PrunePlan prune_plan(const sina_hip_align_params *p, float wmax, float wmin, uint32_t maxL, bool profile_batch) {
+    PrunePlan pp;
+    const char *off = getenv("SINA_HIP_DP_PRUNE");
+    if (off && off[0] == '0') return pp;
+    if (profile_batch || (p->weights != nullptr && p->n_weights > 0) || p->insertion == SINA_INSERTION_FORBID) return pp;
+    // gaps must cost, node weights must not be negative (a match gains match_score * weight, nothing else gains)
+    if (!(p->gap_penalty >= 0.f) || !(p->gap_ext_penalty >= 0.f) || !(wmin >= 0.f) || !std::isfinite(wmax)) return pp;
+    const float kappa = std::max(0.f, std::max(p->match_score, p->mismatch_score));
+    if (!std::isfinite(kappa)) return pp;
+    pp.kappa64 = 64.0f * 1.0001f * kappa;
+    pp.amax = prune_gain_units(wmax, pp.kappa64);
+    // (the bounds are exact float32 integers in units of 1/64 only below 2^24)
+    if (pp.amax > 250u || (uint64_t)pp.amax * maxL >= (1u << 23)) return pp;
+    if (pp.kappa64 <= 0.f) pp.kappa64 = 1e-30f;  // (no step gains anything: every node's gain is the one unit of margin)
+    pp.on = 1;
+    return pp;
+}
+
 // Host-side preparation of a range of host-built graphs: descriptors, row records
 // (sink flag, spill slot for rows with a successor further than W rows away).
 struct HostPrep {
     std::vector<QDesc> qd;
     std::vector<uint4> rec;
+    std::vector<uint32_t> rgain;  // the DP kernel's row-skip bound per node (common.h), filled when kappa64 > 0
+    bool rgain_ok = true;         // ... and valid: every DAG of the range is laid out by columns
+    float wmax = 0.f, wmin = 0.f; // node weights of the range
     std::vector<uint32_t> pred;  // id | (LDS slot or spill row) << 16 | spilled << 31 (what mesh_dp_kernel reads)
     std::vector<uint32_t> last;  // scratch: last successor per row
     uint64_t tb_cells = 0, spill_rows = 0, cells = 0;
 };
 
 static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint32_t q0, uint32_t q1, int Lp, int W,
-                       HostPrep *hp) {
+                       HostPrep *hp, float kappa64) {
     const uint64_t nbase = g->node_off[q0], ebase = g->edge_off[q0];
     const uint64_t nn = g->node_off[q1] - nbase;
     hp->qd.resize(q1 - q0);
     hp->rec.resize(nn);
+    hp->rgain.assign(kappa64 > 0.f ? nn : 0, 0u);
+    hp->rgain_ok = true;
     hp->pred.resize(g->edge_off[q1] - ebase + 8);
     hp->tb_cells = hp->spill_rows = hp->cells = 0;
     uint32_t erec_cursor = 0;
@@ -117,16 +143,44 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
         }
         for (uint32_t m = 0; m < N; m++) {
             uint32_t first_far = 0;
+            uint32_t dist = po[m + 1] > po[m] ? 0u : kRecDistFar;
             for (uint32_t e = po[m]; e < po[m + 1]; e++) {
                 const uint32_t p = g->pred[eo + e];
                 const uint32_t pw = rec[p].w == kRowNone ? 0u : rec[p].w;  // (kRowNone: in registers for this row)
                 const bool sp = (pw & kRowSpilled) != 0;
                 if (sp && first_far == 0) first_far = e - po[m] + 1;
+                dist = std::max(dist, m - p);
                 hp->pred[d.edge_off + e] = p | ((pw & 0x7FFFu) << 16) | (sp ? kPredSpilled : 0u);
             }
-            rec[m].z |= first_far << 24;
+            rec[m].z |= (first_far << 24) | (std::min(dist, kRecDistFar) << kRecDistShift);
         }
         if (nsp > kMaxSpillRows) SH_FAIL("align_graphs: too many spill rows for one query");
+        // The row-skip bound, as the device DAG build computes it (graph_build.hip step 9): R(m) = the sum, over the
+        // columns right of node m's, of the column's best node's gain.  It is a bound only for a DAG laid out like
+        // mseq's -- columns ascend with the node ids, every edge leads to a column further right --, which a caller's
+        // arrays need not be: checked here, and a launch holding a DAG that is not runs without the skip.
+        if (kappa64 > 0.f) {
+            uint32_t *rg = hp->rgain.data() + d.node_off;
+            const uint32_t *pos = g->node_pos + no;
+            bool ok = true;
+            for (uint32_t m = 0; m < N && ok; m++) {
+                if (m > 0 && pos[m] < pos[m - 1]) ok = false;
+                for (uint32_t e = po[m]; e < po[m + 1] && ok; e++)
+                    if (pos[g->pred[eo + e]] >= pos[m]) ok = false;
+            }
+            if (!ok) hp->rgain_ok = false;
+            uint32_t right = 0;  // columns right of the one being finished
+            for (uint32_t m = N; ok && m > 0;) {
+                uint32_t first = m - 1, mx = 0;
+                while (first > 0 && pos[first - 1] == pos[m - 1]) first--;
+                for (uint32_t j = first; j < m; j++) {
+                    mx = std::max(mx, prune_gain_units(g->node_weight[no + j], kappa64));
+                    rg[j] = right;
+                }
+                right += mx;
+                m = first;
+            }
+        }
         d.n_spill = nsp;
         hp->spill_rows += nsp;
         hp->tb_cells += (uint64_t)N * Lp;
@@ -139,7 +193,7 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
 // query masks are already in the context's device buffers; copies results back.
 int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint32_t bq, uint64_t n_node_entries,
                   uint64_t tb_cells, uint64_t spill_rows, uint64_t cells, uint64_t nqm, const sina_hip_align_params *p, uint32_t width,
-                  sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value) {
+                  sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value, const PrunePlan &pp) {
     hipStream_t s = c->stream;
     const int Lp = pl.geom.Lp();
     const bool weighted = p->weights != nullptr && p->n_weights > 0;
@@ -161,6 +215,9 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         c->out_pos.reserve(4 * std::max<uint64_t>(nqm, 1)))
         return 1;
     if (want_dbg_value && c->dbg.reserve(4 * tb_cells)) return 1;
+    // (debug read-back of the planes: rows the kernel skips leave their trace-back cells unwritten -- "untouched cell"
+    // everywhere first, so that unpacking them stays inside the DAG)
+    if (c->dbg_planes && !forbid) SH_CHECK(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(plane.ptr), (unsigned short)kTbNone, tb_cells, s));
     // longest queries first (workgroups start in index order; see mesh_dp_kernel)
     std::vector<uint32_t> order(bq);
     for (uint32_t q = 0; q < bq; q++) order[q] = q;
@@ -191,6 +248,25 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     a.gp = p->gap_penalty;
     a.gpe = p->gap_ext_penalty;
     a.prof16 = c->profile_batch ? c->prof16.as<float>() : nullptr;
+    // certified row skip (mesh_dp.hip): the guess the launch's queries start with -- what the store has learnt
+    // from the queries before, or SINA_HIP_DP_PRUNE_RHO
+    c->last_bq = bq;
+    c->last_prune_step = pp.on ? pp.amax : 0u;
+    a.rgain = pp.on ? c->rgain.as<uint32_t>() : nullptr;
+    a.prune = pp.on;
+    a.prune_amax = pp.amax;
+    a.prune_rho = 0.f;
+    bool rho_fixed = false;
+    if (pp.on) {
+        if (const char *r = getenv("SINA_HIP_DP_PRUNE_RHO")) {
+            a.prune_rho = (float)atof(r);
+            rho_fixed = a.prune_rho > 0.f;
+        }
+        if (!rho_fixed) {
+            std::lock_guard<std::mutex> slk(c->st->stats_mu);
+            a.prune_rho = c->st->prune_rho;
+        }
+    }
     {
         uint32_t max_n = 0;
         for (uint32_t q = 0; q < bq; q++) max_n = std::max<uint32_t>(max_n, qd_host[q].N);
@@ -268,9 +344,10 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         SH_CHECK(hipEventRecord(c->ev[2], s));
     }
     // (h_out_pos was sized for the whole call by the entry point; this range's columns go to their place in it)
-    if (c->h_out.reserve(sizeof(sina_hip_align_out) * bq)) return 1;
+    if (c->h_out.reserve(sizeof(sina_hip_align_out) * bq) || c->h_res.reserve(sizeof(DpResult) * bq)) return 1;
     unsigned char *staged_pos = static_cast<unsigned char *>(c->h_out_pos.p) + 4 * c->out_pos_base;
     SH_CHECK(hipMemcpyAsync(c->h_out.p, c->out.p, sizeof(sina_hip_align_out) * bq, hipMemcpyDeviceToHost, s));
+    SH_CHECK(hipMemcpyAsync(c->h_res.p, c->res.p, sizeof(DpResult) * bq, hipMemcpyDeviceToHost, s));
     SH_CHECK(hipMemcpyAsync(staged_pos, c->out_pos.p, 4 * nqm, hipMemcpyDeviceToHost, s));
     SH_CHECK(wait_stream(c, s));
     memcpy(out, c->h_out.p, sizeof(sina_hip_align_out) * bq);
@@ -285,6 +362,33 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         if (e == hipSuccess) shared = std::min(ms, std::max(0.f, to_prev_end));
         else (void)hipGetLastError();  // (the launch before has not ended yet: cannot happen behind a chain; counted as no overlap)
     }
+    // what the launch actually swept (certified row skip), and what its queries say about the next launch's guess
+    const uint32_t kstrip = 64u * (uint32_t)pl.geom.B;
+    uint64_t rows_nominal = 0, rows_swept = 0, cells_swept = 0, n_pruned = 0, n_second = 0, n_full = 0;
+    std::vector<float> ratios;
+    const DpResult *hres = c->h_res.as<DpResult>();
+    for (uint32_t q = 0; q < bq; q++) {
+        const uint64_t strips = (qd_host[q].L - 1) / kstrip + 1;
+        rows_nominal += strips * qd_host[q].N;
+        const DpResult &r = hres[q];
+        if (r.attempts == 0) {  // (a kernel that sweeps everything)
+            rows_swept += strips * qd_host[q].N;
+            cells_swept += (uint64_t)qd_host[q].N * qd_host[q].L;
+            continue;
+        }
+        rows_swept += r.rows_done;
+        cells_swept += r.cells_done;
+        n_pruned++;
+        n_second += r.attempts == 2 ? 1 : 0;
+        n_full += r.attempts >= 3 ? 1 : 0;
+        if (r.status == 0 && r.gain0 > 0.f && r.raw < 0.f) ratios.push_back(-r.raw / r.gain0);
+    }
+    float rho_seen = -1.f;
+    if (!ratios.empty()) {  // the launch's 2nd percentile of optimum / bound, less a margin
+        const size_t k = ratios.size() / 50;
+        std::nth_element(ratios.begin(), ratios.begin() + (std::ptrdiff_t)k, ratios.end());
+        rho_seen = ratios[k] - 0.01f;
+    }
     std::lock_guard<std::mutex> slk(c->st->stats_mu);
     c->st->stats.dp_ms += ms;
     c->st->stats.dp_busy_ms += ms - shared;
@@ -292,6 +396,18 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     c->st->stats.backtrack_ms += ms;
     c->st->stats.dp_cells += cells;
     c->st->stats.dp_launches++;
+    c->st->stats.dp_rows += rows_nominal;
+    c->st->stats.dp_rows_swept += rows_swept;
+    c->st->stats.dp_cells_swept += cells_swept;
+    c->st->stats.dp_queries_pruned += n_pruned;
+    c->st->stats.dp_second_attempts += n_second;
+    c->st->stats.dp_full_sweeps += n_full;
+    if (rho_seen > 0.f) {  // down at once (a second sweep per query is what a bold guess costs), up by halves
+        float &rho = c->st->prune_rho;
+        rho = rho_seen < rho ? rho_seen : 0.5f * (rho + rho_seen);
+        rho = std::min(0.99f, std::max(0.05f, rho));
+    }
+    c->st->stats.dp_prune_rho = c->st->prune_rho;
     return 0;
 }
 
@@ -350,6 +466,16 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
     if (plan_dp(c, maxL, &pl)) return 1;
     const int Lp = pl.geom.Lp();
     if (upload_weights(c, p)) return 1;
+    float wmax = 0.f, wmin = 0.f;
+    if (!g->node_score16 && g->node_weight) {
+        const uint64_t n_all = g->node_off[nq] - g->node_off[0];
+        for (uint64_t i = 0; i < n_all; i++) {
+            const float w = g->node_weight[g->node_off[0] + i];
+            wmax = (i == 0 || w > wmax) ? w : wmax;
+            wmin = (i == 0 || w < wmin) ? w : wmin;
+        }
+    }
+    const PrunePlan pp = prune_plan(p, wmax, wmin, maxL, g->node_score16 != nullptr);
 
     const uint64_t tb_budget_cells = tb_plane_budget(c) / tb_cell_bytes(forbid);
     HostPrep hp;
@@ -366,14 +492,15 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         }
         q1 = dp_round_range(q0, q1, nq, dp_wave_slots(c, pl.geom.B));
         if (dbg_vm) q1 = q0 + 1;
-        if (prep_range(g, qoff, q0, q1, Lp, pl.W, &hp)) return 1;
+        c->dbg_planes = dbg_vm != nullptr;
+        if (prep_range(g, qoff, q0, q1, Lp, pl.W, &hp, pp.on ? pp.kappa64 : 0.f)) return 1;
         const uint32_t bq = q1 - q0;
         const uint64_t nbase = g->node_off[q0], nn = g->node_off[q1] - nbase;
         const uint64_t ebase = g->edge_off[q0], ne = g->edge_off[q1] - ebase;
         const uint64_t qbase = qoff[q0], nqm = qoff[q1] - qbase;
         if (c->qd.reserve(sizeof(QDesc) * bq) || c->rec.reserve(sizeof(uint4) * nn) || c->node_pos.reserve(4 * nn) ||
             c->pred.reserve(4 * std::max<uint64_t>(ne, 1)) || c->succ_minpos.reserve(4 * nn) ||
-            c->qmask.reserve(nqm))
+            c->qmask.reserve(nqm) || (pp.on && c->rgain.reserve(4 * nn)))
             return 1;
         hipStream_t s = c->stream;
         SH_CHECK(hipMemcpyAsync(c->qd.p, hp.qd.data(), sizeof(QDesc) * bq, hipMemcpyHostToDevice, s));
@@ -383,6 +510,9 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         if (g->succ_minpos)
             SH_CHECK(hipMemcpyAsync(c->succ_minpos.p, g->succ_minpos + nbase, 4 * nn, hipMemcpyHostToDevice, s));
         SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qbase, nqm, hipMemcpyHostToDevice, s));
+        PrunePlan pp_launch = pp;
+        if (!hp.rgain_ok) pp_launch.on = 0;
+        if (pp.on) SH_CHECK(hipMemcpyAsync(c->rgain.p, hp.rgain.data(), 4 * nn, hipMemcpyHostToDevice, s));
         c->profile_batch = g->node_score16 != nullptr;
         if (c->profile_batch) {  // --fs-no-graph: the profile's match-term tables (sina_hip.h)
             if (!g->self_score16) SH_FAIL("align_graphs: node_score16 without self_score16");
@@ -393,7 +523,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         }
         c->out_pos_base = qbase - qoff[0];
         if (run_dp_device(c, pl, hp.qd.data(), bq, nn, hp.tb_cells, hp.spill_rows, hp.cells, nqm, p, g->width, out + q0,
-                          out_pos ? out_pos + qbase : nullptr, dbg_value_host != nullptr))
+                          out_pos ? out_pos + qbase : nullptr, dbg_value_host != nullptr, pp_launch))
             return 1;
         if (dbg_vm) {  // single-query debug: unpack the planes
             const QDesc &d = hp.qd[0];
@@ -653,6 +783,35 @@ int sina_hip_debug_mesh(sina_hip_ctx *c, const sina_hip_graph_batch *g, const ui
     sina_hip_align_out o;
     std::vector<uint32_t> pos(qlen);
     return align_graphs_impl(c, g, qmask, qoff, p, &o, pos.data(), value, tb_vm, tb_vs);
+}
+
+int sina_hip_debug_dp_info(sina_hip_ctx *c, uint32_t q, sina_hip_dp_info *out) {
+    if (!c || !out) SH_FAIL("debug_dp_info: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (q >= c->last_bq || !c->res.p) SH_FAIL("debug_dp_info: no such query in the last launch");
+    SH_CHECK(hipSetDevice(c->device));
+    DpResult r;
+    SH_CHECK(hipMemcpy(&r, c->res.as<DpResult>() + q, sizeof r, hipMemcpyDeviceToHost));
+    out->end_m = r.end_m;
+    out->end_s = r.end_s;
+    out->raw = r.raw;
+    out->status = r.status;
+    out->rows_swept = r.rows_done;
+    out->cells_swept = r.cells_done;
+    out->attempts = r.attempts;
+    out->gain0 = r.gain0;
+    out->ubound = r.ubound;
+    out->prune_step = c->last_prune_step;
+    return 0;
+}
+
+int sina_hip_debug_rgain(sina_hip_ctx *c, uint32_t n, uint32_t *out) {
+    if (!c || !out) SH_FAIL("debug_rgain: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->rgain.p || c->rgain.cap < 4 * (size_t)n) SH_FAIL("debug_rgain: no bound of that many nodes on the device");
+    SH_CHECK(hipSetDevice(c->device));
+    SH_CHECK(hipMemcpy(out, c->rgain.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int sina_hip_get_stats(sina_hip_ctx *c, sina_hip_stats *s) {

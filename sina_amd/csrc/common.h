@@ -150,7 +150,8 @@ struct QDesc {
 //   y = node weight (float bits, mseq.cpp:113)
 //   z = #pred | iupac mask << 8 | flags << 16 | (index of the first spilled predecessor + 1) << 24
 //       flags bit0: sink = no successors; bit1: some successor is further than kFarLds rows away
-//       (such a row is kept in a spill row: it would hold an LDS slot for hundreds of rows)
+//       (such a row is kept in a spill row: it would hold an LDS slot for hundreds of rows);
+//       bits 2..7: distance to the furthest predecessor (kRecDistShift)
 //   w = where the finished row {value, gapm_val} is kept for its successors:
 //       0xFFFFFFFF nowhere (no successors, or the next row is the only one: the DP kernel hands the
 //       row just finished to the next one in registers), kRowSpilled | spill row index, or the LDS
@@ -162,6 +163,11 @@ struct QDesc {
 //   id | (LDS slot or spill row index) << 16 | spilled << 31
 constexpr uint32_t kRecSink = 1u << 16;
 constexpr uint32_t kRecFence = 1u << 17;
+// flags bits 2..7 (z bits 18..23): how far back the row's furthest predecessor is, in rows (1..62; 63: further, or
+// the row has none).  The DP kernel's row skip asks "were ALL of the last d rows dead in this strip" instead of
+// looking its predecessors up one by one (mesh_dp.hip PRUNE).
+constexpr int kRecDistShift = 18;
+constexpr uint32_t kRecDistFar = 63u;
 constexpr uint32_t kRowNone = 0xFFFFFFFFu;
 constexpr uint32_t kRowSpilled = 0x80000000u;
 constexpr uint32_t kPredSpilled = 0x80000000u;
@@ -227,6 +233,36 @@ struct DpResult {
     uint32_t end_m, end_s;
     float raw;
     int32_t status;
+    // certified row skip (mesh_dp.hip, PRUNE; zeros from a launch that does not prune): what the query's wave
+    // actually swept -- (row, strip) pairs and real cells, summed over its attempts --, the attempts it took
+    // (1: the launch's guess of the bound held; 2: the first attempt's own result served as the bound; 3: swept
+    // in full), its bound on the gain any path can still collect at the first cell, and the bound U on the
+    // optimum that the last attempt ran with and certified (+inf: swept in full)
+    uint32_t rows_done, cells_done, attempts;
+    float gain0, ubound;
+    uint32_t pad_;
+};
+static_assert(sizeof(DpResult) == 40, "downloaded as an array");
+
+// ---- certified row skip: the bound
+// T(m, s) = U + min(a * (L-1-s), R(m)) bounds the value a cell may have and still lie on a path that ends at U or
+// below: every query base still to come gains at most a, every DAG column right of pos(m) at most its best
+// node's gain, gaps cost (gap penalties >= 0).  All of it in units of 1/64 so that T is EXACT in float32 (the
+// induction needs T(source) - gain >= T(target) to hold as computed, not just as written): a node's gain is
+// rounded up to a multiple of 1/64 plus one unit of margin for the float rounding of the cell values.
+constexpr float kPruneUnit = 1.0f / 64.0f;
+// gain of a match at a node of weight w, in units (kappa64 = 64 * max(match gain per unit weight) * 1.0001)
+__host__ __device__ inline uint32_t prune_gain_units(float w, float kappa64) {
+    const float x = w * kappa64;
+    uint32_t u = (uint32_t)x;
+    if ((float)u < x) u++;
+    return u + 1u;
+}
+// what a launch may prune with: non-negative gap costs and weights, sums that stay exact
+struct PrunePlan {
+    int on = 0;
+    float kappa64 = 0.f;   // 64 * 1.0001 * max(-ms, -mms, 0): match gain per unit of node weight
+    uint32_t amax = 0;     // largest gain of one match step in the launch, in units
 };
 
 // Every cell is at most its deletion candidate from any predecessor, value[p][s] + gap_open, and rows
@@ -257,6 +293,13 @@ struct DpArgs {
     float ms, mms, gp, gpe;     // scheme ctor args: -match, -mismatch, gap, gapext
     const float *prof16;        // --fs-no-graph: match term per node and query mask [16 * node + mask], else nullptr
     DryArgs dry;                // (heavy_launch::dry(): tells the next launch when this one's queue has run dry)
+    // certified row skip (mesh_dp_simple_kernel<.., PRUNE>): per node the gain still to come right of its column
+    // (units of kPruneUnit, indexed like rec), the launch's guess rho of optimum / first-cell bound, the largest
+    // gain of one step; prune == 0: every row of every strip is swept
+    const uint32_t *rgain;
+    int prune;
+    float prune_rho;
+    uint32_t prune_amax;
 };
 
 struct BtArgs {
@@ -314,6 +357,9 @@ int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl);
 int upload_weights(sina_hip_ctx *c, const sina_hip_align_params *p);
 int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint32_t bq, uint64_t n_node_entries,
                   uint64_t tb_cells, uint64_t spill_rows, uint64_t cells, uint64_t nqm, const sina_hip_align_params *p, uint32_t width,
-                  sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value);
+                  sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value, const PrunePlan &pp);
+// What a launch may skip rows with (api.hip): the scoring of `p` (non-negative gap costs, the simple scheme), the
+// largest and smallest node weight it will see, its longest query.  SINA_HIP_DP_PRUNE=0: never.
+PrunePlan prune_plan(const sina_hip_align_params *p, float wmax, float wmin, uint32_t maxL, bool profile_batch);
 
 }  // namespace sina_hip

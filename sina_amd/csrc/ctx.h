@@ -69,6 +69,11 @@ struct sina_hip_store {
     // largest capacity any context has needed for each scratch buffer so far: a new fork reserves
     // these at once (hipMalloc / hipFree synchronise the device; never in steady state)
     size_t cap_hint[64] = {};  // (indexed like sina_hip_ctx::scratch(): kNumScratch entries)
+    // certified row skip of the DP kernel (mesh_dp.hip PRUNE): the guess rho of "optimum / bound on the whole gain"
+    // the next launch starts its queries with, learnt from the queries aligned so far (run_dp_device; under stats_mu).
+    // Results never depend on it: a guess that is too bold costs the queries it fails a second sweep, a timid one
+    // a wider band.
+    float prune_rho = 0.80f;
     sina_hip_stats stats;
     // Trace-back planes -- tens of GB each, the one allocation whose size follows the launch -- belong
     // to the DEVICE, not to a context: only one DP kernel runs at a time, so two planes serve any number
@@ -101,8 +106,12 @@ struct sina_hip_ctx {
     // per-batch scratch, grown on demand and reused
     sina_hip::DevBuf qd, order, rec, node_pos, pred, succ_minpos, qmask, spill, edge, res, weights, out, out_pos, dbg;
     sina_hip::DevBuf prof16, self16;  // --fs-no-graph: match-term tables of a profile batch (sina_hip_graph_batch)
+    sina_hip::DevBuf rgain;           // per DAG node: bound on the gain still to come (the DP kernel's row skip, common.h)
+    sina_hip::HostBuf h_res;          // pinned copy of a launch's DpResults (row-skip statistics, the next launch's guess)
     bool profile_batch = false;       // the launch being prepared is one (set by sina_hip_align_graphs)
     void *last_tb = nullptr;  // the plane of the last launch (debug read-back: sina_hip_debug_mesh)
+    bool dbg_planes = false;  // the launch being prepared is sina_hip_debug_mesh's: its planes are unpacked cell by cell
+    uint32_t last_bq = 0, last_prune_step = 0;  // queries / assumed largest step gain of the last launch (sina_hip_debug_dp_info)
     sina_hip::DevBuf k_qoff, k_scores, k_out_ids, k_out_scores, k_out_n, k_tmp0, k_tmp1, k_tmp2;
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes, g_wtab;
     sina_hip::DevBuf s_qab, s_qoff, s_cand, s_coff, s_out;  // search-stage comparison
@@ -115,14 +124,14 @@ struct sina_hip_ctx {
 
     size_t lds_budget = 0;  // LDS per DP workgroup; 0 = what keeps the register-limited occupancy (dp_default_lds_budget)
 
-    static constexpr int kNumScratch = 36;
+    static constexpr int kNumScratch = 37;
     static_assert(kNumScratch <= 64, "sina_hip_store::cap_hint is too short");
     void scratch(sina_hip::DevBuf **all) {
         sina_hip::DevBuf *list[kNumScratch] = {&qd, &rec, &node_pos, &pred, &succ_minpos, &qmask, &spill, &res,
                                                &weights, &out, &out_pos, &k_qoff, &k_scores, &k_out_ids,
                                                &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2, &g_fam_ids,
                                                &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab, &order,
-                                               &s_qab, &s_qoff, &s_cand, &s_coff, &s_out, &edge, &prof16, &self16};
+                                               &s_qab, &s_qoff, &s_cand, &s_coff, &s_out, &edge, &prof16, &self16, &rgain};
         for (int i = 0; i < kNumScratch; i++) all[i] = list[i];
     }
     void publish_hints() {  // after a call: remember how big my buffers had to be
@@ -147,7 +156,7 @@ struct sina_hip_ctx {
     int prewarm(int kind) {
         sina_hip::DevBuf *search[] = {&k_qoff, &k_scores, &k_out_ids, &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2, &qmask};
         sina_hip::DevBuf *align[] = {&qd, &order, &rec, &node_pos, &pred, &succ_minpos, &qmask, &spill, &edge, &res, &weights, &out,
-                                     &out_pos, &g_fam_ids, &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab};
+                                     &out_pos, &g_fam_ids, &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab, &rgain};
         sina_hip::DevBuf *compare[] = {&s_qab, &s_qoff, &s_cand, &s_coff, &s_out};
         sina_hip::DevBuf **list = kind == 0 ? search : (kind == 1 ? align : compare);
         const size_t n = kind == 0 ? sizeof search / sizeof *search : (kind == 1 ? sizeof align / sizeof *align : sizeof compare / sizeof *compare);
@@ -164,6 +173,7 @@ struct sina_hip_ctx {
         dbg.release();
         h_out.release();
         h_out_pos.release();
+        h_res.release();
         for (auto &h : h_stage) h.release();
         if (owns_store && st) {
             if (st->heavy) (void)hipStreamDestroy(st->heavy);

@@ -83,6 +83,8 @@ struct GraphArgs {
     uint32_t member_cap;
     int W;                     // DP ring depth: edges longer than this need a spill row
     int want_smin;             // succ_min is read by somebody (--insertion=forbid, the debug entry): else it is not touched at all
+    uint32_t *rgain;           // [nq][ncap] or nullptr: the DP kernel's row-skip bound R(m) (step 9; units: common.h)
+    float kappa64;             // ... 64 * 1.0001 * (largest match gain per unit of node weight)
     DryArgs dry;               // (ctx.h, heavy_launch: tells the launch queued behind when the last workgroup has started)
 };
 
@@ -559,17 +561,48 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
         const uint4 r = rec[i];
         const uint32_t np = r.z & 0xFFu;
         uint32_t first_far = 0;
+        uint32_t dist = np ? 0u : kRecDistFar;  // (ids ascend: the first predecessor is the furthest)
         for (uint32_t x = 0; x < np; x++) {
             const uint32_t pa = pred[r.x + x];
             uint32_t pw = in_lds ? codeL[pa] : rec[pa].w;
             if (pw == kRowNone) pw = 0;  // (kept in registers for this row: the entry's slot is not read)
             const bool sp = (pw & kRowSpilled) != 0;
             if (sp && first_far == 0) first_far = x + 1;
+            dist = max(dist, i - pa);
             pred[r.x + x] = pa | ((pw & 0x7FFFu) << 16) | (sp ? kPredSpilled : 0u);
         }
-        rec[i].z = r.z | (first_far << 24);
+        rec[i].z = r.z | (first_far << 24) | (min(dist, kRecDistFar) << kRecDistShift);
     }
     GP(11)
+    // 9. the DP kernel's row-skip bound (common.h "the bound", mesh_dp.hip PRUNE): R(m) = what a path can still gain
+    // right of node m's column = the sum, over the occupied columns right of it, of the column's best node's gain
+    // (an edge always leads to a column further right, a path takes at most one node per column).  Integer units:
+    // the sums are exact and do not depend on the order of the scan.  The nodes of a column have consecutive ids:
+    // the thread of a column's FIRST node finds the column's maximum; an exclusive scan of "maximum at the first
+    // node, 0 elsewhere" gives every column the total of the columns left of it.
+    if (a.rgain != nullptr) {
+        uint32_t *rg = a.rgain + (size_t)q * a.ncap;
+        uint32_t *cw = last;  // (`last` was read for the last time in step 7)
+        __syncthreads();
+        for (uint32_t i = tid; i < N; i += kGT) {
+            const uint32_t pos = node_pos[i];
+            if (i > 0 && node_pos[i - 1] == pos) continue;
+            uint32_t mx = 0;
+            for (uint32_t j = i; j < N && node_pos[j] == pos; j++) {
+                mx = max(mx, prune_gain_units(__uint_as_float(rec[j].y), a.kappa64));
+                cw[j] = 0;
+            }
+            cw[i] = mx;
+        }
+        __syncthreads();
+        const uint32_t total = block_exscan(cw, cw, N, s_tmp);
+        for (uint32_t i = tid; i < N; i += kGT) {
+            const uint32_t pos = node_pos[i];
+            if (i > 0 && node_pos[i - 1] == pos) continue;
+            const uint32_t right = (i + 1 < N) ? total - cw[i + 1] : 0u;  // (cw[i + 1] = columns up to and including mine)
+            for (uint32_t j = i; j < N && node_pos[j] == pos; j++) rg[j] = right;
+        }
+    }
     GP_FLUSH
 }
 
@@ -601,7 +634,7 @@ struct BuiltGraphs {
 // Builds the DAGs of bq families (fam_off is absolute, first family = q0) into the context's
 // rec / node_pos / succ_minpos / pred buffers; grows the per-query caps and retries on overflow.
 int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t *fam_off, uint32_t q0,
-                        uint32_t bq, float fs_weight, int W, BuiltGraphs *bg, bool want_smin) {
+                        uint32_t bq, float fs_weight, int W, BuiltGraphs *bg, bool want_smin, float kappa64) {
     hipStream_t s = c->stream;
     if (ensure_ref_off_host(c)) return 1;  // (a store that arrived by broadcast reads it back once)
     // weight table: the reference's expression (mseq.cpp:113) evaluated on the host
@@ -643,7 +676,8 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
             c->g_tmp1.reserve(8 * (uint64_t)bq) ||
             c->rec.reserve(sizeof(uint4) * (uint64_t)bq * ncap) || c->node_pos.reserve(4 * (uint64_t)bq * ncap) ||
             c->succ_minpos.reserve(4 * (uint64_t)bq * ncap) || c->g_tmp3.reserve(4 * (uint64_t)bq * ncap) ||
-            c->pred.reserve(4 * pred_total) || c->g_sizes.reserve(16 * (uint64_t)bq))
+            c->pred.reserve(4 * pred_total) || c->g_sizes.reserve(16 * (uint64_t)bq) ||
+            (kappa64 > 0.f && c->rgain.reserve(4 * (uint64_t)bq * ncap)))
             return 1;
         if (upload(c, 1, c->g_fam_ids.p, fam_ids + fam_off[q0], 4 * foff[bq], s) ||
             upload(c, 2, c->g_fam_off.p, foff.data(), 8 * ((uint64_t)bq + 1), s) ||
@@ -669,6 +703,8 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         ga.member_cap = (uint32_t)graph_member_cap(max_f);
         ga.W = W;
         ga.want_smin = want_smin ? 1 : 0;
+        ga.rgain = kappa64 > 0.f ? c->rgain.as<uint32_t>() : nullptr;
+        ga.kappa64 = kappa64;
         if (allow_full_lds(reinterpret_cast<const void *>(family_graph_kernel))) return 1;
         bg->sizes.resize(4 * (size_t)bq);
         {
@@ -811,7 +847,11 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
         } else {
             for (uint32_t q = 0; q < bq; q++) dag_of[q] = q;
         }
-        if (build_family_graphs(c, b_ids, b_off, b_q0, n_dags, p->fs_weight, pl.W, &bg, p->insertion == SINA_INSERTION_FORBID)) return 1;
+        // (certified row skip of the DP kernel: the DAG build adds every node's bound on the gain still to come)
+        PrunePlan pp = prune_plan(p, (float)(1.0 / (double)(p->fs_weight + 1) + (double)p->fs_weight), p->fs_weight >= 0.f ? 0.f : -1.f, maxL, false);
+        if (build_family_graphs(c, b_ids, b_off, b_q0, n_dags, p->fs_weight, pl.W, &bg, p->insertion == SINA_INSERTION_FORBID,
+                                pp.on ? pp.kappa64 : 0.f))
+            return 1;
         {
             std::lock_guard<std::mutex> slk(c->st->stats_mu);
             c->st->stats.dags_built += n_dags;
@@ -863,7 +903,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
             c->profile_batch = false;  // (device-built DAGs: never a profile)
             c->out_pos_base = qbase - qoff[0];
             if (run_dp_device(c, pl, qd.data(), rq, (uint64_t)n_dags * bg.ncap, tbc, sprows, cells, nqm, p, c->st->width,
-                              out + q0 + r0, out_pos ? out_pos + qbase : nullptr, false))
+                              out + q0 + r0, out_pos ? out_pos + qbase : nullptr, false, pp))
                 return 1;
             r0 = r1;
         }
@@ -894,7 +934,8 @@ int sina_hip_debug_family_graph(sina_hip_ctx *c, const uint32_t *fam_ids, uint32
     SH_CHECK(hipSetDevice(c->device));
     const uint64_t foff[2] = {0, F};
     BuiltGraphs bg;
-    if (build_family_graphs(c, fam_ids, foff, 0, 1, fs_weight, (int)ring_depth, &bg, true)) return 1;
+    // (with the row-skip bound for the default scoring: sina_hip_debug_rgain reads it back)
+    if (build_family_graphs(c, fam_ids, foff, 0, 1, fs_weight, (int)ring_depth, &bg, true, fs_weight >= 0.f ? 64.0f * 1.0001f * 2.0f : 0.f)) return 1;
     const uint32_t N = bg.sizes[0];
     std::vector<uint4> rec(N);
     std::vector<uint32_t> pr(bg.sizes[1] + 8);

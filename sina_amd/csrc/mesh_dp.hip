@@ -959,6 +959,9 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
         r.end_m = em;
         r.end_s = es;
         r.raw = ev;
+        r.rows_done = r.cells_done = r.attempts = r.pad_ = 0u;  // (no row skip in the general kernel)
+        r.gain0 = 0.f;
+        r.ubound = __builtin_inff();
         resv[qi] = r;
     }
 }
@@ -995,7 +998,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
 // Everything else (weighted scheme, --insertion=forbid, gap_open < gap_extend, huge gap costs) runs
 // mesh_dp_kernel.  Results are bit-identical between the two: tests/test_gpu_parity.py runs every
 // simple-scheme plane test through both (SINA_HIP_DP_GENERIC=1 forces the generic kernel).
-template <int B, bool DBG>
+template <int B, bool DBG, bool PRUNE>
 #ifndef SINA_DP_SIMPLE_WAVES8
 #define SINA_DP_SIMPLE_WAVES8 3  // waves per SIMD the B = 8 kernel is compiled for
 #endif
@@ -1003,7 +1006,8 @@ __global__ void __launch_bounds__(64, (B <= 4 ? 4 : (B <= 8 ? SINA_DP_SIMPLE_WAV
 mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ orderv, const uint4 *__restrict__ recv,
                       const uint32_t *__restrict__ predv, const uint8_t *__restrict__ qmaskv, void *__restrict__ tbv,
                       float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev, uint64_t edge_stride,
-                      uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe, DryArgs dry) {
+                      uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe, DryArgs dry,
+                      const uint32_t *__restrict__ rgainv, float prune_rho, uint32_t prune_amax) {
     static_assert(B % 4 == 0, "16-byte accesses per array");
     constexpr int kStrip = 64 * B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1025,11 +1029,39 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     float *spill = spillv + uniform(d.spill_off) * (size_t)(2 * Lp);
     const uint64_t q_off = uniform(d.q_off);
 
-    // end-cell search (mesh.h:567-592), accumulated over the strips
     const uint32_t strip_last = (L - 1) / (uint32_t)kStrip;
     const int lane_last = (int)(((L - 1) / B) & 63u);
     const int k_last = (int)((L - 1) % B);
-    float lc_min = 0.f, lc_snk0 = 0.f;
+
+    // ---- certified row skip (PRUNE; the bound and its units: common.h, the proof: DESIGN.md 3.1).  A cell whose
+    // value exceeds T(m, s) = U + min(a * (L-1-s), R(m)) cannot lie on a path that ends at U or below, and whatever
+    // is computed FROM such a cell exceeds T where it arrives: a row whose inputs in this strip all exceed their T
+    // is not swept at all -- its successors read kDead in its place -- and every cell at or below its T still comes
+    // out bit for bit.  If the end cell found has a value <= U, it, its value and every cell of its trace-back
+    // path are the full sweep's (certificate); if not, the wave sweeps again with a bound that cannot fail twice:
+    // attempt 1 U = -rho * (bound on the whole gain), rho the launch's guess; 2: U = what attempt 1 found (a real
+    // path's cost); 3: no bound.  All bounds are integers in units of 1/64 (exact in float32 below 2^24 units).
+    constexpr int32_t kNoBound = 1 << 29;
+    constexpr float kDead = 1000000.0f;  // what a skipped row shows its successors: the reference's own "unreached" (mesh.h:290)
+    const uint32_t *__restrict__ rgain = PRUNE ? rgainv + node_off : nullptr;
+    int32_t U64 = kNoBound;
+    float gain0 = 0.f;
+    if constexpr (PRUNE) {
+        // the whole alignment right of the first node, its own column included (<= one step's largest gain)
+        const uint32_t g_cols = uniform(rgain[0]) + prune_amax, g_len = prune_amax * (L - 1);
+        const uint32_t g0 = g_cols < g_len ? g_cols : g_len;
+        gain0 = (float)g0 * kPruneUnit;
+        U64 = -(int32_t)uniform((uint32_t)(int32_t)(prune_rho * (float)g0));  // (rounded towards zero: the looser side)
+    }
+    uint32_t rows_done = 0, cells_done = 0, attempt = 0;
+    uint32_t res_m = 0, res_s = 0;
+    float res_v = 0.f;
+    int32_t res_status = 0;
+    for (;;) {  // attempts (one without PRUNE)
+    ++attempt;
+    const float U_f = (float)U64 * kPruneUnit;
+    // end-cell search (mesh.h:567-592), accumulated over the strips
+    float lc_min = PRUNE ? __builtin_inff() : 0.f, lc_snk0 = 0.f;
     uint32_t lc_arg = 0;
     bool lc_any = false;
     float all_min = __builtin_inff();
@@ -1078,10 +1110,48 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
 #pragma unroll
     for (int i = 0; i < B / 4; i++) prev_v.v[i] = prev_g.v[i] = typename Cells<B>::V{0.f, 0.f, 0.f, 0.f};
 
+    // ---- row skip, per strip: the bound of my first cell (the largest of my cells' bounds), which of the last 64
+    // rows were dead in this strip (bit d-1: row m-d), which LDS slots / whether the hand-over registers already
+    // show kDead, the rows swept
+    float A_lane = 0.f;
+    uint64_t dead_hist = 0;
+    uint32_t slot_dead = 0, rows_strip = 0;
+    bool prev_dead = false;
+    // strip 0: the first row whose column 0 -- initial value 1, where an alignment may start for free -- is above
+    // its bound U + min(a * (L-1), R(m)): R falls with the row (graph_build.hip step 9), so it is a threshold
+    uint32_t m_col0_dead = 0;
+    // the record of row m+1 (the skip path has no work to hide a load behind: records come two rows ahead), and
+    // whether cur_pe holds THIS row's predecessor entries (a skipped row does not fetch the next row's)
+    uint4 nxt = cur;
+    bool pe_valid = true;
+    if constexpr (PRUNE) {
+        A_lane = (float)(U64 + (int32_t)prune_amax * ((int32_t)(L - 1) - (int32_t)s0)) * kPruneUnit;
+        nxt = rec[N > 1u ? 1u : 0u];
+        if (strip == 0) {
+            if (U64 + (int32_t)(prune_amax * (L - 1)) < 64) {
+                m_col0_dead = 0;
+            } else {
+                uint32_t lo = 0, hi = N;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (U64 + (int32_t)uniform(rgain[mid]) < 64) hi = mid;
+                    else lo = mid + 1;
+                }
+                m_col0_dead = lo;
+            }
+        }
+    }
+
     for (uint32_t m = 0; m < N; ++m) {
         if ((m & 127u) == 0) issue_priority_by_progress(strip * N + m, S * N);
         const uint32_t m_next = m + 1 < N ? m + 1 : m;
-        const uint4 nrec = rec[m_next];
+        uint4 nrec, nrec2 = cur;
+        if constexpr (PRUNE) {
+            nrec = nxt;
+            nrec2 = rec[m + 2 < N ? m + 2 : N - 1];
+        } else {
+            nrec = rec[m_next];
+        }
         u32x4 nedge = {0, 0, 0, 0};
         if (have_left_strip) nedge = sload16(e_in + (uint64_t)m_next * sizeof(EdgeRec));
 
@@ -1093,6 +1163,81 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         const float vM = ms * wgt, vX = mms * wgt;  // scoring_schemes.h:154
         const float edge_val = __uint_as_float(cur_edge.x);
         const bool is_sink = (r_z & kRecSink) != 0;
+
+        // ---- row skip: nothing that enters this row in this strip can still lie on a path that ends at U or below
+        // -- the cell left of my strip (strip 0: column 0's initial value 1) is above its bound, and so were all
+        // cells (this strip's and the one left of it) of all rows back to the furthest predecessor -- so neither
+        // can anything in it.  Scalar only: the row's record, a shift register of the last 64 rows' verdicts, the
+        // flag the strip to the left stored with its edge record (EdgeRec::gmax).
+        bool edge_dead = false;
+        uint32_t cur_rg = 0;
+        if constexpr (PRUNE) {
+            edge_dead = have_left_strip ? (cur_edge.w == 0u) : (m >= m_col0_dead);
+            const uint32_t dist = (r_z >> kRecDistShift) & 63u;
+            const uint64_t need = (1ull << dist) - 1ull;  // (dist 63 = "further, or no predecessor": never all ones below)
+            const bool skip = edge_dead && dist != kRecDistFar && (dead_hist & need) == need;
+            if (skip) {
+                if (lane == 63 && have_right_strip) {
+                    EdgeRec er;
+                    er.bnd = kDead;
+                    er.xv = kDead;
+                    er.xe = 0u;
+                    er.gmax = 0u;
+                    e_out[m] = er;
+                }
+                if (r_keep != kRowNone) {
+                    float dead_cells[B];
+#pragma unroll
+                    for (int k = 0; k < B; k++) dead_cells[k] = kDead;
+                    if (!(r_keep & kRowSpilled)) {
+                        if (!((slot_dead >> r_keep) & 1u)) {
+                            unsigned char *myslot = ring + (size_t)r_keep * kSlotBytes;
+                            store_slot<B>(reinterpret_cast<float *>(myslot), lane, dead_cells);
+                            store_slot<B>(reinterpret_cast<float *>(myslot + kValBytes), lane, dead_cells);
+                            if (lane0) *reinterpret_cast<float *>(myslot + 2 * kValBytes) = kDead;
+                            slot_dead |= 1u << r_keep;
+                        }
+                    } else {
+                        float *row = spill + (size_t)(r_keep & ~kRowSpilled) * (2 * Lp);
+                        store_cells<B>(row + s0, dead_cells);
+                        store_cells<B>(row + Lp + s0, dead_cells);
+                    }
+                }
+                if (!prev_dead) {
+#pragma unroll
+                    for (int i = 0; i < B / 4; i++) prev_v.v[i] = prev_g.v[i] = typename Cells<B>::V{kDead, kDead, kDead, kDead};
+                    prev_dead = true;
+                }
+                prev_edge_val = kDead;
+                if (is_sink) {  // (end-cell search: a dead cell never wins it; sinks[0] is where it starts)
+                    if (!sk_any) {
+                        snk0 = m;
+                        if (strip == strip_last) lc_snk0 = kDead;
+                    }
+                    sk_any = true;
+                }
+                if constexpr (DBG) {
+                    if (qi == 0) {
+                        float dead_cells[B];
+#pragma unroll
+                        for (int k = 0; k < B; k++) dead_cells[k] = kDead;
+                        store_cells<B>(dbg_value + (size_t)m * Lp + s0, dead_cells);
+                    }
+                }
+                dead_hist = (dead_hist << 1) | 1ull;
+                cur = nrec;
+                nxt = nrec2;
+                cur_edge = nedge;
+                pe_valid = false;
+                continue;
+            }
+            ++rows_strip;
+            if (!pe_valid) {  // (the row before was skipped: my predecessor entries were not fetched ahead)
+                cur_pe = sload16(pred_addr + (uint64_t)r_pb * 4);
+                sload_wait(cur_pe);
+            }
+            cur_rg = rgain[m];
+        }
 
         // ---- match / mismatch score of my cells against this row: comp() = (row mask & query mask) != 0
         // (aligned_base.h:153), one class test per set bit of the row's mask (an empty mask: NaN, in no class mask)
@@ -1357,6 +1502,18 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
 
         sload_wait(npe);
         if (have_left_strip) sload_wait(nedge);
+        // ---- row skip: is any cell of this row (of this strip) at or below its bound?  Per lane the smallest of
+        // its cells against the bound of its first one (the largest: bounds fall by a per column), capped by U + R(m)
+        float Bm_f = 0.f;
+        bool row_dead = false;
+        if constexpr (PRUNE) {
+            Bm_f = (float)(U64 + (int32_t)cur_rg) * kPruneUnit;
+            float lm = fv[0];
+#pragma unroll
+            for (int k = 1; k + 1 < B; k += 2) lm = min3_raw(lm, fv[k], fv[k + 1]);
+            if constexpr (B % 2 == 0) lm = min2_raw(lm, fv[B - 1]);
+            row_dead = !any_lane(lm <= min2_raw(A_lane, Bm_f)) && (edge_dead || !have_left_strip);
+        }
         // ---- publish: edge record for the strip to my right, the row for its successors
         if (lane == 63 && have_right_strip) {
             EdgeRec er;
@@ -1364,6 +1521,8 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             er.xv = ex_v;
             er.xe = ex_e ? 0x80000000u : 0u;
             er.gmax = 0u;
+            // (row skip: is my last cell -- what the next strip's first column starts from -- at or below ITS bound)
+            if constexpr (PRUNE) er.gmax = (fv[B - 1] <= min2_raw(A_lane - (float)((B - 1) * (int32_t)prune_amax) * kPruneUnit, Bm_f)) ? 1u : 0u;
             e_out[m] = er;
         }
         if (r_keep != kRowNone) {
@@ -1372,6 +1531,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                 store_slot<B>(reinterpret_cast<float *>(myslot), lane, fv);
                 store_slot<B>(reinterpret_cast<float *>(myslot + kValBytes), lane, gm);
                 if (lane0 && have_left_strip) *reinterpret_cast<float *>(myslot + 2 * kValBytes) = edge_val;
+                if constexpr (PRUNE) slot_dead &= ~(1u << r_keep);
             } else {
                 float *row = spill + (size_t)(r_keep & ~kRowSpilled) * (2 * Lp);
                 store_cells<B>(row + s0, fv);
@@ -1444,6 +1604,12 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             prev_g.v[i] = typename Cells<B>::V{gm[4 * i], gm[4 * i + 1], gm[4 * i + 2], gm[4 * i + 3]};
         }
         prev_edge_val = edge_val;
+        if constexpr (PRUNE) {
+            nxt = nrec2;
+            pe_valid = true;
+            prev_dead = false;
+            dead_hist = (dead_hist << 1) | (row_dead ? 1ull : 0ull);
+        }
     }
     if (sk_any && (!all_any || sk_min < all_min || (sk_min == all_min && sk_m < all_m))) {
         all_min = sk_min;
@@ -1451,6 +1617,10 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         all_s = sk_s;
     }
     all_any = all_any || sk_any;
+    if constexpr (PRUNE) {
+        rows_done += rows_strip;
+        cells_done += rows_strip * min((uint32_t)kStrip, L - strip * (uint32_t)kStrip);
+    }
     // my edge records and spill rows must have left this CU before the next strip reads them back
     // (through the scalar cache, whose lines of this query's records -- none can be cached yet, the
     // region is 64-byte aligned and read by this wave only -- are dropped for good measure)
@@ -1459,17 +1629,12 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         __builtin_amdgcn_s_dcache_inv();
     }
     }  // strips
-    SH_PROF_FLUSH
-#ifdef SH_PROF_TIMERS
-    if (lane == 0 && blockIdx.x < 16384) g_dp_span[2 * blockIdx.x + 1] = wall_clock64();
-#endif
 
-    const float v1min = __shfl(lc_min, lane_last);
-    const float v_snk0 = __shfl(lc_snk0, lane_last);
-    const uint32_t v1arg = __shfl(lc_arg, lane_last);
-    if (lane == 0) {
-        DpResult r;
-        r.status = 0;
+    {   // the end cell (every lane: the certificate below is the wave's decision)
+        const float v1min = __shfl(lc_min, lane_last);
+        const float v_snk0 = __shfl(lc_snk0, lane_last);
+        const uint32_t v1arg = __shfl(lc_arg, lane_last);
+        res_status = 0;
         uint32_t em = snk0, es = L - 1;
         float ev = v_snk0;
         if (v1min < v_snk0) {
@@ -1481,10 +1646,45 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             es = all_s;
             ev = all_min;
         }
-        if (!all_any) r.status = -2;
-        r.end_m = em;
-        r.end_s = es;
-        r.raw = ev;
+        if (!all_any) res_status = -2;
+        res_m = uniform(em);
+        res_s = uniform(es);
+        res_v = __uint_as_float(uniform(__float_as_uint(ev)));
+    }
+    if constexpr (!PRUNE) break;
+    // ---- the certificate: an end cell at or below U is the full sweep's, and so is its path
+    if (res_status != 0 || res_v <= U_f) break;
+    // not certified: sweep again.  What attempt 1 found under too tight a bound is still the cost of a path (or
+    // kDead-ish if everything was cut off): the optimum is at most that -- and if some quirk of the recurrence
+    // (mesh.h:340: a gap is only extended where it IS the cell's value) makes even that wrong, attempt 2's own
+    // certificate fails and attempt 3 sweeps everything.
+    if (attempt == 1 && res_v < 100000.0f) {  // (beyond that the units leave float32's exact integers: sweep in full)
+        const float up = res_v * 64.0f;
+        int32_t u = (int32_t)up;
+        if ((float)u < up) u++;
+        U64 = u;
+    } else {
+        U64 = kNoBound;
+    }
+    // (the edge records of this attempt's last strip boundary are rewritten before they are read again; the
+    // scalar cache may still hold lines of them: dropped at the end of every strip that has a right neighbour)
+    }  // attempts
+    SH_PROF_FLUSH
+#ifdef SH_PROF_TIMERS
+    if (lane == 0 && blockIdx.x < 16384) g_dp_span[2 * blockIdx.x + 1] = wall_clock64();
+#endif
+    if (lane == 0) {
+        DpResult r;
+        r.status = res_status;
+        r.end_m = res_m;
+        r.end_s = res_s;
+        r.raw = res_v;
+        r.rows_done = PRUNE ? rows_done : 0u;
+        r.cells_done = PRUNE ? cells_done : 0u;
+        r.attempts = PRUNE ? attempt : 0u;
+        r.gain0 = gain0;
+        r.ubound = PRUNE ? (U64 == kNoBound ? __builtin_inff() : (float)U64 * kPruneUnit) : __builtin_inff();
+        r.pad_ = 0u;
         resv[qi] = r;
     }
 }
@@ -1829,10 +2029,15 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
     // configuration): the specialised kernel; SINA_HIP_DP_GENERIC=1 keeps the generic one (parity tests)
     static const bool generic_only = getenv("SINA_HIP_DP_GENERIC") != nullptr && atoi(getenv("SINA_HIP_DP_GENERIC")) != 0;
     if (!weighted && !forbid && a.below_init && a.gp >= a.gpe && !generic_only && a.prof16 == nullptr) {
-        auto kfn = a.dbg_value ? mesh_dp_simple_kernel<B, true> : mesh_dp_simple_kernel<B, false>;
+        // (certified row skip: launches of two strips or more -- in a single strip column 0, where an alignment may
+        // start at any row for free, keeps every row in play)
+        const bool prune = a.prune && a.rgain != nullptr && n_strips >= 2;
+        auto kfn = prune ? (a.dbg_value ? mesh_dp_simple_kernel<B, true, true> : mesh_dp_simple_kernel<B, false, true>)
+                         : (a.dbg_value ? mesh_dp_simple_kernel<B, true, false> : mesh_dp_simple_kernel<B, false, false>);
         if (allow_full_lds(reinterpret_cast<const void *>(kfn))) return 1;
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.qmask, a.tb, a.dbg_value, a.spill,
-                           a.edge, a.edge_stride, n_strips, a.res, a.ms, a.mms, a.gp, a.gpe, a.dry);
+                           a.edge, a.edge_stride, n_strips, a.res, a.ms, a.mms, a.gp, a.gpe, a.dry, a.rgain, a.prune_rho,
+                           a.prune_amax);
     } else if (!weighted && !forbid && a.below_init) SH_LAUNCH(false, false, true);
     else if (!weighted && !forbid) SH_LAUNCH(false, false, false);
     else if (weighted && !forbid) SH_LAUNCH(true, false, false);

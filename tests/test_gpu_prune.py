@@ -1,0 +1,151 @@
+"""GPU parity of the DP kernel's certified row skip (mesh_dp.hip PRUNE): whatever bound a launch
+guesses, (a) every cell whose reference value is at or below the bound the kernel ended up using is the reference's
+bit for bit -- value, value_midx, value_sidx -- and every other cell is above its bound, (b) the finished alignments
+are the oracle's, (c) a guess that is too bold is caught by the certificate and the query is swept again."""
+import numpy as np
+import pytest
+
+from sina_amd import capi, pipeline, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _bound_plane(info, rg, N, L):
+    """T(m, s) = U + min(a * (L-1-s), R(m)) in units of 1/64, as float64 (common.h, "the bound")."""
+    a = float(info["prune_step"])
+    rem = a * (L - 1 - np.arange(L, dtype=np.float64))
+    t = np.minimum(rem[None, :], rg.astype(np.float64)[:, None]) / 64.0
+    return info["ubound"] + t
+
+
+def _check_planes(ctx, cells, vm, vs, val):
+    N, L = val.shape
+    info = ctx.dp_info(0)
+    assert info["attempts"] >= 1, "the launch did not go through the skipping kernel"
+    if np.isinf(info["ubound"]):     # third attempt: swept in full
+        alive = np.ones((N, L), bool)
+    else:
+        T = _bound_plane(info, ctx.rgain(N), N, L)
+        alive = cells["value"].astype(np.float64) <= T
+        assert (val[~alive].astype(np.float64) > T[~alive]).all(), "a cell the reference has above its bound came out at or below it"
+    assert (util.f32_bits(val)[alive] == util.f32_bits(cells["value"])[alive]).all()
+    assert (vm[alive] == cells["value_midx"][alive]).all()
+    assert (vs[alive] == cells["value_sidx"][alive]).all()
+    return info, alive
+
+
+SIMPLE_CASES = [i for i, c in enumerate(util.MESH_CASES)
+                if not c["scheme"]["weighted"] and not c["scheme"]["forbid"] and c["scheme"]["gap"] >= c["scheme"]["gapext"]]
+
+
+@pytest.mark.parametrize("rho", [None, "0.3", "0.9", "0.98", "2"])
+def test_row_skip_planes_equal_oracle_at_or_below_the_bound(oracle, gpu_ctx, monkeypatch, rho):
+    """The reference-parts mesh cases of the simple scheme (families of 1..41, fs-weight 0 / 1 / 2.5, one full
+    16S family) under forced multi-strip geometries, with the launch's guess left to the library (None) or
+    forced: timid (0.3), plausible (0.9), bold (0.98) and impossible (2: no path gains twice the bound -- every
+    query fails its first certificate and is swept again under the bound the first attempt found)."""
+    if rho is not None:
+        monkeypatch.setenv("SINA_HIP_DP_PRUNE_RHO", rho)
+    n_skipping = n_second = 0
+    for ci in SIMPLE_CASES:
+        case = util.MESH_CASES[ci]
+        fam, qa, width, w, sch = util.mesh_case_inputs(case)
+        cs = [oracle.Cseq.from_packed("f%d" % i, a, width) for i, a in enumerate(fam)]
+        q = oracle.Cseq.from_packed("q", qa, len(qa))
+        opts = oracle.align_opts(match_score=sch["match"], mismatch_score=sch["mismatch"], gap_penalty=sch["gap"],
+                                 gap_ext_penalty=sch["gapext"], fs_weight=sch["fs_weight"])
+        cells = oracle.mesh_compute(cs, q, opts, weight=sch["fs_weight"])
+        g = util.graph_dict(cs, sch["fs_weight"])
+        L = len(qa)
+        geoms = [None] if L > 1000 else ["%d,4" % (64 * ((L + 255) // 256 + (ci % 2))), "%d,8" % (64 * ((L + 511) // 512 + 1))]
+        for geom in geoms:
+            if geom:
+                monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+            else:
+                monkeypatch.delenv("SINA_HIP_DP_GEOM", raising=False)
+            if geom and int(geom.split(",")[0]) < 128:
+                continue   # (a single strip: the kernel does not skip)
+            gb = gpu_ctx.graph_batch([g], width)
+            p = gpu_ctx.params(match_score=sch["match"], mismatch_score=sch["mismatch"], gap_penalty=sch["gap"],
+                               gap_ext_penalty=sch["gapext"], fs_weight=sch["fs_weight"])
+            vm, vs, val = gpu_ctx.debug_mesh(gb, (qa >> 24).astype(np.uint8), p, prune=True)
+            info, alive = _check_planes(gpu_ctx, cells, vm, vs, val)
+            n_second += info["attempts"] >= 2
+            strips = (L - 1) // (64 * int((geom or "192,8").split(",")[1])) + 1
+            n_skipping += info["rows_swept"] < strips * g["n"] * info["attempts"]
+            # the end cell and its value are the oracle's
+            want = oracle.align(cs, q, oracle.align_opts(match_score=sch["match"], mismatch_score=sch["mismatch"],
+                                                         gap_penalty=sch["gap"], gap_ext_penalty=sch["gapext"],
+                                                         fs_weight=sch["fs_weight"], realign=1))
+            if want["status"] == 0:
+                assert info["status"] == 0
+    if rho == "2":
+        assert n_second >= len(SIMPLE_CASES)        # every launch was caught by its certificate
+    if rho in (None, "0.9"):
+        assert n_skipping >= 3                        # ... and rows are actually skipped
+
+
+@pytest.mark.parametrize("rho", [None, "0.5", "0.97", "3"])
+def test_row_skip_pipeline_equals_oracle(oracle, monkeypatch, rho):
+    """Full-length 16S queries end to end (device DAG build with its column bound, three-strip DP, walk, assembly)
+    with the guess left alone or forced: family, alignment, head / tail / quality, log text equal the oracle's;
+    rows are skipped; a bold guess costs second attempts, never a different result."""
+    if rho is not None:
+        monkeypatch.setenv("SINA_HIP_DP_PRUNE_RHO", rho)
+    refs = synth.make_refs(3000, length=1500, width=50000, seed=52)
+    qs = synth.make_queries(refs, 24, seed=53)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    st = pipeline.Store(":mem:prune%s" % rho, refs)
+    try:
+        st.build_index(10, False)
+        pl = pipeline.Pipeline(st)
+        pl.run(qs.mask, qs.off, batch=24, inflight=1)
+        n_dp = 0
+        for qi in range(qs.n):
+            q = util.query_cseq(qs, qi, upper=False)
+            ids, sc, fflog = idx.famfinder(q, oracle.ff_opts())
+            want = oracle.align([cs[i] for i in ids], q, oracle.align_opts())
+            got = pl.result(qi)
+            assert got["status"] == want["status"], (qi, got["log"], want["log"])
+            assert (got["packed"] == want["packed"]).all(), qi
+            assert (got["head"], got["tail"], got["qual"]) == (want["head"], want["tail"], want["qual"])
+            if want["status"] == 0:
+                assert got["log"] == fflog + want["log"]
+                n_dp += 1
+        assert n_dp >= 20
+        s = st.stats()
+        assert s["dp_queries_pruned"] >= n_dp
+        assert s["dp_rows_swept"] > 0 and s["dp_cells_swept"] > 0
+        if rho == "3":
+            assert s["dp_second_attempts"] >= n_dp
+        elif rho != "0.97":     # (bold: many of these queries pay a second attempt)
+            assert s["dp_rows_swept"] < 0.75 * s["dp_rows"]
+        if rho is None:
+            assert s["dp_second_attempts"] + s["dp_full_sweeps"] <= n_dp // 4
+        pl.close()
+    finally:
+        st.close()
+
+
+def test_device_column_bound_covers_every_path(oracle, gpu_ctx):
+    """The bound R(m) the device DAG build emits: for every edge p -> m of the DAG, R(p) >= gain(m) + R(m), gain(m)
+    at least 64 * 2 * weight(m) + 1 units -- what the skip's induction needs (common.h)."""
+    refs = synth.make_refs(300, length=600, width=6000, seed=91, long_del_prob=0.4)
+    ctx = capi.Context(0)
+    try:
+        ctx.upload_refs(refs.ab, refs.off, refs.width)
+        rng = np.random.default_rng(92)
+        for F in (1, 7, 40):
+            ids = rng.choice(refs.n, size=F, replace=False).astype(np.uint32)
+            g = ctx.debug_family_graph(ids, fs_weight=1.0)
+            rg = ctx.rgain(g["n"]).astype(np.int64)
+            gain = np.ceil(64.0 * 2.0 * g["weight"].astype(np.float64)) + 1
+            for m in range(g["n"]):
+                for p in g["pred"][g["pred_off"][m]:g["pred_off"][m + 1]]:
+                    assert rg[p] >= gain[m] + rg[m], (F, m, p)
+            assert (np.diff(rg) <= 0).all()      # ids ascend with the column
+            assert rg[-1] == 0
+    finally:
+        ctx.close()

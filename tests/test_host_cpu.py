@@ -25,7 +25,7 @@ def test_abi_library_exports_every_declared_symbol():
     L = capi.load()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.sina_hip_abi_version() == 3
+    assert L.sina_hip_abi_version() == 4
 
 
 def test_abi_rejects_bad_arguments_without_gpu():
@@ -204,13 +204,15 @@ def test_dp_kernels_have_no_inflight_scalar_load_reads(tmp_path):
     out = str(tmp_path / "mesh_dp.s")
     subprocess.run(["make", "-C", src, "isa", "B=" + str(tmp_path)], check=True, capture_output=True, timeout=900)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_inflight_spills.py"), out,
-                        "mesh_dp_simple_kernelILi8ELb0E", "mesh_dp_kernelILi8ELb1ELb1ELb0ELb0E",
+                        "mesh_dp_simple_kernelILi8ELb0ELb0E", "mesh_dp_simple_kernelILi8ELb0ELb1E",
+                        "mesh_dp_kernelILi8ELb1ELb1ELb0ELb0E",
                         "mesh_dp_kernelILi12ELb0ELb1ELb0ELb0E"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
-    m = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_mix.py"), out, "simple,8,0"],
+    m = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_mix.py"), out, "simple,8,0,0", "simple,8,0,1"],
                        capture_output=True, text=True)
-    assert m.returncode == 0 and "mesh_dp_simple_kernel<8,0> row loop" in m.stdout, m.stdout + m.stderr
+    assert m.returncode == 0 and "mesh_dp_simple_kernel<8,0,0> row loop" in m.stdout, m.stdout + m.stderr
+    assert "mesh_dp_simple_kernel<8,0,1> row loop" in m.stdout, m.stdout + m.stderr
 
 
 def test_fasta_gzip_in_and_out(tmp_path):

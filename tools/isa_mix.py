@@ -30,8 +30,8 @@ def kernels(lines):
             m = re.search(r"mesh_dp_kernelILi(\d+)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", l)
             start = (tuple(int(x) for x in m.groups()), i)
         elif l.startswith("_ZN") and "mesh_dp_simple_kernel" in l and ":" in l:
-            m = re.search(r"mesh_dp_simple_kernelILi(\d+)ELb(\d)E", l)
-            start = (("simple", int(m.group(1)), int(m.group(2))), i)
+            m = re.search(r"mesh_dp_simple_kernelILi(\d+)ELb(\d)ELb(\d)E", l)
+            start = (("simple", int(m.group(1)), int(m.group(2)), int(m.group(3))), i)
         elif start and l.strip().startswith("s_endpgm"):
             out.append((start[0], start[1], i))
             start = None
@@ -118,7 +118,7 @@ def main():
     for var, a, b in kernels(lines):
         if want and var not in want:
             continue
-        if not want and var[-1]:
+        if not want and (var[2] if var[0] == "simple" else var[-1]):  # (debug-plane variants)
             continue
         ins = instrs(lines, a, b)
         la, lb = find_row_loop(ins)
@@ -134,7 +134,7 @@ def main():
             mm = re.match(r"; (NumVgprs|NumSgprs|SGPRSpill|ScratchSize|Occupancy|sgpr_spill_count): (\d+)", l.strip())
             if mm:
                 meta.setdefault(mm.group(1), mm.group(2))
-        name = "mesh_dp_simple_kernel<%d,%d>" % var[1:] if var[0] == "simple" else "mesh_dp_kernel<%d,%d,%d,%d,%d>" % var
+        name = "mesh_dp_simple_kernel<%d,%d,%d>" % var[1:] if var[0] == "simple" else "mesh_dp_kernel<%d,%d,%d,%d,%d>" % var
         print("%s row loop: %d instructions   [VGPRs %s, waves/SIMD %s, scratch %s]" % (
             name, n, meta.get("NumVgprs"), meta.get("Occupancy"), meta.get("ScratchSize")))
         print("  VALU %d (arith %d, v_mov %d = vgpr %d + sgpr %d + const %d, dpp moves %d)  lane ops %d (spill traffic %d)" % (
