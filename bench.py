@@ -430,31 +430,36 @@ def main():
     # kernel trace's "average duration" multiplies out to; it counts every overlap twice.
     dp_ms_sum = s1["dp_ms"] - s0["dp_ms"]
     dp_ms = s1["dp_busy_ms"] - s0["dp_busy_ms"]
-    dp_cells = s1["dp_cells"] - s0["dp_cells"]
+    dp_cells = s1["dp_cells"] - s0["dp_cells"]            # nominal: N x L of every query (what the reference fills)
     dp_launches = s1["dp_launches"] - s0["dp_launches"]
-    achieved = DP_BYTES_PER_CELL * dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+    # The DP kernel skips rows of a strip that provably cannot hold a cell of the optimal path (certified: csrc/mesh_dp.hip
+    # PRUNE): the roofline is priced on the cells it actually COMPUTED -- a failed certificate's second
+    # sweep included --, the nominal count is reported beside it.
+    dp_cells_swept = s1["dp_cells_swept"] - s0["dp_cells_swept"]
+    dp_rows, dp_rows_swept = s1["dp_rows"] - s0["dp_rows"], s1["dp_rows_swept"] - s0["dp_rows_swept"]
+    achieved = DP_BYTES_PER_CELL * dp_cells_swept / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
 
     # HBM bytes per DP launch from the PMC passes of this same command (tools/prof_bench.sh ->
-    # profiles/r04_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), and the DP kernel's VALU
-    # wave-instructions per cell from its SQ pass (tools/prof_dp_pmc.sh -> profiles/r04_dp_valu.json);
+    # profiles/r05_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), and the DP kernel's VALU
+    # wave-instructions per COMPUTED cell from its SQ pass (tools/prof_dp_pmc.sh -> profiles/r05_dp_valu.json);
     # both only if they were recorded on this kernel source revision, else null
     dp_kernel_name = "mesh_dp_simple_kernel"  # (SINA defaults: simple scheme, gap_open >= gap_extend; mesh_dp.hip)
     dp_traffic, traffic_note = None, "no PMC profile recorded for this kernel source + configuration"
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic.json")))
         meta = tj.get("_meta", {})
         if (meta.get("kernel_source_rev") == kernel_source_rev() and meta.get("batch") == a.batch and
                 meta.get("sub_batch") == a.sub_batch and meta.get("refs") == a.refs and
                 meta.get("length") == a.length and meta.get("window") == a.window):
             dp_traffic = tj[dp_kernel_name]["hbm_bytes"]
             traffic_note = ("HBM bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from the separate "
-                            "--pmc passes of this same command recorded in profiles/r04_traffic.json (same kernel "
+                            "--pmc passes of this same command recorded in profiles/r05_traffic.json (same kernel "
                             "source revision and configuration as this run; not measured by this run)")
     except Exception:
         pass
     valu_per_cell = None
     try:
-        vj = json.load(open(os.path.join(ROOT, "profiles", "r04_dp_valu.json")))
+        vj = json.load(open(os.path.join(ROOT, "profiles", "r05_dp_valu.json")))
         if vj.get("kernel_source_rev") == kernel_source_rev():
             valu_per_cell = float(vj["valu_wave_instructions_per_cell"])
     except Exception:
@@ -524,14 +529,31 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": dp_traffic,
                 "traffic_unit": traffic_note,
-                "algorithmic_bytes_per_launch": DP_BYTES_PER_CELL * dp_cells / dp_launches if dp_launches else 0,
-                "cells_per_launch": dp_cells / dp_launches if dp_launches else 0,
+                "algorithmic_bytes_per_launch": DP_BYTES_PER_CELL * dp_cells_swept / dp_launches if dp_launches else 0,
+                "cells_computed_per_launch": dp_cells_swept / dp_launches if dp_launches else 0,
+                "cells_nominal_per_launch": dp_cells / dp_launches if dp_launches else 0,
+                "cells_computed_frac": dp_cells_swept / dp_cells if dp_cells else 0.0,
+                "wave_rows_computed_frac": dp_rows_swept / dp_rows if dp_rows else 0.0,
                 "ms_per_launch": dp_ms / dp_launches if dp_launches else 0,
                 "ms_per_launch_start_to_end": dp_ms_sum / dp_launches if dp_launches else 0,
-                "frac_by_start_to_end": (DP_BYTES_PER_CELL * dp_cells / (dp_ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS
+                "frac_by_start_to_end": (DP_BYTES_PER_CELL * dp_cells_swept / (dp_ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS
                                          if dp_ms_sum > 0 else 0.0),
-                "gcells_per_s": dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0,
-                "note": "contractual accounting (SURVEY 8d): 8 algorithmic bytes per mesh cell against the HBM peak; "
+                "gcells_per_s": dp_cells_swept / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0,
+                "gcells_per_s_nominal": dp_cells / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0,
+                "row_skip": {
+                    "queries": s1["dp_queries_pruned"] - s0["dp_queries_pruned"],
+                    "second_attempts": s1["dp_second_attempts"] - s0["dp_second_attempts"],
+                    "full_sweeps": s1["dp_full_sweeps"] - s0["dp_full_sweeps"],
+                    "guess_rho": s1["dp_prune_rho"],
+                    "what": "certified-exact: a (row, 512-column strip) is swept only if a cell in it can still lie on a "
+                            "path ending at or below the query's bound U (value <= U + bound on the gain still to come); "
+                            "certificate: the end cell found has value <= U, else the query is swept again (second_attempts: "
+                            "under the bound the first attempt found; full_sweeps: without one).  cells_computed counts "
+                            "every sweep; results are bit-identical to the full sweep (tests/test_gpu_prune.py, verify)",
+                },
+                "note": "contractual accounting (SURVEY 8d): 8 algorithmic bytes per COMPUTED mesh cell against the HBM peak "
+                        "(cells_nominal = N x L of every query, what the reference fills, is reported beside it and is NOT "
+                        "what achieved / frac are priced on); "
                         "the kernel writes 2 B per cell and is bound by VALU issue, see roofline_valu.  Timed "
                         "region: HIP events around every launch on the FIFO streams it runs on.  Launches are chained: "
                         "a DP launch starts when the one before it has DISPATCHED its last workgroup, so two DP "
@@ -541,10 +563,11 @@ def main():
                         "trace's average duration gives; tools/kt_union.py on the committed trace gives both); "
                         "`isolated` = one extra untimed step with a single batch in flight, nothing overlapping",
                 "isolated": {
-                    "achieved": DP_BYTES_PER_CELL * iso["dp_cells"] / (iso["dp_ms"] * 1e-3) / 1e9,
-                    "frac": DP_BYTES_PER_CELL * iso["dp_cells"] / (iso["dp_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "achieved": DP_BYTES_PER_CELL * iso["dp_cells_swept"] / (iso["dp_ms"] * 1e-3) / 1e9,
+                    "frac": DP_BYTES_PER_CELL * iso["dp_cells_swept"] / (iso["dp_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "ms_per_launch": iso["dp_ms"] / max(1, iso["dp_launches"]),
-                    "gcells_per_s": iso["dp_cells"] / (iso["dp_ms"] * 1e-3) / 1e9,
+                    "gcells_per_s": iso["dp_cells_swept"] / (iso["dp_ms"] * 1e-3) / 1e9,
+                    "gcells_per_s_nominal": iso["dp_cells"] / (iso["dp_ms"] * 1e-3) / 1e9,
                 },
             },
             # what actually binds the kernel: VALU wave-instructions (SQ_INSTS_VALU of the same kernel source,
@@ -552,10 +575,10 @@ def main():
             "roofline_valu": None if valu_per_cell is None or dp_ms <= 0 else {
                 "kernel": dp_kernel_name,
                 "bound": "valu",
-                "achieved": valu_per_cell * dp_cells / (dp_ms * 1e-3) / 1e12,
+                "achieved": valu_per_cell * dp_cells_swept / (dp_ms * 1e-3) / 1e12,
                 "peak": 1024 * 2.4e9 / 2 / 1e12,
                 "unit": "T wave-instructions/s",
-                "frac": valu_per_cell * dp_cells / (dp_ms * 1e-3) / (1024 * 2.4e9 / 2),
+                "frac": valu_per_cell * dp_cells_swept / (dp_ms * 1e-3) / (1024 * 2.4e9 / 2),
                 "valu_wave_instructions_per_cell": valu_per_cell,
                 "note": "SQ_INSTS_VALU per launch / cells per launch of the DP kernel alone (tools/prof_dp_pmc.sh), "
                         "x this run's cells; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave-instruction "

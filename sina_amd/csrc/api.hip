@@ -58,7 +58,7 @@ PrunePlan prune_plan(const sina_hip_align_params *p, float wmax, float wmin, uin
 struct HostPrep {
     std::vector<QDesc> qd;
     std::vector<uint4> rec;
-    std::vector<uint32_t> rgain;  // the DP kernel's row-skip bound per node (common.h), filled when kappa64 > 0
+    std::vector<uint2> rgain;     // the DP kernel's row-skip bound per node + its last successor (common.h), filled when kappa64 > 0
     bool rgain_ok = true;         // ... and valid: every DAG of the range is laid out by columns
     float wmax = 0.f, wmin = 0.f; // node weights of the range
     std::vector<uint32_t> pred;  // id | (LDS slot or spill row) << 16 | spilled << 31 (what mesh_dp_kernel reads)
@@ -72,7 +72,7 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
     const uint64_t nn = g->node_off[q1] - nbase;
     hp->qd.resize(q1 - q0);
     hp->rec.resize(nn);
-    hp->rgain.assign(kappa64 > 0.f ? nn : 0, 0u);
+    hp->rgain.assign(kappa64 > 0.f ? nn : 0, uint2{0u, 0u});
     hp->rgain_ok = true;
     hp->pred.resize(g->edge_off[q1] - ebase + 8);
     hp->tb_cells = hp->spill_rows = hp->cells = 0;
@@ -116,6 +116,13 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
                 if (m - p > (uint32_t)kFarLds) rec[p].z |= kRecFence;
             }
         }
+        d.first_sink = 0;
+        d.pad_ = 0;
+        for (uint32_t m = 0; m < N; m++)
+            if (rec[m].z & kRecSink) {
+                d.first_sink = m;
+                break;
+            }
         // LDS slots by liveness, first free slot wins; a row that finds none is spilled.  Rows are
         // allocated in independent segments (dp_slot_segment, common.h), like the device DAG build does.
         uint32_t nsp = 0;
@@ -160,7 +167,7 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
         // mseq's -- columns ascend with the node ids, every edge leads to a column further right --, which a caller's
         // arrays need not be: checked here, and a launch holding a DAG that is not runs without the skip.
         if (kappa64 > 0.f) {
-            uint32_t *rg = hp->rgain.data() + d.node_off;
+            uint2 *rg = hp->rgain.data() + d.node_off;
             const uint32_t *pos = g->node_pos + no;
             bool ok = true;
             for (uint32_t m = 0; m < N && ok; m++) {
@@ -175,7 +182,7 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
                 while (first > 0 && pos[first - 1] == pos[m - 1]) first--;
                 for (uint32_t j = first; j < m; j++) {
                     mx = std::max(mx, prune_gain_units(g->node_weight[no + j], kappa64));
-                    rg[j] = right;
+                    rg[j] = uint2{right, last[j]};
                 }
                 right += mx;
                 m = first;
@@ -215,6 +222,8 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         c->out_pos.reserve(4 * std::max<uint64_t>(nqm, 1)))
         return 1;
     if (want_dbg_value && c->dbg.reserve(4 * tb_cells)) return 1;
+    // (rows the kernel never visits show the value a skipped row shows its successors)
+    if (want_dbg_value && pp.on) SH_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->dbg.p), 0x49742400 /* 1e6f */, tb_cells, s));
     // (debug read-back of the planes: rows the kernel skips leave their trace-back cells unwritten -- "untouched cell"
     // everywhere first, so that unpacking them stays inside the DAG)
     if (c->dbg_planes && !forbid) SH_CHECK(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(plane.ptr), (unsigned short)kTbNone, tb_cells, s));
@@ -252,7 +261,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     // from the queries before, or SINA_HIP_DP_PRUNE_RHO
     c->last_bq = bq;
     c->last_prune_step = pp.on ? pp.amax : 0u;
-    a.rgain = pp.on ? c->rgain.as<uint32_t>() : nullptr;
+    a.reach = pp.on ? c->rgain.as<uint2>() : nullptr;
     a.prune = pp.on;
     a.prune_amax = pp.amax;
     a.prune_rho = 0.f;
@@ -383,12 +392,11 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         n_full += r.attempts >= 3 ? 1 : 0;
         if (r.status == 0 && r.gain0 > 0.f && r.raw < 0.f) ratios.push_back(-r.raw / r.gain0);
     }
+    // The launch's smallest optimum / bound, less a margin: a query whose first bound fails pays a second sweep, and
+    // the launch ends with its slowest wave -- one such query among the last to start costs the whole device a sweep's
+    // time, so the guess aims at NO failures among queries like the ones seen (a wider band costs a few per cent).
     float rho_seen = -1.f;
-    if (!ratios.empty()) {  // the launch's 2nd percentile of optimum / bound, less a margin
-        const size_t k = ratios.size() / 50;
-        std::nth_element(ratios.begin(), ratios.begin() + (std::ptrdiff_t)k, ratios.end());
-        rho_seen = ratios[k] - 0.01f;
-    }
+    if (!ratios.empty()) rho_seen = *std::min_element(ratios.begin(), ratios.end()) - 0.015f;
     std::lock_guard<std::mutex> slk(c->st->stats_mu);
     c->st->stats.dp_ms += ms;
     c->st->stats.dp_busy_ms += ms - shared;
@@ -500,7 +508,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         const uint64_t qbase = qoff[q0], nqm = qoff[q1] - qbase;
         if (c->qd.reserve(sizeof(QDesc) * bq) || c->rec.reserve(sizeof(uint4) * nn) || c->node_pos.reserve(4 * nn) ||
             c->pred.reserve(4 * std::max<uint64_t>(ne, 1)) || c->succ_minpos.reserve(4 * nn) ||
-            c->qmask.reserve(nqm) || (pp.on && c->rgain.reserve(4 * nn)))
+            c->qmask.reserve(nqm) || (pp.on && c->rgain.reserve(8 * nn)))
             return 1;
         hipStream_t s = c->stream;
         SH_CHECK(hipMemcpyAsync(c->qd.p, hp.qd.data(), sizeof(QDesc) * bq, hipMemcpyHostToDevice, s));
@@ -512,7 +520,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask + qbase, nqm, hipMemcpyHostToDevice, s));
         PrunePlan pp_launch = pp;
         if (!hp.rgain_ok) pp_launch.on = 0;
-        if (pp.on) SH_CHECK(hipMemcpyAsync(c->rgain.p, hp.rgain.data(), 4 * nn, hipMemcpyHostToDevice, s));
+        if (pp.on) SH_CHECK(hipMemcpyAsync(c->rgain.p, hp.rgain.data(), 8 * nn, hipMemcpyHostToDevice, s));
         c->profile_batch = g->node_score16 != nullptr;
         if (c->profile_batch) {  // --fs-no-graph: the profile's match-term tables (sina_hip.h)
             if (!g->self_score16) SH_FAIL("align_graphs: node_score16 without self_score16");
@@ -808,9 +816,11 @@ int sina_hip_debug_dp_info(sina_hip_ctx *c, uint32_t q, sina_hip_dp_info *out) {
 int sina_hip_debug_rgain(sina_hip_ctx *c, uint32_t n, uint32_t *out) {
     if (!c || !out) SH_FAIL("debug_rgain: null argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    if (!c->rgain.p || c->rgain.cap < 4 * (size_t)n) SH_FAIL("debug_rgain: no bound of that many nodes on the device");
+    if (!c->rgain.p || c->rgain.cap < 8 * (size_t)n) SH_FAIL("debug_rgain: no bound of that many nodes on the device");
     SH_CHECK(hipSetDevice(c->device));
-    SH_CHECK(hipMemcpy(out, c->rgain.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<uint2> tmp(n);
+    SH_CHECK(hipMemcpy(tmp.data(), c->rgain.p, 8 * (size_t)n, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) out[i] = tmp[i].x;
     return 0;
 }
 

@@ -143,7 +143,10 @@ struct QDesc {
     uint32_t N, L;
     uint32_t n_spill;
     uint32_t erec_off;   // into a strip boundary's edge records: regions start on 64-byte lines (4 records), see EdgeRec
+    uint32_t first_sink; // sinks[0]: the row the end-cell search starts from (mesh.h:567); the row-skipping kernel may never visit it
+    uint32_t pad_;
 };
+static_assert(sizeof(QDesc) == 64, "uploaded as an array");
 
 // Row record of one DAG node, read through the scalar cache once per row:
 //   x = first predecessor (offset into this query's pred list)
@@ -294,9 +297,9 @@ struct DpArgs {
     const float *prof16;        // --fs-no-graph: match term per node and query mask [16 * node + mask], else nullptr
     DryArgs dry;                // (heavy_launch::dry(): tells the next launch when this one's queue has run dry)
     // certified row skip (mesh_dp_simple_kernel<.., PRUNE>): per node the gain still to come right of its column
-    // (units of kPruneUnit, indexed like rec), the launch's guess rho of optimum / first-cell bound, the largest
-    // gain of one step; prune == 0: every row of every strip is swept
-    const uint32_t *rgain;
+    // (units of kPruneUnit) and how far its successors reach, the launch's guess rho of optimum / first-cell
+    // bound, the largest gain of one step; prune == 0: every row of every strip is swept
+    const uint2 *reach;         // per node {R(m), id of its last successor (0: none)}, indexed like rec
     int prune;
     float prune_rho;
     uint32_t prune_amax;

@@ -47,6 +47,7 @@ namespace {
 constexpr int kGT = SINA_GRAPH_THREADS;  // threads per workgroup (the phases are latency-bound: more loads in flight per LDS byte)
 constexpr uint32_t kNoPrev = 0xFFFFu;
 constexpr int kMaxFam = 128;
+constexpr int kSz = 8;  // u32 words the kernel reports per query (GraphArgs::sizes)
 #ifndef SINA_GRAPH_KTC
 #define SINA_GRAPH_KTC 160  // (measured, 3072 families of 40: 96 -> 3.05 ms, 128 -> 2.54, 160 -> 2.40, 192 -> 3.12: a third workgroup per CU no longer fits)
 #endif
@@ -76,14 +77,14 @@ struct GraphArgs {
     uint32_t *succ_min;        // [nq][ncap]
     uint32_t *far_mark;        // [nq][ncap] last successor row of every node (0: none)
     uint32_t *pred;            // per query area of total-family-bases entries
-    uint32_t *sizes;           // [nq][4]: N, raw edge entries, n_spill, status (0 ok, 2 N cap, 4 spill rows)
+    uint32_t *sizes;           // [nq][kSz]: N, raw edge entries, n_spill, status (0 ok, 2 N cap, 4 spill rows), first sink row
     uint32_t width, ncap;
     uint32_t tile_bytes;       // LDS bytes of the tile tables (reused by the slot allocation)
     uint32_t member_off;       // LDS offset of the per-member arrays (behind the tile tables), entries each
     uint32_t member_cap;
     int W;                     // DP ring depth: edges longer than this need a spill row
     int want_smin;             // succ_min is read by somebody (--insertion=forbid, the debug entry): else it is not touched at all
-    uint32_t *rgain;           // [nq][ncap] or nullptr: the DP kernel's row-skip bound R(m) (step 9; units: common.h)
+    uint2 *reach;              // [nq][ncap] or nullptr: the DP kernel's row-skip bound R(m) (step 9; units: common.h) + last successor
     float kappa64;             // ... 64 * 1.0001 * (largest match gain per unit of node weight)
     DryArgs dry;               // (ctx.h, heavy_launch: tells the launch queued behind when the last workgroup has started)
 };
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
     // LDS as ncolT: cl8 is read for the last time in step 4, ncolT is filled after it
     uint8_t *cl8 = ncolT;
 
-    uint32_t *sz = a.sizes + 4 * (size_t)q;
+    uint32_t *sz = a.sizes + kSz * (size_t)q;
     for (uint32_t j = tid; j < F; j += kGT) {
         const uint32_t id = a.fam_ids[f0 + j];
         s_ids[j] = id;
@@ -477,11 +478,14 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
     const uint32_t n_seg = (N + seg_len - 1) / seg_len;
     uint32_t *codeL = reinterpret_cast<uint32_t *>(tile);
     const bool in_lds = (size_t)N * 4 <= a.tile_bytes;
+    if (tid == 0) s_tmp[kGT / 64 + 1] = 0xFFFFFFFFu;  // first sink row
+    __syncthreads();
     for (uint32_t i = tid; i < N; i += kGT) {
         uint32_t z = rec[i].z;
         const uint32_t l = last[i];
         if (l == 0) {  // (a successor's id is greater than its predecessor's: never 0)
             z |= kRecSink;
+            atomicMin(&s_tmp[kGT / 64 + 1], i);
             if (a.want_smin) smin[i] = 1000000u;  // "no successor" sentinel of mesh.h:480
         }
         if (l > i && l - i > (uint32_t)kFarLds) z |= kRecFence;
@@ -552,6 +556,7 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
             sz[1] = E;
             sz[2] = tot;
             sz[3] = (tot > kMaxSpillRows) ? 4u : 0u;
+            sz[4] = s_tmp[kGT / 64 + 1];
         }
     }
     __syncthreads();
@@ -580,9 +585,11 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
     // the sums are exact and do not depend on the order of the scan.  The nodes of a column have consecutive ids:
     // the thread of a column's FIRST node finds the column's maximum; an exclusive scan of "maximum at the first
     // node, 0 elsewhere" gives every column the total of the columns left of it.
-    if (a.rgain != nullptr) {
-        uint32_t *rg = a.rgain + (size_t)q * a.ncap;
-        uint32_t *cw = last;  // (`last` was read for the last time in step 7)
+    if (a.reach != nullptr) {
+        uint2 *rg = a.reach + (size_t)q * a.ncap;
+        // (scratch: nobody reads succ_min in a launch that skips rows -- want_smin is --insertion=forbid; the debug
+        // entry wants both and gets the last successors overwritten instead)
+        uint32_t *cw = a.want_smin ? last : smin;
         __syncthreads();
         for (uint32_t i = tid; i < N; i += kGT) {
             const uint32_t pos = node_pos[i];
@@ -600,7 +607,7 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
             const uint32_t pos = node_pos[i];
             if (i > 0 && node_pos[i - 1] == pos) continue;
             const uint32_t right = (i + 1 < N) ? total - cw[i + 1] : 0u;  // (cw[i + 1] = columns up to and including mine)
-            for (uint32_t j = i; j < N && node_pos[j] == pos; j++) rg[j] = right;
+            for (uint32_t j = i; j < N && node_pos[j] == pos; j++) rg[j] = uint2{right, a.want_smin ? 0u : last[j]};
         }
     }
     GP_FLUSH
@@ -628,7 +635,7 @@ namespace {
 struct BuiltGraphs {
     uint32_t ncap = 0;
     std::vector<uint64_t> pred_off;  // per query, into c->pred
-    std::vector<uint32_t> sizes;     // per query: N, raw edge entries, n_spill, status
+    std::vector<uint32_t> sizes;     // per query: kSz words -- N, raw edge entries, n_spill, status, first sink row
 };
 
 // Builds the DAGs of bq families (fam_off is absolute, first family = q0) into the context's
@@ -676,8 +683,8 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
             c->g_tmp1.reserve(8 * (uint64_t)bq) ||
             c->rec.reserve(sizeof(uint4) * (uint64_t)bq * ncap) || c->node_pos.reserve(4 * (uint64_t)bq * ncap) ||
             c->succ_minpos.reserve(4 * (uint64_t)bq * ncap) || c->g_tmp3.reserve(4 * (uint64_t)bq * ncap) ||
-            c->pred.reserve(4 * pred_total) || c->g_sizes.reserve(16 * (uint64_t)bq) ||
-            (kappa64 > 0.f && c->rgain.reserve(4 * (uint64_t)bq * ncap)))
+            c->pred.reserve(4 * pred_total) || c->g_sizes.reserve(4 * kSz * (uint64_t)bq) ||
+            (kappa64 > 0.f && c->rgain.reserve(8 * (uint64_t)bq * ncap)))
             return 1;
         if (upload(c, 1, c->g_fam_ids.p, fam_ids + fam_off[q0], 4 * foff[bq], s) ||
             upload(c, 2, c->g_fam_off.p, foff.data(), 8 * ((uint64_t)bq + 1), s) ||
@@ -703,10 +710,10 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         ga.member_cap = (uint32_t)graph_member_cap(max_f);
         ga.W = W;
         ga.want_smin = want_smin ? 1 : 0;
-        ga.rgain = kappa64 > 0.f ? c->rgain.as<uint32_t>() : nullptr;
+        ga.reach = kappa64 > 0.f ? c->rgain.as<uint2>() : nullptr;
         ga.kappa64 = kappa64;
         if (allow_full_lds(reinterpret_cast<const void *>(family_graph_kernel))) return 1;
-        bg->sizes.resize(4 * (size_t)bq);
+        bg->sizes.resize(kSz * (size_t)bq);
         {
             heavy_launch hl(c, s, kHeavyGraph);  // (a device-filling kernel: ctx.h)
             SH_CHECK(hipEventRecord(c->ev[6], hl.stream()));
@@ -722,9 +729,9 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
             if (hl.done()) return 1;
             if (getenv("SINA_HIP_DEBUG_SYNC")) fprintf(stderr, "[sina_hip] DAG build kernel done: %u families, ncap %u\n", bq, ncap);
         }
-        if (download(c, 4, c->g_sizes.p, 16 * (uint64_t)bq, s)) return 1;
+        if (download(c, 4, c->g_sizes.p, 4 * kSz * (uint64_t)bq, s)) return 1;
         SH_CHECK(wait_stream(c, s));
-        memcpy(bg->sizes.data(), c->h_stage[4].p, 16 * (uint64_t)bq);
+        memcpy(bg->sizes.data(), c->h_stage[4].p, 4 * kSz * (uint64_t)bq);
         float gms = 0;
         SH_CHECK(hipEventElapsedTime(&gms, c->ev[6], c->ev[7]));
         {
@@ -733,8 +740,8 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         }
         uint32_t need_n = 0;
         for (uint32_t q = 0; q < bq; q++) {
-            if (bg->sizes[4 * q + 3] == 2) need_n = std::max(need_n, bg->sizes[4 * q]);
-            if (bg->sizes[4 * q + 3] == 4) SH_FAIL("align_families: too many spill rows for one query");
+            if (bg->sizes[kSz * q + 3] == 2) need_n = std::max(need_n, bg->sizes[kSz * q]);
+            if (bg->sizes[kSz * q + 3] == 4) SH_FAIL("align_families: too many spill rows for one query");
         }
         if (!need_n) break;
         if (attempt >= 3 || need_n > 65535u) SH_FAIL("align_families: family DAG exceeds device limits");
@@ -866,7 +873,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
             std::vector<QDesc> qd;
             while (r1 < bq) {
                 const uint32_t u = dag_of[r1];  // (this query's DAG among the chunk's distinct ones)
-                const uint32_t N = bg.sizes[4 * u];
+                const uint32_t N = bg.sizes[kSz * u];
                 if (r1 > r0 && tbc + (uint64_t)N * Lp > tb_budget_cells) break;
                 QDesc d;
                 d.node_off = (uint64_t)u * bg.ncap;
@@ -876,7 +883,9 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
                 d.spill_off = sprows;
                 d.N = N;
                 d.L = (uint32_t)(qoff[q0 + r1 + 1] - qoff[q0 + r1]);
-                d.n_spill = bg.sizes[4 * u + 2];
+                d.n_spill = bg.sizes[kSz * u + 2];
+                d.first_sink = bg.sizes[kSz * u + 4];
+                d.pad_ = 0;
                 d.erec_off = erec_cursor;
                 erec_cursor += dp_edge_entries(N);
                 qd.push_back(d);

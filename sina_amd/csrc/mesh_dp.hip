@@ -1007,7 +1007,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                       const uint32_t *__restrict__ predv, const uint8_t *__restrict__ qmaskv, void *__restrict__ tbv,
                       float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev, uint64_t edge_stride,
                       uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe, DryArgs dry,
-                      const uint32_t *__restrict__ rgainv, float prune_rho, uint32_t prune_amax) {
+                      const uint2 *__restrict__ reachv, float prune_rho, uint32_t prune_amax) {
     static_assert(B % 4 == 0, "16-byte accesses per array");
     constexpr int kStrip = 64 * B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1043,12 +1043,14 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     // path's cost); 3: no bound.  All bounds are integers in units of 1/64 (exact in float32 below 2^24 units).
     constexpr int32_t kNoBound = 1 << 29;
     constexpr float kDead = 1000000.0f;  // what a skipped row shows its successors: the reference's own "unreached" (mesh.h:290)
-    const uint32_t *__restrict__ rgain = PRUNE ? rgainv + node_off : nullptr;
+    // per node {R(m) in units, id of its last successor (0: none)}: what a row found alive can still reach
+    const uint2 *__restrict__ reach = PRUNE ? reachv + node_off : nullptr;
+    const uint32_t first_sink = uniform(d.first_sink);
     int32_t U64 = kNoBound;
     float gain0 = 0.f;
     if constexpr (PRUNE) {
         // the whole alignment right of the first node, its own column included (<= one step's largest gain)
-        const uint32_t g_cols = uniform(rgain[0]) + prune_amax, g_len = prune_amax * (L - 1);
+        const uint32_t g_cols = uniform(reach[0].x) + prune_amax, g_len = prune_amax * (L - 1);
         const uint32_t g0 = g_cols < g_len ? g_cols : g_len;
         gain0 = (float)g0 * kPruneUnit;
         U64 = -(int32_t)uniform((uint32_t)(int32_t)(prune_rho * (float)g0));  // (rounded towards zero: the looser side)
@@ -1060,13 +1062,33 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     for (;;) {  // attempts (one without PRUNE)
     ++attempt;
     const float U_f = (float)U64 * kPruneUnit;
-    // end-cell search (mesh.h:567-592), accumulated over the strips
-    float lc_min = PRUNE ? __builtin_inff() : 0.f, lc_snk0 = 0.f;
+    // end-cell search (mesh.h:567-592), accumulated over the strips.  (PRUNE: the search starts at sinks[0], a row
+    // the wave may never visit -- its id comes with the query, its value is kDead unless it is swept)
+    float lc_min = PRUNE ? __builtin_inff() : 0.f, lc_snk0 = PRUNE ? kDead : 0.f;
     uint32_t lc_arg = 0;
     bool lc_any = false;
     float all_min = __builtin_inff();
-    uint32_t all_m = 0, all_s = 0xffffffffu, snk0 = 0;
-    bool all_any = false;
+    uint32_t all_m = 0, all_s = 0xffffffffu, snk0 = PRUNE ? first_sink : 0u;
+    bool all_any = PRUNE;  // (a DAG has a sink: its last row)
+    // Where an alignment may start for free -- column 0 of any row, any column of a row without predecessors: initial
+    // value 1 -- is above its bound U + min(a * (L-1-s), R(m)) from this row on, whatever the column: R falls with the
+    // row (graph_build.hip step 9), so it is a threshold, found once per attempt.
+    uint32_t m_free_dead = 0;
+    // rows of the strip just finished whose last cell was at or below its bound (first, last; none: first = ~0): all
+    // a later strip can start from
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    uint32_t out_first = kNone, out_last = 0;
+    if constexpr (PRUNE) {
+        if (U64 + (int32_t)(prune_amax * (L - 1)) >= 64) {
+            uint32_t lo = 0, hi = N;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (U64 + (int32_t)uniform(reach[mid].x) < 64) hi = mid;
+                else lo = mid + 1;
+            }
+            m_free_dead = lo;
+        }
+    }
 
     SH_PROF_DECL
 #ifdef SH_PROF_TIMERS
@@ -1099,63 +1121,70 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     bool sk_any = false;
 
     const uint64_t pred_addr = uniform((uint64_t)pred);
-    uint4 cur = rec[0];
+    // ---- row skip, the strip's limits.  A row of this strip can only be at or below its bound through the cell left
+    // of it (strip 0: column 0), a predecessor row, or by being a free start.  So the sweep starts at the first row
+    // the strip to the left left alive and ends -- cut, at stop_at -- once the row is past the last of those
+    // (edge_end), past every successor of every row found alive, and free starts are out of the question (their
+    // threshold row, or a strip whose first column already rules them out).
+    uint32_t m_begin = 0, edge_end = 0, stop_at = 0;
+    if constexpr (PRUNE) {
+        // (a row without predecessors below m_free_dead can be at or below its bound in this strip)
+        const bool free_starts = U64 + (int32_t)prune_amax * ((int32_t)(L - 1) - (int32_t)(strip * (uint32_t)kStrip)) >= 64;
+        if (strip == 0) {
+            edge_end = m_free_dead;
+        } else {
+            edge_end = out_first != kNone ? out_last + 1u : 0u;
+            if (!free_starts) m_begin = out_first != kNone ? out_first : N;
+        }
+        stop_at = (free_starts && m_free_dead > edge_end) ? m_free_dead : edge_end;
+        out_first = kNone;
+        out_last = 0;
+    }
+    const uint32_t jump_lo = m_begin;  // rows below were not swept in this strip: what reads one reads kDead
+    uint4 cur = rec[m_begin < N ? m_begin : 0u];
     u32x4 cur_pe = sload16(pred_addr + (uint64_t)cur.x * 4);
     u32x4 cur_edge = {0, 0, 0, 0};
-    if (have_left_strip) cur_edge = sload16(e_in);
+    if (have_left_strip) cur_edge = sload16(e_in + (uint64_t)(m_begin < N ? m_begin : 0u) * sizeof(EdgeRec));
     sload_wait(cur_pe);
     sload_wait(cur_edge);
     Cells<B> prev_v, prev_g;  // the row just finished (common.h: a row whose only successor is the next row is kept nowhere else)
-    float prev_edge_val = 0.f;
+    float prev_edge_val = (PRUNE && m_begin > 0) ? kDead : 0.f;
 #pragma unroll
-    for (int i = 0; i < B / 4; i++) prev_v.v[i] = prev_g.v[i] = typename Cells<B>::V{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < B / 4; i++) {
+        const float z = (PRUNE && m_begin > 0) ? kDead : 0.f;
+        prev_v.v[i] = prev_g.v[i] = typename Cells<B>::V{z, z, z, z};
+    }
 
     // ---- row skip, per strip: the bound of my first cell (the largest of my cells' bounds), which of the last 64
     // rows were dead in this strip (bit d-1: row m-d), which LDS slots / whether the hand-over registers already
     // show kDead, the rows swept
     float A_lane = 0.f;
-    uint64_t dead_hist = 0;
+    uint64_t dead_hist = (PRUNE && m_begin > 0) ? ~0ull : 0ull;
     uint32_t slot_dead = 0, rows_strip = 0;
-    bool prev_dead = false;
-    // strip 0: the first row whose column 0 -- initial value 1, where an alignment may start for free -- is above
-    // its bound U + min(a * (L-1), R(m)): R falls with the row (graph_build.hip step 9), so it is a threshold
-    uint32_t m_col0_dead = 0;
-    // the record of row m+1 (the skip path has no work to hide a load behind: records come two rows ahead), and
+    bool prev_dead = PRUNE && m_begin > 0;
     // whether cur_pe holds THIS row's predecessor entries (a skipped row does not fetch the next row's)
-    uint4 nxt = cur;
     bool pe_valid = true;
-    if constexpr (PRUNE) {
-        A_lane = (float)(U64 + (int32_t)prune_amax * ((int32_t)(L - 1) - (int32_t)s0)) * kPruneUnit;
-        nxt = rec[N > 1u ? 1u : 0u];
-        if (strip == 0) {
-            if (U64 + (int32_t)(prune_amax * (L - 1)) < 64) {
-                m_col0_dead = 0;
-            } else {
-                uint32_t lo = 0, hi = N;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (U64 + (int32_t)uniform(rgain[mid]) < 64) hi = mid;
-                    else lo = mid + 1;
-                }
-                m_col0_dead = lo;
-            }
-        }
-    }
+    if constexpr (PRUNE) A_lane = (float)(U64 + (int32_t)prune_amax * ((int32_t)(L - 1) - (int32_t)s0)) * kPruneUnit;
 
-    for (uint32_t m = 0; m < N; ++m) {
+    for (uint32_t m = m_begin; m < N; ++m) {
+        if constexpr (PRUNE) {
+            if (m >= stop_at) break;  // the cut: nothing from here on can be at or below its bound
+        }
         if ((m & 127u) == 0) issue_priority_by_progress(strip * N + m, S * N);
         const uint32_t m_next = m + 1 < N ? m + 1 : m;
-        uint4 nrec, nrec2 = cur;
-        if constexpr (PRUNE) {
-            nrec = nxt;
-            nrec2 = rec[m + 2 < N ? m + 2 : N - 1];
-        } else {
-            nrec = rec[m_next];
-        }
+        const uint4 nrec = rec[m_next];
         u32x4 nedge = {0, 0, 0, 0};
         if (have_left_strip) nedge = sload16(e_in + (uint64_t)m_next * sizeof(EdgeRec));
 
         SH_PROF(0)
+        if constexpr (PRUNE) {
+            // (the strip to the left was cut before this row: what memory holds in place of its edge record is some
+            // earlier sweep's -- the row's cells there are above their bounds, it shows what a skipped row shows)
+            if (have_left_strip && m >= edge_end) {
+                cur_edge.x = cur_edge.y = __float_as_uint(kDead);
+                cur_edge.z = cur_edge.w = 0u;
+            }
+        }
         // ---- row scalars
         const uint32_t r_pb = cur.x, r_z = cur.z, r_keep = cur.w;
         const uint32_t npred = r_z & 0xffu, mmask = (r_z >> 8) & 0xfu;
@@ -1170,9 +1199,10 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         // can anything in it.  Scalar only: the row's record, a shift register of the last 64 rows' verdicts, the
         // flag the strip to the left stored with its edge record (EdgeRec::gmax).
         bool edge_dead = false;
-        uint32_t cur_rg = 0;
+        uint2 cur_reach = {0u, 0u};
         if constexpr (PRUNE) {
-            edge_dead = have_left_strip ? (cur_edge.w == 0u) : (m >= m_col0_dead);
+            // (edge records of rows at or beyond edge_end may be stale: the strip to the left was cut before them)
+            edge_dead = m >= edge_end || (have_left_strip && cur_edge.w == 0u);
             const uint32_t dist = (r_z >> kRecDistShift) & 63u;
             const uint64_t need = (1ull << dist) - 1ull;  // (dist 63 = "further, or no predecessor": never all ones below)
             const bool skip = edge_dead && dist != kRecDistFar && (dead_hist & need) == need;
@@ -1209,13 +1239,6 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                     prev_dead = true;
                 }
                 prev_edge_val = kDead;
-                if (is_sink) {  // (end-cell search: a dead cell never wins it; sinks[0] is where it starts)
-                    if (!sk_any) {
-                        snk0 = m;
-                        if (strip == strip_last) lc_snk0 = kDead;
-                    }
-                    sk_any = true;
-                }
                 if constexpr (DBG) {
                     if (qi == 0) {
                         float dead_cells[B];
@@ -1225,8 +1248,8 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                     }
                 }
                 dead_hist = (dead_hist << 1) | 1ull;
+                if (have_left_strip) sload_wait(nedge);
                 cur = nrec;
-                nxt = nrec2;
                 cur_edge = nedge;
                 pe_valid = false;
                 continue;
@@ -1236,7 +1259,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                 cur_pe = sload16(pred_addr + (uint64_t)r_pb * 4);
                 sload_wait(cur_pe);
             }
-            cur_rg = rgain[m];
+            cur_reach = reach[m];
         }
 
         // ---- match / mismatch score of my cells against this row: comp() = (row mask & query mask) != 0
@@ -1265,12 +1288,18 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         uint32_t ltag[B], tl[B];
         // a predecessor row {value, gapm_val} of my columns + value[p][s0-1]: out of its LDS slot or spill row
         auto load_pred = [&](uint32_t pe, Cells<B> &sv, Cells<B> &sg, float &left_of_strip) {
-            if (pe & kPredSpilled) {
+            if (PRUNE && (pe & 0xffffu) < jump_lo) {  // a row the strip's sweep started behind: nothing was kept for it
+#pragma unroll
+                for (int i = 0; i < B / 4; i++) sv.v[i] = sg.v[i] = typename Cells<B>::V{kDead, kDead, kDead, kDead};
+                left_of_strip = kDead;
+            } else if (pe & kPredSpilled) {
                 const float *row = spill + (size_t)((pe >> 16) & 0x7FFFu) * (2 * Lp);
                 sv.load(row + s0);
                 sg.load(row + Lp + s0);
                 left_of_strip = 0.f;
-                if (lane0 && have_left_strip) left_of_strip = row[s0 - 1];
+                // (PRUNE: a row at or beyond edge_end was not swept in the strip to the left -- its spill row's
+                // columns there are some earlier sweep's)
+                if (lane0 && have_left_strip) left_of_strip = (PRUNE && (pe & 0xffffu) >= edge_end) ? kDead : row[s0 - 1];
                 // (consume the global loads inside this rare branch: mesh_dp_kernel)
 #pragma unroll
                 for (int i = 0; i < B / 4; i++) {
@@ -1507,22 +1536,32 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         float Bm_f = 0.f;
         bool row_dead = false;
         if constexpr (PRUNE) {
-            Bm_f = (float)(U64 + (int32_t)cur_rg) * kPruneUnit;
+            Bm_f = (float)(U64 + (int32_t)cur_reach.x) * kPruneUnit;
             float lm = fv[0];
 #pragma unroll
             for (int k = 1; k + 1 < B; k += 2) lm = min3_raw(lm, fv[k], fv[k + 1]);
             if constexpr (B % 2 == 0) lm = min2_raw(lm, fv[B - 1]);
             row_dead = !any_lane(lm <= min2_raw(A_lane, Bm_f)) && (edge_dead || !have_left_strip);
+            if (!row_dead && cur_reach.y >= stop_at) stop_at = cur_reach.y + 1u;  // (a row found alive: its successors may be)
         }
         // ---- publish: edge record for the strip to my right, the row for its successors
+        // (row skip: is my last cell -- what the next strip's first column starts from -- at or below ITS bound)
+        bool out_alive = false;
+        if constexpr (PRUNE) {
+            if (have_right_strip) {
+                out_alive = fv[B - 1] <= min2_raw(A_lane - (float)((B - 1) * (int32_t)prune_amax) * kPruneUnit, Bm_f);
+                if ((__builtin_amdgcn_ballot_w64(out_alive) >> 63) != 0ull) {
+                    if (out_first == kNone) out_first = m;
+                    out_last = m;
+                }
+            }
+        }
         if (lane == 63 && have_right_strip) {
             EdgeRec er;
             er.bnd = fv[B - 1];
             er.xv = ex_v;
             er.xe = ex_e ? 0x80000000u : 0u;
-            er.gmax = 0u;
-            // (row skip: is my last cell -- what the next strip's first column starts from -- at or below ITS bound)
-            if constexpr (PRUNE) er.gmax = (fv[B - 1] <= min2_raw(A_lane - (float)((B - 1) * (int32_t)prune_amax) * kPruneUnit, Bm_f)) ? 1u : 0u;
+            er.gmax = (PRUNE && out_alive) ? 1u : 0u;
             e_out[m] = er;
         }
         if (r_keep != kRowNone) {
@@ -1564,7 +1603,11 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                 lc_arg = m;
                 lc_any = true;
             }
-            if (own_last && is_sink && !sk_any) lc_snk0 = v;
+            if constexpr (PRUNE) {
+                if (own_last && m == first_sink) lc_snk0 = v;
+            } else {
+                if (own_last && is_sink && !sk_any) lc_snk0 = v;
+            }
         }
         // step 2: sink rows x every column of this strip
         if (is_sink) {
@@ -1585,7 +1628,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                 bv = b ? ov : bv;
                 bs = b ? os : bs;
             }
-            if (!sk_any) snk0 = m;
+            if (!PRUNE && !sk_any) snk0 = m;
             if (bv < sk_min) {
                 sk_min = bv;
                 sk_m = m;
@@ -1605,7 +1648,6 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         }
         prev_edge_val = edge_val;
         if constexpr (PRUNE) {
-            nxt = nrec2;
             pe_valid = true;
             prev_dead = false;
             dead_hist = (dead_hist << 1) | (row_dead ? 1ull : 0ull);
@@ -2031,12 +2073,12 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
     if (!weighted && !forbid && a.below_init && a.gp >= a.gpe && !generic_only && a.prof16 == nullptr) {
         // (certified row skip: launches of two strips or more -- in a single strip column 0, where an alignment may
         // start at any row for free, keeps every row in play)
-        const bool prune = a.prune && a.rgain != nullptr && n_strips >= 2;
+        const bool prune = a.prune && a.reach != nullptr && n_strips >= 2;
         auto kfn = prune ? (a.dbg_value ? mesh_dp_simple_kernel<B, true, true> : mesh_dp_simple_kernel<B, false, true>)
                          : (a.dbg_value ? mesh_dp_simple_kernel<B, true, false> : mesh_dp_simple_kernel<B, false, false>);
         if (allow_full_lds(reinterpret_cast<const void *>(kfn))) return 1;
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.qmask, a.tb, a.dbg_value, a.spill,
-                           a.edge, a.edge_stride, n_strips, a.res, a.ms, a.mms, a.gp, a.gpe, a.dry, a.rgain, a.prune_rho,
+                           a.edge, a.edge_stride, n_strips, a.res, a.ms, a.mms, a.gp, a.gpe, a.dry, a.reach, a.prune_rho,
                            a.prune_amax);
     } else if (!weighted && !forbid && a.below_init) SH_LAUNCH(false, false, true);
     else if (!weighted && !forbid) SH_LAUNCH(false, false, false);

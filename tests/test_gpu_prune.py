@@ -149,3 +149,46 @@ def test_device_column_bound_covers_every_path(oracle, gpu_ctx):
             assert rg[-1] == 0
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("rho", [None, "0.6", "0.95", "2"])
+def test_row_skip_narrow_band_after_wide_ones(oracle, gpu_ctx, monkeypatch, rho):
+    """A query that IS a member of its family (the optimum runs along one reference: the narrowest band there is,
+    strips cut early, later strips sweeping rows the strip to their left never reached) right after queries with
+    wide bands on the same context -- whatever earlier sweeps left in the edge records, spill rows and row slots
+    must not be read as this sweep's.  Planes against the oracle's where at or below the bound, alignments through
+    sina_hip_align_graphs against the oracle's."""
+    if rho is not None:
+        monkeypatch.setenv("SINA_HIP_DP_PRUNE_RHO", rho)
+    refs = synth.make_refs(400, length=1500, width=50000, seed=61, long_del_prob=0.5)
+    cs = util.cseqs_from_refs(refs)
+    rng = np.random.default_rng(62)
+    qs = synth.make_queries(refs, 6, seed=63, sub=0.08, dele=0.02, ins=0.02)
+    fam_ids = rng.choice(refs.n, size=40, replace=False)
+    fam = [cs[i] for i in fam_ids]
+    g = util.graph_dict(fam)
+    gb = gpu_ctx.graph_batch([g], refs.width)
+    cases = [util.query_cseq(qs, i) for i in range(3)]                       # divergent queries: wide bands
+    member = cs[int(fam_ids[7])]
+    mm = ((refs.seq(int(fam_ids[7])) >> 24) & 0x0f).astype(np.uint8)
+    exact = oracle.Cseq.from_packed("member", np.arange(len(mm), dtype=np.uint32) | (mm.astype(np.uint32) << 24), len(mm))
+    cases += [exact, util.query_cseq(qs, 3), exact]
+    for q in cases:
+        qm = (q.packed() >> 24).astype(np.uint8)
+        cells = oracle.mesh_compute(fam, q)
+        vm, vs, val = gpu_ctx.debug_mesh(gb, qm, gpu_ctx.params(), prune=True)
+        _check_planes(gpu_ctx, cells, vm, vs, val)
+        out, pos = gpu_ctx.align_graphs(gb, qm, np.array([0, len(qm)], np.uint64), gpu_ctx.params())
+        ref = oracle.align(fam, q, oracle.align_opts(realign=1)) if q is not exact else None
+        assert out[0]["status"] == 0
+        if ref is not None and ref["status"] == 0:
+            aligned, _ = util.finish_alignment(qm, out[0], pos[:len(qm)], refs.width)
+            assert aligned == ref["aligned"]
+        else:   # (the aligner would copy the member's alignment: compare the walk with the oracle's planes instead)
+            end_v = np.float32(out[0]["raw"])
+            snk = g["snk"]
+            best = min(cells["value"][:, -1].min(), cells["value"][snk].min())
+            assert util.f32_bits(np.float32(best)) == util.f32_bits(end_v)
+            got_cols = refs.width - 1 - pos[:len(qm)][::-1]
+            own = (refs.seq(int(fam_ids[7])) & 0xFFFFFF).astype(np.uint32)
+            assert (got_cols == own).mean() > 0.97

@@ -49,15 +49,21 @@ sys.path.insert(0, os.getcwd())
 try:
     import bench
     cells = None
+    swept = 1.0  # (the certified row skip: fraction of the nominal cells the kernel computed, second sweeps included)
     for f in sorted(glob.glob(d + "/run*.log")):
         for l in open(f):
-            m = re.search(r"cells ([0-9.e+]+)", l)
+            m = re.search(r" cells ([0-9.e+]+) ", l)
             if m:
                 cells = float(m.group(1))
+            m = re.search(r"cells swept ([0-9.]+)", l)
+            if m:
+                swept = float(m.group(1))
+    if cells:
+        cells *= swept
     if cells and g("SQ_INSTS_VALU"):
         json.dump({"kernel_source_rev": bench.kernel_source_rev(), "valu_wave_instructions_per_launch": g("SQ_INSTS_VALU"),
-                   "cells_per_launch": cells, "valu_wave_instructions_per_cell": g("SQ_INSTS_VALU") / cells,
-                   "what": "tools/prof_dp_pmc.sh: SQ_INSTS_VALU of the DP kernel alone, tools/perf_dp.py workload"},
+                   "cells_per_launch": cells, "cells_computed_frac": swept, "valu_wave_instructions_per_cell": g("SQ_INSTS_VALU") / cells,
+                   "what": "tools/prof_dp_pmc.sh: SQ_INSTS_VALU of the DP kernel alone per COMPUTED cell, tools/perf_dp.py workload"},
                   open(d + "/dp_valu.json", "w"), indent=1)
 except Exception as e:
     print("no dp_valu.json:", e)
