@@ -128,3 +128,37 @@ def test_three_rank_remainder_shards_and_ordered_merge(tmp_path):
     assert [int(q) for q, _ in merged] == list(range(20))
     assert [str(p) for _, p in merged] == ["aligned-%d-by-rank-%d" % (q, 0 if q < 7 else (1 if q < 14 else 2)) for q in range(20)]
     assert sdist.merge_by_seqno([(2, "c"), (0, "a"), (1, "b")], None) == [(0, "a"), (1, "b"), (2, "c")]
+
+
+def _worker_merge_at_size(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from sina_amd import dist as sdist
+    r, lr, w, dist = sdist.init(backend="gloo")
+    n = 10000
+    # round-robin ownership (the ranks' sequence numbers interleave), 6 KB of payload per query
+    local = [(q, bytes([q % 251]) * 6144) for q in range(rank, n, world)]
+    local.reverse()
+    stats = {}
+    merged = sdist.merge_by_seqno(local, dist, dst=1, stats=stats)
+    if rank == 1:
+        assert [q for q, _ in merged] == list(range(n))
+        assert all(p == bytes([q % 251]) * 6144 for q, p in merged[::97])
+        assert stats["received_items"] == n - len(local) and stats["sent_items"] == 0
+    else:
+        assert merged is None
+        assert stats["received_items"] == 0 and stats["sent_items"] == len(local)   # nothing comes back to a sender
+    with open(os.path.join(out_dir, "ok%d" % rank), "w") as f:
+        f.write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ordered_merge_is_a_gather_at_size(tmp_path):
+    """--preserve-order at run size (src/sina.cpp:529-538): 10 000 results of 6 KB each from three ranks (gloo),
+    sequence numbers interleaved, arrive at ONE rank in order; the other ranks send their share and receive
+    nothing (until round 4 every rank received every rank's results)."""
+    port = _free_port()
+    mp.spawn(_worker_merge_at_size, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(3))

@@ -192,3 +192,63 @@ def test_row_skip_narrow_band_after_wide_ones(oracle, gpu_ctx, monkeypatch, rho)
             got_cols = refs.width - 1 - pos[:len(qm)][::-1]
             own = (refs.seq(int(fam_ids[7])) & 0xFFFFFF).astype(np.uint32)
             assert (got_cols == own).mean() > 0.97
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_row_skip_plane_fuzz(oracle, monkeypatch, seed):
+    """The mesh plane fuzz of test_gpu_edges.py with the row skip in play: seeded random families (1 - 60 members,
+    divergence, long deletions, ambiguity codes, lower case), scoring parameters, fs-weight, LDS budget, a forced
+    multi-strip geometry and a random guess (left alone, timid, bold, impossible).  Where the launch went through
+    the skipping kernel: every cell at or below its bound is the oracle's, every other one above it; where it did
+    not (insertion=forbid, extend > open ...): the planes are the oracle's cell for cell."""
+    rng = np.random.default_rng(7700 + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]  # noqa: E731
+    for attempt in range(8):
+        length = int(pick([150, 320, 700]))
+        refs = synth.make_refs(int(pick([8, 40, 90])), length=length, width=int(length * pick([3, 8])), seed=7800 + seed + 1000 * attempt,
+                               n_clades=int(pick([1, 3, 8])), clade_div=float(pick([0.05, 0.2, 0.4])),
+                               sub_hi=float(pick([0.02, 0.1, 0.3])), del_rate=float(pick([0.0, 0.01, 0.08])),
+                               ins_rate=float(pick([0.0, 0.005, 0.05])), long_del_prob=float(pick([0.0, 0.3, 1.0])),
+                               amb_rate=float(pick([0.0, 0.03])), lower_rate=float(pick([0.0, 0.1])))
+        cs = util.cseqs_from_refs(refs)
+        usable = [i for i in range(refs.n) if cs[i].size >= 40]
+        if usable:
+            break
+    assert usable
+    fam = [cs[i] for i in list(rng.permutation(usable)[:int(pick([1, 2, 7, 40, 60]))])]
+    src = (refs.seq(usable[int(rng.integers(0, len(usable)))]) >> 24) & 0x0f
+    lo = int(rng.integers(0, max(1, len(src) // 4)))
+    qm = src[lo:].copy()
+    mut = rng.random(len(qm)) < float(pick([0.0, 0.05, 0.3]))
+    qm[mut] = rng.choice([1, 2, 4, 8, 15, 3], size=int(mut.sum()))
+    qm = qm.astype(np.uint8)
+    q = oracle.Cseq.from_packed("fz%d" % seed, np.arange(len(qm), dtype=np.uint32) | (qm.astype(np.uint32) << 24), len(qm))
+    b = int(pick([4, 8]))
+    strips = (len(qm) + 64 * b - 1) // (64 * b) + int(pick([0, 1]))
+    # (narrow lanes make several strips out of these short queries)
+    if strips < 2:
+        b, strips = 4, max(2, (len(qm) + 255) // 256)
+    if len(qm) > 64 * b * strips:
+        strips = (len(qm) + 64 * b - 1) // (64 * b)
+    monkeypatch.setenv("SINA_HIP_DP_GEOM", "%d,%d" % (64 * strips, b))
+    rho = pick([None, None, "0.2", "0.7", "0.97", "2.5"])
+    if rho:
+        monkeypatch.setenv("SINA_HIP_DP_PRUNE_RHO", rho)
+    if rng.integers(0, 3) == 0:
+        monkeypatch.setenv("SINA_HIP_DP_LDS_KB", str(pick([5, 9])))
+    gp, gpe = pick([(5, 2), (4, 1.5), (3, 3), (6, 0.5), (0.3, 0.1), (2, 3)])
+    opts = dict(match_score=float(pick([2, 3, 0.7])), mismatch_score=float(pick([-1, -2, -0.1])), gap_penalty=float(gp),
+                gap_ext_penalty=float(gpe), insertion=int(pick([0, 0, 0, 1])), fs_weight=float(pick([1.0, 0.0, 2.5])))
+    ctx = capi.Context(0)
+    try:
+        cells = oracle.mesh_compute(fam, q, oracle.align_opts(**opts), weight=opts["fs_weight"])
+        gb = ctx.graph_batch([util.graph_dict(fam, weight=opts["fs_weight"])], refs.width)
+        popts = {k: v for k, v in opts.items() if k != "fs_weight"}
+        vm, vs, val = ctx.debug_mesh(gb, qm, ctx.params(**popts), prune=True)
+        if ctx.dp_info(0)["attempts"] == 0:
+            assert (util.f32_bits(val) == util.f32_bits(cells["value"])).all()
+            assert (vm == cells["value_midx"]).all() and (vs == cells["value_sidx"]).all()
+        else:
+            _check_planes(ctx, cells, vm, vs, val)
+    finally:
+        ctx.close()
