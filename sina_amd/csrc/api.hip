@@ -12,12 +12,6 @@ namespace sina_hip {
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
 
-static size_t env_size(const char *name, size_t dflt) {
-    const char *v = getenv(name);
-    if (!v || !*v) return dflt;
-    return (size_t)strtoull(v, nullptr, 10);
-}
-
 int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl) {
     if (!pick_geom(maxL, &pl->geom)) SH_FAIL("align: query longer than SINA_HIP_MAX_QUERY_LEN bases");
     const size_t slot = dp_slot_bytes(pl->geom), fixed = dp_fixed_lds_bytes(pl->geom);
@@ -33,7 +27,7 @@ int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl) {
 }
 
 // SINA_HIP_DP_PRUNE=0 switches the DP kernel's certified row skip off (every row of every strip is swept);
-// SINA_HIP_DP_PRUNE_RHO=<x> fixes the launches' guess of optimum / bound (tests: 2 = too bold for any query, every
+// SINA_HIP_TEST="rho=<x>" fixes the launches' guess of optimum / bound (tests: 2 = too bold for any query, every
 // query takes the second attempt; 0.01 = nearly no bound).  Read per launch.
 PrunePlan prune_plan(const sina_hip_align_params *p, float wmax, float wmin, uint32_t maxL, bool profile_batch) {
     PrunePlan pp;
@@ -267,8 +261,8 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     a.prune_rho = 0.f;
     bool rho_fixed = false;
     if (pp.on) {
-        if (const char *r = getenv("SINA_HIP_DP_PRUNE_RHO")) {
-            a.prune_rho = (float)atof(r);
+        if (const std::string r = test_knob("rho"); !r.empty()) {
+            a.prune_rho = (float)atof(r.c_str());
             rho_fixed = a.prune_rho > 0.f;
         }
         if (!rho_fixed) {
@@ -314,7 +308,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     // are queued right behind their DP kernel on the same FIFO stream: they start the moment it ends, run beside
     // the launch that started in its drain (the other FIFO stream), and the launch after that -- often the next DP
     // launch -- is ordered behind them by the stream itself.  SINA_HIP_BT_ON_FIFO=0: the context's stream.
-    static const bool bt_fifo_wanted = !(getenv("SINA_HIP_BT_ON_FIFO") && getenv("SINA_HIP_BT_ON_FIFO")[0] == '0');
+    static const bool bt_fifo_wanted = !(experiment_env("SINA_HIP_BT_ON_FIFO") && experiment_env("SINA_HIP_BT_ON_FIFO")[0] == '0');
     bool bt_done = false;
     {
         // the DP kernel: on the store's heavy stream, behind the uploads queued on c->stream; the
@@ -340,13 +334,13 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
             bt_done = true;
         }
         if (hl.done()) return 1;
-        if (getenv("SINA_HIP_DEBUG_SYNC")) fprintf(stderr, "[sina_hip] DP kernel done: %u queries, geometry %dx%d, weighted %d forbid %d\n", bq, pl.geom.T, pl.geom.B, (int)weighted, (int)forbid);
+        if (experiment_env("SINA_HIP_DEBUG_SYNC")) fprintf(stderr, "[sina_hip] DP kernel done: %u queries, geometry %dx%d, weighted %d forbid %d\n", bq, pl.geom.T, pl.geom.B, (int)weighted, (int)forbid);
         if (token.owns_lock()) SH_CHECK(wait_event(c->ev[1]));
     }
     if (!bt_done) {
         if (launch_backtrack(b, s)) return 1;
         if (p->assemble && launch_assemble(b, s)) return 1;
-        if (getenv("SINA_HIP_DEBUG_SYNC")) {
+        if (experiment_env("SINA_HIP_DEBUG_SYNC")) {
             SH_CHECK(hipStreamSynchronize(s));
             fprintf(stderr, "[sina_hip] backtrack kernel done\n");
         }
@@ -428,7 +422,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
 // 5 ms late in half of the launches, ran beside the next DP launch and took 16 ms instead of 7
 // (profiles/r04_bt_delay.txt).  SINA_HIP_STREAM_PRIO=1 restores the priorities.
 int make_streams(sina_hip_ctx *c) {
-    static const bool prio = getenv("SINA_HIP_STREAM_PRIO") && getenv("SINA_HIP_STREAM_PRIO")[0] == '1';
+    static const bool prio = experiment_env("SINA_HIP_STREAM_PRIO") && experiment_env("SINA_HIP_STREAM_PRIO")[0] == '1';
     if (!prio) {
         SH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         SH_CHECK(hipStreamCreateWithFlags(&c->stream_dp, hipStreamNonBlocking));
@@ -676,7 +670,7 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
         return 1;
     }
     c->bind_hints();
-    c->lds_budget = env_size("SINA_HIP_DP_LDS_KB", 0) * 1024;
+    c->lds_budget = (size_t)std::max(0, atoi(test_knob("lds_kb").c_str())) * 1024;  // (test hook: LDS per DP workgroup)
     if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 1) {
         (void)hipGetLastError();
         c->n_cu = 256;

@@ -18,6 +18,39 @@ namespace sina_hip {
 
 void set_error(const std::string &msg);
 
+// ---- environment.  What the library reads at run time (all of it listed in INTEGRATION.md):
+//   SINA_HIP_TB_GB, SINA_HIP_TB_PLANES   size / number of the device's trace-back planes (ctx.h)
+//   SINA_HIP_DP_PRUNE=0                  the DP kernel sweeps every row of every strip (no certified row skip)
+//   SINA_HIP_CHAIN=0|1                   chained launches off / on under a counter-collecting profiler (ctx.h)
+//   SINA_HIP_NO_RUNTIME_DEFAULTS         the load-time constructor leaves the process environment alone (api.hip)
+//   SINA_HIP_TRACE_ALLOC                 one line per device / pinned allocation
+//   SINA_HIP_TEST="key=value;..."        test hooks (tests/ only): geom=T,B  generic=1  dense_div=N  lds_kb=N  rho=X
+// The experiment switches of rounds 1-4 (SINA_HIP_SERIALIZE, _DP_BURST, _GRAPH_DRY, _BT_ON_FIFO, _STREAM_PRIO,
+// _SHARE_DAGS, _DP_ROUNDS, _DEBUG_SYNC) exist only in a build made with -DSINA_EXPERIMENTS
+// (make -C sina_amd/csrc VARIANT=exp EXTRA=-DSINA_EXPERIMENTS): the production library does not look at them.
+inline const char *experiment_env(const char *name) {
+#ifdef SINA_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+// value of `key` in SINA_HIP_TEST ("" if absent); read every time: tests change it between calls
+inline std::string test_knob(const char *key) {
+    const char *e = getenv("SINA_HIP_TEST");
+    if (!e) return std::string();
+    const std::string s(e), k = std::string(key) + "=";
+    size_t at = 0;
+    while (at < s.size()) {
+        size_t end = s.find(';', at);
+        if (end == std::string::npos) end = s.size();
+        if (s.compare(at, k.size(), k) == 0) return s.substr(at + k.size(), end - at - k.size());
+        at = end + 1;
+    }
+    return std::string();
+}
+
 #define SH_CHECK(expr)                                                                      \
     do {                                                                                    \
         hipError_t _e = (expr);                                                             \

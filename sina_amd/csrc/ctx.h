@@ -326,7 +326,7 @@ namespace sina_hip {
 // taking turns through a host-side token.
 inline bool serialize_kernels() {
     static const bool on = [] {
-        const char *v = getenv("SINA_HIP_SERIALIZE");
+        const char *v = sina_hip::experiment_env("SINA_HIP_SERIALIZE");
         return !(v && *v == '0');
     }();
     return on;
@@ -420,7 +420,7 @@ enum heavy_kind { kHeavyKmer = 0, kHeavyGraph = 1, kHeavyDp = 2 };
 constexpr int kHeavyDepth = 2;
 inline int heavy_order_policy() {
     static const int mode = [] {
-        const char *v = getenv("SINA_HIP_DP_BURST");
+        const char *v = experiment_env("SINA_HIP_DP_BURST");
         return v && *v ? atoi(v) : -1;
     }();
     return mode;

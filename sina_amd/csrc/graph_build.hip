@@ -721,13 +721,13 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
             // that starts in it begins with a stagger it carries to its own end (measured: 142.1 k sequences/s with
             // the signal, 143.1 k without, DP 49.5 against 48.3 ms per launch; profiles/r04_chain_ab.txt).
             // SINA_HIP_GRAPH_DRY=1 (experiments): the build tells its follower when its queue has run dry, like a DP launch.
-            static const bool graph_dry = getenv("SINA_HIP_GRAPH_DRY") && getenv("SINA_HIP_GRAPH_DRY")[0] == '1';
+            static const bool graph_dry = experiment_env("SINA_HIP_GRAPH_DRY") && experiment_env("SINA_HIP_GRAPH_DRY")[0] == '1';
             ga.dry = graph_dry ? hl.dry() : DryArgs{nullptr, nullptr, 0};
             hipLaunchKernelGGL(family_graph_kernel, dim3(bq), dim3(kGT), glds, hl.stream(), ga);
             SH_CHECK(hipGetLastError());
             SH_CHECK(hipEventRecord(c->ev[7], hl.stream()));
             if (hl.done()) return 1;
-            if (getenv("SINA_HIP_DEBUG_SYNC")) fprintf(stderr, "[sina_hip] DAG build kernel done: %u families, ncap %u\n", bq, ncap);
+            if (experiment_env("SINA_HIP_DEBUG_SYNC")) fprintf(stderr, "[sina_hip] DAG build kernel done: %u families, ncap %u\n", bq, ncap);
         }
         if (download(c, 4, c->g_sizes.p, 4 * kSz * (uint64_t)bq, s)) return 1;
         SH_CHECK(wait_stream(c, s));
@@ -786,7 +786,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
     // query than two (a fourth adds 2 % and another 22 GB per trace-back plane; SINA_HIP_DP_ROUNDS); the DP
     // launches below are whole rounds where the trace-back budget cuts a chunk
     const uint32_t slots = dp_wave_slots(c, pl.geom.B);
-    static const uint32_t rounds = getenv("SINA_HIP_DP_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("SINA_HIP_DP_ROUNDS"))) : 3u;
+    static const uint32_t rounds = experiment_env("SINA_HIP_DP_ROUNDS") ? (uint32_t)std::max(1, atoi(experiment_env("SINA_HIP_DP_ROUNDS"))) : 3u;
     const uint32_t chunk_q = rounds * slots;
     BuiltGraphs bg;
     std::vector<uint32_t> dag_of;      // per query of the chunk: which of the chunk's distinct DAGs is its family's
@@ -798,7 +798,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
         // row-slot assignment depend on nothing else): amplicons of one region against one reference clade.  The
         // DAG is built once per distinct family of the chunk; every query keeps its own trace-back cells, spill
         // rows and edge records.  (SINA_HIP_SHARE_DAGS=0: one build per query.)
-        static const bool share = !(getenv("SINA_HIP_SHARE_DAGS") && getenv("SINA_HIP_SHARE_DAGS")[0] == '0');
+        static const bool share = !(experiment_env("SINA_HIP_SHARE_DAGS") && experiment_env("SINA_HIP_SHARE_DAGS")[0] == '0');
         dag_of.assign(bq, 0);
         uint32_t n_dags = bq;
         const uint32_t *b_ids = fam_ids;

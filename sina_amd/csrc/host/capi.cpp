@@ -646,11 +646,12 @@ int sina_host_set_option(const char *stage, const char *name, const char *value)
 
 // The driver allocates and frees tens of MB of trays per batch: keep what the allocator got from the
 // kernel (no trimming, no per-vector mmap) so that steady-state batches do not page-fault their
-// memory in again.  Process-wide; SINA_HOST_MALLOPT=0 leaves the allocator alone.
+// memory in again.  Process-wide; a host that sets SINA_HIP_NO_RUNTIME_DEFAULTS (the library's "leave my process
+// alone" switch, include/sina_hip.h) keeps its allocator settings too.
 static void tune_allocator() {
     static const bool once = [] {
-        const char *v = getenv("SINA_HOST_MALLOPT");
-        if (v && *v == '0') return false;
+        const char *v = getenv("SINA_HIP_NO_RUNTIME_DEFAULTS");
+        if (v && *v && !(v[0] == '0' && v[1] == 0)) return false;
         mallopt(M_TRIM_THRESHOLD, 1 << 30);
         mallopt(M_TOP_PAD, 64 << 20);
         mallopt(M_MMAP_THRESHOLD, 256 << 20);
@@ -831,9 +832,8 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
                 }
             };
             handover found, aligned;
-            // (SINA_HOST_FINDERS: famfinder threads; they run ahead by `found.cap` finished batches)
-            const char *nf_env = getenv("SINA_HOST_FINDERS");
-            const uint32_t n_find = nf_env ? (uint32_t)std::max(1, atoi(nf_env)) : (inflight >= 4 ? 3 : (inflight >= 3 ? 2 : 1));
+            // (famfinder threads; they run ahead by `found.cap` finished batches)
+            const uint32_t n_find = inflight >= 4 ? 3 : (inflight >= 3 ? 2 : 1);
             const uint32_t n_align = inflight, n_sink = 1;
             try {  // the contexts the threads below will lease, made and warmed before any of them starts
                 const auto store = reference_store::get(aligner::opts->database);

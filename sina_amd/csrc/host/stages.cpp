@@ -776,18 +776,10 @@ static unsigned count_query_kmers(const uint8_t *m, size_t n, unsigned k, bool c
 // amplicon runs are dominated by repeats.  A GPU batch is thousands of queries wide, so the analogue is inside the
 // batch: items with the same key bytes (and, for the aligner, the same family) go to the device ONCE, and every
 // item reads the slot of its first occurrence.  rep[i] = index of the first item equal to item i; returns the
-// number of distinct items.  set_batch_dedup(false) / SINA_HOST_DEDUP=0 switch it off (tests compare both ways).
-static std::atomic<int> g_dedup{-1};  // -1: ask the environment (SINA_HOST_DEDUP=0 switches it off)
+// number of distinct items.  set_batch_dedup(false) switches it off (tests compare both ways).
+static std::atomic<int> g_dedup{1};  // (set_batch_dedup(false): tests compare against the un-deduplicated run)
 void set_batch_dedup(bool on) { g_dedup.store(on ? 1 : 0); }
-static bool dedup_enabled() {
-    const int v = g_dedup.load(std::memory_order_relaxed);
-    if (v >= 0) return v != 0;
-    static const bool from_env = [] {
-        const char *e = getenv("SINA_HOST_DEDUP");
-        return !(e && *e == '0');
-    }();
-    return from_env;
-}
+static bool dedup_enabled() { return g_dedup.load(std::memory_order_relaxed) != 0; }
 template <class Hash, class Equal>
 static size_t group_equal_items(size_t n, Hash &&hash_of, Equal &&equal, std::vector<uint32_t> &rep) {
     rep.resize(n);

@@ -629,7 +629,7 @@ static int ensure_dense(sina_hip_ctx *c) {
     hipStream_t s = c->stream;
     const uint32_t nk = 1u << (2 * st->k);
     uint32_t div_ = 32;
-    if (const char *e_ = getenv("SINA_HIP_DENSE_DIV")) div_ = (uint32_t)std::max(1, atoi(e_));
+    if (const std::string e_ = test_knob("dense_div"); !e_.empty()) div_ = (uint32_t)std::max(1, atoi(e_.c_str()));
     const uint32_t thresh = std::max<uint32_t>(256u, st->n_refs / div_);
     const uint32_t ntiles = (st->n_refs + kTileRefs - 1) / kTileRefs;
     st->dense_words = ntiles * (uint32_t)(kTileRefs / 32);

@@ -997,7 +997,7 @@ mesh_dp_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ order
 // instructions, 592: a packed add issues slower than the two adds it replaces).
 // Everything else (weighted scheme, --insertion=forbid, gap_open < gap_extend, huge gap costs) runs
 // mesh_dp_kernel.  Results are bit-identical between the two: tests/test_gpu_parity.py runs every
-// simple-scheme plane test through both (SINA_HIP_DP_GENERIC=1 forces the generic kernel).
+// simple-scheme plane test through both (SINA_HIP_TEST=generic=1 forces the generic kernel).
 template <int B, bool DBG, bool PRUNE>
 #ifndef SINA_DP_SIMPLE_WAVES8
 #define SINA_DP_SIMPLE_WAVES8 3  // waves per SIMD the B = 8 kernel is compiled for
@@ -2068,8 +2068,8 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
                            n_strips, a.res, a.ms, a.mms, a.gp, a.gpe, a.prof16, a.dry);                  \
     } while (0)
     // the simple scheme with gap_open >= gap_extend in a launch below the initial value (every BASELINE
-    // configuration): the specialised kernel; SINA_HIP_DP_GENERIC=1 keeps the generic one (parity tests)
-    static const bool generic_only = getenv("SINA_HIP_DP_GENERIC") != nullptr && atoi(getenv("SINA_HIP_DP_GENERIC")) != 0;
+    // configuration): the specialised kernel; SINA_HIP_TEST=generic=1 keeps the generic one (parity tests)
+    const bool generic_only = atoi(test_knob("generic").c_str()) != 0;
     if (!weighted && !forbid && a.below_init && a.gp >= a.gpe && !generic_only && a.prof16 == nullptr) {
         // (certified row skip: launches of two strips or more -- in a single strip column 0, where an alignment may
         // start at any row for free, keeps every row in play)
@@ -2123,10 +2123,11 @@ static const double kLaneRate[] = {226.0, 461.0, 403.0};  // Gcell/s of the B = 
 constexpr int kMaxStrips = 40;  // 40 x 256 columns (B = 4) cover SINA_HIP_MAX_QUERY_LEN
 
 bool pick_geom(uint32_t maxL, DpGeom *g) {
-    // tuning override: SINA_HIP_DP_GEOM="T,B" (used if it covers the batch's longest query)
-    if (const char *ov = getenv("SINA_HIP_DP_GEOM")) {
+    // test hook: SINA_HIP_TEST="geom=T,B" (used if it covers the batch's longest query)
+    const std::string ov = test_knob("geom");
+    if (!ov.empty()) {
         int t = 0, b = 0;
-        if (sscanf(ov, "%d,%d", &t, &b) == 2 && (uint32_t)(t * b) >= maxL && t % 64 == 0 && t >= 64 &&
+        if (sscanf(ov.c_str(), "%d,%d", &t, &b) == 2 && (uint32_t)(t * b) >= maxL && t % 64 == 0 && t >= 64 &&
             t <= 64 * kMaxStrips && (b == 4 || b == 8 || b == 12)) {
             g->T = t;
             g->B = b;

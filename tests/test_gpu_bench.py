@@ -39,10 +39,11 @@ _CHILD = r"""
 import hashlib, sys
 sys.path.insert(0, %r)
 from sina_amd import pipeline, synth
-refs = synth.make_refs(500, length=320, width=3200, seed=51, amb_rate=0.01, lower_rate=0.02)
+# (700 bases: two 512-column strips per query, so that the DP kernel's row skip is in play)
+refs = synth.make_refs(500, length=700, width=5600, seed=51, amb_rate=0.01, lower_rate=0.02)
 qs = synth.make_queries(refs, 240, seed=77, ins=0.01, dele=0.01, lower_rate=0.03)
 st = pipeline.Store(":mem:order-policy", refs)
-pl = pipeline.Pipeline(st, famfinder={"fs-min-len": 100, "fs-full-len": 250})
+pl = pipeline.Pipeline(st, famfinder={"fs-min-len": 100, "fs-full-len": 550})
 h = hashlib.sha1()
 for rep in range(2):
     pl.run(qs.mask, qs.off, batch=30, inflight=4)
@@ -55,18 +56,20 @@ print("RESULT", h.hexdigest())
 """
 
 
-@pytest.mark.parametrize("env", [{"SINA_HIP_CHAIN": "0"}, {"SINA_HIP_DP_BURST": "0"}, {"SINA_HIP_DP_BURST": "1"},
-                                 {"SINA_HIP_NO_RUNTIME_DEFAULTS": "1"}, {"SINA_HIP_BT_ON_FIFO": "0", "SINA_HIP_STREAM_PRIO": "1"},
-                                 {"SINA_HIP_GRAPH_DRY": "1", "SINA_HIP_SHARE_DAGS": "0"}])
+@pytest.mark.parametrize("env", [{"SINA_HIP_CHAIN": "0"}, {"SINA_HIP_NO_RUNTIME_DEFAULTS": "1"}, {"SINA_HIP_DP_PRUNE": "0"},
+                                 {"SINA_HIP_TB_PLANES": "3", "SINA_HIP_TB_GB": "24"}, {"SINA_HIP_TRACE_ALLOC": "1"},
+                                 {"SINA_HIP_TEST": "rho=2"}, {"SINA_HIP_TEST": "generic=1;dense_div=1"}])
 def test_launch_order_settings_do_not_change_results(env):
-    """Chained launches (the kernel behind a DP launch starts when that launch's queue has run dry), the order the
-    admission queue hands launches over in, where the backtrack walk is queued, stream priorities, DAG sharing and
-    the opt-out of the library's load-time environment defaults are scheduling / bookkeeping only:
-    eight batches in flight twice over give the same trays bit for bit under every setting."""
+    """EVERY environment variable the production library reads (csrc/common.h; INTEGRATION.md lists them) is
+    scheduling / bookkeeping / which exact code path computes the same thing: chained launches, the load-time
+    environment defaults, the DP kernel's certified row skip (off; and with a guess no query can meet, so that every
+    one is swept twice), the trace-back plane pool, allocation tracing, the test hooks (generic DP kernel, no dense
+    posting-list bitmaps).  Eight batches in flight twice over give the same trays bit for bit under every setting.
+    (The experiment switches of rounds 1-4 exist only in -DSINA_EXPERIMENTS builds.)"""
     def run(extra):
         e = dict(os.environ)
-        for k in ("SINA_HIP_CHAIN", "SINA_HIP_DP_BURST", "SINA_HIP_NO_RUNTIME_DEFAULTS", "SINA_HIP_BT_ON_FIFO",
-                  "SINA_HIP_STREAM_PRIO", "SINA_HIP_GRAPH_DRY", "SINA_HIP_SHARE_DAGS"):
+        for k in ("SINA_HIP_CHAIN", "SINA_HIP_NO_RUNTIME_DEFAULTS", "SINA_HIP_DP_PRUNE", "SINA_HIP_TB_PLANES", "SINA_HIP_TB_GB",
+                  "SINA_HIP_TRACE_ALLOC", "SINA_HIP_TEST"):
             e.pop(k, None)
         e.update(extra)
         p = subprocess.run([sys.executable, "-c", _CHILD % ROOT], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)

@@ -57,9 +57,9 @@ def test_mesh_plane_fuzz(oracle, gpu_ctx, monkeypatch, seed):
     q, qm = _cseq("fuzz%d" % seed, qm)
     geom = pick([None, None, "64,4", "128,4", "64,8", "128,8", "64,12", "128,12"])
     if geom and len(qm) <= int(geom.split(",")[0]) * int(geom.split(",")[1]):
-        monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+        util.set_knobs(monkeypatch, geom=geom)
     if rng.integers(0, 3) == 0:
-        monkeypatch.setenv("SINA_HIP_DP_LDS_KB", str(pick([5, 9])))
+        util.set_knobs(monkeypatch, lds_kb=pick([5, 9]))
     gp, gpe = pick([(5, 2), (4, 1.5), (2, 3), (3, 3), (6, 0.5), (0.3, 0.1)])
     opts = dict(match_score=float(pick([2, 3, 0.7])), mismatch_score=float(pick([-1, -2, -0.1])), gap_penalty=float(gp),
                 gap_ext_penalty=float(gpe), insertion=int(pick([0, 0, 1])), fs_weight=float(pick([1.0, 0.0, 2.5])))

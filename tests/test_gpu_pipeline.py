@@ -98,7 +98,7 @@ def test_pipeline_fs_no_graph_profile(oracle, world, monkeypatch, geom, al, oal)
     and iupac code; the DP kernel reads the match term from that table."""
     refs, cs, idx, st = world
     if geom:
-        monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+        util.set_knobs(monkeypatch, geom=geom)
     qs = synth.make_queries(refs, 24, seed=57, window=(0.3, 120), ins=0.02, dele=0.02, lower_rate=0.05, amb_rate=0.02)
     ff = {"fs-min-len": 100, "fs-full-len": 250}
     pl = pipeline.Pipeline(st, famfinder=ff, aligner=dict(al, **{"fs-no-graph": True}))
@@ -112,12 +112,12 @@ def test_pipeline_fs_no_graph_profile(oracle, world, monkeypatch, geom, al, oal)
 @pytest.mark.parametrize("geom", ["128,12", "256,12", "128,8", "384,4"])
 @pytest.mark.parametrize("insertion", ["forbid", "shift"])
 def test_pipeline_forced_multi_strip_geometries(oracle, world, monkeypatch, geom, insertion):
-    """The same 24 queries under DP geometries forced with SINA_HIP_DP_GEOM -- several strips of 12, 8
+    """The same 24 queries under DP geometries forced with SINA_HIP_TEST="geom=T,B" -- several strips of 12, 8
     and 4 columns per lane, with and without --insertion=forbid (32-bit trace-back cells).  The
     12-column forbid kernels once restored garbage for a scalar load that was spilled while in flight
     (mesh_dp.hip, sload16): 17 or more queries in a launch crashed the GPU."""
     refs, cs, idx, st = world
-    monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+    util.set_knobs(monkeypatch, geom=geom)
     qs = synth.make_queries(refs, 24, seed=53, window=(0.3, 120), ins=0.02, dele=0.02, lower_rate=0.05)
     ff = {"fs-min-len": 100, "fs-full-len": 250}
     pl = pipeline.Pipeline(st, famfinder=ff, aligner={"insertion": insertion})
@@ -197,7 +197,7 @@ def test_pipeline_weighted_scheme(oracle, world, monkeypatch, geom, insertion):
     to fill more than one round of the 12-column kernels' scalar-register-starved variants."""
     refs, cs, idx, st = world
     if geom:
-        monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+        util.set_knobs(monkeypatch, geom=geom)
     rng = np.random.default_rng(8)
     w = rng.uniform(0.3, 1.4, size=refs.width).astype(np.float32)
     st.add_filter("posvar", w)
@@ -236,7 +236,7 @@ def test_pipeline_option_fuzz(oracle, world, monkeypatch, seed):
     pick = lambda xs: xs[int(rng.integers(0, len(xs)))]  # noqa: E731
     geom = pick([None, None, "64,8", "128,8", "128,12", "192,4", "256,4"])
     if geom:
-        monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+        util.set_knobs(monkeypatch, geom=geom)
     overhang, lowercase, insertion = pick(["attach", "remove", "edge"]), pick(["none", "original", "unaligned"]), pick(["shift", "forbid"])
     ms, mms = float(pick([2, 3, 1.5])), float(pick([-1, -2, -0.5]))
     gp, gpe = pick([(5, 2), (4, 1.5), (2, 3), (3, 3), (6, 0.5)])
@@ -296,7 +296,7 @@ def test_pipeline_mixed_query_lengths(oracle, world, monkeypatch, geom, insertio
     only the strips up to its own last column (mesh_dp_kernel: S per query)."""
     refs, cs, idx, st = world
     if geom:
-        monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+        util.set_knobs(monkeypatch, geom=geom)
     parts = [synth.make_queries(refs, 6, seed=70 + i, window=w, ins=0.01, dele=0.01)
              for i, w in enumerate([(0.4, 40), (0.2, 130), (0.1, 260), None])]
     masks = [p.seq(i) for p in parts for i in range(p.n)]

@@ -46,7 +46,7 @@ def test_row_skip_planes_equal_oracle_at_or_below_the_bound(oracle, gpu_ctx, mon
     forced: timid (0.3), plausible (0.9), bold (0.98) and impossible (2: no path gains twice the bound -- every
     query fails its first certificate and is swept again under the bound the first attempt found)."""
     if rho is not None:
-        monkeypatch.setenv("SINA_HIP_DP_PRUNE_RHO", rho)
+        util.set_knobs(monkeypatch, rho=rho)
     n_skipping = n_second = 0
     for ci in SIMPLE_CASES:
         case = util.MESH_CASES[ci]
@@ -61,9 +61,9 @@ def test_row_skip_planes_equal_oracle_at_or_below_the_bound(oracle, gpu_ctx, mon
         geoms = [None] if L > 1000 else ["%d,4" % (64 * ((L + 255) // 256 + (ci % 2))), "%d,8" % (64 * ((L + 511) // 512 + 1))]
         for geom in geoms:
             if geom:
-                monkeypatch.setenv("SINA_HIP_DP_GEOM", geom)
+                util.set_knobs(monkeypatch, geom=geom)
             else:
-                monkeypatch.delenv("SINA_HIP_DP_GEOM", raising=False)
+                util.set_knobs(monkeypatch, geom=None)
             if geom and int(geom.split(",")[0]) < 128:
                 continue   # (a single strip: the kernel does not skip)
             gb = gpu_ctx.graph_batch([g], width)
@@ -92,7 +92,7 @@ def test_row_skip_pipeline_equals_oracle(oracle, monkeypatch, rho):
     with the guess left alone or forced: family, alignment, head / tail / quality, log text equal the oracle's;
     rows are skipped; a bold guess costs second attempts, never a different result."""
     if rho is not None:
-        monkeypatch.setenv("SINA_HIP_DP_PRUNE_RHO", rho)
+        util.set_knobs(monkeypatch, rho=rho)
     refs = synth.make_refs(3000, length=1500, width=50000, seed=52)
     qs = synth.make_queries(refs, 24, seed=53)
     cs = util.cseqs_from_refs(refs)
@@ -159,7 +159,7 @@ def test_row_skip_narrow_band_after_wide_ones(oracle, gpu_ctx, monkeypatch, rho)
     must not be read as this sweep's.  Planes against the oracle's where at or below the bound, alignments through
     sina_hip_align_graphs against the oracle's."""
     if rho is not None:
-        monkeypatch.setenv("SINA_HIP_DP_PRUNE_RHO", rho)
+        util.set_knobs(monkeypatch, rho=rho)
     refs = synth.make_refs(400, length=1500, width=50000, seed=61, long_del_prob=0.5)
     cs = util.cseqs_from_refs(refs)
     rng = np.random.default_rng(62)
@@ -230,12 +230,12 @@ def test_row_skip_plane_fuzz(oracle, monkeypatch, seed):
         b, strips = 4, max(2, (len(qm) + 255) // 256)
     if len(qm) > 64 * b * strips:
         strips = (len(qm) + 64 * b - 1) // (64 * b)
-    monkeypatch.setenv("SINA_HIP_DP_GEOM", "%d,%d" % (64 * strips, b))
+    util.set_knobs(monkeypatch, geom="%d,%d" % (64 * strips, b))
     rho = pick([None, None, "0.2", "0.7", "0.97", "2.5"])
     if rho:
-        monkeypatch.setenv("SINA_HIP_DP_PRUNE_RHO", rho)
+        util.set_knobs(monkeypatch, rho=rho)
     if rng.integers(0, 3) == 0:
-        monkeypatch.setenv("SINA_HIP_DP_LDS_KB", str(pick([5, 9])))
+        util.set_knobs(monkeypatch, lds_kb=pick([5, 9]))
     gp, gpe = pick([(5, 2), (4, 1.5), (3, 3), (6, 0.5), (0.3, 0.1), (2, 3)])
     opts = dict(match_score=float(pick([2, 3, 0.7])), mismatch_score=float(pick([-1, -2, -0.1])), gap_penalty=float(gp),
                 gap_ext_penalty=float(gpe), insertion=int(pick([0, 0, 0, 1])), fs_weight=float(pick([1.0, 0.0, 2.5])))

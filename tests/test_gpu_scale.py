@@ -38,20 +38,16 @@ def _scores_and_topk_equal(ctx, idx, qs, maxes=(1, 41, 410, 4096)):
 
 
 @pytest.mark.parametrize("dense_div,expect_dense", [(None, "some"), ("1", "none"), ("1000000", "many")])
-def test_kmer_multi_tile_dense_equals_oracle(oracle, wide, dense_div, expect_dense):
+def test_kmer_multi_tile_dense_equals_oracle(oracle, wide, monkeypatch, dense_div, expect_dense):
     """kmer_count_kernel + kmer_select_kernel on the code path every BASELINE config runs: several
     reference tiles and posting lists counted from bitmaps (kmer_search.cpp:366-420, idset.h:315-337).
-    SINA_HIP_DENSE_DIV moves the list-length threshold (n_refs / div, at least 256): 1 switches the
+    SINA_HIP_TEST="dense_div=N" moves the list-length threshold (n_refs / div, at least 256): 1 switches the
     bitmaps off, a huge value makes every list above 256 references a bitmap -- the results must not
     depend on it."""
     refs, cs, qs = wide
     idx = oracle.Index(cs, k=10)
     off, ids = idx.csr()
-    old = os.environ.get("SINA_HIP_DENSE_DIV")
-    if dense_div is None:
-        os.environ.pop("SINA_HIP_DENSE_DIV", None)
-    else:
-        os.environ["SINA_HIP_DENSE_DIV"] = dense_div
+    util.set_knobs(monkeypatch, dense_div=dense_div)
     ctx = capi.Context(0)
     try:
         ctx.upload_refs(refs.ab, refs.off, refs.width)
@@ -67,10 +63,6 @@ def test_kmer_multi_tile_dense_equals_oracle(oracle, wide, dense_div, expect_den
             assert nd == int((ln > 256).sum()) and nd > 500
     finally:
         ctx.close()
-        if old is None:
-            os.environ.pop("SINA_HIP_DENSE_DIV", None)
-        else:
-            os.environ["SINA_HIP_DENSE_DIV"] = old
 
 
 @pytest.mark.parametrize("regime", ["spread", "identical", "two_groups", "unrelated"])
@@ -118,7 +110,7 @@ def test_kmer_search_fuzz(oracle, monkeypatch, seed):
     k, nofast = int(pick([6, 8, 10, 10])), bool(rng.integers(0, 2))
     dd = pick([None, None, "1", "8", "1000000"])
     if dd:
-        monkeypatch.setenv("SINA_HIP_DENSE_DIV", dd)
+        util.set_knobs(monkeypatch, dense_div=dd)
     cs = util.cseqs_from_refs(refs)
     idx = oracle.Index(cs, k=k, nofast=nofast)
     qs = synth.make_queries(refs, 5, seed=7200 + seed, sub=float(pick([0.0, 0.03, 0.2])), amb_rate=float(pick([0.0, 0.02])))

@@ -172,3 +172,20 @@ def plane_hash(a):
     b = np.ascontiguousarray(a)
     b = b.view(np.uint32) if b.dtype == np.float32 else b.astype(np.uint32)
     return np.frombuffer(hashlib.sha1(b.tobytes()).digest()[:8], np.uint64)[0]
+
+
+def set_knobs(monkeypatch, **kw):
+    """Test hooks of the library, all in ONE environment variable (csrc/common.h test_knob):
+    SINA_HIP_TEST="geom=T,B;generic=1;dense_div=N;lds_kb=N;rho=X".  A value of None removes the key; the other keys
+    of the variable stay as they are."""
+    import os
+    cur = dict(x.split("=", 1) for x in os.environ.get("SINA_HIP_TEST", "").split(";") if "=" in x)
+    for k, v in kw.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    if cur:
+        monkeypatch.setenv("SINA_HIP_TEST", ";".join("%s=%s" % kv for kv in cur.items()))
+    else:
+        monkeypatch.delenv("SINA_HIP_TEST", raising=False)

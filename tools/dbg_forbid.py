@@ -1,5 +1,5 @@
-"""--insertion=forbid through the pipeline under a forced DP geometry (SINA_HIP_DP_GEOM): crash hunt.
-usage: SINA_HIP_DP_GEOM=T,B tools/dbg_forbid.py [n_queries] [window]"""
+"""--insertion=forbid through the pipeline under a forced DP geometry (SINA_HIP_TEST=geom=T,B): crash hunt.
+usage: SINA_HIP_TEST=geom=T,B tools/dbg_forbid.py [n_queries] [window]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sina_amd import pipeline, synth
@@ -18,5 +18,5 @@ if os.environ.get("DBG_ABL"):
     from sina_amd import capi
     capi.load().sina_hip_debug_dp_ablate(int(os.environ["DBG_ABL"]))
 pl.run(qs.mask[qs.off[q0]:qs.off[q1]], off, batch=q1 - q0, inflight=1)
-print("ok", os.environ.get("SINA_HIP_DP_GEOM"), q0, q1, sum(1 for q in range(q1 - q0) if pl.result(q)["status"] == 0), "aligned")
+print("ok", os.environ.get("SINA_HIP_TEST"), q0, q1, sum(1 for q in range(q1 - q0) if pl.result(q)["status"] == 0), "aligned")
 pl.close(); st.close()

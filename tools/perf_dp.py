@@ -54,7 +54,7 @@ for mask in masks:
         print("abl %d wall %.3fs dp %.2f ms bt %.2f ms cells %.0f  -> %.1f Gcell/s  q/s(dp) %.0f" % (
             mask, dt, dp, st['backtrack_ms'] - s0['backtrack_ms'], cells, cells / dp / 1e6, nq / dp * 1e3))
         rows = st['dp_rows'] - s0['dp_rows']
-        if rows:  # the certified row skip (SINA_HIP_DP_PRUNE=0: off; SINA_HIP_DP_PRUNE_RHO: the guess)
+        if rows:  # the certified row skip (SINA_HIP_DP_PRUNE=0: off; SINA_HIP_TEST=rho=X: the guess)
             print("      rows swept %.3f of %d  cells swept %.3f  second attempts %d  full sweeps %d  of %d queries  next guess %.3f" % (
                 (st['dp_rows_swept'] - s0['dp_rows_swept']) / rows, rows, (st['dp_cells_swept'] - s0['dp_cells_swept']) / cells,
                 st['dp_second_attempts'] - s0['dp_second_attempts'], st['dp_full_sweeps'] - s0['dp_full_sweeps'],

@@ -3,6 +3,6 @@
 export SINA_HIP_TB_GB=${SINA_HIP_TB_GB:-72}
 for x in "$@"; do
   g=${x%%:*}; nq=${x##*:}
-  echo "== SINA_HIP_DP_GEOM=$g nq=$nq"
-  SINA_HIP_DP_GEOM=$g python3 tools/perf_dp.py $nq 2>&1 | tail -2
+  echo "== SINA_HIP_TEST=geom=$g nq=$nq"
+  SINA_HIP_TEST=geom=$g python3 tools/perf_dp.py $nq 2>&1 | tail -2
 done
