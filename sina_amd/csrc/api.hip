@@ -326,6 +326,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         if (hl.lk.owns_lock() && c->st->dp_end[0]) {  // (under the queue's lock: launch order = dp_seq order)
             dp_no = c->st->dp_seq++;
             SH_CHECK(hipEventRecord(c->st->dp_end[dp_no % 8], hl.stream()));
+            c->st->dp_end_no[dp_no % 8].store(dp_no, std::memory_order_release);
         }
         if (hl.chained && bt_fifo_wanted) {
             if (launch_backtrack(b, hl.stream())) return 1;
@@ -359,11 +360,15 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     SH_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     // ... of which this launch shared the device with the DP launch before it (chained launches, ctx.h)
     float shared = 0;
-    if (dp_no != ~0ull && dp_no > 0) {
+    // (the ring has eight slots and this thread reads it outside the queue's lock: a slot that has been re-recorded by
+    // launch dp_no + 7 meanwhile is not the predecessor's any more -- its number says so -- and counts as no overlap,
+    // as does a predecessor that has not ended yet: a short launch can end before the drain of the one before it)
+    if (dp_no != ~0ull && dp_no > 0 && c->st->dp_end_no[(dp_no - 1) % 8].load(std::memory_order_acquire) == dp_no - 1) {
         float to_prev_end = 0;
         const hipError_t e = hipEventElapsedTime(&to_prev_end, c->ev[0], c->st->dp_end[(dp_no - 1) % 8]);
-        if (e == hipSuccess) shared = std::min(ms, std::max(0.f, to_prev_end));
-        else (void)hipGetLastError();  // (the launch before has not ended yet: cannot happen behind a chain; counted as no overlap)
+        if (e == hipSuccess && c->st->dp_end_no[(dp_no - 1) % 8].load(std::memory_order_acquire) == dp_no - 1)
+            shared = std::min(ms, std::max(0.f, to_prev_end));
+        else (void)hipGetLastError();
     }
     // what the launch actually swept (certified row skip), and what its queries say about the next launch's guess
     const uint32_t kstrip = 64u * (uint32_t)pl.geom.B;
@@ -659,8 +664,16 @@ int sina_hip_init(int device, sina_hip_ctx **ctx) {
             can_wait_value = 0;
         }
         if (!can_wait_value) return 0;
-        const size_t bytes = 4 * (1 + (size_t)sina_hip_store::kDryCounters);
+        // (the flag word in signal memory -- what hipStreamWaitValue32 is documented for --, the counters in a plain block;
+        // a runtime that will not give signal memory leaves the store unchained)
+        if (hipExtMallocWithFlags(reinterpret_cast<void **>(&st->dry_flag), 8, hipMallocSignalMemory) != hipSuccess) {
+            (void)hipGetLastError();
+            st->dry_flag = nullptr;
+            return 0;
+        }
+        const size_t bytes = 4 * (size_t)sina_hip_store::kDryCounters;
         if (hipMalloc(reinterpret_cast<void **>(&st->dry_mem), bytes) != hipSuccess) return 1;
+        if (hipMemset(st->dry_flag, 0, 8) != hipSuccess) return 1;
         return hipMemset(st->dry_mem, 0, bytes) != hipSuccess ? 1 : 0;
     };
     if (finish_ctx(c) || make_heavy(c->st)) {

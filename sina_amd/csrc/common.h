@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -73,7 +75,7 @@ struct DevBuf {
     // the largest capacity any context of the store has needed for THIS buffer so far (sina_hip_store::cap_hint;
     // nullptr: none): a buffer that has to grow goes there at once -- a context allocates only what its kind of
     // call uses, and each of those once
-    const size_t *hint = nullptr;
+    const std::atomic<size_t> *hint = nullptr;
     // (hipFree / hipMalloc synchronise the whole device and stall every other context's stream:
     // grow in big steps so that batch-to-batch size jitter never reallocates in steady state)
     int reserve(size_t bytes) {
@@ -82,7 +84,7 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
         size_t want = bytes + bytes / 4 + 4096;
-        if (hint && *hint > want) want = *hint;
+        if (hint) want = std::max(want, hint->load(std::memory_order_relaxed));
         trace_alloc(want);
         SH_CHECK(hipMalloc(&p, want));
         cap = want;

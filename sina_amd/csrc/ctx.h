@@ -43,7 +43,11 @@ struct sina_hip_store {
     // that ran dry), [1 + seq % kDryCounters] that launch's count of started workgroups.
     hipStream_t heavy2 = nullptr;
     hipEvent_t heavy_done[2] = {nullptr, nullptr};  // end of the last launch queued on heavy / heavy2
+    // dry_flag: the word hipStreamWaitValue32 waits on -- SIGNAL memory (hipExtMallocWithFlags(hipMallocSignalMemory),
+    // what the HIP header documents for that call); dry_mem: the launches' counters of started workgroups, plain memory
+    uint32_t *dry_flag = nullptr;
     uint32_t *dry_mem = nullptr;
+    std::atomic<bool> chain_broken{false};  // a chained wait timed out once (heavy_launch::done): launches wait for ends from now on
     static constexpr uint32_t kDryCounters = 64;
     uint32_t heavy_seq = 0;          // launches queued so far (guarded by heavy_mu, like everything below)
     int heavy_turn = 0;              // the stream the next launch goes to
@@ -65,10 +69,11 @@ struct sina_hip_store {
     // during which ANY DP kernel was resident -- the sum of the launches' durations minus their overlaps, which
     // are measured against the end event of the launch before (a ring: launch k records dp_end[k % 8])
     hipEvent_t dp_end[8] = {};
+    std::atomic<uint64_t> dp_end_no[8] = {};  // which launch's end slot k holds (written under heavy_mu when it is recorded)
     uint64_t dp_seq = 0;
     // largest capacity any context has needed for each scratch buffer so far: a new fork reserves
     // these at once (hipMalloc / hipFree synchronise the device; never in steady state)
-    size_t cap_hint[64] = {};  // (indexed like sina_hip_ctx::scratch(): kNumScratch entries)
+    std::atomic<size_t> cap_hint[64] = {};  // (indexed like sina_hip_ctx::scratch(): kNumScratch entries; read without a lock)
     // certified row skip of the DP kernel (mesh_dp.hip PRUNE): the guess rho of "optimum / bound on the whole gain"
     // the next launch starts its queries with, learnt from the queries aligned so far (run_dp_device; under stats_mu).
     // Results never depend on it: a guess that is too bold costs the queries it fails a second sweep, a timid one
@@ -89,6 +94,8 @@ struct sina_hip_store {
         bool busy[kMax] = {false, false, false, false};
         int n = 2;            // SINA_HIP_TB_PLANES
         uint64_t budget = 0;  // bytes per plane; 0 = not decided yet
+        uint64_t now_budget = 0;  // ... capped by what the device could give when `now_made` planes existed
+        int now_made = -1;
     } tb_pool;
 };
 
@@ -137,9 +144,11 @@ struct sina_hip_ctx {
     void publish_hints() {  // after a call: remember how big my buffers had to be
         sina_hip::DevBuf *all[kNumScratch];
         scratch(all);
-        std::lock_guard<std::mutex> lk(st->stats_mu);
-        for (int i = 0; i < kNumScratch; i++)
-            if (all[i]->cap > st->cap_hint[i]) st->cap_hint[i] = all[i]->cap;
+        for (int i = 0; i < kNumScratch; i++) {  // (a maximum: compare-exchange until mine is in or beaten)
+            size_t seen = st->cap_hint[i].load(std::memory_order_relaxed);
+            while (all[i]->cap > seen && !st->cap_hint[i].compare_exchange_weak(seen, all[i]->cap, std::memory_order_relaxed)) {
+            }
+        }
     }
     // Every scratch buffer knows where the store keeps the largest capacity any context needed for it: a buffer
     // that grows goes there in one step (DevBuf::reserve).  Until round 4 a new fork allocated ALL its buffers at
@@ -161,7 +170,7 @@ struct sina_hip_ctx {
         sina_hip::DevBuf **list = kind == 0 ? search : (kind == 1 ? align : compare);
         const size_t n = kind == 0 ? sizeof search / sizeof *search : (kind == 1 ? sizeof align / sizeof *align : sizeof compare / sizeof *compare);
         for (size_t i = 0; i < n; i++) {
-            const size_t want = list[i]->hint ? *list[i]->hint : 0;
+            const size_t want = list[i]->hint ? list[i]->hint->load(std::memory_order_relaxed) : 0;
             if (want > list[i]->cap && list[i]->reserve_exact(want)) return 1;
         }
         return 0;
@@ -181,6 +190,7 @@ struct sina_hip_ctx {
             for (auto &e : st->heavy_done)
                 if (e) (void)hipEventDestroy(e);
             if (st->dry_mem) (void)hipFree(st->dry_mem);
+            if (st->dry_flag) (void)hipFree(st->dry_flag);
             for (auto &e : st->dp_end)
                 if (e) (void)hipEventDestroy(e);
             st->ref_ab.release();
@@ -221,17 +231,26 @@ inline uint64_t tb_plane_budget(sina_hip_ctx *c) {
     // failing in hipMalloc.  (SINA_HIP_TB_GB still wins: an explicit size is taken as given.)
     // (asked only while the pool is still being built: once every plane exists launches repeat their sizes, and
     // hipMemGetInfo is not a call to make per batch)
-    bool building = false;
-    for (int i = 0; i < tp.n; i++) building = building || tp.plane[i].cap == 0;
-    if (building && !(getenv("SINA_HIP_TB_GB") && atof(getenv("SINA_HIP_TB_GB")) > 0)) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            uint64_t held = 0;
-            for (int i = 0; i < tp.n; i++) held += tp.plane[i].cap;
-            const uint64_t now = (uint64_t)((double)(free_b + held) * 0.84 / tp.n);
-            return std::max<uint64_t>((uint64_t)1 << 28, std::min<uint64_t>(tp.budget, now));
+    // (asked while the pool is still being built -- and latched per number of planes made so far: with one context in
+    // flight the second plane is never made, and a budget that moved with the free memory on every call made the
+    // launch sizes stop repeating)
+    int made = 0;
+    for (int i = 0; i < tp.n; i++) made += tp.plane[i].cap != 0 ? 1 : 0;
+    if (made < tp.n && !(getenv("SINA_HIP_TB_GB") && atof(getenv("SINA_HIP_TB_GB")) > 0)) {
+        if (tp.now_made != made || tp.now_budget == 0) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                uint64_t held = 0;
+                for (int i = 0; i < tp.n; i++) held += tp.plane[i].cap;
+                const uint64_t now = (uint64_t)((double)(free_b + held) * 0.84 / tp.n);
+                tp.now_budget = std::max<uint64_t>((uint64_t)1 << 28, std::min<uint64_t>(tp.budget, now));
+                tp.now_made = made;
+            } else {
+                (void)hipGetLastError();
+                return tp.budget;
+            }
         }
-        (void)hipGetLastError();
+        return tp.now_budget;
     }
     return tp.budget;
 }
@@ -337,13 +356,18 @@ inline bool serialize_kernels() {
 // waited) -- with seven host threads of a pipeline waiting for the GPU most of the time that was a
 // third of the process's CPU time.  Poll-and-sleep instead: the wake-up is at most ~100 us late,
 // which only matters if nothing else is queued behind on the heavy stream.
-inline hipError_t wait_event(hipEvent_t ev) {
+constexpr double kChainTimeoutS = 120.0;
+// (timeout_s > 0: gives up with hipErrorNotReady after that long)
+inline hipError_t wait_event(hipEvent_t ev, double timeout_s = 0.0) {
     long ns = 50000;  // 50 us, growing to 1 ms: short waits are answered fast, a 17 ms DP kernel costs ~25 wake-ups
+    double waited = 0.0;
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
+        if (timeout_s > 0.0 && waited > timeout_s) return hipErrorNotReady;
         timespec ts{0, ns};
         nanosleep(&ts, nullptr);
+        waited += ns * 1e-9;
         if (ns < 1000000) ns += ns / 2;
     }
 }
@@ -442,7 +466,7 @@ struct heavy_launch {
         sina_hip_store *st = c->st;
         failed = hipEventRecord(c->ev[10], own) != hipSuccess;
         lk = std::unique_lock<std::mutex>(st->heavy_mu);
-        const bool chain = chain_kernels() && st->heavy2 && st->dry_mem;
+        const bool chain = chain_kernels() && st->heavy2 && st->dry_mem && !st->chain_broken.load(std::memory_order_relaxed);
         chained = chain;
         if (chain) {
             const uint64_t me = st->heavy_ticket++;
@@ -481,7 +505,7 @@ struct heavy_launch {
         failed = failed || hipStreamWaitEvent(hs, c->ev[10], 0) != hipSuccess;
         if (chain && st->heavy_prev_any) {
             if (st->heavy_prev_dry)
-                failed = failed || hipStreamWaitValue32(hs, st->dry_mem, st->heavy_prev_seq, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess;
+                failed = failed || hipStreamWaitValue32(hs, st->dry_flag, st->heavy_prev_seq, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess;
             else
                 failed = failed || hipStreamWaitEvent(hs, st->heavy_done[turn ^ 1], 0) != hipSuccess;
         }
@@ -492,9 +516,9 @@ struct heavy_launch {
     DryArgs dry() {
         DryArgs d{nullptr, nullptr, 0};
         sina_hip_store *st = c->st;
-        if (!lk.owns_lock() || !chain_kernels() || !st->heavy2 || !st->dry_mem) return d;
-        d.flag = st->dry_mem;
-        d.counter = st->dry_mem + 1 + my_seq % sina_hip_store::kDryCounters;
+        if (!lk.owns_lock() || !chained) return d;
+        d.flag = st->dry_flag;
+        d.counter = st->dry_mem + my_seq % sina_hip_store::kDryCounters;
         d.seq = my_seq;
         signals_dry = true;
         return d;
@@ -509,7 +533,7 @@ struct heavy_launch {
         failed = failed || hipEventRecord(c->ev[11], hs) != hipSuccess;
         if (lk.owns_lock()) {
             sina_hip_store *st = c->st;
-            if (chain_kernels() && st->heavy2 && st->dry_mem) {
+            if (chained) {
                 failed = failed || hipEventRecord(st->heavy_done[turn], hs) != hipSuccess;
                 st->heavy_prev_dry = signals_dry && !failed;
                 st->heavy_prev_seq = my_seq;
@@ -519,7 +543,19 @@ struct heavy_launch {
             lk.unlock();
             c->st->heavy_cv.notify_all();
         }
-        failed = failed || wait_event(c->ev[11]) != hipSuccess;
+        // A tool that serialises kernels across queues in the order it intercepts them (a counter-collecting profiler
+        // is the one known: chain_kernels()) can let the runtime's wait-value poller in before the launch it waits
+        // for, and then nothing runs again.  A chained launch that has not ended after kChainTimeoutS is taken for
+        // that: the call fails with a message that names the cause, and the store stops chaining.
+        const hipError_t we = wait_event(c->ev[11], chained ? kChainTimeoutS : 0.0);
+        if (we == hipErrorNotReady) {
+            c->st->chain_broken.store(true, std::memory_order_relaxed);
+            leave();
+            set_error("heavy_launch: a chained launch did not end within 120 s -- a tool that serialises kernels across "
+                      "queues? (set SINA_HIP_CHAIN=0); the store waits for launch ends from now on");
+            return 1;
+        }
+        failed = failed || we != hipSuccess;
         leave();
         if (failed) set_error("heavy_launch: event hand-over failed");
         return failed ? 1 : 0;

@@ -382,6 +382,18 @@ int sina_host_run_fasta(const char *in_path, const char *out_path, const char *l
         fasta_run r(in_path, out_path, log_path, do_search, show_dist);
         if (batch == 0) batch = 1024;
         tune_allocator();
+        try {  // the contexts the node threads below will lease, made and warmed before any of them starts
+            const auto store = reference_store::get(aligner::opts->database);
+            const auto sstore = do_search ? reference_store::get(search_filter_database()) : nullptr;
+            store->reserve_workers(reference_store::dev_search, 1 + (sstore == store ? 1 : 0));
+            store->reserve_workers(reference_store::dev_align, 1);
+            if (sstore) {
+                if (sstore != store) sstore->reserve_workers(reference_store::dev_search, 1);
+                sstore->reserve_workers(reference_store::dev_compare, 1);
+            }
+        } catch (const std::exception &) {
+            // (a store that cannot be opened yet is reported by the stage that needs it)
+        }
         // bounded hand-over between the nodes; batches stay in input order (one thread per node: FIFO)
         struct chan {
             std::mutex mu;

@@ -648,6 +648,8 @@ void reference_store::ensure_index(unsigned k, bool nofast) {
                             hit[it->second] = 1;
                         }
                     }
+                    // (a corrupt or foreign cache may name ids beyond its own name list: rebuilt, not followed)
+                    for (size_t i = 0; i < ids.size() && usable; i++) usable = ids[i] < remap.size();
                     if (usable) {
                         for (auto &id : ids) id = remap[id];
                         parallel_for(offsets.size() - 1, [&](size_t km) {

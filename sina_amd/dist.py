@@ -77,6 +77,9 @@ def merge_by_seqno(local, dist, dst=0, chunk=2048, device=None, stats=None):
     if dist is None:
         return mine
     world, rank = dist.get_world_size(), dist.get_rank()
+    if device is None and str(dist.get_backend()) == "nccl":  # (RCCL moves device tensors only)
+        import torch
+        device = torch.device("cuda", torch.cuda.current_device())
     rounds = int(reduce_max((len(mine) + chunk - 1) // chunk, dist, device))
     parts = [[] for _ in range(world)] if rank == dst else None
     received = 0
