@@ -267,17 +267,18 @@ int sina_hip_debug_mesh(sina_hip_ctx *ctx, const sina_hip_graph_batch *g, const 
 /* Test hooks for the certified row skip: what the DP kernel reported for query q of the context's LAST launch
  * (attempts 0: that launch swept everything), and the first n entries of the per-node bound R(m) the last launch /
  * the last sina_hip_debug_family_graph left on the device (units of 1/64; entry i belongs to node i of the launch's
- * first DAG).  prune_step = the largest gain of one match step the launch assumed, same units. */
+ * first DAG) with C(m), the number of occupied columns right of the node's.  prune_step = the largest gain of one
+ * match step the launch assumed, prune_gmin = the smallest column maximum of query q's DAG, same units. */
 typedef struct sina_hip_dp_info {
     uint32_t end_m, end_s;
     float raw;
     int32_t status;
     uint32_t rows_swept, cells_swept, attempts;
     float gain0, ubound;
-    uint32_t prune_step;
+    uint32_t prune_step, prune_gmin;
 } sina_hip_dp_info;
 int sina_hip_debug_dp_info(sina_hip_ctx *ctx, uint32_t q, sina_hip_dp_info *out);
-int sina_hip_debug_rgain(sina_hip_ctx *ctx, uint32_t n, uint32_t *out);
+int sina_hip_debug_rgain(sina_hip_ctx *ctx, uint32_t n, uint32_t *out, uint32_t *cols_right /* C(m), may be NULL */);
 
 /* Test hook: the DAG the GPU builds for ONE family (ids into the uploaded store, in family
  * order), in compact CSR form, for comparison with mseq (src/mseq.cpp:47-118).

@@ -79,7 +79,7 @@ class Stats(C.Structure):
 class DpInfo(C.Structure):
     _fields_ = [("end_m", C.c_uint32), ("end_s", C.c_uint32), ("raw", C.c_float), ("status", C.c_int32),
                 ("rows_swept", C.c_uint32), ("cells_swept", C.c_uint32), ("attempts", C.c_uint32),
-                ("gain0", C.c_float), ("ubound", C.c_float), ("prune_step", C.c_uint32)]
+                ("gain0", C.c_float), ("ubound", C.c_float), ("prune_step", C.c_uint32), ("prune_gmin", C.c_uint32)]
 
 
 _lib = None
@@ -126,7 +126,7 @@ def load():
                                               f32p, u32p, u32p, u32p, u8p, u32p, C.c_uint32, C.c_uint32]
     L.sina_hip_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.sina_hip_debug_dp_info.argtypes = [vp, C.c_uint32, C.POINTER(DpInfo)]
-    L.sina_hip_debug_rgain.argtypes = [vp, C.c_uint32, u32p]
+    L.sina_hip_debug_rgain.argtypes = [vp, C.c_uint32, u32p, u32p]
     _lib = L
     return L
 
@@ -365,10 +365,12 @@ class Context:
         return {f[0]: getattr(d, f[0]) for f in DpInfo._fields_}
 
     def rgain(self, n):
-        """First n entries of the per-node row-skip bound the last launch / debug_family_graph left on the device."""
+        """First n entries of the per-node row-skip bound the last launch / debug_family_graph left on the device:
+        (R(m) in units of 1/64, C(m) = occupied columns right of the node's)."""
         out = np.zeros(max(n, 1), np.uint32)
-        self._check(self.L.sina_hip_debug_rgain(self.h, n, _ptr(out, u32p)))
-        return out[:n]
+        cols = np.zeros(max(n, 1), np.uint32)
+        self._check(self.L.sina_hip_debug_rgain(self.h, n, _ptr(out, u32p), _ptr(cols, u32p)))
+        return out[:n], cols[:n]
 
     def stats(self):
         s = Stats()

@@ -111,7 +111,7 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
             }
         }
         d.first_sink = 0;
-        d.pad_ = 0;
+        d.gmin = 0;
         for (uint32_t m = 0; m < N; m++)
             if (rec[m].z & kRecSink) {
                 d.first_sink = m;
@@ -170,17 +170,20 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
                     if (pos[g->pred[eo + e]] >= pos[m]) ok = false;
             }
             if (!ok) hp->rgain_ok = false;
-            uint32_t right = 0;  // columns right of the one being finished
+            uint32_t right = 0, cols_right = 0, gmin = 0xFFFFFFFFu;  // columns right of the one being finished
             for (uint32_t m = N; ok && m > 0;) {
                 uint32_t first = m - 1, mx = 0;
                 while (first > 0 && pos[first - 1] == pos[m - 1]) first--;
                 for (uint32_t j = first; j < m; j++) {
                     mx = std::max(mx, prune_gain_units(g->node_weight[no + j], kappa64));
-                    rg[j] = uint2{right, last[j]};
+                    rg[j] = uint2{right, last[j] | (cols_right << 16)};
                 }
                 right += mx;
+                cols_right++;
+                gmin = std::min(gmin, mx);
                 m = first;
             }
+            d.gmin = ok ? gmin : 0u;
         }
         d.n_spill = nsp;
         hp->spill_rows += nsp;
@@ -817,17 +820,23 @@ int sina_hip_debug_dp_info(sina_hip_ctx *c, uint32_t q, sina_hip_dp_info *out) {
     out->gain0 = r.gain0;
     out->ubound = r.ubound;
     out->prune_step = c->last_prune_step;
+    QDesc d;
+    SH_CHECK(hipMemcpy(&d, c->qd.as<QDesc>() + q, sizeof d, hipMemcpyDeviceToHost));
+    out->prune_gmin = d.gmin;
     return 0;
 }
 
-int sina_hip_debug_rgain(sina_hip_ctx *c, uint32_t n, uint32_t *out) {
+int sina_hip_debug_rgain(sina_hip_ctx *c, uint32_t n, uint32_t *out, uint32_t *cols_right) {
     if (!c || !out) SH_FAIL("debug_rgain: null argument");
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->rgain.p || c->rgain.cap < 8 * (size_t)n) SH_FAIL("debug_rgain: no bound of that many nodes on the device");
     SH_CHECK(hipSetDevice(c->device));
     std::vector<uint2> tmp(n);
     SH_CHECK(hipMemcpy(tmp.data(), c->rgain.p, 8 * (size_t)n, hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < n; i++) out[i] = tmp[i].x;
+    for (uint32_t i = 0; i < n; i++) {
+        out[i] = tmp[i].x;
+        if (cols_right) cols_right[i] = tmp[i].y >> 16;
+    }
     return 0;
 }
 

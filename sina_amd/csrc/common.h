@@ -179,7 +179,7 @@ struct QDesc {
     uint32_t n_spill;
     uint32_t erec_off;   // into a strip boundary's edge records: regions start on 64-byte lines (4 records), see EdgeRec
     uint32_t first_sink; // sinks[0]: the row the end-cell search starts from (mesh.h:567); the row-skipping kernel may never visit it
-    uint32_t pad_;
+    uint32_t gmin;       // row skip: the smallest "best gain of a column" of the DAG, units of kPruneUnit (what a path forfeits per column it leaves out)
 };
 static_assert(sizeof(QDesc) == 64, "uploaded as an array");
 
@@ -283,9 +283,11 @@ struct DpResult {
 static_assert(sizeof(DpResult) == 40, "downloaded as an array");
 
 // ---- certified row skip: the bound
-// T(m, s) = U + min(a * (L-1-s), R(m)) bounds the value a cell may have and still lie on a path that ends at U or
-// below: every query base still to come gains at most a, every DAG column right of pos(m) at most its best
-// node's gain, gaps cost (gap penalties >= 0).  All of it in units of 1/64 so that T is EXACT in float32 (the
+// T(m, s) = U + min(a * r, R(m) - gmin * max(0, C(m) - r)), r = L-1-s the query bases still to come, bounds the value
+// a cell may have and still lie on a path that ends at U or below: every query base gains at most a; every DAG
+// column right of pos(m) at most its best node's gain (R(m) = their sum, C(m) = their number) -- and a path takes
+// one column per base at most, so of C(m) columns it leaves C(m) - r out, each worth gmin or more; gaps cost (gap
+// penalties >= 0).  All of it in units of 1/64 so that T is EXACT in float32 (the
 // induction needs T(source) - gain >= T(target) to hold as computed, not just as written): a node's gain is
 // rounded up to a multiple of 1/64 plus one unit of margin for the float rounding of the cell values.
 constexpr float kPruneUnit = 1.0f / 64.0f;
@@ -334,7 +336,7 @@ struct DpArgs {
     // certified row skip (mesh_dp_simple_kernel<.., PRUNE>): per node the gain still to come right of its column
     // (units of kPruneUnit) and how far its successors reach, the launch's guess rho of optimum / first-cell
     // bound, the largest gain of one step; prune == 0: every row of every strip is swept
-    const uint2 *reach;         // per node {R(m), id of its last successor (0: none)}, indexed like rec
+    const uint2 *reach;         // per node {R(m), id of its last successor (0: none) | C(m) << 16}, indexed like rec
     int prune;
     float prune_rho;
     uint32_t prune_amax;

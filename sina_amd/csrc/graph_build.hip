@@ -84,7 +84,7 @@ struct GraphArgs {
     uint32_t member_cap;
     int W;                     // DP ring depth: edges longer than this need a spill row
     int want_smin;             // succ_min is read by somebody (--insertion=forbid, the debug entry): else it is not touched at all
-    uint2 *reach;              // [nq][ncap] or nullptr: the DP kernel's row-skip bound R(m) (step 9; units: common.h) + last successor
+    uint2 *reach;              // [nq][ncap] or nullptr: the DP kernel's row-skip bound (step 9; units: common.h): {R(m), last successor | C(m) << 16}
     float kappa64;             // ... 64 * 1.0001 * (largest match gain per unit of node weight)
     DryArgs dry;               // (ctx.h, heavy_launch: tells the launch queued behind when the last workgroup has started)
 };
@@ -590,6 +590,7 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
         // (scratch: nobody reads succ_min in a launch that skips rows -- want_smin is --insertion=forbid; the debug
         // entry wants both and gets the last successors overwritten instead)
         uint32_t *cw = a.want_smin ? last : smin;
+        if (tid == 0) s_tmp[kGT / 64 + 2] = 0xFFFFFFFFu;  // smallest column maximum
         __syncthreads();
         for (uint32_t i = tid; i < N; i += kGT) {
             const uint32_t pos = node_pos[i];
@@ -600,14 +601,17 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
                 cw[j] = 0;
             }
             cw[i] = mx;
+            atomicMin(&s_tmp[kGT / 64 + 2], mx);
         }
         __syncthreads();
+        if (tid == 0) sz[5] = s_tmp[kGT / 64 + 2];
         const uint32_t total = block_exscan(cw, cw, N, s_tmp);
         for (uint32_t i = tid; i < N; i += kGT) {
             const uint32_t pos = node_pos[i];
             if (i > 0 && node_pos[i - 1] == pos) continue;
             const uint32_t right = (i + 1 < N) ? total - cw[i + 1] : 0u;  // (cw[i + 1] = columns up to and including mine)
-            for (uint32_t j = i; j < N && node_pos[j] == pos; j++) rg[j] = uint2{right, a.want_smin ? 0u : last[j]};
+            const uint32_t cols_right = NC - 1u - rank(pos);                 // (the dense column index of step 2)
+            for (uint32_t j = i; j < N && node_pos[j] == pos; j++) rg[j] = uint2{right, (a.want_smin ? 0u : last[j]) | (cols_right << 16)};
         }
     }
     GP_FLUSH
@@ -885,7 +889,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
                 d.L = (uint32_t)(qoff[q0 + r1 + 1] - qoff[q0 + r1]);
                 d.n_spill = bg.sizes[kSz * u + 2];
                 d.first_sink = bg.sizes[kSz * u + 4];
-                d.pad_ = 0;
+                d.gmin = bg.sizes[kSz * u + 5];
                 d.erec_off = erec_cursor;
                 erec_cursor += dp_edge_entries(N);
                 qd.push_back(d);

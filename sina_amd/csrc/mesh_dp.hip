@@ -1007,7 +1007,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                       const uint32_t *__restrict__ predv, const uint8_t *__restrict__ qmaskv, void *__restrict__ tbv,
                       float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev, uint64_t edge_stride,
                       uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe, DryArgs dry,
-                      const uint2 *__restrict__ reachv, float prune_rho, uint32_t prune_amax) {
+                      const uint2 *__restrict__ reachv, float prune_rho, uint32_t prune_amax, uint32_t n_slots) {
     static_assert(B % 4 == 0, "16-byte accesses per array");
     constexpr int kStrip = 64 * B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1043,19 +1043,31 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     // path's cost); 3: no bound.  All bounds are integers in units of 1/64 (exact in float32 below 2^24 units).
     constexpr int32_t kNoBound = 1 << 29;
     constexpr float kDead = 1000000.0f;  // what a skipped row shows its successors: the reference's own "unreached" (mesh.h:290)
-    // per node {R(m) in units, id of its last successor (0: none)}: what a row found alive can still reach
+    // per node {R(m) in units, id of its last successor (0: none) | C(m) << 16}: what a row found alive can still reach
     const uint2 *__restrict__ reach = PRUNE ? reachv + node_off : nullptr;
+    const uint32_t gmin = uniform(d.gmin);  // what a path forfeits per column it leaves out, units
+
     const uint32_t first_sink = uniform(d.first_sink);
     int32_t U64 = kNoBound;
     float gain0 = 0.f;
+    // U + R(m) - gmin * max(0, C(m) - r), units: the bound's second term at a cell with r query bases to come
+    auto col_bound = [&](uint2 rc, int32_t r) -> int32_t {
+        const int32_t excess = (int32_t)(rc.y >> 16) - r;
+        return U64 + (int32_t)rc.x - (excess > 0 ? (int32_t)gmin * excess : 0);
+    };
     if constexpr (PRUNE) {
         // the whole alignment right of the first node, its own column included (<= one step's largest gain)
-        const uint32_t g_cols = uniform(reach[0].x) + prune_amax, g_len = prune_amax * (L - 1);
+        // (all columns: those right of node 0's and its own)
+        const uint2 r0 = reach[0];
+        const int32_t excess0 = (int32_t)(r0.y >> 16) + 1 - (int32_t)(L - 1);
+        const uint32_t g_cols = uniform(r0.x) + prune_amax - (excess0 > 0 ? gmin * (uint32_t)excess0 : 0u), g_len = prune_amax * (L - 1);
         const uint32_t g0 = g_cols < g_len ? g_cols : g_len;
         gain0 = (float)g0 * kPruneUnit;
         U64 = -(int32_t)uniform((uint32_t)(int32_t)(prune_rho * (float)g0));  // (rounded towards zero: the looser side)
     }
     uint32_t rows_done = 0, cells_done = 0, attempt = 0;
+    const float gmin_f = (float)gmin * kPruneUnit;
+    SH_PROF_DECL
     uint32_t res_m = 0, res_s = 0;
     float res_v = 0.f;
     int32_t res_status = 0;
@@ -1071,8 +1083,9 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     uint32_t all_m = 0, all_s = 0xffffffffu, snk0 = PRUNE ? first_sink : 0u;
     bool all_any = PRUNE;  // (a DAG has a sink: its last row)
     // Where an alignment may start for free -- column 0 of any row, any column of a row without predecessors: initial
-    // value 1 -- is above its bound U + min(a * (L-1-s), R(m)) from this row on, whatever the column: R falls with the
-    // row (graph_build.hip step 9), so it is a threshold, found once per attempt.
+    // value 1 -- is above its bound from this row on, whatever the column: the bound's second term falls with the row
+    // (a column further right: R loses that column's gain, gmin or more, and C - r one column, worth gmin) and, in a
+    // row, with the column, so its value at column 0 is a threshold, found once per attempt.
     uint32_t m_free_dead = 0;
     // rows of the strip just finished whose last cell was at or below its bound (first, last; none: first = ~0): all
     // a later strip can start from
@@ -1083,16 +1096,15 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             uint32_t lo = 0, hi = N;
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (U64 + (int32_t)uniform(reach[mid].x) < 64) hi = mid;
+                if (col_bound(reach[mid], (int32_t)(L - 1)) < 64) hi = mid;
                 else lo = mid + 1;
             }
             m_free_dead = lo;
         }
     }
 
-    SH_PROF_DECL
 #ifdef SH_PROF_TIMERS
-    if (lane == 0 && blockIdx.x < 16384) g_dp_span[2 * blockIdx.x] = wall_clock64();
+    if (attempt == 1 && lane == 0 && blockIdx.x < 16384) g_dp_span[2 * blockIdx.x] = wall_clock64();
 #endif
     // trace-back tags (16-bit cells, common.h)
     constexpr uint32_t kXL = kTb16XLast, kExtXL = kTb16Ext | kTb16XLast;
@@ -1148,23 +1160,38 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     sload_wait(cur_pe);
     sload_wait(cur_edge);
     Cells<B> prev_v, prev_g;  // the row just finished (common.h: a row whose only successor is the next row is kept nowhere else)
-    float prev_edge_val = (PRUNE && m_begin > 0) ? kDead : 0.f;
+    float prev_edge_val = 0.f;
 #pragma unroll
-    for (int i = 0; i < B / 4; i++) {
-        const float z = (PRUNE && m_begin > 0) ? kDead : 0.f;
-        prev_v.v[i] = prev_g.v[i] = typename Cells<B>::V{z, z, z, z};
-    }
+    for (int i = 0; i < B / 4; i++) prev_v.v[i] = prev_g.v[i] = typename Cells<B>::V{0.f, 0.f, 0.f, 0.f};
 
-    // ---- row skip, per strip: the bound of my first cell (the largest of my cells' bounds), which of the last 64
-    // rows were dead in this strip (bit d-1: row m-d), which LDS slots / whether the hand-over registers already
-    // show kDead, the rows swept
-    float A_lane = 0.f;
-    uint64_t dead_hist = (PRUNE && m_begin > 0) ? ~0ull : 0ull;
+    // ---- row skip, per strip: the bound of my first cell (the largest of my cells' bounds), how many rows in a row
+    // right before this one were dead in this strip, which LDS slots already show kDead, whether the row before was
+    // not swept (the hand-over registers then hold some older row: a skipped row touches NO vector register -- anything
+    // it changed there would be a copy on the swept rows' path, where the loop's two back edges meet), the rows swept
+    float A_lane = 0.f, r_lane = 0.f;
+    uint32_t dead_run = (PRUNE && m_begin > 0) ? 64u : 0u;
     uint32_t slot_dead = 0, rows_strip = 0;
     bool prev_dead = PRUNE && m_begin > 0;
     // whether cur_pe holds THIS row's predecessor entries (a skipped row does not fetch the next row's)
     bool pe_valid = true;
-    if constexpr (PRUNE) A_lane = (float)(U64 + (int32_t)prune_amax * ((int32_t)(L - 1) - (int32_t)s0)) * kPruneUnit;
+    if constexpr (PRUNE) {
+        A_lane = (float)(U64 + (int32_t)prune_amax * ((int32_t)(L - 1) - (int32_t)s0)) * kPruneUnit;
+        r_lane = (float)((int32_t)(L - 1) - (int32_t)s0);  // query bases to come behind my first cell
+        if (m_begin > 0) {
+            // the sweep starts behind rows that may own row slots: every slot shows kDead until a swept row takes it
+            // (what a row of this strip reads in a slot then is its predecessor's or kDead, never an older sweep's)
+            float dead_cells[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) dead_cells[k] = kDead;
+            for (uint32_t x = 0; x < n_slots; x++) {
+                unsigned char *slot = ring + (size_t)x * kSlotBytes;
+                store_slot<B>(reinterpret_cast<float *>(slot), lane, dead_cells);
+                store_slot<B>(reinterpret_cast<float *>(slot + kValBytes), lane, dead_cells);
+                if (lane0) *reinterpret_cast<float *>(slot + 2 * kValBytes) = kDead;
+            }
+            slot_dead = (1u << n_slots) - 1u;
+        }
+    }
 
     for (uint32_t m = m_begin; m < N; ++m) {
         if constexpr (PRUNE) {
@@ -1203,9 +1230,8 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         if constexpr (PRUNE) {
             // (edge records of rows at or beyond edge_end may be stale: the strip to the left was cut before them)
             edge_dead = m >= edge_end || (have_left_strip && cur_edge.w == 0u);
-            const uint32_t dist = (r_z >> kRecDistShift) & 63u;
-            const uint64_t need = (1ull << dist) - 1ull;  // (dist 63 = "further, or no predecessor": never all ones below)
-            const bool skip = edge_dead && dist != kRecDistFar && (dead_hist & need) == need;
+            const uint32_t dist = (r_z >> kRecDistShift) & 63u;  // (63 = "further, or no predecessor": never skipped)
+            const bool skip = edge_dead && dist != kRecDistFar && dist <= dead_run;
             if (skip) {
                 if (lane == 63 && have_right_strip) {
                     EdgeRec er;
@@ -1233,12 +1259,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                         store_cells<B>(row + Lp + s0, dead_cells);
                     }
                 }
-                if (!prev_dead) {
-#pragma unroll
-                    for (int i = 0; i < B / 4; i++) prev_v.v[i] = prev_g.v[i] = typename Cells<B>::V{kDead, kDead, kDead, kDead};
-                    prev_dead = true;
-                }
-                prev_edge_val = kDead;
+                prev_dead = true;
                 if constexpr (DBG) {
                     if (qi == 0) {
                         float dead_cells[B];
@@ -1247,7 +1268,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                         store_cells<B>(dbg_value + (size_t)m * Lp + s0, dead_cells);
                     }
                 }
-                dead_hist = (dead_hist << 1) | 1ull;
+                ++dead_run;
                 if (have_left_strip) sload_wait(nedge);
                 cur = nrec;
                 cur_edge = nedge;
@@ -1288,11 +1309,13 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         uint32_t ltag[B], tl[B];
         // a predecessor row {value, gapm_val} of my columns + value[p][s0-1]: out of its LDS slot or spill row
         auto load_pred = [&](uint32_t pe, Cells<B> &sv, Cells<B> &sg, float &left_of_strip) {
-            if (PRUNE && (pe & 0xffffu) < jump_lo) {  // a row the strip's sweep started behind: nothing was kept for it
+            if (pe & kPredSpilled) {
+                if (PRUNE && (pe & 0xffffu) < jump_lo) {  // a row the strip's sweep started behind: its spill row is some older sweep's
 #pragma unroll
-                for (int i = 0; i < B / 4; i++) sv.v[i] = sg.v[i] = typename Cells<B>::V{kDead, kDead, kDead, kDead};
-                left_of_strip = kDead;
-            } else if (pe & kPredSpilled) {
+                    for (int i = 0; i < B / 4; i++) sv.v[i] = sg.v[i] = typename Cells<B>::V{kDead, kDead, kDead, kDead};
+                    left_of_strip = kDead;
+                    return;
+                }
                 const float *row = spill + (size_t)((pe >> 16) & 0x7FFFu) * (2 * Lp);
                 sv.load(row + s0);
                 sg.load(row + Lp + s0);
@@ -1318,8 +1341,15 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         // the last predecessor (only it can be the previous row, ids ascend): out of the registers the
         // previous row left it in, or loaded INTO them -- the previous row is needed by nothing else then
         auto last_pred = [&](uint32_t pe, float &left_of_strip) {
-            if ((pe & 0xffffu) + 1 == m) left_of_strip = prev_edge_val;
-            else load_pred(pe, prev_v, prev_g, left_of_strip);
+            if (PRUNE && prev_dead && (pe & 0xffffu) + 1 == m) {  // the previous row was not swept: it shows kDead
+#pragma unroll
+                for (int i = 0; i < B / 4; i++) prev_v.v[i] = prev_g.v[i] = typename Cells<B>::V{kDead, kDead, kDead, kDead};
+                left_of_strip = kDead;
+            } else if ((pe & 0xffffu) + 1 == m) {
+                left_of_strip = prev_edge_val;
+            } else {
+                load_pred(pe, prev_v, prev_g, left_of_strip);
+            }
         };
         auto left_value = [&](const Cells<B> &sv, float left_of_strip) -> float {
             float svl = lane_shr1(sv[B - 1]);  // value[p][s0-1] lives in the lane to my left
@@ -1533,23 +1563,27 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         if (have_left_strip) sload_wait(nedge);
         // ---- row skip: is any cell of this row (of this strip) at or below its bound?  Per lane the smallest of
         // its cells against the bound of its first one (the largest: bounds fall by a per column), capped by U + R(m)
-        float Bm_f = 0.f;
+        float Bm_f = 0.f, nc_f = 0.f;
         bool row_dead = false;
         if constexpr (PRUNE) {
+            // (U + R(m)) - gmin * max(0, C(m) - r): every term a multiple of 1/64 below 2^18 -- exact in float32
             Bm_f = (float)(U64 + (int32_t)cur_reach.x) * kPruneUnit;
+            nc_f = (float)(cur_reach.y >> 16);
             float lm = fv[0];
 #pragma unroll
             for (int k = 1; k + 1 < B; k += 2) lm = min3_raw(lm, fv[k], fv[k + 1]);
             if constexpr (B % 2 == 0) lm = min2_raw(lm, fv[B - 1]);
-            row_dead = !any_lane(lm <= min2_raw(A_lane, Bm_f)) && (edge_dead || !have_left_strip);
-            if (!row_dead && cur_reach.y >= stop_at) stop_at = cur_reach.y + 1u;  // (a row found alive: its successors may be)
+            const float t_cols = __builtin_fmaf(-gmin_f, __builtin_fmaxf(nc_f - r_lane, 0.f), Bm_f);
+            row_dead = !any_lane(lm <= min2_raw(A_lane, t_cols)) && (edge_dead || !have_left_strip);
+            if (!row_dead && (cur_reach.y & 0xffffu) >= stop_at) stop_at = (cur_reach.y & 0xffffu) + 1u;  // (a row found alive: its successors may be)
         }
         // ---- publish: edge record for the strip to my right, the row for its successors
         // (row skip: is my last cell -- what the next strip's first column starts from -- at or below ITS bound)
         bool out_alive = false;
         if constexpr (PRUNE) {
             if (have_right_strip) {
-                out_alive = fv[B - 1] <= min2_raw(A_lane - (float)((B - 1) * (int32_t)prune_amax) * kPruneUnit, Bm_f);
+                const float t_cols = __builtin_fmaf(-gmin_f, __builtin_fmaxf(nc_f - r_lane + (float)(B - 1), 0.f), Bm_f);
+                out_alive = fv[B - 1] <= min2_raw(A_lane - (float)((B - 1) * (int32_t)prune_amax) * kPruneUnit, t_cols);
                 if ((__builtin_amdgcn_ballot_w64(out_alive) >> 63) != 0ull) {
                     if (out_first == kNone) out_first = m;
                     out_last = m;
@@ -1650,7 +1684,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         if constexpr (PRUNE) {
             pe_valid = true;
             prev_dead = false;
-            dead_hist = (dead_hist << 1) | (row_dead ? 1ull : 0ull);
+            dead_run = row_dead ? dead_run + 1u : 0u;
         }
     }
     if (sk_any && (!all_any || sk_min < all_min || (sk_min == all_min && sk_m < all_m))) {
@@ -2079,7 +2113,7 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
         if (allow_full_lds(reinterpret_cast<const void *>(kfn))) return 1;
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.qmask, a.tb, a.dbg_value, a.spill,
                            a.edge, a.edge_stride, n_strips, a.res, a.ms, a.mms, a.gp, a.gpe, a.dry, a.reach, a.prune_rho,
-                           a.prune_amax);
+                           a.prune_amax, (uint32_t)(lds / dp_slot_bytes(DpGeom{64 * (int)n_strips, B})));
     } else if (!weighted && !forbid && a.below_init) SH_LAUNCH(false, false, true);
     else if (!weighted && !forbid) SH_LAUNCH(false, false, false);
     else if (weighted && !forbid) SH_LAUNCH(true, false, false);

@@ -11,12 +11,14 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def _bound_plane(info, rg, N, L):
-    """T(m, s) = U + min(a * (L-1-s), R(m)) in units of 1/64, as float64 (common.h, "the bound")."""
-    a = float(info["prune_step"])
-    rem = a * (L - 1 - np.arange(L, dtype=np.float64))
-    t = np.minimum(rem[None, :], rg.astype(np.float64)[:, None]) / 64.0
-    return info["ubound"] + t
+def _bound_plane(info, rg_cols, N, L):
+    """T(m, s) = U + min(a * r, R(m) - gmin * max(0, C(m) - r)), r = L-1-s, in units of 1/64, as float64 (common.h,
+    "the bound")."""
+    rg, cols = rg_cols
+    a, gmin = float(info["prune_step"]), float(info["prune_gmin"])
+    r = (L - 1 - np.arange(L, dtype=np.float64))[None, :]
+    second = rg.astype(np.float64)[:, None] - gmin * np.maximum(0.0, cols.astype(np.float64)[:, None] - r)
+    return info["ubound"] + np.minimum(a * r, second) / 64.0
 
 
 def _check_planes(ctx, cells, vm, vs, val):
@@ -140,13 +142,17 @@ def test_device_column_bound_covers_every_path(oracle, gpu_ctx):
         for F in (1, 7, 40):
             ids = rng.choice(refs.n, size=F, replace=False).astype(np.uint32)
             g = ctx.debug_family_graph(ids, fs_weight=1.0)
-            rg = ctx.rgain(g["n"]).astype(np.int64)
+            rg, cols = ctx.rgain(g["n"])
+            rg, cols = rg.astype(np.int64), cols.astype(np.int64)
             gain = np.ceil(64.0 * 2.0 * g["weight"].astype(np.float64)) + 1
             for m in range(g["n"]):
                 for p in g["pred"][g["pred_off"][m]:g["pred_off"][m + 1]]:
                     assert rg[p] >= gain[m] + rg[m], (F, m, p)
             assert (np.diff(rg) <= 0).all()      # ids ascend with the column
             assert rg[-1] == 0
+            # C(m) = occupied columns right of the node's
+            ucols = np.unique(g["pos"])
+            assert (cols == len(ucols) - 1 - np.searchsorted(ucols, g["pos"])).all()
     finally:
         ctx.close()
 
