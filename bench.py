@@ -588,6 +588,25 @@ def main():
                         "per wave-instruction and SIMD, it takes ~2.4 -- the rest is dependency stalls and scalar work that "
                         "three waves per SIMD do not hide (DESIGN.md 3.1, 8)",
             },
+            # the other device-filling kernels against the same HBM roofline (SURVEY 8d's algorithmic bytes): the DAG build
+            # -- the families' packed bases read once, the DAGs written once -- and the k-mer count -- 4 B per posting of
+            # the query's k-mers + the int16 score row cleared and read (2 x 2 B per reference)
+            "roofline_other": {
+                "family_graph_kernel": (lambda b, ms: None if ms <= 0 else {
+                    "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": b / (ms * 1e-3) / 1e9,
+                    "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b / max(1, s1["graph_launches"] - s0["graph_launches"]),
+                    "ms_per_launch": ms / max(1, s1["graph_launches"] - s0["graph_launches"]),
+                    "note": "latency-bound in barrier-separated phases (DESIGN 3.3): start-to-end time in the chained pipeline, "
+                            "where the build starts in the DP launch's drain; kernels_ms_per_step_isolated has it alone"})(
+                    s1["graph_bytes"] - s0["graph_bytes"], s1["graph_ms"] - s0["graph_ms"]),
+                "kmer_count_kernel": (lambda b, ms: None if ms <= 0 else {
+                    "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": b / (ms * 1e-3) / 1e9,
+                    "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": b / max(1, s1["kmer_launches"] - s0["kmer_launches"]),
+                    "ms_per_launch": ms / max(1, s1["kmer_launches"] - s0["kmer_launches"])})(
+                    4.0 * (s1["postings"] - s0["postings"]) + 4.0 * a.refs * (s1["kmer_queries"] - s0["kmer_queries"]),
+                    s1["kmer_count_ms"] - s0["kmer_count_ms"]),
+            },
             "kernels_ms_per_step_isolated": {
                 "kmer_count_kernel": iso["kmer_count_ms"],
                 "kmer_select_kernel": iso["kmer_select_ms"],

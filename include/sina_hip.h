@@ -323,6 +323,9 @@ typedef struct sina_hip_stats {
                                     first attempt found) ...                                                      */
     uint64_t dp_full_sweeps;     /* ... and whose second did too (swept in full)                                 */
     double dp_prune_rho;         /* gauge: the guess (optimum / bound on the whole gain) the next launch starts with */
+    uint64_t graph_bytes;        /* device DAG build, algorithmic bytes: the families' packed bases read once, the DAGs
+                                    (row records, columns, row-skip bounds, predecessor lists) written once          */
+    uint32_t graph_launches, kmer_queries; /* DAG-build launches; queries searched by the k-mer count kernel           */
 } sina_hip_stats;
 int sina_hip_get_stats(sina_hip_ctx *ctx, sina_hip_stats *s);
 

@@ -73,7 +73,8 @@ class Stats(C.Structure):
                 ("n_dense_lists", C.c_uint32), ("dp_busy_ms", C.c_double), ("dags_built", C.c_uint64),
                 ("dags_used", C.c_uint64), ("dp_rows", C.c_uint64), ("dp_rows_swept", C.c_uint64),
                 ("dp_cells_swept", C.c_uint64), ("dp_queries_pruned", C.c_uint64), ("dp_second_attempts", C.c_uint64),
-                ("dp_full_sweeps", C.c_uint64), ("dp_prune_rho", C.c_double)]
+                ("dp_full_sweeps", C.c_uint64), ("dp_prune_rho", C.c_double), ("graph_bytes", C.c_uint64),
+                ("graph_launches", C.c_uint32), ("kmer_queries", C.c_uint32)]
 
 
 class DpInfo(C.Structure):

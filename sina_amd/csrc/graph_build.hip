@@ -739,8 +739,13 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         float gms = 0;
         SH_CHECK(hipEventElapsedTime(&gms, c->ev[6], c->ev[7]));
         {
+            uint64_t bytes = 0;  // algorithmic: the families' bases in, the DAGs out
+            for (uint32_t q = 0; q < bq; q++)
+                bytes += 4 * elems[q] + (uint64_t)bg->sizes[kSz * q] * (16 + 4 + (kappa64 > 0.f ? 8 : 0)) + 4 * (uint64_t)bg->sizes[kSz * q + 1];
             std::lock_guard<std::mutex> slk(c->st->stats_mu);
             c->st->stats.graph_ms += gms;
+            c->st->stats.graph_bytes += bytes;
+            c->st->stats.graph_launches++;
         }
         uint32_t need_n = 0;
         for (uint32_t q = 0; q < bq; q++) {

@@ -888,6 +888,7 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
         c->st->stats.kmer_select_ms += ms;
         c->st->stats.postings += visited;
         c->st->stats.kmer_launches++;
+        c->st->stats.kmer_queries += bq;
     }
     return 0;
 }
