@@ -121,6 +121,11 @@ struct CountArgs {
     const uint32_t *dense_id;
     const uint32_t *dense_bits;
     uint32_t dense_words;
+    // CAND (kmer_count_kernel<true>): instead of the score row, the references that can still be among the top
+    // `topm` -- keys (score + 32768) << 32 | id, at most cand_cap per query; cand_n[q] = how many there were
+    unsigned long long *cand;
+    uint32_t *cand_n;
+    uint32_t cand_cap, topm;
 };
 
 constexpr uint32_t kNoDense = 0xFFFFFFFFu;
@@ -155,9 +160,20 @@ __global__ void fill_dense(const uint32_t *idx_off, const uint32_t *idx_ids, con
 // its cursor (kWide loads of 1 KiB in flight, four consecutive postings per lane), bumps the LDS
 // counters of those below the tile end (a prefix, the lists being sorted) and advances the
 // cursor: there is no search, and the tile is written out once.  (64 VGPRs: two workgroups per CU.)
+// CAND: the score row never leaves the chip.  Top-M by (score desc, id desc) only needs the references whose score
+// reaches the M-th largest score -- and tile 0 alone already holds M references that reach t0 = the M-th largest of
+// its 1024 per-thread maxima (each maximum is the score of a different reference), so the final cut is t0 or more:
+// every tile hands the references with score >= t0 (a few dozen per tile; ties included) to a candidate list, and
+// kmer_select_cand_kernel sorts that list.  Saves the row's write and the select kernel's two passes over it
+// (2 + 4 bytes per reference and query: at 500 000 references 3 MB per query, and the 2 GiB score matrix that cut
+// a 9216-query search into five launches).  More candidates than the list holds (a giant group of equal scores):
+// cand_n says so and the host repeats the launch with the score rows.
+template <bool CAND>
 __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) kmer_count_kernel(CountArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t n_kmers, next_kmer, n_dense_q;
+    __shared__ uint32_t c_cnt[8], c_ncand;
+    __shared__ int c_t0;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);                 // [kTileRefs/2]
     uint32_t *cur = hist + kTileRefs / 2;                                // [kmax]
     uint32_t *end = cur + a.kmax;                                        // [kmax]
@@ -170,7 +186,11 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
     const int lane = tid & 63;
     const uint8_t *qm = a.qmask + a.qoff[q];
     const uint32_t len = (uint32_t)(a.qoff[q + 1] - a.qoff[q]);
-    if (tid == 0) n_kmers = n_dense_q = 0;
+    if (tid == 0) {
+        n_kmers = n_dense_q = 0;
+        c_ncand = 0;
+        c_t0 = 0;
+    }
     for (uint32_t i = tid; i < len; i += kCountThreads) qb[i] = qm[i];
     __syncthreads();
     unsigned long long mine = 0;
@@ -213,6 +233,25 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
             if (i >= nk) break;
             uint32_t c = cur[i];
             const uint32_t e = end[i];
+            // First a probe of 64 postings, one per lane.  Most visits end here: 1250 of a query's ~1330 cursor lists
+            // are short -- ~130 postings at 500 000 references, eight or so per tile -- and the wide loop below costs
+            // such a visit a hundred instructions (the kernel is bound by instruction issue, not by the round trips:
+            // 32 waves per CU hide those).  The lists are ascending: the postings of this tile are a prefix.
+            {
+                const uint32_t x = c + (uint32_t)lane;
+                const uint32_t id = x < e ? a.idx_ids[x] : 0xFFFFFFFFu;
+                const bool in = id < tile_hi;
+                if (in) {
+                    const uint32_t r = id - tile_lo;
+                    atomicAdd(&hist[r >> 1], 1u << (16 * (r & 1)));
+                }
+                const uint32_t cnt = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(in));
+                c += cnt;
+                if (cnt < 64u) {
+                    if (lane == 0) cur[i] = c;
+                    continue;
+                }
+            }
             // kWide x 1 KiB in flight per wave: every lane reads four consecutive postings per load
             // (most postings sit in a few hundred long lists -- k-mers of conserved regions -- and
             // one wave streams each of them: bytes in flight are what bounds it)
@@ -302,11 +341,76 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
             }
             __syncthreads();
         }
-        // tile scores out: two int16 per 32-bit store (row stride is even)
-        uint32_t *dst = reinterpret_cast<uint32_t *>(row + tile_lo);
-        const uint32_t words = (tile_hi - tile_lo + 1) / 2;
-        for (uint32_t i = tid; i < words; i += kCountThreads) dst[i] = hist[i];
-        __syncthreads();
+        if constexpr (!CAND) {
+            // tile scores out: two int16 per 32-bit store (row stride is even)
+            uint32_t *dst = reinterpret_cast<uint32_t *>(row + tile_lo);
+            const uint32_t words = (tile_hi - tile_lo + 1) / 2;
+            for (uint32_t i = tid; i < words; i += kCountThreads) dst[i] = hist[i];
+            __syncthreads();
+        } else {
+            // my 32 references of the tile: words 16 tid .. 16 tid + 15 (word j of lane l in step (j - l) mod 16)
+            uint32_t w[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) w[(jj + lane) & 15] = hist[16 * tid + ((jj + lane) & 15)];
+            const uint32_t my_lo = tile_lo + 32u * tid;
+            if (t == 0) {
+                // t0: the topm-th largest of the 1024 per-thread maxima (8-way search: seven ballots per pass)
+                int mx = -1;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (my_lo + 2 * j < a.n_refs) mx = max(mx, (int)(w[j] & 0xffffu));
+                    if (my_lo + 2 * j + 1 < a.n_refs) mx = max(mx, (int)(w[j] >> 16));
+                }
+                int lo = 0, hi = (int)min(len, (uint32_t)kMaxQueryLen) + 1;  // count(max >= lo) >= topm > count(max >= hi)
+                for (int guard = 0; guard < 8 && hi - lo > 1; ++guard) {
+                    if (tid < 8) c_cnt[tid] = 0;
+                    __syncthreads();
+                    int th[7];
+#pragma unroll
+                    for (int x = 0; x < 7; x++) {
+                        const int tx = lo + (int)(((long long)(hi - lo) * (x + 1)) / 8);
+                        th[x] = tx > lo ? tx : lo + 1;
+                        const uint32_t c = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(mx >= th[x]));
+                        if (lane == 0 && c) atomicAdd(&c_cnt[x], c);
+                    }
+                    __syncthreads();
+                    int nlo = lo, nhi = hi;
+                    bool hi_set = false;
+#pragma unroll
+                    for (int x = 0; x < 7; x++) {
+                        if (th[x] >= hi) continue;
+                        if (c_cnt[x] >= a.topm) nlo = th[x];
+                        else if (!hi_set) {
+                            nhi = th[x];
+                            hi_set = true;
+                        }
+                    }
+                    lo = nlo;
+                    hi = nhi;
+                    __syncthreads();
+                }
+                if (tid == 0) c_t0 = lo;
+                __syncthreads();
+            }
+            const int t0 = c_t0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t id = my_lo + 2 * j + h;
+                    const int v = (int)((w[j] >> (16 * h)) & 0xffffu);
+                    if (id < a.n_refs && v >= t0) {
+                        const uint32_t slot = atomicAdd(&c_ncand, 1u);
+                        if (slot < a.cand_cap)
+                            a.cand[(size_t)q * a.cand_cap + slot] = ((unsigned long long)(uint32_t)(v + 32768) << 32) | id;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if constexpr (CAND) {
+        if (tid == 0) a.cand_n[q] = c_ncand;
     }
     // postings visited = sum of the list lengths of the query's k-mers (each read once)
 #pragma unroll
@@ -610,6 +714,56 @@ __global__ void __launch_bounds__(kSelThreads) kmer_select_kernel(SelectArgs a) 
     if (threadIdx.x == 0) a.out_n[q] = n < M ? n : M;
 }
 
+// Top-M out of the candidate list kmer_count_kernel<true> left for the query: a bitonic sort of its keys (score,
+// id) descending.  out_n = 0xFFFFFFFF: the list overflowed -- the host repeats the launch with the score rows.
+struct SelectCandArgs {
+    const unsigned long long *cand;
+    const uint32_t *cand_n;
+    uint32_t cand_cap;
+    uint32_t *out_ids;
+    float *out_scores;
+    uint32_t *out_n;
+    uint32_t max;
+};
+__global__ void __launch_bounds__(kSelThreads) kmer_select_cand_kernel(SelectCandArgs a) {
+    __shared__ unsigned long long cand[kSelMax];
+    const uint32_t q = blockIdx.x;
+    const uint32_t have = a.cand_n[q];
+    if (have > a.cand_cap) {
+        if (threadIdx.x == 0) a.out_n[q] = 0xFFFFFFFFu;
+        return;
+    }
+    const uint32_t n = have, M = a.max;
+    uint32_t P = 1;
+    while (P < n) P <<= 1;
+    for (uint32_t i = threadIdx.x; i < P; i += kSelThreads) cand[i] = i < n ? a.cand[(size_t)q * a.cand_cap + i] : 0ull;
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
+        for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (uint32_t i = threadIdx.x; i < P; i += kSelThreads) {
+                const uint32_t ixj = i ^ j2;
+                if (ixj > i) {
+                    const unsigned long long x = cand[i], y = cand[ixj];
+                    const bool desc = ((i & k2) == 0);
+                    if (desc ? (x < y) : (x > y)) {
+                        cand[i] = y;
+                        cand[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < M; i += kSelThreads) {
+        if (i < n) {
+            const unsigned long long c = cand[i];
+            a.out_ids[(size_t)q * a.max + i] = (uint32_t)c;
+            a.out_scores[(size_t)q * a.max + i] = (float)((int)(uint32_t)(c >> 32) - 32768);
+        }
+    }
+    if (threadIdx.x == 0) a.out_n[q] = n < M ? n : M;
+}
+
 }  // namespace
 
 static int index_ready(sina_hip_ctx *c) {
@@ -659,11 +813,18 @@ static int ensure_dense(sina_hip_ctx *c) {
 }
 
 // counts + selects for nq queries whose masks are already on the device
+// (the candidate-list path, kmer_count_kernel<true>: at least two tiles of references -- tile 0 must hold `max`
+// of them --, a top-M small enough for the list; SINA_HIP_TEST=kmer_rows=1 keeps the score rows)
+constexpr uint32_t kCandCap = 4096, kCandMaxM = 128;
+static bool kmer_cand_path(const sina_hip_ctx *c, uint32_t max) {
+    return max <= kCandMaxM && c->st->n_refs >= 2u * (uint32_t)kTileRefs && atoi(test_knob("kmer_rows").c_str()) == 0;
+}
 static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint64_t *d_qoff, uint32_t nq,
-                            uint32_t max, uint32_t max_qlen, bool want_scores_only) {
+                            uint32_t max, uint32_t max_qlen, bool want_scores_only, bool cand_path) {
     hipStream_t s = c->stream;
     const uint32_t stride = (c->st->n_refs + 7u) & ~7u;  // rows 16-byte aligned (vector loads in the select kernel)
-    if (c->k_scores.reserve((size_t)nq * stride * 2 + 64) || c->k_tmp2.reserve(8) || c->k_tmp0.reserve(4 * (size_t)nq))
+    if ((!cand_path && c->k_scores.reserve((size_t)nq * stride * 2 + 64)) || c->k_tmp2.reserve(8) || c->k_tmp0.reserve(4 * (size_t)nq) ||
+        (cand_path && (c->k_tmp1.reserve(8 * (size_t)nq * kCandCap) || c->k_out_n.reserve((size_t)nq * 4))))
         return 1;
     SH_CHECK(hipMemsetAsync(c->k_tmp2.p, 0, 8, s));
     CountArgs ca;
@@ -683,15 +844,34 @@ static int kmer_topk_device(sina_hip_ctx *c, const uint8_t *d_qmask, const uint6
     ca.dense_id = c->st->n_dense ? c->st->dense_id.as<uint32_t>() : nullptr;
     ca.dense_bits = c->st->dense_bits.as<uint32_t>();
     ca.dense_words = c->st->dense_words;
+    ca.cand = cand_path ? c->k_tmp1.as<unsigned long long>() : nullptr;
+    ca.cand_n = cand_path ? c->k_out_n.as<uint32_t>() : nullptr;  // (kmer_select_cand_kernel turns it into out_n in place)
+    ca.cand_cap = kCandCap;
+    ca.topm = max;
     const size_t clds = (size_t)kTileRefs * 2 + (size_t)ca.kmax * 9 + 64;
-    if (allow_full_lds(reinterpret_cast<const void *>(kmer_count_kernel))) return 1;
+    if (allow_full_lds(reinterpret_cast<const void *>(kmer_count_kernel<false>)) ||
+        allow_full_lds(reinterpret_cast<const void *>(kmer_count_kernel<true>)))
+        return 1;
     heavy_launch hl(c, s, kHeavyKmer);  // (count + select: device-filling kernels, ctx.h)
     const hipStream_t hs = hl.stream();
     SH_CHECK(hipEventRecord(c->ev[3], hs));
-    hipLaunchKernelGGL(kmer_count_kernel, dim3(nq), dim3(kCountThreads), clds, hs, ca);
+    if (cand_path) hipLaunchKernelGGL(kmer_count_kernel<true>, dim3(nq), dim3(kCountThreads), clds, hs, ca);
+    else hipLaunchKernelGGL(kmer_count_kernel<false>, dim3(nq), dim3(kCountThreads), clds, hs, ca);
     SH_CHECK(hipGetLastError());
     SH_CHECK(hipEventRecord(c->ev[4], hs));
-    if (!want_scores_only) {
+    if (cand_path) {
+        if (c->k_out_ids.reserve((size_t)nq * max * 4) || c->k_out_scores.reserve((size_t)nq * max * 4)) return 1;
+        SelectCandArgs sc;
+        sc.cand = ca.cand;
+        sc.cand_n = ca.cand_n;
+        sc.cand_cap = kCandCap;
+        sc.out_ids = c->k_out_ids.as<uint32_t>();
+        sc.out_scores = c->k_out_scores.as<float>();
+        sc.out_n = c->k_out_n.as<uint32_t>();
+        sc.max = max;
+        hipLaunchKernelGGL(kmer_select_cand_kernel, dim3(nq), dim3(kSelThreads), 0, hs, sc);
+        SH_CHECK(hipGetLastError());
+    } else if (!want_scores_only) {
         if (c->k_out_ids.reserve((size_t)nq * max * 4) || c->k_out_scores.reserve((size_t)nq * max * 4) ||
             c->k_out_n.reserve((size_t)nq * 4))
             return 1;
@@ -866,29 +1046,52 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
     for (uint32_t q = 0; q <= nq; q++) rel[q] = qoff[q] - qoff[0];
     if (upload(c, 7, c->qmask.p, qmask + qoff[0], nqm, s) || upload(c, 8, c->k_qoff.p, rel.data(), 8 * ((uint64_t)nq + 1), s))
         return 1;
-    for (uint32_t q0 = 0; q0 < nq; q0 += per) {
-        const uint32_t bq = std::min(per, nq - q0);
-        if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>() + q0, bq, max, max_qlen, false)) return 1;
-        // (the kernels have finished: kmer_topk_device waits for the heavy stream; results come back
-        // through pinned staging -- see HostBuf in common.h)
+    // one launch range: kernels, results back through pinned staging, statistics; *overflow = a candidate list of the
+    // range did not hold its query's candidates (nothing was copied out then: the caller repeats the range with rows)
+    auto run_range = [&](uint32_t q0, uint32_t bq, bool cand_path, bool *overflow) -> int {
+        if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>() + q0, bq, max, max_qlen, false, cand_path)) return 1;
+        // (the kernels have finished: kmer_topk_device waits for the heavy stream)
         if (download(c, 9, c->k_out_ids.p, (size_t)bq * max * 4, s) || download(c, 10, c->k_out_scores.p, (size_t)bq * max * 4, s) ||
             download(c, 11, c->k_out_n.p, (size_t)bq * 4, s) || download(c, 0, c->k_tmp2.p, 8, s))
             return 1;
         SH_CHECK(wait_stream(c, s));
+        *overflow = false;
+        if (cand_path) {
+            const uint32_t *n = static_cast<const uint32_t *>(c->h_stage[11].p);
+            for (uint32_t q = 0; q < bq && !*overflow; q++) *overflow = n[q] == 0xFFFFFFFFu;
+        }
+        unsigned long long visited = 0;
+        memcpy(&visited, c->h_stage[0].p, 8);
+        float ms = 0, ms2 = 0;
+        SH_CHECK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+        SH_CHECK(hipEventElapsedTime(&ms2, c->ev[4], c->ev[5]));
+        {
+            std::lock_guard<std::mutex> slk(c->st->stats_mu);
+            c->st->stats.kmer_count_ms += ms;
+            c->st->stats.kmer_select_ms += ms2;
+            c->st->stats.kmer_launches++;
+            if (!*overflow) {
+                c->st->stats.postings += visited;
+                c->st->stats.kmer_queries += bq;
+            }
+        }
+        if (*overflow) return 0;
         memcpy(out_ids + (size_t)q0 * max, c->h_stage[9].p, (size_t)bq * max * 4);
         memcpy(out_scores + (size_t)q0 * max, c->h_stage[10].p, (size_t)bq * max * 4);
         memcpy(out_n + q0, c->h_stage[11].p, (size_t)bq * 4);
-        unsigned long long visited = 0;
-        memcpy(&visited, c->h_stage[0].p, 8);
-        float ms = 0;
-        SH_CHECK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
-        std::lock_guard<std::mutex> slk(c->st->stats_mu);
-        c->st->stats.kmer_count_ms += ms;
-        SH_CHECK(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
-        c->st->stats.kmer_select_ms += ms;
-        c->st->stats.postings += visited;
-        c->st->stats.kmer_launches++;
-        c->st->stats.kmer_queries += bq;
+        return 0;
+    };
+    const bool cand_path = kmer_cand_path(c, max);
+    const uint32_t per_cand = 16384;  // (candidate lists: 32 KB per query)
+    for (uint32_t q0 = 0; q0 < nq; q0 += cand_path ? per_cand : per) {
+        const uint32_t bq = std::min(cand_path ? per_cand : per, nq - q0);
+        bool overflow = false;
+        if (run_range(q0, bq, cand_path, &overflow)) return 1;
+        if (overflow)  // a giant group of equal scores somewhere in the range: the score rows and the full select
+            for (uint32_t r0 = q0; r0 < q0 + bq; r0 += per) {
+                bool dummy = false;
+                if (run_range(r0, std::min(per, q0 + bq - r0), false, &dummy)) return 1;
+            }
     }
     return 0;
 }
@@ -904,7 +1107,7 @@ int sina_hip_kmer_scores(sina_hip_ctx *c, const uint8_t *qmask, uint32_t qlen, i
     if (c->qmask.reserve(std::max<uint32_t>(qlen, 1)) || c->k_qoff.reserve(16)) return 1;
     SH_CHECK(hipMemcpyAsync(c->qmask.p, qmask, qlen, hipMemcpyHostToDevice, s));
     SH_CHECK(hipMemcpyAsync(c->k_qoff.p, rel, 16, hipMemcpyHostToDevice, s));
-    if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>(), 1, 1, std::max<uint32_t>(qlen, 1), true)) return 1;
+    if (kmer_topk_device(c, c->qmask.as<uint8_t>(), c->k_qoff.as<uint64_t>(), 1, 1, std::max<uint32_t>(qlen, 1), true, false)) return 1;
     SH_CHECK(hipMemcpyAsync(scores, c->k_scores.p, (size_t)c->st->n_refs * 2, hipMemcpyDeviceToHost, s));
     SH_CHECK(hipStreamSynchronize(s));
     return 0;

@@ -58,7 +58,7 @@ print("RESULT", h.hexdigest())
 
 @pytest.mark.parametrize("env", [{"SINA_HIP_CHAIN": "0"}, {"SINA_HIP_NO_RUNTIME_DEFAULTS": "1"}, {"SINA_HIP_DP_PRUNE": "0"},
                                  {"SINA_HIP_TB_PLANES": "3", "SINA_HIP_TB_GB": "24"}, {"SINA_HIP_TRACE_ALLOC": "1"},
-                                 {"SINA_HIP_TEST": "rho=2"}, {"SINA_HIP_TEST": "generic=1;dense_div=1"}])
+                                 {"SINA_HIP_TEST": "rho=2"}, {"SINA_HIP_TEST": "generic=1;dense_div=1;kmer_rows=1"}])
 def test_launch_order_settings_do_not_change_results(env):
     """EVERY environment variable the production library reads (csrc/common.h; INTEGRATION.md lists them) is
     scheduling / bookkeeping / which exact code path computes the same thing: chained launches, the load-time

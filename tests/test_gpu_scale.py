@@ -94,6 +94,42 @@ def test_kmer_select_regimes_equal_oracle(oracle, regime):
         ctx.close()
 
 
+@pytest.mark.parametrize("regime", ["spread", "identical", "two_groups", "unrelated"])
+def test_kmer_candidate_lists_equal_oracle(oracle, monkeypatch, regime):
+    """The search's candidate-list path (kmer_count_kernel<true>: at 65 536 references and more, for top-M up to 128
+    the score rows never leave the chip -- every tile hands the references that reach tile 0's M-th largest
+    per-thread maximum to a list, a sort of the list gives the top M) against the oracle's partial_sort on (score,
+    id): spread-out scores, ONE giant group of equal scores and queries that share next to nothing with the
+    references (the list overflows: the launch is repeated with the score rows), two groups; and the same searches
+    with the rows forced (SINA_HIP_TEST=kmer_rows=1) give the same bytes."""
+    kw = dict(length=200, width=1600, long_del_prob=0.0)
+    n = 70000
+    if regime == "spread":
+        refs = synth.make_refs(n, seed=131, n_clades=50, sub_lo=0.01, sub_hi=0.2, **kw)
+    elif regime == "identical":
+        refs = synth.make_refs(n, seed=132, n_clades=1, sub_lo=0.0, sub_hi=0.0, del_rate=0.0, ins_rate=0.0, **kw)
+    elif regime == "two_groups":
+        refs = synth.make_refs(n, seed=133, n_clades=2, sub_lo=0.0, sub_hi=0.0, del_rate=0.0, ins_rate=0.0, **kw)
+    else:
+        refs = synth.make_refs(n, seed=134, n_clades=8, **kw)
+    src = synth.make_refs(64, seed=135, n_clades=4, **kw) if regime == "unrelated" else refs
+    qs = synth.make_queries(src, 6, seed=136)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    ctx = capi.Context(0)
+    try:
+        ctx.upload_refs(refs.ab, refs.off, refs.width)
+        ctx.build_index(10, False)
+        _scores_and_topk_equal(ctx, idx, qs, maxes=(1, 7, 41, 128, 129, 410))
+        fused = [ctx.kmer_topk(qs.mask, qs.off, m) for m in (1, 41, 128)]
+        util.set_knobs(monkeypatch, kmer_rows=1)
+        rows = [ctx.kmer_topk(qs.mask, qs.off, m) for m in (1, 41, 128)]
+        for f, r in zip(fused, rows):
+            assert all((x == y).all() for x, y in zip(f, r))
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SINA_FUZZ_SEEDS", "8"))))
 def test_kmer_search_fuzz(oracle, monkeypatch, seed):
     """Seeded random k-mer searches: reference counts on both sides of one tile (32 768) and of the
