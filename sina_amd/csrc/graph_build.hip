@@ -589,7 +589,8 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
         uint2 *rg = a.reach + (size_t)q * a.ncap;
         // (scratch: nobody reads succ_min in a launch that skips rows -- want_smin is --insertion=forbid; the debug
         // entry wants both and gets the last successors overwritten instead)
-        uint32_t *cw = a.want_smin ? last : smin;
+        // (in LDS where the rows' words fit the tile tables' space: step 8 was the last reader of the slot codes there)
+        uint32_t *cw = in_lds ? codeL : (a.want_smin ? last : smin);
         if (tid == 0) s_tmp[kGT / 64 + 2] = 0xFFFFFFFFu;  // smallest column maximum
         __syncthreads();
         for (uint32_t i = tid; i < N; i += kGT) {
@@ -611,9 +612,10 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
             if (i > 0 && node_pos[i - 1] == pos) continue;
             const uint32_t right = (i + 1 < N) ? total - cw[i + 1] : 0u;  // (cw[i + 1] = columns up to and including mine)
             const uint32_t cols_right = NC - 1u - rank(pos);                 // (the dense column index of step 2)
-            for (uint32_t j = i; j < N && node_pos[j] == pos; j++) rg[j] = uint2{right, (a.want_smin ? 0u : last[j]) | (cols_right << 16)};
+            for (uint32_t j = i; j < N && node_pos[j] == pos; j++) rg[j] = uint2{right, ((a.want_smin && !in_lds) ? 0u : last[j]) | (cols_right << 16)};
         }
     }
+    GP(12)
     GP_FLUSH
 }
 

@@ -23,8 +23,8 @@ if hasattr(lib, "sina_hip_debug_graph_profile"):
     a = (ctypes.c_ulonglong * 16)()
     lib.sina_hip_debug_graph_profile(a, 1)
     names = ["bitmap", "rank+init", "tile clear", "tile fill", "tile nodes", "tile scans", "tile prev", "tile emit",
-             "(after tiles)", "sinks/fence", "slot alloc", "pred encode"]
-    tot = float(sum(a[:12]))
+             "(after tiles)", "sinks/fence", "slot alloc", "pred encode", "skip bound"]
+    tot = float(sum(a[:13]))
     for i, nme in enumerate(names):
         print("%-14s %5.1f%%  %9.0f ticks per family" % (nme, 100 * a[i] / tot, a[i] / (3.0 * nq)))
     print("total %.0f ticks per family (thread 0 of each workgroup, 3 launches)" % (tot / (3.0 * nq)))
