@@ -258,3 +258,43 @@ def test_row_skip_plane_fuzz(oracle, monkeypatch, seed):
             _check_planes(ctx, cells, vm, vs, val)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("frac,rho", [(0.0, None), (0.3, None), (0.46, None), (0.3, "0.97"), (0.46, "3")])
+def test_row_skip_partial_queries_equal_oracle(oracle, monkeypatch, frac, rho):
+    """Queries that cover only part of the alignment -- 800-base windows at its start, in its middle and at its end:
+    two strips, so the row skip is in play, and the alignment begins and ends somewhere inside the DAG: free starts
+    (column 0 of any row), free ends (the last column of any row, any column of a sink), long stretches of rows on
+    either side of the window that only the free-start rule keeps in play.  Trays against the oracle's."""
+    if rho is not None:
+        util.set_knobs(monkeypatch, rho=rho)
+    refs = synth.make_refs(3000, length=1500, width=50000, seed=72)
+    qs = synth.make_queries(refs, 16, seed=73, window=(frac, 800))
+    assert all(700 <= len(qs.seq(i)) <= 800 for i in range(qs.n))
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    st = pipeline.Store(":mem:prune-part-%s-%s" % (frac, rho), refs)
+    try:
+        st.build_index(10, False)
+        pl = pipeline.Pipeline(st, famfinder={"fs-min-len": 100})
+        pl.run(qs.mask, qs.off, batch=16, inflight=1)
+        n_dp = 0
+        for qi in range(qs.n):
+            q = util.query_cseq(qs, qi, upper=False)
+            ids, sc, fflog = idx.famfinder(q, oracle.ff_opts(fs_min_len=100))
+            got = pl.result(qi)
+            if len(ids) == 0:
+                assert got["status"] == 2
+                continue
+            want = oracle.align([cs[i] for i in ids], q, oracle.align_opts())
+            assert got["status"] == want["status"], (qi, got["log"], want["log"])
+            assert (got["packed"] == want["packed"]).all(), qi
+            assert (got["head"], got["tail"], got["qual"]) == (want["head"], want["tail"], want["qual"])
+            if want["status"] == 0:
+                assert got["log"] == fflog + want["log"]
+                n_dp += 1
+        assert n_dp >= 12
+        assert st.stats()["dp_queries_pruned"] >= n_dp
+        pl.close()
+    finally:
+        st.close()
