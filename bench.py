@@ -603,7 +603,12 @@ def main():
                     "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": b / (ms * 1e-3) / 1e9,
                     "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_launch": b / max(1, s1["kmer_launches"] - s0["kmer_launches"]),
-                    "ms_per_launch": ms / max(1, s1["kmer_launches"] - s0["kmer_launches"])})(
+                    "ms_per_launch": ms / max(1, s1["kmer_launches"] - s0["kmer_launches"]),
+                    "note": "SURVEY 8d's accounting (4 B per posting of the query's k-mers + 2 x 2 B per reference for the score "
+                            "row); the kernel moves LESS than that -- dense lists are read as bitmaps (n/8 B per list instead "
+                            "of 4 B per posting) and, with candidate lists (stores of 65 536 references and more), the score "
+                            "row never leaves LDS -- so the fraction can exceed 1; measured HBM bytes per launch: "
+                            "profiles/r05_bench_summary.txt (23.6 GB per 9216 queries at 100 k references = 4.1 TB/s)"})(
                     4.0 * (s1["postings"] - s0["postings"]) + 4.0 * a.refs * (s1["kmer_queries"] - s0["kmer_queries"]),
                     s1["kmer_count_ms"] - s0["kmer_count_ms"]),
             },
