@@ -15,7 +15,7 @@
 //           ascending posting list; the references are processed in tiles of 32768 whose int16
 //           counters live in LDS (two per 32-bit word); a wave streams a list from its cursor with
 //           2 x 1 KiB loads in flight into LDS atomics -- no search -- and the tile is written out
-//           once.  Lists longer than 1/32 of the references are kept a second time as bitmaps and
+//           once.  Lists longer than 1/64 of the references are kept a second time as bitmaps and
 //           counted bit-sliced in registers (carry-save adders, no atomics).
 //   select: one workgroup per query: the cut score by an 8-way search on "how many scores are >= t"
 //           (reductions over 16-byte loads; an LDS histogram serialises on the few low bins every
@@ -772,9 +772,11 @@ static int index_ready(sina_hip_ctx *c) {
     return 0;
 }
 
-// Posting lists longer than 1/32 of the references (k-mers of conserved regions: a few hundred per
+// Posting lists longer than 1/64 of the references (k-mers of conserved regions: a few hundred per
 // query hold 97 % of its postings) as bitmaps over the references, zero-padded to whole tiles, for
-// the count kernel's atomic-free path.  Built from the CSR index by the first search after the
+// the count kernel's atomic-free path.  (By bytes a bitmap breaks even with a list at 1/32; the bitmaps of all
+// queries in flight are the same few thousand and come out of L2 / MALL, the lists out of HBM: 1/64 .. 1/128
+// measured 4 % faster at 100 000 references, 9 % at 500 000 -- tools/perf_kmer_dense.py.)  Built from the CSR index by the first search after the
 // index changed (also when the index arrived by broadcast), under the store's mutex.
 static int ensure_dense(sina_hip_ctx *c) {
     sina_hip_store *st = c->st;
@@ -782,7 +784,7 @@ static int ensure_dense(sina_hip_ctx *c) {
     if (st->dense_ready) return 0;
     hipStream_t s = c->stream;
     const uint32_t nk = 1u << (2 * st->k);
-    uint32_t div_ = 32;
+    uint32_t div_ = 64;
     if (const std::string e_ = test_knob("dense_div"); !e_.empty()) div_ = (uint32_t)std::max(1, atoi(e_.c_str()));
     const uint32_t thresh = std::max<uint32_t>(256u, st->n_refs / div_);
     const uint32_t ntiles = (st->n_refs + kTileRefs - 1) / kTileRefs;

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def wide(oracle):
     """70 000 short references in six clades: three reference tiles, 200+ posting lists longer than
-    1/32 of the references (the dense-bitmap path), an oracle index that builds in seconds."""
+    1/64 of the references (the dense-bitmap path), an oracle index that builds in seconds."""
     refs = synth.make_refs(70000, length=200, width=2000, seed=5, n_clades=6)
     cs = util.cseqs_from_refs(refs)
     qs = synth.make_queries(refs, 12, seed=6, amb_rate=0.01)
