@@ -10,27 +10,34 @@
 //     the predecessor ids ascending and unique; sources / sinks implicit.
 //
 // How it maps to the hardware: one workgroup per query; the alignment is walked in tiles of
-// kTC occupied columns so that the [column][family member] tables stay in LDS:
+// kTC occupied columns.  Every step inside a tile is parallel over the family's BASES in the tile
+// ("entries": member j's bases from its cursor on, a contiguous stretch of at most kTC; a wave takes
+// 64 consecutive slots of one member, so the member's cursor / length / offset are scalars) and
+// meets the other members of a column only through LDS atomics -- no thread ever walks the F members
+// of a column (rounds 2-4 did: one thread per column for the nodes, one per node for the edges, 37 %
+// of the kernel's time in loops of F iterations that a third of the threads sat out):
 //   1. occupied-column bitmap in LDS (atomicOr per base), prefix-popcount -> dense
 //      column index ("rank") of every alignment column;
-//   2. per tile: every member's bases that fall into the tile (a contiguous stretch of its
-//      sequence, found with a per-member cursor) drop their mask into tabm[column][member];
-//   3. one thread per column scans its F entries in family order: first appearance of
-//      a mask opens a node (exact reference order), later ones count; block scans
-//      turn per-column node / raw-edge counts into node ids and CSR segments (running totals
-//      carry across tiles);
-//   4. per base again: the node of the member's PREVIOUS base (same tile: table lookup; earlier
-//      tile: carried per member) goes into tabp[column][member];
-//   5. one thread per column emits node records and, per node, inserts the
-//      predecessor ids into a sorted unique list in its CSR segment; atomicMin / atomicMax
-//      collect the successor minimum column (for --insertion=forbid) and the last successor;
+//   2. per tile, per entry: tile column, character -> the column's set of characters (atomicOr);
+//   3. nodes per column = popcount, block scan -> node ids of the columns; per entry atomicMin of the
+//      member index into its (column, character) slot: the order of first appearance in the family
+//      (exact reference order) is the rank of that minimum among the column's characters -- one
+//      thread per column sorts its handful of minima;
+//   4. per entry: its node, its predecessor's node (the entry to its left, or what the member carried
+//      over from earlier tiles); member count and raw edge count of the node by atomicAdd; the
+//      predecessor as ONE BIT of a 64-bit word per node (bit d-1: the node d ids back -- ids ascend
+//      with the column, so the set bits from the top down are the predecessors ascending and unique);
+//      the few predecessors further back than 64 ids (long deletions) by rounds of atomicMin;
+//   5. one thread per node writes record and predecessor list; atomicMin / atomicMax collect the
+//      successor minimum column (for --insertion=forbid) and the last successor;
 //   6. sinks and fence flags; LDS-slot / spill-row assignment for the DP kernel by liveness
-//      (sequential over the rows: one wave, bookkeeping on the scalar unit); predecessor entries.
-// HBM traffic: the family's bases three times (bitmap, masks, previous nodes) and the DAG once.
+//      (sequential over the rows: 16 lanes, a segment each); predecessor entries; the row skip's bound.
+// HBM traffic: the family's bases twice (bitmap, entries) and the DAG once.
 // All arithmetic is integer except the node weight, which is looked up in a table the
 // HOST computed with the reference's own mixed double/float expression.
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 #include "ctx.h"
@@ -42,16 +49,22 @@ namespace {
 #define SINA_GRAPH_THREADS 512
 #endif
 #ifndef SINA_GRAPH_MINWAVES
-#define SINA_GRAPH_MINWAVES 6  // (3 workgroups of 8 waves per CU: <= 80 VGPRs)
+#define SINA_GRAPH_MINWAVES 8  // (4 workgroups of 8 waves per CU: <= 64 VGPRs, 38.5 KB of LDS each for families of 40)
 #endif
 constexpr int kGT = SINA_GRAPH_THREADS;  // threads per workgroup (the phases are latency-bound: more loads in flight per LDS byte)
 constexpr uint32_t kNoPrev = 0xFFFFu;
 constexpr int kMaxFam = 128;
 constexpr int kSz = 8;  // u32 words the kernel reports per query (GraphArgs::sizes)
 #ifndef SINA_GRAPH_KTC
-#define SINA_GRAPH_KTC 160  // (measured, 3072 families of 40: 96 -> 3.05 ms, 128 -> 2.54, 160 -> 2.40, 192 -> 3.12: a third workgroup per CU no longer fits)
+#define SINA_GRAPH_KTC 128  // (a multiple of 64: a wave takes 64 consecutive entry slots of one member)
+#endif
+#ifndef SINA_GRAPH_TNW
+#define SINA_GRAPH_TNW 512  // nodes whose per-node words are in LDS at a time (a tile with more takes them in column-aligned windows)
 #endif
 constexpr int kTC = SINA_GRAPH_KTC;  // occupied columns per LDS tile (< 255: tile columns are bytes, 255 = none)
+constexpr int kTNW = SINA_GRAPH_TNW;
+static_assert(kTC % 64 == 0 && kTC < 255 && kTNW >= 32 && kTNW % 2 == 0, "tile geometry");
+static_assert((kMaxFam * (kTC / 64) + SINA_GRAPH_THREADS / 64 - 1) / (SINA_GRAPH_THREADS / 64) <= 64, "far-entry flags of a wave fit 64 bits");
 
 #ifdef SINA_DP_PROFILE
 // profiling build (make PROFILE=1): per-phase s_memtime totals of thread 0, tools/perf_graph.py
@@ -79,15 +92,41 @@ struct GraphArgs {
     uint32_t *pred;            // per query area of total-family-bases entries
     uint32_t *sizes;           // [nq][kSz]: N, raw edge entries, n_spill, status (0 ok, 2 N cap, 4 spill rows), first sink row
     uint32_t width, ncap;
-    uint32_t tile_bytes;       // LDS bytes of the tile tables (reused by the slot allocation)
-    uint32_t member_off;       // LDS offset of the per-member arrays (behind the tile tables), entries each
+    uint32_t tile_bytes;       // LDS bytes of the tile tables (reused by the slot allocation) = bitmap_off
+    uint32_t bitmap_off;       // LDS offset of the occupied-column bitmap (behind the tile tables)
+    uint32_t member_off;       // LDS offset of the per-member records (behind the bitmap and its ranks)
     uint32_t member_cap;
+    uint32_t fam_cap;          // rows of the entry table in LDS: the launch's largest family
     int W;                     // DP ring depth: edges longer than this need a spill row
     int want_smin;             // succ_min is read by somebody (--insertion=forbid, the debug entry): else it is not touched at all
     uint2 *reach;              // [nq][ncap] or nullptr: the DP kernel's row-skip bound (step 9; units: common.h): {R(m), last successor | C(m) << 16}
     float kappa64;             // ... 64 * 1.0001 * (largest match gain per unit of node weight)
     DryArgs dry;               // (ctx.h, heavy_launch: tells the launch queued behind when the last workgroup has started)
 };
+
+// per family member, in LDS
+struct Member {
+    uint64_t beg;            // offset of its bases in the store
+    uint32_t len;
+    uint32_t cur, curn;      // first base at/after the tile, ... after it
+    uint32_t carry, carryn;  // node of the last base before the tile, ... of the last base in it
+    uint32_t id;
+};
+static_assert(sizeof(Member) == 32, "LDS layout");
+// LDS offsets of the tables whose size is a compile-time constant
+constexpr uint32_t kOCpos = 0;
+constexpr uint32_t kONbase = kOCpos + 4 * kTC;
+constexpr uint32_t kOPres = kONbase + 4 * (kTC + 2);
+constexpr uint32_t kOWA = kOPres + 4 * kTC;
+constexpr uint32_t kOWC = kOWA + 4 * kTNW;
+constexpr uint32_t kOWD = kOWC + 4 * kTNW;
+constexpr uint32_t kOWB = (kOWD + 4 * kTNW + 7) & ~7u;
+constexpr uint32_t kOLi = kOWB + 8 * kTNW;
+constexpr uint32_t kONn = kOLi + 32 * kTC;
+constexpr uint32_t kONfar = kONn + kTC;
+constexpr uint32_t kOMask = kONfar + kTNW;
+constexpr uint32_t kONcol = kOMask + kTNW;
+constexpr uint32_t kOE = (kONcol + kTNW + 15) & ~15u;
 
 // exclusive scan of in[0..n) into out[0..n) (may alias if same type); returns the total.
 template <typename In, typename Out>
@@ -123,65 +162,100 @@ __device__ uint32_t block_exscan(const In *in, Out *out, uint32_t n, uint32_t *t
     return total;
 }
 
-__global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(GraphArgs a) {
+// the same with the input behind a function of the index
+template <typename Get, typename Out>
+__device__ uint32_t block_exscan_f(uint32_t n, Get get, Out *out, uint32_t *tmp) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = (n + kGT - 1) / kGT;
+    const uint32_t b = min(n, tid * chunk), e = min(n, b + chunk);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; i++) s += get(i);
+    uint32_t x = s;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) tmp[wave] = x;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < kGT / 64; w++) {
+        if (w < wave) base += tmp[w];
+        total += tmp[w];
+    }
+    uint32_t run = base + x - s;
+    __syncthreads();
+    for (uint32_t i = b; i < e; i++) {
+        const uint32_t v = get(i);
+        out[i] = (Out)run;
+        run += v;
+    }
+    __syncthreads();
+    return total;
+}
+
+__global__ void __launch_bounds__(kGT) __attribute__((amdgpu_waves_per_eu(SINA_GRAPH_MINWAVES, SINA_GRAPH_MINWAVES))) family_graph_kernel(GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // per family member (sized by the launch's largest family, at least 16: s_ids doubles as the
-    // slot allocator's per-segment counters) -- dynamic, so that small families leave the LDS to a
-    // fourth workgroup per CU
-    uint64_t *s_beg = reinterpret_cast<uint64_t *>(smem + a.member_off);
-    uint32_t *s_ids = reinterpret_cast<uint32_t *>(s_beg + a.member_cap);
-    uint32_t *s_len = s_ids + a.member_cap;
-    uint32_t *s_cur = s_len + a.member_cap, *s_curn = s_cur + a.member_cap;      // first base of member j at/after the tile
-    uint32_t *s_carry = s_curn + a.member_cap, *s_carryn = s_carry + a.member_cap;  // node of member j's last base before the tile
     __shared__ uint32_t s_tmp[kGT / 64 + 8];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     dry_signal(a.dry, gridDim.x, tid == 0);
     const uint32_t nwords = (a.width + 31) / 32;
     const uint64_t f0 = a.fam_off[q];
     const uint32_t F = (uint32_t)(a.fam_off[q + 1] - f0);
-    const uint32_t FS = (F + 1) | 1u;  // table row stride (u16 units)
-    // LDS carve
-    uint32_t *bitmap = reinterpret_cast<uint32_t *>(smem);                 // [nwords]
+    // LDS carve.  Everything whose size is known at compile time comes first: its addresses are immediates of the
+    // LDS instructions, not scalars that have to stay live (the kernel runs with 100 SGPRs and spilled 109 more
+    // when every table had a run-time base).
+    uint32_t *cposT = reinterpret_cast<uint32_t *>(smem + kOCpos);          // [kTC] alignment column
+    uint32_t *nbaseT = reinterpret_cast<uint32_t *>(smem + kONbase);        // [kTC + 2] first node of the column (tile-local); [tc] = nodes of the tile
+    uint32_t *presT = reinterpret_cast<uint32_t *>(smem + kOPres);          // [kTC] the column's characters, bit m: mask value m occurs
+    uint32_t *wA = reinterpret_cast<uint32_t *>(smem + kOWA);               // [kTNW] per node of the window: members | raw edges << 16
+    uint32_t *wC = reinterpret_cast<uint32_t *>(smem + kOWC);               // [kTNW] first member of the node's character; then: smallest far predecessor not yet listed
+    uint32_t *wD = reinterpret_cast<uint32_t *>(smem + kOWD);               // [kTNW] start of the CSR segment (raw entries before it in the window)
+    unsigned long long *wB = reinterpret_cast<unsigned long long *>(smem + kOWB);  // [kTNW] predecessors at distance 1..64, a bit each
+    uint8_t *liOf = smem + kOLi;                                            // [kTC * 32] by (column's first node + index of the character among the column's): place in family order
+    uint8_t *nn = smem + kONn;                                              // [kTC] nodes per column
+    uint8_t *nfarN = smem + kONfar;                                         // [kTNW] far predecessors listed so far
+    uint8_t *maskN = smem + kOMask;                                         // [kTNW]
+    uint8_t *ncolN = smem + kONcol;                                         // [kTNW] tile column of the node
+    // entry (member j, slot): tile column | mask << 8 | "first base of the member" << 13, kEAbsent (column 255): not in the tile
+    uint16_t *eE = reinterpret_cast<uint16_t *>(smem + kOE);                // [fam_cap][kTC]
+    // ... then what is sized by the launch: the occupied-column bitmap and its ranks, the family members
+    uint32_t *bitmap = reinterpret_cast<uint32_t *>(smem + a.bitmap_off);   // [nwords]
     uint16_t *wrank = reinterpret_cast<uint16_t *>(bitmap + nwords);        // [nwords]
-    unsigned char *tile = smem + ((6 * (size_t)nwords + 15) & ~(size_t)15);
-    uint32_t *cposT = reinterpret_cast<uint32_t *>(tile);                   // [kTC] alignment column
-    uint32_t *nbaseT = cposT + kTC;                                         // [kTC] first node id
-    uint32_t *ebaseT = nbaseT + kTC;                                        // [kTC] first raw edge slot
-    uint8_t *nn = reinterpret_cast<uint8_t *>(ebaseT + kTC);                // [kTC] nodes per column
-    uint8_t *rc = nn + kTC;                                                 // [kTC] raw edges per column
-    // tabm[c][j]: mask (8) | local node index (5) << 8 | first base of the member << 13 ; 0 = absent
-    uint16_t *tabm = reinterpret_cast<uint16_t *>(rc + kTC);                // [kTC][FS]
-    uint16_t *tabp = tabm + (size_t)kTC * FS;                               // [kTC][FS] previous node, 0xFFFF none
-    uint8_t *ncolT = reinterpret_cast<uint8_t *>(tabp + (size_t)kTC * FS);  // [kTC * 32] tile column of every node of the tile
-    // [F][kTC] tile column of member j's (s_cur[j] + slot)-th base, 255: not in the tile -- the same
-    // LDS as ncolT: cl8 is read for the last time in step 4, ncolT is filled after it
-    uint8_t *cl8 = ncolT;
+    Member *mb = reinterpret_cast<Member *>(smem + a.member_off);           // [member_cap >= 16: .id doubles as the slot allocator's per-segment counters]
+    constexpr uint32_t kEAbsent = 0x00FFu, kEFirst = 1u << 13;
+    constexpr uint32_t kCH = kTC / 64, kNW = kGT / 64;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_tasks = F * kCH;  // (member, 64 slots) pairs, a wave each
 
     uint32_t *sz = a.sizes + kSz * (size_t)q;
     for (uint32_t j = tid; j < F; j += kGT) {
         const uint32_t id = a.fam_ids[f0 + j];
-        s_ids[j] = id;
-        s_beg[j] = a.ref_off[id];
-        s_len[j] = (uint32_t)(a.ref_off[id + 1] - a.ref_off[id]);
-        s_cur[j] = s_curn[j] = 0;
-        s_carry[j] = s_carryn[j] = kNoPrev;
+        mb[j].id = id;
+        mb[j].beg = a.ref_off[id];
+        mb[j].len = (uint32_t)(a.ref_off[id + 1] - a.ref_off[id]);
+        mb[j].cur = mb[j].curn = 0;
+        mb[j].carry = mb[j].carryn = kNoPrev;
     }
     for (uint32_t i = tid; i < nwords; i += kGT) bitmap[i] = 0;
     __syncthreads();
     GP_DECL
 
     // 1. occupied columns
-    // (latency-bound: four members' loads are in flight per thread before the first is used)
-    for (uint32_t j0 = 0; j0 < F; j0 += 4) {
-        const uint32_t maxlen = max(max(s_len[j0], j0 + 1 < F ? s_len[j0 + 1] : 0u),
-                                    max(j0 + 2 < F ? s_len[j0 + 2] : 0u, j0 + 3 < F ? s_len[j0 + 3] : 0u));
+    // (latency-bound: eight members' loads are in flight per thread before the first is used)
+    for (uint32_t j0 = 0; j0 < F; j0 += 8) {
+        uint32_t maxlen = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) maxlen = max(maxlen, j0 + u < F ? mb[j0 + u].len : 0u);
         for (uint32_t i = tid; i < maxlen; i += kGT) {
-            uint32_t ab[4];
+            uint32_t ab[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                ab[u] = (j0 + u < F && i < s_len[j0 + u]) ? a.ref_ab[s_beg[j0 + u] + i] : 0xFFFFFFFFu;
+            for (int u = 0; u < 8; u++)
+                ab[u] = (j0 + u < F && i < mb[j0 + u].len) ? a.ref_ab[mb[j0 + u].beg + i] : 0xFFFFFFFFu;
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < 8; u++)
                 if (ab[u] != 0xFFFFFFFFu) {
                     const uint32_t pos = ab[u] & 0xFFFFFFu;
                     atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
@@ -243,220 +317,219 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
 
     for (uint32_t c0 = 0; c0 < NC; c0 += kTC) {
         const uint32_t tc = min((uint32_t)kTC, NC - c0);
-        {   // clear the mask table (u32 stores; FS odd, kTC even: the element count is even)
-            uint32_t *z = reinterpret_cast<uint32_t *>(tabm);
-            for (uint32_t i = tid; i < (uint32_t)kTC * FS / 2; i += kGT) z[i] = 0;
-        }
+        for (uint32_t i = tid; i < (uint32_t)kTC; i += kGT) presT[i] = 0;
         __syncthreads();
         GP(2)
-        // 3a. masks of this tile: member j's bases cur[j].. as long as their column is in the tile (a
-        // contiguous stretch of at most kTC bases); the tile column of every such base is kept in
-        // cl8 so that nothing below has to rank a position again
-        for (uint32_t idx0 = tid; idx0 < F * (uint32_t)kTC; idx0 += 4 * kGT) {
-            // (latency-bound: four loads in flight per thread)
-            uint32_t abv[4];
+        // 2. the entries of this tile: member j's bases cur[j].. as long as their column is in the tile (a
+        // contiguous stretch of at most kTC bases)
+        // (latency-bound: eight tasks' loads are in flight per wave before the first is used)
+        for (uint32_t t4 = wave; t4 < n_tasks; t4 += 8 * kNW) {
+            uint32_t abv[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t idx = idx0 + (uint32_t)u * kGT;
+            for (int u = 0; u < 8; u++) {
+                const uint32_t task = t4 + (uint32_t)u * kNW;
                 abv[u] = 0xFFFFFFFFu;  // (no packed base looks like this: the mask byte has five bits)
-                if (idx < F * (uint32_t)kTC) {
-                    const uint32_t j = idx / kTC, i = s_cur[j] + idx % kTC;
-                    if (i < s_len[j]) abv[u] = a.ref_ab[s_beg[j] + i];
+                if (task < n_tasks) {
+                    // (the member is the same for the whole wave: its cursor, length and offset on the scalar unit)
+                    const uint32_t j = task / kCH;
+                    const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[j].cur);
+                    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[j].len);
+                    const uint64_t beg = mb[j].beg;
+                    const uint64_t begs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(beg >> 32)) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)beg);
+                    const uint32_t i = cur + (task % kCH) * 64u + lane;
+                    if (i < len) abv[u] = a.ref_ab[begs + i];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t idx = idx0 + (uint32_t)u * kGT;
-                if (idx >= F * (uint32_t)kTC) continue;
-                const uint32_t j = idx / kTC, slot = idx % kTC, i = s_cur[j] + slot;
-                uint32_t cl = 255;
+            for (int u = 0; u < 8; u++) {
+                const uint32_t task = t4 + (uint32_t)u * kNW;
+                if (task >= n_tasks) continue;
+                const uint32_t j = task / kCH, slot0 = (task % kCH) * 64u, slot = slot0 + lane;
+                const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[j].cur);
+                uint32_t ev = kEAbsent;
                 if (abv[u] != 0xFFFFFFFFu) {
                     const uint32_t ab = abv[u];
                     const uint32_t pos = ab & 0xFFFFFFu;
                     const uint32_t c = rank(pos) - c0;
                     if (c < tc) {
-                        cl = c;
-                        tabm[c * FS + j] = (uint16_t)(((ab >> 24) & 0xFFu) | (i == 0 ? (1u << 13) : 0u));
+                        const uint32_t m = (ab >> 24) & 0x1Fu;
+                        ev = c | (m << 8) | (cur + slot == 0 ? kEFirst : 0u);
+                        atomicOr(&presT[c], 1u << m);
                         cposT[c] = pos;
                     }
                 }
-                cl8[j * kTC + slot] = (uint8_t)cl;
+                eE[j * (uint32_t)kTC + slot] = (uint16_t)ev;
+                // the member's last base in this tile moves its cursor (its bases in the tile are the first lanes of
+                // its tasks)
+                const uint32_t n_in = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ev != kEAbsent));
+                if (n_in && lane == 0) atomicMax(&mb[j].curn, cur + slot0 + n_in);
             }
         }
         __syncthreads();
-        // the member's last base in this tile moves its cursor
-        for (uint32_t idx = tid; idx < F * (uint32_t)kTC; idx += kGT) {
-            const uint32_t j = idx / kTC, slot = idx % kTC;
-            if (cl8[j * kTC + slot] != 255 && (slot + 1 == (uint32_t)kTC || cl8[j * kTC + slot + 1] == 255))
-                s_curn[j] = s_cur[j] + slot + 1;
-        }
+        for (uint32_t c = tid; c < tc; c += kGT) nn[c] = (uint8_t)__popc(presT[c]);
         __syncthreads();
         GP(3)
-        // 3b. per column: nodes in order of first appearance (family order), raw edge count
-        for (uint32_t c = tid; c < tc; c += kGT) {
-            uint32_t seen = 0;          // bit m: mask value m already has a node in this column
-            uint64_t idx0 = 0, idx1 = 0, idx2 = 0;  // local node index of mask m, 5 bits each (12/12/8 masks)
-            uint32_t k = 0, raw = 0;
-            uint16_t *row = tabm + c * FS;
-            for (uint32_t j0 = 0; j0 < F; j0 += 8) {  // (eight LDS reads in flight, as in step 5)
-                uint32_t tv[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) tv[u] = (j0 + u < F) ? (uint32_t)row[j0 + u] : 0u;
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint32_t t = tv[u];
-                    const uint32_t m = t & 0x1Fu;
-                    if ((t & 0xFFu) == 0) continue;
-                    uint32_t li;
-                    if (!((seen >> m) & 1u)) {
-                        seen |= 1u << m;
-                        li = k++;
-                        if (m < 12) idx0 |= (uint64_t)li << (5 * m);
-                        else if (m < 24) idx1 |= (uint64_t)li << (5 * (m - 12));
-                        else idx2 |= (uint64_t)li << (5 * (m - 24));
-                    } else {
-                        li = (m < 12) ? (uint32_t)(idx0 >> (5 * m)) & 31u
-                             : (m < 24) ? (uint32_t)(idx1 >> (5 * (m - 12))) & 31u
-                                        : (uint32_t)(idx2 >> (5 * (m - 24))) & 31u;
-                    }
-                    row[j0 + u] = (uint16_t)(t | (li << 8));
-                    if (!(t & (1u << 13))) raw++;
-                }
-            }
-            nn[c] = (uint8_t)k;
-            rc[c] = (uint8_t)raw;
-        }
-        __syncthreads();
-        GP(4)
         const uint32_t tn = block_exscan(nn, nbaseT, tc, s_tmp);
-        const uint32_t te = block_exscan(rc, ebaseT, tc, s_tmp);
-        GP(5)
-        // 4. node of every base's predecessor base (the member's previous base: one slot to the left,
-        // or -- for its first base in the tile -- what the previous tiles carried over)
-        for (uint32_t idx = tid; idx < F * (uint32_t)kTC; idx += kGT) {
-            const uint32_t j = idx / kTC, slot = idx % kTC;
-            const uint32_t cl = cl8[j * kTC + slot];
-            if (cl == 255) continue;
-            const uint32_t i = s_cur[j] + slot;
-            const uint32_t node = N + nbaseT[cl] + ((tabm[cl * FS + j] >> 8) & 31u);
-            uint32_t pn = kNoPrev;
-            if (slot > 0) {
-                const uint32_t pl = cl8[j * kTC + slot - 1];
-                pn = N + nbaseT[pl] + ((tabm[pl * FS + j] >> 8) & 31u);
-            } else if (i > 0) {
-                pn = s_carry[j];
-            }
-            tabp[cl * FS + j] = (uint16_t)pn;
-            if (i + 1 == s_curn[j]) s_carryn[j] = node;
-        }
-        __syncthreads();
-        for (uint32_t c = tid; c < tc; c += kGT)  // (cl8 is dead: its LDS becomes the node -> column map)
-            for (uint32_t k = 0; k < nn[c]; k++) ncolT[nbaseT[c] + k] = (uint8_t)c;
+        if (tid == 0) nbaseT[tc] = tn;
         for (uint32_t ln = tid; ln < tn; ln += kGT)  // this tile's nodes: no successor seen yet
             if (N + ln < a.ncap) {
                 last[N + ln] = 0;
                 if (a.want_smin) smin[N + ln] = 0xFFFFFFFFu;
             }
         __syncthreads();
-        GP(6)
-        // 5. node records + sorted unique predecessor lists: one thread per NODE of the tile (a column
-        // has 1.7 nodes on average and up to five or so: threads per column would wait for the widest
-        // column of their wave).  One pass over the column's F members gives the node its member
-        // count, mask, the raw edge entries of the column's earlier nodes (= where its CSR segment
-        // starts) and its predecessors.
-        for (uint32_t ln = tid; ln < tn; ln += kGT) {
-            const uint32_t c = ncolT[ln];
-            const uint32_t k = ln - nbaseT[c];
-            const uint16_t *rowm = tabm + c * FS;
-            const uint16_t *rowp = tabp + c * FS;
-            const uint32_t pos = cposT[c];
-            const uint32_t node = N + ln;
-            uint32_t cnt = 0, np = 0, rawk = 0, raw_before = 0, mask = 0;
-            // sorted unique predecessor ids, first in registers (8 cover all but freak
-            // columns): no read-modify-write round trips to the CSR segment in HBM
-            uint32_t pl[8];
-#pragma unroll
-            for (int t8 = 0; t8 < 8; t8++) pl[t8] = 0xFFFFFFFFu;
-            bool overflow = false;
-            uint32_t recent = 0xFFFFFFFFu;  // (most members of a node come from the same previous node)
-            // (the column's entries eight at a time: the LDS reads of a batch are in flight together
-            // instead of one round trip per family member)
-            for (uint32_t j0 = 0; j0 < F; j0 += 8) {
-                uint32_t tv[8], pv[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const bool in = j0 + u < F;
-                    tv[u] = in ? (uint32_t)rowm[j0 + u] : 0u;
-                    pv[u] = in ? (uint32_t)rowp[j0 + u] : 0u;
+        GP(5)
+        uint32_t te = 0;  // raw edge entries of the tile's windows so far
+        for (uint32_t ca = 0; ca < tc;) {
+            // the window: columns [ca, cb) -- as many as have their nodes' words in LDS together (nearly always the tile)
+            const uint32_t w0 = nbaseT[ca];
+            uint32_t cb = tc;
+            if (tn - w0 > (uint32_t)kTNW) {
+                uint32_t lo = ca + 1, hi = tc;  // (a column has at most 32 nodes: one always fits)
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1) / 2;
+                    if (nbaseT[mid] - w0 <= (uint32_t)kTNW) lo = mid;
+                    else hi = mid - 1;
                 }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint32_t t = tv[u];
-                    if ((t & 0xFFu) == 0) continue;
-                    const uint32_t lj = (t >> 8) & 31u;
-                    const bool has_prev = !(t & (1u << 13));
-                    if (lj < k) raw_before += has_prev ? 1u : 0u;
-                    if (lj != k) continue;
-                    mask = t & 0xFFu;
-                    cnt++;
-                    if (!has_prev) continue;
-                    rawk++;
-                    uint32_t x = pv[u];
-                    if (x == recent) continue;
-                    recent = x;
-#pragma unroll
-                    for (int t8 = 0; t8 < 8; t8++) {  // bubble x into place; a duplicate turns into the pad value
-                        const uint32_t y = pl[t8];
-                        if (x == y) x = 0xFFFFFFFFu;
-                        const bool sw = x < y;
-                        pl[t8] = sw ? x : y;
-                        x = sw ? y : x;
-                    }
-                    overflow = overflow || (x != 0xFFFFFFFFu);
+                cb = lo;
+            }
+            const uint32_t wn = nbaseT[cb] - w0;
+            for (uint32_t i = tid; i < wn; i += kGT) {
+                wA[i] = 0;
+                wB[i] = 0;
+                wC[i] = 0xFFFFFFFFu;  // (first the smallest member index of the node's character, then the far predecessors)
+                nfarN[i] = 0;
+            }
+            __syncthreads();
+            // 3. first appearance of every (column, character) in family order
+            for (uint32_t task = wave; task < n_tasks; task += kNW) {
+                const uint32_t j = task / kCH, slot = (task % kCH) * 64u + lane;
+                const uint32_t ev = eE[j * (uint32_t)kTC + slot];
+                const uint32_t c = ev & 0xFFu;
+                if (c >= ca && c < cb) {
+                    const uint32_t m = (ev >> 8) & 31u;
+                    atomicMin(&wC[nbaseT[c] + __popc(presT[c] & ((1u << m) - 1u)) - w0], j);
                 }
             }
-            const uint32_t seg = E + ebaseT[c] + raw_before;
-            if (node < a.ncap) {
-                if (!overflow) {
-#pragma unroll
-                    for (int t8 = 0; t8 < 8; t8++) {
-                        const uint32_t pa = pl[t8];
-                        if (pa != 0xFFFFFFFFu) {
-                            pred[seg + np] = pa;
-                            np++;
-                            if (a.want_smin) atomicMin(&smin[pa], pos);
-                            atomicMax(&last[pa], node);
-                        }
+            __syncthreads();
+            for (uint32_t c = ca + tid; c < cb; c += kGT) {
+                const uint32_t base = nbaseT[c], k = nn[c];
+                uint32_t pp = presT[c];
+                for (uint32_t x = 0; x < k; x++) {
+                    const uint32_t mj = wC[base - w0 + x];
+                    uint32_t r = 0;
+                    for (uint32_t y = 0; y < k; y++) r += (wC[base - w0 + y] < mj) ? 1u : 0u;
+                    liOf[base + x] = (uint8_t)r;
+                    maskN[base - w0 + r] = (uint8_t)(__ffs(pp) - 1);
+                    ncolN[base - w0 + r] = (uint8_t)c;
+                    pp &= pp - 1u;
+                }
+            }
+            __syncthreads();
+            GP(4)
+            // 4. members and raw edges per node; the predecessor of every entry.  An entry's node: the column's first
+            // node + the place of its character (liOf is complete for this window and the ones before: the entry to
+            // the left is in one of them)
+            auto node_of = [&](uint32_t ev) -> uint32_t {
+                const uint32_t c = ev & 0xFFu, m = (ev >> 8) & 31u;
+                const uint32_t b = nbaseT[c];
+                return b + liOf[b + __popc(presT[c] & ((1u << m) - 1u))];
+            };
+            unsigned long long farbits = 0;  // my entries (by round of the task loop) whose predecessor is more than 64 ids back
+            {
+                uint32_t it = 0;
+                for (uint32_t task = wave; task < n_tasks; task += kNW, it++) {
+                    const uint32_t j = task / kCH, slot = (task % kCH) * 64u + lane;
+                    const uint32_t ev = eE[j * (uint32_t)kTC + slot];
+                    const uint32_t c = ev & 0xFFu;
+                    const bool mine = c >= ca && c < cb;
+                    const uint32_t ln = mine ? node_of(ev) : 0u;
+                    // (the entry to the left is the lane to the left, except for the first slot of a task)
+                    uint32_t lnp = __shfl_up(ln, 1);
+                    const bool left_mine = __shfl_up(mine ? 1 : 0, 1) != 0;
+                    if (!mine) continue;
+                    const uint32_t node = N + ln;
+                    const bool first = (ev & kEFirst) != 0;
+                    atomicAdd(&wA[ln - w0], first ? 1u : 0x10001u);
+                    if (mb[j].cur + slot + 1 == mb[j].curn) mb[j].carryn = node;
+                    if (!first) {
+                        if (slot && (lane == 0 || !left_mine)) lnp = node_of(eE[j * (uint32_t)kTC + slot - 1]);
+                        const uint32_t pn = slot ? N + lnp : mb[j].carry;
+                        const uint32_t d = node - pn;
+                        if (d <= 64u) atomicOr(&wB[ln - w0], 1ull << (d - 1u));
+                        else farbits |= 1ull << it;
                     }
-                } else {  // more than 8 distinct predecessors: insertion sort in the segment itself
-                    for (uint32_t j = 0; j < F; j++) {
-                        const uint32_t t = rowm[j];
-                        if ((t & 0xFFu) == 0 || ((t >> 8) & 31u) != k || (t & (1u << 13))) continue;
-                        const uint32_t pa = rowp[j];
-                        uint32_t x = 0;
-                        while (x < np && pred[seg + x] < pa) x++;
-                        if (x < np && pred[seg + x] == pa) continue;
-                        for (uint32_t y = np; y > x; y--) pred[seg + y] = pred[seg + y - 1];
-                        pred[seg + x] = pa;
-                        np++;
-                        if (a.want_smin) atomicMin(&smin[pa], pos);
-                        atomicMax(&last[pa], node);
+                }
+            }
+            for (uint32_t i = tid; i < wn; i += kGT) wC[i] = 0xFFFFFFFFu;  // (the first members have been read: barrier above)
+            __syncthreads();
+            GP(6)
+            const uint32_t te_w = block_exscan_f(wn, [&](uint32_t i) { return wA[i] >> 16; }, wD, s_tmp);
+            // far predecessors, smallest first: every round lists one per node
+            while (__syncthreads_or(farbits != 0 ? 1 : 0)) {
+                uint32_t it = 0;
+                for (uint32_t task = wave; task < n_tasks; task += kNW, it++) {
+                    if (!((farbits >> it) & 1ull)) continue;
+                    const uint32_t j = task / kCH, slot = (task % kCH) * 64u + lane;
+                    const uint32_t ln = node_of(eE[j * (uint32_t)kTC + slot]);
+                    const uint32_t pn = slot ? N + node_of(eE[j * (uint32_t)kTC + slot - 1]) : mb[j].carry;
+                    atomicMin(&wC[ln - w0], pn);
+                }
+                __syncthreads();
+                it = 0;
+                for (uint32_t task = wave; task < n_tasks; task += kNW, it++) {
+                    if (!((farbits >> it) & 1ull)) continue;
+                    const uint32_t j = task / kCH, slot = (task % kCH) * 64u + lane;
+                    const uint32_t ln = node_of(eE[j * (uint32_t)kTC + slot]);
+                    const uint32_t pn = slot ? N + node_of(eE[j * (uint32_t)kTC + slot - 1]) : mb[j].carry;
+                    if (wC[ln - w0] == pn) farbits &= ~(1ull << it);
+                }
+                __syncthreads();
+                for (uint32_t i = tid; i < wn; i += kGT) {
+                    const uint32_t v = wC[i];
+                    if (v == 0xFFFFFFFFu) continue;
+                    const uint32_t node = N + w0 + i;
+                    if (node < a.ncap) {
+                        pred[E + te + wD[i] + nfarN[i]] = v;
+                        if (a.want_smin) atomicMin(&smin[v], cposT[ncolN[i]]);
+                        atomicMax(&last[v], node);
                     }
+                    nfarN[i]++;
+                    wC[i] = 0xFFFFFFFFu;
+                }
+            }
+            // 5. node records + predecessor lists: the far ones are in place, the near ones are the set bits from the top down
+            for (uint32_t i = tid; i < wn; i += kGT) {
+                const uint32_t node = N + w0 + i;
+                if (node >= a.ncap) continue;
+                const uint32_t seg = E + te + wD[i];
+                const uint32_t pos = cposT[ncolN[i]];
+                uint32_t np = nfarN[i];
+                unsigned long long bits = wB[i];
+                while (bits) {
+                    const uint32_t hi = 63u - (uint32_t)__clzll((long long)bits);
+                    bits ^= 1ull << hi;
+                    const uint32_t pa = node - (hi + 1u);
+                    pred[seg + np] = pa;
+                    np++;
+                    if (a.want_smin) atomicMin(&smin[pa], pos);
+                    atomicMax(&last[pa], node);
                 }
                 uint4 r;
                 r.x = seg;
-                r.y = __float_as_uint(wt[cnt]);
-                r.z = (np & 0xFFu) | (mask << 8);
+                r.y = __float_as_uint(wt[wA[i] & 0xFFFFu]);
+                r.z = (np & 0xFFu) | ((uint32_t)maskN[i] << 8);
                 r.w = kRowNone;
                 rec[node] = r;
                 node_pos[node] = pos;
             }
-            (void)rawk;
+            te += te_w;
+            ca = cb;
+            __syncthreads();  // (the window's words are cleared for the next one)
         }
-        __syncthreads();
         for (uint32_t j = tid; j < F; j += kGT) {
-            s_cur[j] = s_curn[j];
-            s_carry[j] = s_carryn[j];
+            mb[j].cur = mb[j].curn;
+            mb[j].carry = mb[j].carryn;
         }
         N += tn;
         E += te;
@@ -476,7 +549,7 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
     // row codes (step 7) when they fit the tile tables' space
     const uint32_t seg_len = dp_slot_segment(N);
     const uint32_t n_seg = (N + seg_len - 1) / seg_len;
-    uint32_t *codeL = reinterpret_cast<uint32_t *>(tile);
+    uint32_t *codeL = reinterpret_cast<uint32_t *>(smem);  // (the tile tables' space: everything in front of the bitmap)
     const bool in_lds = (size_t)N * 4 <= a.tile_bytes;
     if (tid == 0) s_tmp[kGT / 64 + 1] = 0xFFFFFFFFu;  // first sink row
     __syncthreads();
@@ -503,49 +576,56 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
     // (the lanes walk their segments row by row: from LDS when the rows fit the tile tables' space --
     // a dependent global load per row was most of this step's time)
     if (tid < n_seg) {
-        uint32_t fa[8];  // last successor of the row in slot x (0: empty)
+        // (the walk is one dependent chain per lane in a CU that runs 31 other waves: every instruction waits its turn,
+        // so the slot search is compiled for 4 slots -- the DP kernels keep 3 -- and for 8)
+        auto walk = [&](auto kslots) {
+            constexpr int K = decltype(kslots)::value;
+            uint32_t fa[K];  // last successor of the row in slot x (0: empty)
 #pragma unroll
-        for (int x = 0; x < 8; x++) fa[x] = (x < a.W) ? 0u : 0xFFFFFFFFu;
-        uint32_t nsp = 0;
-        const uint32_t b = tid * seg_len, e = min(N, b + seg_len);
-        for (uint32_t m = b; m < e; m++) {
-            uint32_t l, sink, fence;
-            if (in_lds) {
-                const uint32_t cd = codeL[m];
-                l = cd & 0xFFFFu;
-                sink = cd & (1u << 30);
-                fence = cd & (1u << 31);
-            } else {
-                const uint32_t z = rec[m].z;
-                l = last[m];
-                sink = z & kRecSink;
-                fence = z & kRecFence;
+            for (int x = 0; x < K; x++) fa[x] = (x < a.W) ? 0u : 0xFFFFFFFFu;
+            uint32_t nsp = 0;
+            const uint32_t b = tid * seg_len, e = min(N, b + seg_len);
+            for (uint32_t m = b; m < e; m++) {
+                uint32_t l, sink, fence;
+                if (in_lds) {
+                    const uint32_t cd = codeL[m];
+                    l = cd & 0xFFFFu;
+                    sink = cd & (1u << 30);
+                    fence = cd & (1u << 31);
+                } else {
+                    const uint32_t z = rec[m].z;
+                    l = last[m];
+                    sink = z & kRecSink;
+                    fence = z & kRecFence;
+                }
+                uint32_t wv = kRowNone;
+                if (!sink && l != m + 1) {  // (a row only the next row reads is handed over in registers)
+                    // (a row with a successor beyond kFarLds, or in a later segment, is always a spill row)
+                    const bool may_slot = !fence && l < e;
+                    uint32_t slot = K;
+#pragma unroll
+                    for (int x = K - 1; x >= 0; x--) slot = (may_slot && fa[x] <= m) ? (uint32_t)x : slot;
+#pragma unroll
+                    for (int x = 0; x < K; x++) fa[x] = (slot == (uint32_t)x) ? l : fa[x];
+                    wv = slot < (uint32_t)K ? slot : (kRowSpilled | nsp++);
+                }
+                if (in_lds) codeL[m] = wv;
+                else rec[m].w = wv;
             }
-            uint32_t wv = kRowNone;
-            if (!sink && l != m + 1) {  // (a row only the next row reads is handed over in registers)
-                // (a row with a successor beyond kFarLds, or in a later segment, is always a spill row)
-                const bool may_slot = !fence && l < e;
-                uint32_t slot = 8;
-#pragma unroll
-                for (int x = 7; x >= 0; x--) slot = (may_slot && fa[x] <= m) ? (uint32_t)x : slot;
-#pragma unroll
-                for (int x = 0; x < 8; x++) fa[x] = (slot == (uint32_t)x) ? l : fa[x];
-                wv = slot < 8 ? slot : (kRowSpilled | nsp++);
-            }
-            if (in_lds) codeL[m] = wv;
-            else rec[m].w = wv;
-        }
-        s_ids[tid] = nsp;  // (s_ids is free by now: spill rows of my segment)
+            mb[tid].id = nsp;  // (s_ids is free by now: spill rows of my segment)
+        };
+        if (a.W <= 4) walk(std::integral_constant<int, 4>());
+        else walk(std::integral_constant<int, 8>());
     }
     __syncthreads();
     {   // spill rows get their final numbers: segment base + number within the segment
         uint32_t tot = 0;
-        for (uint32_t g = 0; g < n_seg; g++) tot += s_ids[g];
+        for (uint32_t g = 0; g < n_seg; g++) tot += mb[g].id;
         for (uint32_t i = tid; i < N; i += kGT) {
             uint32_t w = in_lds ? codeL[i] : rec[i].w;
             if (w != kRowNone && (w & kRowSpilled)) {
                 uint32_t base = 0;
-                for (uint32_t g = 0; g < i / seg_len; g++) base += s_ids[g];
+                for (uint32_t g = 0; g < i / seg_len; g++) base += mb[g].id;
                 w += base;
             }
             rec[i].w = w;
@@ -619,16 +699,15 @@ __global__ void __launch_bounds__(kGT, SINA_GRAPH_MINWAVES) family_graph_kernel(
     GP_FLUSH
 }
 
+// LDS of one workgroup: the tile tables, the bitmap + ranks (offset: graph_bitmap_off), the member records behind them
+size_t graph_bitmap_off(uint32_t max_family) { return ((size_t)kOE + 2 * (size_t)max_family * kTC + 15) & ~(size_t)15; }
 size_t graph_lds_bytes(uint32_t width, uint32_t max_family) {
     const size_t nwords = (width + 31) / 32;
-    const size_t fs = (max_family + 1) | 1u;
-    return ((6 * nwords + 15) & ~(size_t)15) + (size_t)kTC * (4 + 4 + 4 + 1 + 1) + 2 * 2 * (size_t)kTC * fs +
-           (size_t)kTC * std::max<size_t>(32, fs) + 64;
+    return graph_bitmap_off(max_family) + ((6 * nwords + 15) & ~(size_t)15);
 }
-// the per-member arrays behind that: offset (8-byte aligned) and total
 size_t graph_member_cap(uint32_t max_family) { return std::max<size_t>(16, (max_family + 1) & ~(size_t)1); }
 size_t graph_lds_total(uint32_t width, uint32_t max_family) {
-    return ((graph_lds_bytes(width, max_family) + 7) & ~(size_t)7) + 32 * graph_member_cap(max_family);
+    return graph_lds_bytes(width, max_family) + sizeof(Member) * graph_member_cap(max_family);
 }
 
 }  // namespace
@@ -711,9 +790,11 @@ int build_family_graphs(sina_hip_ctx *c, const uint32_t *fam_ids, const uint64_t
         ga.sizes = c->g_sizes.as<uint32_t>();
         ga.width = c->st->width;
         ga.ncap = ncap;
-        ga.tile_bytes = (uint32_t)(glds_tables - ((6 * (size_t)((c->st->width + 31) / 32) + 15) & ~(size_t)15) - 64);
-        ga.member_off = (uint32_t)((glds_tables + 7) & ~(size_t)7);
+        ga.bitmap_off = (uint32_t)graph_bitmap_off(max_f);
+        ga.tile_bytes = ga.bitmap_off;
+        ga.member_off = (uint32_t)glds_tables;
         ga.member_cap = (uint32_t)graph_member_cap(max_f);
+        ga.fam_cap = max_f;
         ga.W = W;
         ga.want_smin = want_smin ? 1 : 0;
         ga.reach = kappa64 > 0.f ? c->rgain.as<uint2>() : nullptr;

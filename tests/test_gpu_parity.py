@@ -235,6 +235,32 @@ def test_device_family_graph_equals_oracle(oracle, gpu_ctx):
                 assert (g["spill"] == util.row_store_model(o["pred_off"], o["pred"], ring)).all()
 
 
+def test_device_family_graph_many_characters_per_column(oracle, gpu_ctx):
+    """Families whose columns hold a dozen and more different characters (nine in ten bases an ambiguity code, half
+    of them lower case): a tile of the DAG build then has more nodes than it keeps per-node words for in LDS and
+    takes them in windows of whole columns; many nodes have more predecessors than a register list ever held, and
+    the long deletions put predecessors further back than the 64 ids the per-node bit set spans."""
+    refs = synth.make_refs(200, length=300, width=3000, seed=171, amb_rate=0.9, lower_rate=0.5, long_del_prob=0.5)
+    cs = util.cseqs_from_refs(refs)
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    rng = np.random.default_rng(14)
+    seen_wide = False
+    for F in (3, 40, 128):
+        ids = rng.choice(refs.n, size=F, replace=False).astype(np.uint32)
+        g = gpu_ctx.debug_family_graph(ids, 1.0, 4)
+        o = util.graph_dict([cs[i] for i in ids], 1.0)
+        assert g["n"] == o["n"]
+        assert (g["pos"] == o["pos"]).all() and (g["mask"] == o["mask"]).all()
+        assert (util.f32_bits(g["weight"]) == util.f32_bits(o["weight"])).all()
+        assert (g["pred_off"] == o["pred_off"]).all() and (g["pred"] == o["pred"]).all()
+        assert (g["succ_minpos"] == o["succ_minpos"]).all()
+        ncol = len(np.unique(o["pos"]))
+        npred = np.diff(o["pred_off"])
+        far = o["pred"].size and (np.repeat(np.arange(o["n"]), npred) - o["pred"]).max()
+        seen_wide = seen_wide or (o["n"] > 6 * ncol and npred.max() > 8 and far > 64)
+    assert seen_wide
+
+
 def test_align_families_equals_align_graphs(oracle, gpu_ctx, small):
     refs, qs, cs, idx = small
     gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
