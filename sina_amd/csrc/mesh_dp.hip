@@ -1970,6 +1970,158 @@ __global__ void __launch_bounds__(64) backtrack_kernel(BtArgs a) {
 }
 
 
+// The same walk with one LANE per query (launches of kBtLanesMin queries and more).  The wave-per-query kernel
+// above spends a whole wave's issue slots on one logical thread -- 60 instructions per step, 3000 steps, 9216
+// waves: 3 ms of a device whose other kernels (the next batch's DAG build, k-mer search and DP, running beside
+// it) are bound by instruction issue as well.  Here a wave walks 64 queries: 64 times fewer instructions, every
+// look-up a global load of its own (cells 2 bytes, a 64-byte sector each: a quarter of the window refills'
+// traffic), and the walk's latency -- a few dependent round trips per step, the rare branches of any lane paid by
+// the whole wave -- is hidden behind the kernels it runs beside instead of competing with them.
+template <bool LAZY>
+__global__ void __launch_bounds__(64) backtrack_lanes_kernel(BtArgs a) {
+    using cell_t = typename std::conditional<LAZY, uint16_t, uint32_t>::type;
+    const uint32_t q = blockIdx.x * 64u + threadIdx.x;
+    if (q >= a.nq) return;
+    const QDesc d = a.qd[q];
+    const uint32_t L = d.L;
+    const uint32_t Lp = a.Lp;
+    const cell_t *tb = reinterpret_cast<const cell_t *>(a.tb) + d.tb_off;
+    const uint4 *rec = a.rec + d.node_off;
+    const uint32_t *node_pos = a.node_pos + d.node_off;
+    const uint32_t *pred = a.pred + d.edge_off;
+    uint32_t *out = a.out_pos + d.q_off;
+    const DpResult r = a.res[q];
+    sina_hip_align_out o;
+    o.status = r.status;
+    o.end_m = r.end_m;
+    o.end_s = r.end_s;
+    o.raw = r.raw;
+    o.sum_weight = 0.f;
+    o.aligned_bases = 0;
+    o.cutoff_head = o.cutoff_tail = 0;
+    o.n_out = 0;
+    o.assembled = o.nast_total = o.nast_longest = o.nast_last_run = 0;
+    if (r.status != 0) {
+        a.out[q] = o;
+        return;
+    }
+    auto cell_at = [&](uint32_t row, uint32_t col) -> uint32_t { return (uint32_t)tb[(size_t)row * Lp + col]; };
+    auto rec_at = [&](uint32_t row) -> uint4 {  // (.w = the node's column)
+        uint4 rx = rec[row];
+        rx.w = node_pos[row];
+        return rx;
+    };
+    auto pred_at = [&](uint32_t pb, uint32_t e) -> uint32_t { return pred[pb + e] & 0xffffu; };
+    const uint32_t width = a.width;
+    uint32_t m = r.end_m, s = r.end_s;
+    uint32_t n = 0;
+    const uint32_t send = L - 1;
+    auto emit = [&](uint32_t p) { out[n++] = p; };
+
+    // right hand overhang (:594-615)
+    const int tail = (int)(send - s);
+    o.cutoff_tail = tail;
+    uint32_t c = cell_at(m, s);
+    uint4 rm = rec_at(m);
+    if (tail && a.overhang != SINA_OVERHANG_REMOVE) {
+        int pos = (a.overhang == SINA_OVERHANG_ATTACH) ? (int)(width - 1 - rm.w - (uint32_t)tail) : 0;
+        for (int i = 0; i < tail; i++) {
+            const int p = pos++;
+            emit((uint32_t)(p > 0 ? p : 0));
+        }
+    }
+    const uint8_t *qmb = a.qmask + d.q_off;
+    auto mscore_at = [&](const uint4 &rx, uint32_t si) -> float {  // tr.s.match(sum, ab2, ab1) with comp()==true
+        if (a.self16 != nullptr) return a.self16[qmb[si] & 0xfu];
+        const float wgt = __uint_as_float(rx.y);
+        if (a.weights != nullptr) {
+            const uint32_t nw1 = a.n_weights - 1;
+            return a.ms * a.weights[rx.w < nw1 ? rx.w : nw1] * wgt;
+        }
+        return a.ms * wgt;
+    };
+    unsigned int pos = width - 1 - rm.w;
+    float sum_weight = 0.f;
+    int aligned = 0;
+    emit(pos);
+    aligned++;
+    sum_weight = sum_weight + mscore_at(rm, s);
+
+    constexpr uint32_t ext_bit = LAZY ? kTb16Ext : kTbExt;
+    auto gapm_idx = [&](uint32_t x, uint32_t col) -> uint32_t {  // (see backtrack_kernel)
+        for (uint32_t guard = 0; guard < 65536u; ++guard) {
+            const uint32_t cx = cell_at(x, col);
+            const uint4 rx = rec[x];
+            const uint32_t np = rx.z & 0xffu;
+            if (np == 0) return 0u;
+            const uint32_t lastp = pred_at(rx.x, np - 1);
+            if (LAZY ? !(cx & kTb16XLast) : (cx & kTbOpLast) != 0) return lastp;
+            x = lastp;
+        }
+        return 0u;
+    };
+    auto midx_raw = [&](uint32_t cc, uint32_t row, uint32_t pb) -> uint32_t {
+        if (!LAZY) return cc >> 16;
+        const uint32_t t = cc & kTbTypeMask;
+        if (t == kTbIns) return row;
+        if (t == kTbNone) return 0u;
+        return pred_at(pb, cc >> kTb16OrdShift);
+    };
+    auto sidx_of = [&](uint32_t cc, uint32_t row, uint32_t col) -> uint32_t {
+        if (!LAZY) return cc & kTbSMask;
+        const uint32_t t = cc & kTbTypeMask;
+        if (t == kTbNone) return 0u;
+        if (t == kTbMatch) return col - 1;
+        if (t == kTbDel) return col;
+        uint32_t k = col - 1;  // insertion: the gap began where the run of insertion cells to the left ends
+        while (k > 0 && (cell_at(row, k) & kTbTypeMask) == kTbIns) --k;
+        return k;
+    };
+    auto is_deletion_at = [&](uint32_t cc, uint32_t col) -> bool {
+        return LAZY ? (cc & kTbTypeMask) == kTbDel : (cc & kTbSMask) == col;
+    };
+    // :642-685 (a source node has no predecessors)
+    uint32_t npred_m = rm.z & 0xffu;
+    while (s != 0 && npred_m != 0) {
+        const uint32_t snew = sidx_of(c, m, s);
+        const uint32_t vm = midx_raw(c, m, rm.x);
+        m = (c & ext_bit) ? gapm_idx(vm, s) : vm;
+        c = cell_at(m, snew);
+        if (snew != 0 && is_deletion_at(c, snew)) {  // the one-step deletion skip (:653-655)
+            const uint32_t vm2 = midx_raw(c, m, rec[m].x);
+            m = (c & ext_bit) ? gapm_idx(vm2, snew) : vm2;
+            c = cell_at(m, snew);
+        }
+        rm = rec_at(m);
+        npred_m = rm.z & 0xffu;
+        pos = width - 1 - rm.w;
+        while (s != snew) {
+            --s;
+            emit(pos);
+            aligned++;
+            sum_weight = sum_weight + mscore_at(rm, s);
+        }
+    }
+    // left hand overhang (:690-721)
+    if (s != 0) {
+        o.cutoff_head = (int)s;
+        if (a.overhang == SINA_OVERHANG_ATTACH) {
+            while (s-- != 0) {
+                ++pos;
+                emit((width - 1 < pos) ? width - 1 : pos);
+            }
+        } else if (a.overhang == SINA_OVERHANG_EDGE) {
+            int k = (int)s;
+            while (k--) emit(width - (uint32_t)k - 1);
+        }
+    }
+    o.sum_weight = sum_weight;
+    o.aligned_bases = aligned;
+    o.n_out = n;
+    a.out[q] = o;
+}
+
+
 // The cseq container steps that follow the cell walk in backtrack() (src/mesh.h:603-726), for the
 // queries where they are plain -- one wave per query, behind backtrack_kernel on the same stream:
 //   * every emitted base is appended under the container rule (a column left of the sequence's
@@ -2248,8 +2400,16 @@ int launch_assemble(const BtArgs &a0, hipStream_t s) {
     return 0;
 }
 
+// launches of this many queries and more walk one lane per query (backtrack_lanes_kernel): below it the walk's
+// own latency matters more than the instruction slots it takes from its neighbours (SINA_HIP_TEST=bt_lanes=0/1 forces one)
+constexpr uint32_t kBtLanesMin = 2048;
 int launch_backtrack(const BtArgs &a, hipStream_t s) {
-    if (a.lazy_sidx) hipLaunchKernelGGL(backtrack_kernel<true>, dim3(a.nq), dim3(64), 0, s, a);
+    bool lanes = a.nq >= kBtLanesMin;
+    if (const std::string e = test_knob("bt_lanes"); !e.empty()) lanes = atoi(e.c_str()) != 0;
+    if (lanes) {
+        if (a.lazy_sidx) hipLaunchKernelGGL(backtrack_lanes_kernel<true>, dim3((a.nq + 63u) / 64u), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(backtrack_lanes_kernel<false>, dim3((a.nq + 63u) / 64u), dim3(64), 0, s, a);
+    } else if (a.lazy_sidx) hipLaunchKernelGGL(backtrack_kernel<true>, dim3(a.nq), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(backtrack_kernel<false>, dim3(a.nq), dim3(64), 0, s, a);
     SH_CHECK(hipGetLastError());
     return 0;

@@ -230,13 +230,15 @@ def test_pipeline_family_sizes(oracle, world, fs_min, fs_max):
 def test_pipeline_option_fuzz(oracle, world, monkeypatch, seed):
     """Seeded random combinations of the aligner's options, the scoring parameters (incl. gap extension
     above gap opening: the general chain path of the kernel), the weighted scheme, the host / device DAG
-    build, the DP geometry and the query shape -- every case against the oracle, everything compared."""
+    build, the DP geometry, the walk kernel and the query shape -- every case against the oracle, everything compared."""
     refs, cs, idx, st = world
     rng = np.random.default_rng(1000 + seed)
     pick = lambda xs: xs[int(rng.integers(0, len(xs)))]  # noqa: E731
     geom = pick([None, None, "64,8", "128,8", "128,12", "192,4", "256,4"])
     if geom:
         util.set_knobs(monkeypatch, geom=geom)
+    # (the cell walk: one wave per query, or one lane per query as launches of 2048 queries and more do it)
+    util.set_knobs(monkeypatch, bt_lanes=seed % 2)
     overhang, lowercase, insertion = pick(["attach", "remove", "edge"]), pick(["none", "original", "unaligned"]), pick(["shift", "forbid"])
     ms, mms = float(pick([2, 3, 1.5])), float(pick([-1, -2, -0.5]))
     gp, gpe = pick([(5, 2), (4, 1.5), (2, 3), (3, 3), (6, 0.5)])

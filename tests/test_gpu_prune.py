@@ -260,12 +260,14 @@ def test_row_skip_plane_fuzz(oracle, monkeypatch, seed):
         ctx.close()
 
 
-@pytest.mark.parametrize("frac,rho", [(0.0, None), (0.3, None), (0.46, None), (0.3, "0.97"), (0.46, "3")])
-def test_row_skip_partial_queries_equal_oracle(oracle, monkeypatch, frac, rho):
+@pytest.mark.parametrize("frac,rho,lanes", [(0.0, None, 0), (0.3, None, 1), (0.46, None, 0), (0.3, "0.97", 0), (0.46, "3", 1), (0.0, None, 1)])
+def test_row_skip_partial_queries_equal_oracle(oracle, monkeypatch, frac, rho, lanes):
     """Queries that cover only part of the alignment -- 800-base windows at its start, in its middle and at its end:
     two strips, so the row skip is in play, and the alignment begins and ends somewhere inside the DAG: free starts
     (column 0 of any row), free ends (the last column of any row, any column of a sink), long stretches of rows on
-    either side of the window that only the free-start rule keeps in play.  Trays against the oracle's."""
+    either side of the window that only the free-start rule keeps in play.  Trays against the oracle's -- walked back
+    by either kernel (lanes: one lane per query, what launches of 2048 queries and more use)."""
+    util.set_knobs(monkeypatch, bt_lanes=lanes)
     if rho is not None:
         util.set_knobs(monkeypatch, rho=rho)
     refs = synth.make_refs(3000, length=1500, width=50000, seed=72)
@@ -273,7 +275,7 @@ def test_row_skip_partial_queries_equal_oracle(oracle, monkeypatch, frac, rho):
     assert all(700 <= len(qs.seq(i)) <= 800 for i in range(qs.n))
     cs = util.cseqs_from_refs(refs)
     idx = oracle.Index(cs, k=10)
-    st = pipeline.Store(":mem:prune-part-%s-%s" % (frac, rho), refs)
+    st = pipeline.Store(":mem:prune-part-%s-%s-%s" % (frac, rho, lanes), refs)
     try:
         st.build_index(10, False)
         pl = pipeline.Pipeline(st, famfinder={"fs-min-len": 100})
