@@ -43,6 +43,10 @@ PrunePlan prune_plan(const sina_hip_align_params *p, float wmax, float wmin, uin
     // (the bounds are exact float32 integers in units of 1/64 only below 2^24)
     if (pp.amax > 250u || (uint64_t)pp.amax * maxL >= (1u << 23)) return pp;
     if (pp.kappa64 <= 0.f) pp.kappa64 = 1e-30f;  // (no step gains anything: every node's gain is the one unit of margin)
+    // (a launch whose queries fit ONE strip skips nothing -- column 0 keeps every row in play -- so nobody needs the
+    // bound: the DAG build leaves its step 9 out, 9 % of its time for V4 amplicons)
+    DpGeom g;
+    if (pick_geom(maxL, &g) && g.T <= 64) return pp;
     pp.on = 1;
     return pp;
 }
