@@ -377,6 +377,7 @@ size_t dp_default_lds_budget(const DpGeom &g);  // LDS per workgroup that keeps 
 int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
                    size_t lds_bytes, hipStream_t s);
 int launch_backtrack(const BtArgs &a, hipStream_t s);
+bool backtrack_by_lanes(const BtArgs &a);  // one lane per query (large launches of 16S-long queries), else one wave per query
 int launch_assemble(const BtArgs &a, hipStream_t s);  // (after launch_backtrack, same stream)
 // raises a kernel's dynamic-LDS ceiling to a CU's 160 KB, once per kernel and process (mesh_dp.hip)
 int allow_full_lds(const void *kernel);

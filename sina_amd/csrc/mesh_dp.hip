@@ -2400,13 +2400,18 @@ int launch_assemble(const BtArgs &a0, hipStream_t s) {
     return 0;
 }
 
-// launches of this many queries and more walk one lane per query (backtrack_lanes_kernel): below it the walk's
-// own latency matters more than the instruction slots it takes from its neighbours (SINA_HIP_TEST=bt_lanes=0/1 forces one)
-constexpr uint32_t kBtLanesMin = 2048;
-int launch_backtrack(const BtArgs &a, hipStream_t s) {
-    bool lanes = a.nq >= kBtLanesMin;
+// launches of this many queries and more, none longer than kBtLanesMaxLen, walk one lane per query
+// (backtrack_lanes_kernel).  The lanes' walk takes a microsecond per step whatever the launch: smaller launches are
+// done sooner by a wave per query, and a launch of 23S-long queries (6000 steps: 14 ms) is waited for by a pipeline
+// that holds two batches of them (77.9 k sequences/s with lanes, 82 k without).  SINA_HIP_TEST=bt_lanes=0/1 forces one.
+constexpr uint32_t kBtLanesMin = 2048, kBtLanesMaxLen = 2048;
+bool backtrack_by_lanes(const BtArgs &a) {
+    bool lanes = a.nq >= kBtLanesMin && a.asm_cap <= kBtLanesMaxLen;
     if (const std::string e = test_knob("bt_lanes"); !e.empty()) lanes = atoi(e.c_str()) != 0;
-    if (lanes) {
+    return lanes;
+}
+int launch_backtrack(const BtArgs &a, hipStream_t s) {
+    if (backtrack_by_lanes(a)) {
         if (a.lazy_sidx) hipLaunchKernelGGL(backtrack_lanes_kernel<true>, dim3((a.nq + 63u) / 64u), dim3(64), 0, s, a);
         else hipLaunchKernelGGL(backtrack_lanes_kernel<false>, dim3((a.nq + 63u) / 64u), dim3(64), 0, s, a);
     } else if (a.lazy_sidx) hipLaunchKernelGGL(backtrack_kernel<true>, dim3(a.nq), dim3(64), 0, s, a);
