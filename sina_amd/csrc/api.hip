@@ -335,10 +335,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
             SH_CHECK(hipEventRecord(c->st->dp_end[dp_no % 8], hl.stream()));
             c->st->dp_end_no[dp_no % 8].store(dp_no, std::memory_order_release);
         }
-        // (the wave-per-query walk follows its DP kernel on the FIFO stream; the lane-per-query walk -- a launch of its
-        // own latency, 3 ms and more, and next to no instructions -- would hold up the kernel two places behind on that
-        // stream: it goes to the context's stream once the host has seen the DP kernel end, beside whatever runs then)
-        if (hl.chained && bt_fifo_wanted && !backtrack_by_lanes(b)) {
+        if (hl.chained && bt_fifo_wanted) {
             if (launch_backtrack(b, hl.stream())) return 1;
             if (p->assemble && launch_assemble(b, hl.stream())) return 1;
             SH_CHECK(hipEventRecord(c->ev[2], hl.stream()));

@@ -2400,11 +2400,15 @@ int launch_assemble(const BtArgs &a0, hipStream_t s) {
     return 0;
 }
 
-// launches of this many queries and more, none longer than kBtLanesMaxLen, walk one lane per query
-// (backtrack_lanes_kernel).  The lanes' walk takes a microsecond per step whatever the launch: smaller launches are
-// done sooner by a wave per query, and a launch of 23S-long queries (6000 steps: 14 ms) is waited for by a pipeline
-// that holds two batches of them (77.9 k sequences/s with lanes, 82 k without).  SINA_HIP_TEST=bt_lanes=0/1 forces one.
-constexpr uint32_t kBtLanesMin = 2048, kBtLanesMaxLen = 2048;
+// Launches of kBtLanesMin queries and more, none longer than kBtLanesMaxLen, walk one lane per query
+// (backtrack_lanes_kernel).  The lanes' walk takes a microsecond per step whatever the launch (3.2 ms for 16S), the
+// waves' walk 0.33 us of the device's instruction issue per query: at 9216 queries the two are the same 3 ms, and
+// the lanes' are latency that the launches queued behind on the other FIFO stream cover (k-mer search 5.8 ms, DAG
+// build 4.5) where the waves' are instructions taken from them.  A smaller launch is done sooner by waves -- with
+// half the queries duplicates (4608 per launch, neighbours of 2-3 ms) lanes cost 6 %: 380 k against 406 k sequences/s,
+// on the FIFO stream or off it -- and a launch of 23S-long queries (6000 steps, 14 ms) is waited for by a pipeline
+// that holds two batches of them.  SINA_HIP_TEST=bt_lanes=0/1 forces one.
+constexpr uint32_t kBtLanesMin = 8192, kBtLanesMaxLen = 2048;
 bool backtrack_by_lanes(const BtArgs &a) {
     bool lanes = a.nq >= kBtLanesMin && a.asm_cap <= kBtLanesMaxLen;
     if (const std::string e = test_knob("bt_lanes"); !e.empty()) lanes = atoi(e.c_str()) != 0;

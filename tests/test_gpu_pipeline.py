@@ -237,7 +237,7 @@ def test_pipeline_option_fuzz(oracle, world, monkeypatch, seed):
     geom = pick([None, None, "64,8", "128,8", "128,12", "192,4", "256,4"])
     if geom:
         util.set_knobs(monkeypatch, geom=geom)
-    # (the cell walk: one wave per query, or one lane per query as launches of 2048 queries and more do it)
+    # (the cell walk: one wave per query, or one lane per query as launches of 8192 queries and more do it)
     util.set_knobs(monkeypatch, bt_lanes=seed % 2)
     overhang, lowercase, insertion = pick(["attach", "remove", "edge"]), pick(["none", "original", "unaligned"]), pick(["shift", "forbid"])
     ms, mms = float(pick([2, 3, 1.5])), float(pick([-1, -2, -0.5]))

@@ -266,7 +266,7 @@ def test_row_skip_partial_queries_equal_oracle(oracle, monkeypatch, frac, rho, l
     two strips, so the row skip is in play, and the alignment begins and ends somewhere inside the DAG: free starts
     (column 0 of any row), free ends (the last column of any row, any column of a sink), long stretches of rows on
     either side of the window that only the free-start rule keeps in play.  Trays against the oracle's -- walked back
-    by either kernel (lanes: one lane per query, what launches of 2048 queries and more use)."""
+    by either kernel (lanes: one lane per query, what launches of 8192 queries and more use)."""
     util.set_knobs(monkeypatch, bt_lanes=lanes)
     if rho is not None:
         util.set_knobs(monkeypatch, rho=rho)
