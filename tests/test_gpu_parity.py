@@ -1,4 +1,6 @@
 """GPU parity: HIP path (through the C ABI) vs the CPU oracle, bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -259,6 +261,37 @@ def test_device_family_graph_many_characters_per_column(oracle, gpu_ctx):
         far = o["pred"].size and (np.repeat(np.arange(o["n"]), npred) - o["pred"]).max()
         seen_wide = seen_wide or (o["n"] > 6 * ncol and npred.max() > 8 and far > 64)
     assert seen_wide
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SINA_FUZZ_SEEDS", "12"))))
+def test_device_family_graph_fuzz(oracle, gpu_ctx, seed):
+    """Seeded random reference sets (length, alignment width -- the occupied-column bitmap's size --, ambiguity codes,
+    lower case, long deletions, indel rates, clades) and families of 1 .. 128 members in random order: the DAG built on
+    the GPU against mseq in the oracle, everything compared."""
+    rng = np.random.default_rng(7000 + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]  # noqa: E731
+    length = int(pick([60, 150, 300, 700, 1300]))
+    width = int(length * pick([2, 5, 33, 60]))
+    refs = synth.make_refs(140, length=length, width=width, seed=7100 + seed, n_clades=int(pick([1, 3, 8])),
+                           clade_div=float(pick([0.02, 0.12, 0.3])), del_rate=float(pick([0.0, 0.01, 0.1])),
+                           ins_rate=float(pick([0.0, 0.005, 0.05])), long_del_prob=float(pick([0.0, 0.3, 0.9])),
+                           amb_rate=float(pick([0.0, 0.02, 0.5])), lower_rate=float(pick([0.0, 0.1, 0.6])))
+    cs = util.cseqs_from_refs(refs)
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    for F in (int(pick([1, 2, 3, 5])), int(pick([17, 40, 64])), int(pick([100, 127, 128]))):
+        ids = rng.choice(refs.n, size=F, replace=False).astype(np.uint32)
+        fsw, ring = float(pick([1.0, 0.0, 2.5])), int(pick([1, 3, 4, 8]))
+        g = gpu_ctx.debug_family_graph(ids, fsw, ring)
+        o = util.graph_dict([cs[i] for i in ids], fsw)
+        assert g["n"] == o["n"], (seed, F)
+        assert (g["pos"] == o["pos"]).all() and (g["mask"] == o["mask"]).all(), (seed, F)
+        assert (util.f32_bits(g["weight"]) == util.f32_bits(o["weight"])).all(), (seed, F)
+        assert (g["pred_off"] == o["pred_off"]).all() and (g["pred"] == o["pred"]).all(), (seed, F)
+        assert (g["succ_minpos"] == o["succ_minpos"]).all(), (seed, F)
+        sink = np.zeros(o["n"], np.uint8)
+        sink[o["snk"]] = 1
+        assert (g["sink"] == sink).all(), (seed, F)
+        assert (g["spill"] == util.row_store_model(o["pred_off"], o["pred"], ring)).all(), (seed, F)
 
 
 def test_align_families_equals_align_graphs(oracle, gpu_ctx, small):
