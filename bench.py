@@ -596,8 +596,10 @@ def main():
                     "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": b / (ms * 1e-3) / 1e9,
                     "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b / max(1, s1["graph_launches"] - s0["graph_launches"]),
                     "ms_per_launch": ms / max(1, s1["graph_launches"] - s0["graph_launches"]),
-                    "note": "latency-bound in barrier-separated phases (DESIGN 3.3): start-to-end time in the chained pipeline, "
-                            "where the build starts in the DP launch's drain; kernels_ms_per_step_isolated has it alone"})(
+                    "note": "bound by instruction issue (integer / LDS-atomic work in barrier-separated phases, four workgroups per "
+                            "CU: DESIGN 3.3, profiles/r05_graph_sq_counters.txt), not by bytes; this is its start-to-end time in "
+                            "the chained pipeline, where the build starts in the DP launch's drain -- "
+                            "kernels_ms_per_step_isolated has it alone"})(
                     s1["graph_bytes"] - s0["graph_bytes"], s1["graph_ms"] - s0["graph_ms"]),
                 "kmer_count_kernel": (lambda b, ms: None if ms <= 0 else {
                     "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": b / (ms * 1e-3) / 1e9,
@@ -608,7 +610,7 @@ def main():
                             "row); the kernel moves LESS than that -- dense lists are read as bitmaps (n/8 B per list instead "
                             "of 4 B per posting) and, with candidate lists (stores of 65 536 references and more), the score "
                             "row never leaves LDS -- so the fraction can exceed 1; measured HBM bytes per launch: "
-                            "profiles/r05_bench_summary.txt (23.6 GB per 9216 queries at 100 k references = 4.1 TB/s)"})(
+                            "profiles/r05_bench_summary.txt (26 GB per 9216 queries at 100 k references); what bounds it is the bitmap path streaming out of the MALL (profiles/r05_kmer_ablation.txt)"})(
                     4.0 * (s1["postings"] - s0["postings"]) + 4.0 * a.refs * (s1["kmer_queries"] - s0["kmer_queries"]),
                     s1["kmer_count_ms"] - s0["kmer_count_ms"]),
             },
