@@ -294,6 +294,26 @@ def test_device_family_graph_fuzz(oracle, gpu_ctx, seed):
         assert (g["spill"] == util.row_store_model(o["pred_off"], o["pred"], ring)).all(), (seed, F)
 
 
+def test_device_family_graph_at_the_widest_alignment(oracle, gpu_ctx):
+    """The device DAG build at the widest alignment it takes (524 288 columns: the occupied-column bitmap and its ranks
+    are 96 KB of the workgroup's LDS) with families of 40 and of 128 members (the entry table's 32 KB on top): the DAG
+    against the oracle's."""
+    refs = synth.make_refs(130, length=300, width=524288, seed=271, amb_rate=0.02, long_del_prob=0.3)
+    assert refs.width == 524288
+    cs = util.cseqs_from_refs(refs)
+    gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
+    rng = np.random.default_rng(24)
+    for F in (40, 128):
+        ids = rng.choice(refs.n, size=F, replace=False).astype(np.uint32)
+        g = gpu_ctx.debug_family_graph(ids, 1.0, 4)
+        o = util.graph_dict([cs[i] for i in ids], 1.0)
+        assert g["n"] == o["n"]
+        assert (g["pos"] == o["pos"]).all() and (g["mask"] == o["mask"]).all()
+        assert (util.f32_bits(g["weight"]) == util.f32_bits(o["weight"])).all()
+        assert (g["pred_off"] == o["pred_off"]).all() and (g["pred"] == o["pred"]).all()
+        assert o["pos"].max() > 500000
+
+
 def test_align_families_equals_align_graphs(oracle, gpu_ctx, small):
     refs, qs, cs, idx = small
     gpu_ctx.upload_refs(refs.ab, refs.off, refs.width)
