@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 #include "ctx.h"
@@ -297,47 +298,86 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
         // adders (ones / twos / fours) and one ripple of the resulting eights (7 operations per word,
         // no atomics, nothing but registers).
         if (nd) {
-            const uint32_t *bw = a.dense_bits + (size_t)(tile_lo >> 5) + tid;
-            uint32_t ones = 0, twos = 0, fours = 0, hi[7] = {0, 0, 0, 0, 0, 0, 0};  // hi[p]: weight 8 << p
-            auto csa = [](uint32_t &h, uint32_t &l, uint32_t x, uint32_t y, uint32_t z) {
-                const uint32_t u = x ^ y;
-                h = (x & y) | (u & z);
-                l = u ^ z;
-            };
-            for (uint32_t i = 0; i < nd; i += 8) {
-                uint32_t w[8];
+            // (the planes above the fours: as many as the query's number of dense k-mers has bits beyond three -- a
+            // hundred bitmaps need four of the seven; the ripple and the unpacking below are compiled for each count)
+            auto dense_path = [&](auto nhi_c) {
+                constexpr int NHI = decltype(nhi_c)::value;
+                const uint32_t *bw = a.dense_bits + (size_t)(tile_lo >> 5) + tid;
+                uint32_t ones = 0, twos = 0, fours = 0, hi[NHI > 0 ? NHI : 1] = {0};  // hi[p]: weight 8 << p
+                auto csa = [](uint32_t &h, uint32_t &l, uint32_t x, uint32_t y, uint32_t z) {
+                    const uint32_t u = x ^ y;
+                    h = (x & y) | (u & z);
+                    l = u ^ z;
+                };
+                for (uint32_t i = 0; i < nd; i += 8) {
+                    uint32_t w[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) w[u] = (i + u < nd) ? bw[(size_t)*(dtop - (i + u)) * a.dense_words] : 0u;
-                uint32_t twosA, twosB, foursA, foursB, eights;
-                csa(twosA, ones, ones, w[0], w[1]);
-                csa(twosB, ones, ones, w[2], w[3]);
-                csa(foursA, twos, twos, twosA, twosB);
-                csa(twosA, ones, ones, w[4], w[5]);
-                csa(twosB, ones, ones, w[6], w[7]);
-                csa(foursB, twos, twos, twosA, twosB);
-                csa(eights, fours, fours, foursA, foursB);
-                uint32_t carry = eights;
+                    for (int u = 0; u < 8; u++) w[u] = (i + u < nd) ? bw[(size_t)*(dtop - (i + u)) * a.dense_words] : 0u;
+                    uint32_t twosA, twosB, foursA, foursB, eights;
+                    csa(twosA, ones, ones, w[0], w[1]);
+                    csa(twosB, ones, ones, w[2], w[3]);
+                    csa(foursA, twos, twos, twosA, twosB);
+                    csa(twosA, ones, ones, w[4], w[5]);
+                    csa(twosB, ones, ones, w[6], w[7]);
+                    csa(foursB, twos, twos, twosA, twosB);
+                    csa(eights, fours, fours, foursA, foursB);
+                    uint32_t carry = eights;
 #pragma unroll
-                for (int p = 0; p < 7; p++) {
-                    const uint32_t t2 = hi[p] & carry;
-                    hi[p] ^= carry;
-                    carry = t2;
+                    for (int p = 0; p < NHI; p++) {
+                        const uint32_t t2 = hi[p] & carry;
+                        hi[p] ^= carry;
+                        carry = t2;
+                    }
                 }
-            }
-            // add my 32 counts to the tile's counters: words 16 t .. 16 t + 15 are mine alone now
-            // (word j of lane l in step (j - l) mod 16: the lanes of a wave spread over the LDS banks)
+                // add my 32 counts to the tile's counters: words 16 t .. 16 t + 15 are mine alone now
+                if constexpr (NHI <= 5) {
+                    // counts below 256: four references at a time -- their bits of a plane are a nibble, one
+                    // multiplication spreads the nibble's bits over the four bytes of a word (bit i to bit 8 i), the
+                    // planes are or-ed in at their weights; two byte shuffles make the counters' two 16-bit pairs.
+                    // (group g of lane l in step (g - l) mod 8, a 64-bit access each: the lanes of a wave spread over
+                    // the LDS banks)
+#pragma unroll 2
+                    for (int gg = 0; gg < 8; gg++) {
+                        const int g = (gg + lane) & 7;
+                        const int b = 4 * g;
+                        auto spread = [&](uint32_t plane) -> uint32_t { return (((plane >> b) & 0xFu) * 0x00204081u) & 0x01010101u; };
+                        uint32_t acc = spread(ones) | (spread(twos) << 1) | (spread(fours) << 2);
+#pragma unroll
+                        for (int p = 0; p < NHI; p++) acc |= spread(hi[p]) << (3 + p);
+                        uint2 *hw = reinterpret_cast<uint2 *>(&hist[16 * tid + 2 * g]);
+                        uint2 v = *hw;
+                        v.x += (acc & 0xFFu) | ((acc & 0xFF00u) << 8);
+                        v.y += ((acc >> 16) & 0xFFu) | ((acc >> 24) << 16);
+                        *hw = v;
+                    }
+                } else {
+                    // (word j of lane l in step (j - l) mod 16: the lanes of a wave spread over the LDS banks)
 #pragma unroll 4
-            for (int jj = 0; jj < 16; jj++) {
-                const int j = (jj + lane) & 15;
-                const int b0 = 2 * j, b1 = 2 * j + 1;
-                uint32_t cl = ((ones >> b0) & 1u) | (((twos >> b0) & 1u) << 1) | (((fours >> b0) & 1u) << 2);
-                uint32_t ch = ((ones >> b1) & 1u) | (((twos >> b1) & 1u) << 1) | (((fours >> b1) & 1u) << 2);
+                    for (int jj = 0; jj < 16; jj++) {
+                        const int j = (jj + lane) & 15;
+                        const int b0 = 2 * j, b1 = 2 * j + 1;
+                        uint32_t cl = ((ones >> b0) & 1u) | (((twos >> b0) & 1u) << 1) | (((fours >> b0) & 1u) << 2);
+                        uint32_t ch = ((ones >> b1) & 1u) | (((twos >> b1) & 1u) << 1) | (((fours >> b1) & 1u) << 2);
 #pragma unroll
-                for (int p = 0; p < 7; p++) {
-                    cl |= ((hi[p] >> b0) & 1u) << (3 + p);
-                    ch |= ((hi[p] >> b1) & 1u) << (3 + p);
+                        for (int p = 0; p < NHI; p++) {
+                            cl |= ((hi[p] >> b0) & 1u) << (3 + p);
+                            ch |= ((hi[p] >> b1) & 1u) << (3 + p);
+                        }
+                        hist[16 * tid + j] += cl | (ch << 16);
+                    }
                 }
-                hist[16 * tid + j] += cl | (ch << 16);
+            };
+            // (counts up to nd: 32 - clz(nd) bits, three of them in ones / twos / fours)
+            const int bits = 32 - __builtin_clz(nd);
+            switch (bits > 3 ? bits - 3 : 0) {
+            case 0: dense_path(std::integral_constant<int, 0>()); break;
+            case 1: dense_path(std::integral_constant<int, 1>()); break;
+            case 2: dense_path(std::integral_constant<int, 2>()); break;
+            case 3: dense_path(std::integral_constant<int, 3>()); break;
+            case 4: dense_path(std::integral_constant<int, 4>()); break;
+            case 5: dense_path(std::integral_constant<int, 5>()); break;
+            case 6: dense_path(std::integral_constant<int, 6>()); break;
+            default: dense_path(std::integral_constant<int, 7>()); break;
             }
             __syncthreads();
         }
@@ -348,18 +388,22 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
             for (uint32_t i = tid; i < words; i += kCountThreads) dst[i] = hist[i];
             __syncthreads();
         } else {
-            // my 32 references of the tile: words 16 tid .. 16 tid + 15 (word j of lane l in step (j - l) mod 16)
-            uint32_t w[16];
-#pragma unroll
-            for (int jj = 0; jj < 16; jj++) w[(jj + lane) & 15] = hist[16 * tid + ((jj + lane) & 15)];
+            // my 32 references of the tile: words 16 tid .. 16 tid + 15, taken as they are read (pair g of lane l in
+            // step (g - l) mod 8, a 64-bit access each: the lanes of a wave spread over the LDS banks) -- kept in an
+            // array they would be indexed by the lane: sixteen selects per word
             const uint32_t my_lo = tile_lo + 32u * tid;
             if (t == 0) {
                 // t0: the topm-th largest of the 1024 per-thread maxima (8-way search: seven ballots per pass)
                 int mx = -1;
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    if (my_lo + 2 * j < a.n_refs) mx = max(mx, (int)(w[j] & 0xffffu));
-                    if (my_lo + 2 * j + 1 < a.n_refs) mx = max(mx, (int)(w[j] >> 16));
+                for (int gg = 0; gg < 8; gg++) {
+                    const int g = (gg + lane) & 7;
+                    const uint2 wv = *reinterpret_cast<const uint2 *>(&hist[16 * tid + 2 * g]);
+                    const uint32_t id0 = my_lo + 4u * (uint32_t)g;
+                    if (id0 < a.n_refs) mx = max(mx, (int)(wv.x & 0xffffu));
+                    if (id0 + 1 < a.n_refs) mx = max(mx, (int)(wv.x >> 16));
+                    if (id0 + 2 < a.n_refs) mx = max(mx, (int)(wv.y & 0xffffu));
+                    if (id0 + 3 < a.n_refs) mx = max(mx, (int)(wv.y >> 16));
                 }
                 int lo = 0, hi = (int)min(len, (uint32_t)kMaxQueryLen) + 1;  // count(max >= lo) >= topm > count(max >= hi)
                 for (int guard = 0; guard < 8 && hi - lo > 1; ++guard) {
@@ -394,15 +438,19 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
             }
             const int t0 = c_t0;
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
+            for (int gg = 0; gg < 8; gg++) {
+                const int g = (gg + lane) & 7;
+                const uint2 wv = *reinterpret_cast<const uint2 *>(&hist[16 * tid + 2 * g]);
+                // (nearly always none of the four reaches t0: one comparison of the largest decides)
+                const int v4[4] = {(int)(wv.x & 0xffffu), (int)(wv.x >> 16), (int)(wv.y & 0xffffu), (int)(wv.y >> 16)};
+                if (max(max(v4[0], v4[1]), max(v4[2], v4[3])) < t0) continue;
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const uint32_t id = my_lo + 2 * j + h;
-                    const int v = (int)((w[j] >> (16 * h)) & 0xffffu);
-                    if (id < a.n_refs && v >= t0) {
+                for (int h = 0; h < 4; h++) {
+                    const uint32_t id = my_lo + 4u * (uint32_t)g + (uint32_t)h;
+                    if (id < a.n_refs && v4[h] >= t0) {
                         const uint32_t slot = atomicAdd(&c_ncand, 1u);
                         if (slot < a.cand_cap)
-                            a.cand[(size_t)q * a.cand_cap + slot] = ((unsigned long long)(uint32_t)(v + 32768) << 32) | id;
+                            a.cand[(size_t)q * a.cand_cap + slot] = ((unsigned long long)(uint32_t)(v4[h] + 32768) << 32) | id;
                     }
                 }
             }
