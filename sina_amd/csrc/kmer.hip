@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
     for (uint32_t t = 0; t < ntiles; t++) {
         const uint32_t tile_lo = t * kTileRefs;
         const uint32_t tile_hi = min(tile_lo + (uint32_t)kTileRefs, a.n_refs);
-        for (uint32_t i = tid; i < kTileRefs / 2; i += kCountThreads) hist[i] = 0;
+        for (uint32_t i = tid; i < kTileRefs / 8; i += kCountThreads) reinterpret_cast<uint4 *>(hist)[i] = uint4{0u, 0u, 0u, 0u};
         if (tid == 0) next_kmer = 0;
         __syncthreads();
         for (uint32_t guard = 0; guard < (1u << 22); guard++) {
@@ -405,7 +405,8 @@ __global__ void __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per
                     if (id0 + 2 < a.n_refs) mx = max(mx, (int)(wv.y & 0xffffu));
                     if (id0 + 3 < a.n_refs) mx = max(mx, (int)(wv.y >> 16));
                 }
-                int lo = 0, hi = (int)min(len, (uint32_t)kMaxQueryLen) + 1;  // count(max >= lo) >= topm > count(max >= hi)
+                // (no score exceeds the number of the query's k-mers with a posting: every one adds at most 1 to a reference)
+                int lo = 0, hi = (int)(nk + nd) + 1;  // count(max >= lo) >= topm > count(max >= hi)
                 for (int guard = 0; guard < 8 && hi - lo > 1; ++guard) {
                     if (tid < 8) c_cnt[tid] = 0;
                     __syncthreads();
