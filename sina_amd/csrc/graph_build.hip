@@ -195,6 +195,80 @@ __device__ uint32_t block_exscan_f(uint32_t n, Get get, Out *out, uint32_t *tmp)
     return total;
 }
 
+// Step 2 of a tile as a function of its own: the kernel runs with 78 scalar registers at eight waves per SIMD and
+// over a hundred live scalars -- inlined, this loop reloaded a dozen spilled ones per task; outlined, the caller's
+// scalars are put aside once per tile.
+__device__ __attribute__((noinline)) void fill_tile(const uint32_t *__restrict__ ref_ab, uint32_t bitmap_off, uint32_t member_off,
+                                                    uint32_t nwords, uint32_t n_tasks, uint32_t c0, uint32_t tc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *cposT = reinterpret_cast<uint32_t *>(smem + kOCpos);
+    uint32_t *presT = reinterpret_cast<uint32_t *>(smem + kOPres);
+    uint16_t *eE = reinterpret_cast<uint16_t *>(smem + kOE);
+    const uint32_t *bitmap = reinterpret_cast<const uint32_t *>(smem + bitmap_off);
+    const uint16_t *wrank = reinterpret_cast<const uint16_t *>(bitmap + nwords);
+    Member *mb = reinterpret_cast<Member *>(smem + member_off);
+    constexpr uint32_t kEAbsent = 0x00FFu, kEFirst = 1u << 13;
+    constexpr uint32_t kCH = kTC / 64, kNW = kGT / 64;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    auto rank = [&](uint32_t pos) -> uint32_t {
+        return (uint32_t)wrank[pos >> 5] + __popc(bitmap[pos >> 5] & ((1u << (pos & 31)) - 1u));
+    };
+        // (latency-bound: eight tasks' loads are in flight per wave before the first is used)
+        for (uint32_t t4 = wave; t4 < n_tasks; t4 += 8 * kNW) {
+            uint32_t abv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t task = t4 + (uint32_t)u * kNW;
+                abv[u] = 0xFFFFFFFFu;  // (no packed base looks like this: the mask byte has five bits)
+                if (task < n_tasks) {
+                    // (the member is the same for the whole wave: its cursor, length and offset on the scalar unit)
+                    const uint32_t j = task / kCH;
+                    const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[j].cur);
+                    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[j].len);
+                    const uint64_t beg = mb[j].beg;
+                    const uint64_t begs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(beg >> 32)) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)beg);
+                    const uint32_t i = cur + (task % kCH) * 64u + lane;
+                    if (i < len) abv[u] = ref_ab[begs + i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t task = t4 + (uint32_t)u * kNW;
+                if (task >= n_tasks) continue;
+                const uint32_t j = task / kCH, slot0 = (task % kCH) * 64u, slot = slot0 + lane;
+                const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[j].cur);
+                uint32_t ev = kEAbsent;
+                if (abv[u] != 0xFFFFFFFFu) {
+                    const uint32_t ab = abv[u];
+                    const uint32_t pos = ab & 0xFFFFFFu;
+                    const uint32_t c = rank(pos) - c0;
+                    if (c < tc) {
+                        const uint32_t m = (ab >> 24) & 0x1Fu;
+                        ev = c | (m << 8) | (cur + slot == 0 ? kEFirst : 0u);
+                        atomicOr(&presT[c], 1u << m);
+                        cposT[c] = pos;
+                    }
+                }
+                eE[j * (uint32_t)kTC + slot] = (uint16_t)ev;
+                // the member's last base in this tile moves its cursor (its bases in the tile are the first lanes of
+                // its tasks)
+                const uint32_t n_in = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ev != kEAbsent));
+                if (n_in && lane == 0) atomicMax(&mb[j].curn, cur + slot0 + n_in);
+            }
+        }
+}
+
+__device__ __forceinline__ uint32_t node_of_entry(uint32_t ev) {  // tile-local node of an entry: the column's first node + the place of its character
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t *nbaseT = reinterpret_cast<const uint32_t *>(smem + kONbase);
+    const uint32_t *presT = reinterpret_cast<const uint32_t *>(smem + kOPres);
+    const uint8_t *liOf = smem + kOLi;
+    const uint32_t c = ev & 0xFFu, m = (ev >> 8) & 31u;
+    const uint32_t b = nbaseT[c];
+    return b + liOf[b + __popc(presT[c] & ((1u << m) - 1u))];
+}
 __global__ void __launch_bounds__(kGT) __attribute__((amdgpu_waves_per_eu(SINA_GRAPH_MINWAVES, SINA_GRAPH_MINWAVES))) family_graph_kernel(GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t s_tmp[kGT / 64 + 8];
@@ -224,7 +298,7 @@ __global__ void __launch_bounds__(kGT) __attribute__((amdgpu_waves_per_eu(SINA_G
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(smem + a.bitmap_off);   // [nwords]
     uint16_t *wrank = reinterpret_cast<uint16_t *>(bitmap + nwords);        // [nwords]
     Member *mb = reinterpret_cast<Member *>(smem + a.member_off);           // [member_cap >= 16: .id doubles as the slot allocator's per-segment counters]
-    constexpr uint32_t kEAbsent = 0x00FFu, kEFirst = 1u << 13;
+    constexpr uint32_t kEFirst = 1u << 13;
     constexpr uint32_t kCH = kTC / 64, kNW = kGT / 64;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
@@ -322,50 +396,7 @@ __global__ void __launch_bounds__(kGT) __attribute__((amdgpu_waves_per_eu(SINA_G
         GP(2)
         // 2. the entries of this tile: member j's bases cur[j].. as long as their column is in the tile (a
         // contiguous stretch of at most kTC bases)
-        // (latency-bound: eight tasks' loads are in flight per wave before the first is used)
-        for (uint32_t t4 = wave; t4 < n_tasks; t4 += 8 * kNW) {
-            uint32_t abv[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t task = t4 + (uint32_t)u * kNW;
-                abv[u] = 0xFFFFFFFFu;  // (no packed base looks like this: the mask byte has five bits)
-                if (task < n_tasks) {
-                    // (the member is the same for the whole wave: its cursor, length and offset on the scalar unit)
-                    const uint32_t j = task / kCH;
-                    const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[j].cur);
-                    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[j].len);
-                    const uint64_t beg = mb[j].beg;
-                    const uint64_t begs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(beg >> 32)) << 32) |
-                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)beg);
-                    const uint32_t i = cur + (task % kCH) * 64u + lane;
-                    if (i < len) abv[u] = a.ref_ab[begs + i];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t task = t4 + (uint32_t)u * kNW;
-                if (task >= n_tasks) continue;
-                const uint32_t j = task / kCH, slot0 = (task % kCH) * 64u, slot = slot0 + lane;
-                const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[j].cur);
-                uint32_t ev = kEAbsent;
-                if (abv[u] != 0xFFFFFFFFu) {
-                    const uint32_t ab = abv[u];
-                    const uint32_t pos = ab & 0xFFFFFFu;
-                    const uint32_t c = rank(pos) - c0;
-                    if (c < tc) {
-                        const uint32_t m = (ab >> 24) & 0x1Fu;
-                        ev = c | (m << 8) | (cur + slot == 0 ? kEFirst : 0u);
-                        atomicOr(&presT[c], 1u << m);
-                        cposT[c] = pos;
-                    }
-                }
-                eE[j * (uint32_t)kTC + slot] = (uint16_t)ev;
-                // the member's last base in this tile moves its cursor (its bases in the tile are the first lanes of
-                // its tasks)
-                const uint32_t n_in = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ev != kEAbsent));
-                if (n_in && lane == 0) atomicMax(&mb[j].curn, cur + slot0 + n_in);
-            }
-        }
+        fill_tile(a.ref_ab, a.bitmap_off, a.member_off, nwords, n_tasks, c0, tc);
         __syncthreads();
         for (uint32_t c = tid; c < tc; c += kGT) nn[c] = (uint8_t)__popc(presT[c]);
         __syncthreads();
@@ -430,11 +461,7 @@ __global__ void __launch_bounds__(kGT) __attribute__((amdgpu_waves_per_eu(SINA_G
             // 4. members and raw edges per node; the predecessor of every entry.  An entry's node: the column's first
             // node + the place of its character (liOf is complete for this window and the ones before: the entry to
             // the left is in one of them)
-            auto node_of = [&](uint32_t ev) -> uint32_t {
-                const uint32_t c = ev & 0xFFu, m = (ev >> 8) & 31u;
-                const uint32_t b = nbaseT[c];
-                return b + liOf[b + __popc(presT[c] & ((1u << m) - 1u))];
-            };
+            auto node_of = [&](uint32_t ev) -> uint32_t { return node_of_entry(ev); };
             unsigned long long farbits = 0;  // my entries (by round of the task loop) whose predecessor is more than 64 ids back
             {
                 uint32_t it = 0;
