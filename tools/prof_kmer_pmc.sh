@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/prof_graph_pmc.sh <tag> [nq]  -- SQ counter passes over the k-mer count kernel alone (tools/perf_kmer.py, 100 000 references);
+# usage: tools/prof_kmer_pmc.sh <tag> [nq]  -- SQ counter passes over the k-mer count kernel alone (tools/perf_kmer.py, 100 000 references);
 # counters only, one small group per pass (never combined with trace domains other than kernel-trace).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
