@@ -7,6 +7,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <charconv>
 #include <chrono>
 #include <cstring>
 
@@ -35,8 +36,11 @@ struct result {
         width = 0;
         ab = nullptr;
         n_ab = 0;
+        own.clear();
         log.clear();
         family.clear();
+        family_items.clear();
+        family_render = nullptr;
         idty = -1.f;
         searched = false;
         sr_ids.clear();
@@ -46,9 +50,20 @@ struct result {
     int status = 2;  // 0 aligned by DP, 1 alignment copied from a reference, 2 not aligned
     int head = 0, tail = 0, qual = 0;
     uint32_t width = 0;
-    const aligned_base *ab = nullptr;  // the aligned bases, in the pipeline's base arena
+    const aligned_base *ab = nullptr;  // the aligned bases: own.data()
     uint32_t n_ab = 0;
-    std::string log, family;
+    // The aligned bases, TAKEN from the tray's aligned sequence (the two exchange their base lists: the sequence
+    // goes back to its cache with this record's previous block, so neither allocates in steady state).  Until
+    // round 5 the sink copied them into an arena of the pipeline's -- the fifth time a query's 6 KB went through
+    // a core; what a real sink does with them (format, write) it does from the sequence itself.
+    std::vector<aligned_base> own;
+    std::string log;
+    // align_family_slv: as text, or as the list famfinder left (rendered by sina_host_result_family; the store is
+    // kept alive by the pipeline's stages)
+    mutable std::string family;
+    std::vector<uint64_t> family_items;
+    const void *family_owner = nullptr;
+    void (*family_render)(const void *, const uint64_t *, size_t, std::string &) = nullptr;
     float idty = -1.f;              // align_ident_slv (--calc-idty), -1 if not computed
     bool searched = false;          // search stage ran and produced a result vector
     std::vector<uint32_t> sr_ids;   // search results, best first
@@ -75,49 +90,6 @@ struct result {
     } attrs;
 };
 
-// Where the aligned bases of a run's results live: one block for the whole run (a query's result has
-// at most as many bases as the query), kept between runs, on transparent huge pages -- 6 KB of fresh
-// heap per query were two page faults per query, a third of a core in kernel mode.
-struct base_arena {
-    aligned_base *p = nullptr;
-    size_t cap = 0;
-    aligned_base *reserve(size_t n) {
-        if (n <= cap) return p;
-        release();
-        const size_t huge = (size_t)2 << 20;
-        const size_t bytes = ((n * sizeof(aligned_base) + huge - 1) / huge) * huge;
-        void *m = nullptr;
-        if (posix_memalign(&m, huge, bytes) != 0) throw std::bad_alloc();
-        (void)madvise(m, bytes, MADV_HUGEPAGE);
-        p = static_cast<aligned_base *>(m);
-        cap = bytes / sizeof(aligned_base);
-        return p;
-    }
-    void release() {
-        free(p);
-        p = nullptr;
-        cap = 0;
-    }
-    ~base_arena() { release(); }
-    base_arena() = default;
-    base_arena(const base_arena &) = delete;
-    base_arena &operator=(const base_arena &) = delete;
-    base_arena(base_arena &&o) noexcept : p(o.p), cap(o.cap) {
-        o.p = nullptr;
-        o.cap = 0;
-    }
-    base_arena &operator=(base_arena &&o) noexcept {
-        if (this != &o) {
-            release();
-            p = o.p;
-            cap = o.cap;
-            o.p = nullptr;
-            o.cap = 0;
-        }
-        return *this;
-    }
-};
-
 struct pipeline {
     famfinder ff;
     aligner al;
@@ -125,11 +97,10 @@ struct pipeline {
     std::shared_ptr<reference_store> search_store;
     double sf_s = 0;
     // The results of a run, batch by batch: chunk b holds the results of queries [b * chunk_q, (b + 1) * chunk_q)
-    // and the arena their aligned bases live in.  A chunk is sized and reset by the sink when its batch arrives
+    // (each with its aligned bases).  A chunk is sized and reset by the sink when its batch arrives
     // (and kept between runs) -- sizing everything before the first batch was 17 ms of every run's start.
     struct result_chunk {
         std::vector<result> results;
-        base_arena bases;
         uint64_t run = 0;  // the run (pipeline::run_no) whose sink filled it: an older one's results are not this run's
     };
     uint64_t run_no = 0;
@@ -155,38 +126,49 @@ struct pipeline {
     }
 };
 // The sink's work for one tray (what SINA's writer stage does per sequence): log, family, attributes and the
-// aligned bases go into the result record -- the bases into `dst`, room for as many as the query has (a DP
-// alignment has exactly the query's bases, a copied one its reference's: never more than the query, which the
-// copy short-cut requires to be contained in it) -- and the tray gives its objects back.
-void extract_tray(pipeline *p, tray &t, result &r, aligned_base *dst, uint32_t query_bases) {
+// aligned bases go into the result record (a DP alignment has exactly the query's bases, a copied one its
+// reference's: never more than the query, which the copy short-cut requires to be contained in it) -- and the
+// tray gives its objects back.
+void extract_tray(pipeline *p, tray &t, result &r, uint32_t query_bases) {
     r.reset();
     uint64_t tk = host_tsc();
     r.log.assign(t.log.view());  // (no temporary: the result's string keeps its block between runs)
-    if (const std::string *fam = t.input_sequence->string_attr(fn::family)) r.family.assign(*fam);
+    if (const cseq::lazy_text *lz = t.input_sequence->lazy_attr(fn::family)) {  // (the list; the text when it is asked for)
+        r.family_items.assign(lz->items.begin(), lz->items.end());
+        r.family_owner = lz->owner;
+        r.family_render = lz->render;
+    } else if (const std::string *fam = t.input_sequence->string_attr(fn::family)) r.family.assign(*fam);
     else r.family = t.input_sequence->get_attr<std::string>(fn::family);
     if (const std::string *turn = t.input_sequence->string_attr(fn::turn)) r.attrs[fn::turn].assign(*turn);
     else if (t.input_sequence->has_attr(fn::turn)) r.attrs[fn::turn] = t.input_sequence->get_attr<std::string>(fn::turn);
     tk = host_tick("extract: log + family + turn", tk);
     if (t.aligned_sequence) {
         cseq &c = *t.aligned_sequence;
-        r.qual = c.get_attr<int>(fn::qual);
-        r.head = c.get_attr<int>(fn::head);
-        r.tail = c.get_attr<int>(fn::tail);
         r.width = c.getWidth();
         r.status = (r.log.find("copied alignment from") != std::string::npos) ? 1 : 0;
-        for (const auto &kv : c.get_attrs()) {
-            const std::string &k = kv.key();
-            if (k == search_filter::fn_nearest || k.compare(0, 4, "lca_") == 0 || k.compare(0, 5, "copy_") == 0)
-                r.attrs[k] = c.get_attr<std::string>(k);
+        // one walk over the attributes, the stages' own keys told by their interned addresses
+        struct keys_t {
+            const std::string *qual = cseq::attr_key(fn::qual), *head = cseq::attr_key(fn::head), *tail = cseq::attr_key(fn::tail),
+                              *idty = cseq::attr_key(fn::idty), *nearest = cseq::attr_key(search_filter::fn_nearest);
+        };
+        static const keys_t keys;
+        r.idty = -1.f;
+        for (const auto &kv : c.attrs_unsettled()) {
+            const int *iv = std::get_if<int>(&kv.second);
+            if (kv.name == keys.qual) r.qual = iv ? *iv : c.get_attr<int>(fn::qual);
+            else if (kv.name == keys.head) r.head = iv ? *iv : c.get_attr<int>(fn::head);
+            else if (kv.name == keys.tail) r.tail = iv ? *iv : c.get_attr<int>(fn::tail);
+            else if (kv.name == keys.idty) r.idty = c.get_attr<float>(fn::idty);
+            else {
+                const std::string &k = kv.key();
+                if (kv.name == keys.nearest || k.compare(0, 4, "lca_") == 0 || k.compare(0, 5, "copy_") == 0)
+                    r.attrs[k] = c.get_attr<std::string>(k);
+            }
         }
-        r.idty = c.has_attr(fn::idty) ? c.get_attr<float>(fn::idty) : -1.f;
-        // (copied: the sequence keeps its heap block for its next life)
-        if (c.size() > query_bases)
-            throw std::logic_error("result of " + t.input_sequence->getName() + " has " + std::to_string(c.size()) +
-                                   " bases, its query " + std::to_string(query_bases));
-        r.n_ab = (uint32_t)c.size();
-        r.ab = dst;
-        memcpy((void *)dst, c.packed(), sizeof(aligned_base) * (size_t)r.n_ab);
+        (void)query_bases;
+        r.own.swap(c.mutableAlignedBases());
+        r.n_ab = (uint32_t)r.own.size();
+        r.ab = r.own.data();
     }
     if (t.search_result) {
         r.searched = true;
@@ -208,16 +190,17 @@ void fill_query_tray(tray &t, uint32_t q, const uint8_t *qmask, const uint64_t *
     // text, and the previous occupant's would lead this one's)
     t.log.str(std::string());
     t.log.clear();
-    const std::string name = "query" + std::to_string(q);
-    t.input_sequence = object_cache<cseq>::take();
-    t.input_sequence->setName(name);
+    t.input_sequence = object_cache<cseq, cache_query_seq>::take();
+    {
+        char name[24] = "query";
+        char *e = std::to_chars(name + 5, name + sizeof name, q).ptr;
+        t.input_sequence->setName(std::string_view(name, (size_t)(e - name)));
+    }
     tk = host_tick("build: log reset + new cseq", tk);
-    // (written in one piece, not by per-base appends)
-    std::vector<aligned_base> &ab = t.input_sequence->mutableAlignedBases();
+    // (base i in column i: the sequence keeps the mask bytes, cseq.h "dense" -- the packed words are made if a
+    // stage asks for them)
     const uint32_t n_bases = (uint32_t)(qoff[q + 1] - qoff[q]);
-    ab.resize(n_bases);
-    packed_of_masks(reinterpret_cast<uint32_t *>(ab.data()), qmask + qoff[q], n_bases);
-    t.input_sequence->setWidth(n_bases);
+    t.input_sequence->setDenseMasks(qmask + qoff[q], n_bases);
     host_tick("build: bases", tk);
 }
 }  // namespace
@@ -765,12 +748,10 @@ int sina_host_pipeline_run(void *pp, const uint8_t *qmask, const uint64_t *qoff,
             std::vector<tray> &trays = it.trays;
             pipeline::result_chunk &chunk = p->chunks[b0 / batch];
             chunk.results.resize(it.b1 - it.b0);
-            aligned_base *const base_block = chunk.bases.reserve((size_t)(qoff[it.b1] - qoff[b0]));
-            const uint64_t base0 = qoff[b0];
             chunk.run = p->run_no;
             parallel_for(it.b1 - it.b0, [&](size_t i) {  // (what SINA's writer stage does per sequence)
                 const uint32_t q = b0 + (uint32_t)i;
-                extract_tray(p, trays[i], chunk.results[i], base_block + (qoff[q] - base0), (uint32_t)(qoff[q + 1] - qoff[q]));
+                extract_tray(p, trays[i], chunk.results[i], (uint32_t)(qoff[q + 1] - qoff[q]));
             });
         };
         auto take = [&](item &it) -> bool {
@@ -948,7 +929,6 @@ int sina_host_pipeline_run_single_trays(void *pp, const uint8_t *qmask, const ui
         pipeline::result_chunk &chunk = p->chunks[0];
         chunk.results.resize(nq);
         chunk.run = p->run_no;
-        aligned_base *const base_block = chunk.bases.reserve((size_t)(nq ? qoff[nq] - qoff[0] : 1));
         if (failed) memset(failed, 0, nq);
         if (err && err_cap) err[0] = 0;
         batched<famfinder> bff(p->ff, max_batch, linger_us);
@@ -991,7 +971,7 @@ int sina_host_pipeline_run_single_trays(void *pp, const uint8_t *qmask, const ui
                             keep.destroy();
                             continue;
                         }
-                        extract_tray(p, t, chunk.results[q], base_block + (qoff[q] - qoff[0]), (uint32_t)(qoff[q + 1] - qoff[q]));
+                        extract_tray(p, t, chunk.results[q], (uint32_t)(qoff[q + 1] - qoff[q]));
                     } catch (...) {
                         std::lock_guard<std::mutex> lk(err_mu);
                         if (!fatal) fatal = std::current_exception();
@@ -1037,7 +1017,11 @@ const uint32_t *sina_host_result_bases(void *pp, uint32_t q) {
     return reinterpret_cast<const uint32_t *>(result_at(pp, q).ab);
 }
 const char *sina_host_result_log(void *pp, uint32_t q) { return result_at(pp, q).log.c_str(); }
-const char *sina_host_result_family(void *pp, uint32_t q) { return result_at(pp, q).family.c_str(); }
+const char *sina_host_result_family(void *pp, uint32_t q) {
+    const result &r = result_at(pp, q);
+    if (r.family_render && r.family.empty()) r.family_render(r.family_owner, r.family_items.data(), r.family_items.size(), r.family);
+    return r.family.c_str();
+}
 // search stage: number of results (-1: stage did not run for this query), ids/scores best first,
 // string attributes it set on the sequence (nearest_slv, lca_<field>, copy_<acc>_<field>; "" if absent)
 int sina_host_result_search(void *pp, uint32_t q, uint32_t *ids, float *scores, uint32_t cap) {

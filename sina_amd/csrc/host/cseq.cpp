@@ -80,11 +80,13 @@ cseq_base::cseq_base(const char *_name, const char *_data) : name(_name) {
 }
 
 void cseq_base::clearSequence() {
+    drop_masks();
     bases.clear();
     alignment_width = 0;
 }
 
 cseq_base &cseq_base::append(const char *str) {
+    touch();
     // (an aligned line is 97 % gap characters: runs of them are skipped with strspn, which the C
     // library vectorises, instead of a branch per character)
     for (;;) {
@@ -104,6 +106,7 @@ cseq_base &cseq_base::append(const char *str) {
 // Container rule: a base may share the column of its predecessor
 // (insertions are resolved later) but never precede it.
 cseq_base &cseq_base::append(const aligned_base &ab) {
+    touch();
     if (ab.getPosition() >= alignment_width) {
         bases.push_back(ab);
         alignment_width = ab.getPosition();
@@ -114,10 +117,13 @@ cseq_base &cseq_base::append(const aligned_base &ab) {
 }
 
 void cseq_base::setWidth(vidx_type newWidth) {
-    if (bases.empty() || newWidth >= bases.back().getPosition() + 1) {
+    // (a dense sequence's last base sits in column size() - 1; a width that leaves every base where it is
+    // leaves the mask bytes valid too)
+    if (size() == 0 || newWidth >= (unpacked ? (vidx_type)dmask.size() : bases.back().getPosition() + 1)) {
         alignment_width = newWidth;
         return;
     }
+    touch();
     if (newWidth < size()) throw std::runtime_error("Attempted to shrink alignment width below base count");
     // pack the right-most bases against the new right edge
     const unsigned int n = size();
@@ -128,17 +134,21 @@ void cseq_base::setWidth(vidx_type newWidth) {
 }
 
 void cseq_base::reverse() {
+    touch();
     std::reverse(bases.begin(), bases.end());
     for (auto &b : bases) b.setPosition(alignment_width - 1 - b.getPosition());
 }
 void cseq_base::complement() {
+    touch();
     for (auto &b : bases) b.complement();
 }
 void cseq_base::upperCaseAll() {
+    touch();
     for (auto &b : bases) b.setUpperCase();
 }
 
 std::string cseq_base::getAligned(bool nodots, bool dna) const {
+    unpack();
     std::string out;
     out.reserve(alignment_width);
     char gap = nodots ? '-' : '.';  // leading and trailing gaps are dots unless nodots
@@ -156,12 +166,18 @@ std::string cseq_base::getAligned(bool nodots, bool dna) const {
 
 std::string cseq_base::getBases() const {
     std::string s;
+    if (!dmask.empty()) {  // (dense: the letters of the mask bytes)
+        s.reserve(dmask.size());
+        for (const uint8_t m : dmask) s.push_back((char)base_iupac::from_mask(m).iupac_rna());
+        return s;
+    }
     s.reserve(bases.size());
     for (const auto &b : bases) s.push_back((char)b.getBase().iupac_rna());
     return s;
 }
 
 char cseq_base::operator[](vidx_type i) const {
+    unpack();
     auto it = std::lower_bound(bases.begin(), bases.end(), aligned_base(i, '.'));
     if (it != bases.end() && it->getPosition() == i) return (char)it->getBase().iupac_rna();
     return '-';
@@ -196,7 +212,10 @@ const std::string *intern_attr_name(std::string_view key) {
 }
 }  // namespace
 
+const std::string *annotated_cseq::interned(std::string_view key) { return intern_attr_name(key); }
+
 annotated_cseq::variant &annotated_cseq::slot(std::string_view key) {
+    if (lazy.name && *lazy.name == key) lazy.name = nullptr;  // (about to be overwritten: the pending text is moot)
     size_t at = 0;
     for (; at < attributes.size(); at++) {
         const int c = attributes[at].name->compare(key);
@@ -216,6 +235,7 @@ annotated_cseq::variant &annotated_cseq::slot(std::string_view key) {
 // range is too small, the run swallows neighbouring bases, always towards the
 // nearer free column, until it fits.
 void cseq_base::fix_duplicate_positions(std::ostream &log, bool lowercase, bool remove) {
+    touch();
     if (remove) log << "insertion=remove not implemented, using shift; ";
     const long n = (long)bases.size();
     auto col = [&](long i) { return bases[(size_t)i].getPosition(); };

@@ -117,13 +117,30 @@ public:
     cseq_base &append(const std::string &str) { return append(str.c_str()); }
     cseq_base &append(const aligned_base &ab);
 
-    vidx_type size() const { return (vidx_type)bases.size(); }
-    const std::vector<aligned_base> &getAlignedBases() const { return bases; }
-    void setAlignedBases(const std::vector<aligned_base> &vab) { bases = vab; }
-    void setAlignedBases(std::vector<aligned_base> &&vab) { bases = std::move(vab); }
-    std::vector<aligned_base> takeAlignedBases() { return std::move(bases); }  // leaves the sequence empty
+    // ---- an UNALIGNED sequence kept as its iupac masks alone ("dense": base i sits in column i, the width is the
+    // number of bases -- what a reader hands the pipeline before anything has aligned it).  One byte per base, the
+    // byte the device takes, instead of a packed word: building the words (6 KB per 16S query), and famfinder and
+    // the aligner each reading them back to get the bytes again, were three of the five times a query's 6 KB went
+    // through a core.  The packed words are made when somebody asks for them (getAlignedBases, packed, iterators: a
+    // const call that writes -- a sequence is touched by one thread at a time on its way through the stages, the
+    // store's references are never dense); anything that changes the sequence makes them first and drops the bytes.
+    void setDenseMasks(const uint8_t *masks, size_t n) {
+        bases.clear();
+        dmask.reserve((n + 1023) & ~(size_t)1023);  // (in steps of 1 KB: a recycled sequence's block fits its next occupant)
+        dmask.assign(masks, masks + n);
+        unpacked = true;
+        alignment_width = (vidx_type)n;
+    }
+    // the mask bytes if the sequence still is what setDenseMasks made it, else nullptr
+    const uint8_t *denseMasks() const { return dmask.empty() ? nullptr : dmask.data(); }
+
+    vidx_type size() const { return (vidx_type)(unpacked ? dmask.size() : bases.size()); }
+    const std::vector<aligned_base> &getAlignedBases() const { unpack(); return bases; }
+    void setAlignedBases(const std::vector<aligned_base> &vab) { drop_masks(); bases = vab; }
+    void setAlignedBases(std::vector<aligned_base> &&vab) { drop_masks(); bases = std::move(vab); }
+    std::vector<aligned_base> takeAlignedBases() { touch(); return std::move(bases); }  // leaves the sequence empty
     // the base list itself, for writing it in place (a recycled sequence keeps its heap block: resize, fill)
-    std::vector<aligned_base> &mutableAlignedBases() { return bases; }
+    std::vector<aligned_base> &mutableAlignedBases() { touch(); return bases; }
     vidx_type getWidth() const { return alignment_width; }
     void setWidth(vidx_type newWidth);
     void fix_duplicate_positions(std::ostream &log, bool lowercase, bool remove);
@@ -134,27 +151,45 @@ public:
     std::string getAligned(bool nodots = false, bool dna = false) const;
     std::string getBases() const;
     std::string getName() const { return name; }
+    const std::string &name_ref() const { return name; }
     void setName(std::string n) { name = std::move(n); }
+    void setName(std::string_view n) { name.assign(n); }
 
-    iterator begin() { return bases.begin(); }
-    const_iterator begin() const { return bases.begin(); }
-    iterator end() { return bases.end(); }
-    const_iterator end() const { return bases.end(); }
-    const_reverse_iterator rbegin() const { return bases.rbegin(); }
-    const_reverse_iterator rend() const { return bases.rend(); }
-    const aligned_base &getById(idx_type i) const { return bases[i]; }
+    iterator begin() { touch(); return bases.begin(); }
+    const_iterator begin() const { unpack(); return bases.begin(); }
+    iterator end() { touch(); return bases.end(); }
+    const_iterator end() const { unpack(); return bases.end(); }
+    const_reverse_iterator rbegin() const { unpack(); return bases.rbegin(); }
+    const_reverse_iterator rend() const { unpack(); return bases.rend(); }
+    const aligned_base &getById(idx_type i) const { unpack(); return bases[i]; }
     char operator[](vidx_type i) const;
 
-    bool operator==(const cseq_base &rhs) const { return name == rhs.name && bases == rhs.bases; }
+    bool operator==(const cseq_base &rhs) const { return name == rhs.name && getAlignedBases() == rhs.getAlignedBases(); }
     bool operator!=(const cseq_base &rhs) const { return !(*this == rhs); }
     bool operator<(const cseq_base &rhs) const { return name < rhs.name; }
 
     // raw view for the C ABI
-    const uint32_t *packed() const { return reinterpret_cast<const uint32_t *>(bases.data()); }
+    const uint32_t *packed() const { unpack(); return reinterpret_cast<const uint32_t *>(bases.data()); }
 
 private:
+    void unpack() const {  // the packed words of a dense sequence, made on first use (the bytes stay valid)
+        if (!unpacked) return;
+        bases.resize(dmask.size());
+        packed_of_masks(reinterpret_cast<uint32_t *>(bases.data()), dmask.data(), dmask.size());
+        unpacked = false;
+    }
+    void drop_masks() {
+        dmask.clear();
+        unpacked = false;
+    }
+    void touch() {  // before any change: the words exist, the bytes no longer describe the sequence
+        unpack();
+        dmask.clear();
+    }
     std::string name;
-    std::vector<aligned_base> bases;
+    mutable std::vector<aligned_base> bases;
+    std::vector<uint8_t> dmask;     // iupac masks of a dense sequence (empty: not dense, or changed since)
+    mutable bool unpacked{false};   // dense and `bases` not made yet
     unsigned int alignment_width{0};
 };
 
@@ -174,6 +209,17 @@ public:
         const std::string &key() const { return *name; }
     };
     using attr_list = std::vector<attr>;
+    // A string attribute as the LIST its text is made from, the text made when somebody reads it.  famfinder's
+    // align_family_slv is forty "<acc>.<start>:<score> " pieces per query (src/famfinder.cpp:458-470) that a run
+    // writes out only if the field is asked for: composing it for every query was the largest single item of the
+    // host's time per query.  `items` and `owner` mean what `render` takes them to mean; reading the attribute any
+    // way (get_attr, string_attr, has_attr, get_attrs) renders it into its slot first.
+    struct lazy_text {
+        const std::string *name = nullptr;  // interned key of the attribute it stands for (nullptr: none pending)
+        std::vector<uint64_t> items;
+        const void *owner = nullptr;
+        void (*render)(const void *owner, const uint64_t *items, size_t n, std::string &out) = nullptr;
+    };
 
     annotated_cseq(const char *_name, const char *_data = nullptr) : cseq_base(_name, _data) {}
     annotated_cseq() = default;
@@ -184,12 +230,65 @@ public:
         setName(o.getName());
         setWidth(o.getWidth());
         assign_attrs(o.attributes);
+        copy_lazy(o);
+    }
+    // An attribute to be: interned key (attr_key) and an int, float or string value
+    struct attr_init {
+        const std::string *name;
+        enum kind_t { k_int, k_float, k_string } kind;
+        int i;
+        float f;
+        std::string_view s;
+        static attr_init of(const std::string *n, int v) { return attr_init{n, k_int, v, 0.f, {}}; }
+        static attr_init of(const std::string *n, float v) { return attr_init{n, k_float, 0, v, {}}; }
+        static attr_init of(const std::string *n, std::string_view v) { return attr_init{n, k_string, 0, 0.f, v}; }
+    };
+    static const std::string *attr_key(std::string_view key) { return interned(key); }
+    // copy_meta(o) plus the attributes `extra` (ascending by key; one of o's with the same key is replaced), the
+    // list built in one pass in key order: the aligner's working copy with its half dozen result attributes --
+    // set one by one they were half a dozen searches and insertions in the middle of a list of strings
+    void copy_meta_with(const annotated_cseq &o, const attr_init *extra, size_t n_extra) {
+        clearSequence();
+        setName(std::string_view(o.name_ref()));
+        setWidth(o.getWidth());
+        retire_strings();
+        attributes.clear();
+        attributes.reserve(o.attributes.size() + n_extra);
+        size_t e = 0;
+        auto put_extra = [&](const attr_init &x) {
+            if (x.kind == attr_init::k_int) attributes.push_back(attr{x.name, variant(x.i)});
+            else if (x.kind == attr_init::k_float) attributes.push_back(attr{x.name, variant(x.f)});
+            else {
+                std::string mine = fresh_string();
+                mine.assign(x.s);
+                attributes.push_back(attr{x.name, variant(std::move(mine))});
+            }
+        };
+        for (const attr &a : o.attributes) {
+            while (e < n_extra && *extra[e].name < *a.name) put_extra(extra[e++]);
+            if (e < n_extra && (extra[e].name == a.name || *extra[e].name == *a.name)) {
+                put_extra(extra[e++]);
+                continue;
+            }
+            if (const std::string *str = std::get_if<std::string>(&a.second)) {
+                std::string mine = fresh_string();
+                mine.assign(*str);
+                attributes.push_back(attr{a.name, variant(std::move(mine))});
+            } else {
+                attributes.push_back(a);
+            }
+        }
+        while (e < n_extra) put_extra(extra[e++]);
+        copy_lazy(o);
+        for (size_t x = 0; x < n_extra; x++)
+            if (lazy.name && lazy.name == extra[x].name) lazy.name = nullptr;  // (replaced)
     }
     void copy_meta(const annotated_cseq &o) {  // the same into an existing (recycled) object
         clearSequence();
-        setName(o.getName());
+        setName(std::string_view(o.name_ref()));
         setWidth(o.getWidth());
         assign_attrs(o.attributes);
+        copy_lazy(o);
     }
     // Back to the default-constructed state, keeping the heap blocks -- the base list's and those of the
     // attribute strings (family list, date ...: half a dozen blocks per sequence that one pool thread
@@ -200,7 +299,24 @@ public:
         setName(std::string());
         retire_strings();
         attributes.clear();
+        lazy.name = nullptr;
+        lazy.items.clear();
     }
+
+    // `key` becomes a string attribute whose text `render` makes from the returned list (to be filled by the caller)
+    // when it is first read; one such attribute per sequence (a second one settles the first)
+    std::vector<uint64_t> &set_lazy_attr(std::string_view key, const void *owner,
+                                         void (*render)(const void *, const uint64_t *, size_t, std::string &)) {
+        settle();
+        string_slot(key);  // (the slot exists, in key order, empty until read)
+        lazy.name = interned(key);
+        lazy.owner = owner;
+        lazy.render = render;
+        lazy.items.clear();
+        return lazy.items;
+    }
+    // the list behind `key` if its text has not been made yet (a sink that keeps the list instead of the text)
+    const lazy_text *lazy_attr(std::string_view key) const { return lazy.name && *lazy.name == key ? &lazy : nullptr; }
 
     template <typename T> void set_attr(std::string_view key, T val) {
         if constexpr (std::is_same<T, std::string>::value) string_slot(key).assign(val);
@@ -236,15 +352,36 @@ public:
         if (v == nullptr) return dflt;
         return std::visit([&](const auto &x) { return convert<T>(x); }, *v);
     }
-    const attr_list &get_attrs() const { return attributes; }
+    const attr_list &get_attrs() const { settle(); return attributes; }
+    // the same without making a pending lazy text (its slot reads as an empty string): for a reader that looks for
+    // other keys
+    const attr_list &attrs_unsettled() const { return attributes; }
 
 private:
+    static const std::string *interned(std::string_view key);
+    void settle() const {  // the pending text, made (const: the attribute's VALUE does not change, its form does)
+        if (!lazy.name) return;
+        for (attr &a : attributes)
+            if (a.name == lazy.name) {
+                if (std::string *s = std::get_if<std::string>(&a.second)) lazy.render(lazy.owner, lazy.items.data(), lazy.items.size(), *s);
+                break;
+            }
+        lazy.name = nullptr;
+    }
+    void copy_lazy(const annotated_cseq &o) {
+        lazy.name = o.lazy.name;
+        lazy.owner = o.lazy.owner;
+        lazy.render = o.lazy.render;
+        if (o.lazy.name) lazy.items.assign(o.lazy.items.begin(), o.lazy.items.end());
+        else lazy.items.clear();
+    }
     const variant *find(std::string_view key) const {
+        if (lazy.name && *lazy.name == key) settle();
         for (const attr &a : attributes)
             if (*a.name == key) return &a.second;
         return nullptr;
     }
-    variant &slot(std::string_view key);  // the value of `key`, inserted in key order if new (cseq.cpp)
+    variant &slot(std::string_view key);  // the value of `key`, inserted in key order if new (cseq.cpp); settles a pending text of that key
     std::string fresh_string() {
         if (spare.empty()) return std::string();
         std::string s = std::move(spare.back());
@@ -289,7 +426,8 @@ private:
             }
         }
     }
-    attr_list attributes;
+    mutable attr_list attributes;
+    mutable lazy_text lazy;
     std::vector<std::string> spare;  // emptied strings of earlier lives, with their heap blocks
 };
 

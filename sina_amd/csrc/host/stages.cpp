@@ -404,8 +404,8 @@ alignment_stats *alignment_stats::shared_default() {
     return &none;
 }
 void tray::destroy() {  // (src/tray.cpp:77-86; the objects go back to their caches, see object_cache)
-    object_cache<cseq>::give(input_sequence);
-    object_cache<cseq>::give(aligned_sequence);
+    object_cache<cseq, cache_query_seq>::give(input_sequence);
+    object_cache<cseq, cache_aligned_seq>::give(aligned_sequence);
     object_cache<search::result_vector>::give(alignment_reference);
     object_cache<search::result_vector>::give(search_result);
     if (astats != alignment_stats::shared_default()) delete astats;
@@ -452,9 +452,18 @@ std::shared_ptr<reference_store> reference_store::from_packed(const std::string 
         c.setWidth(width);
         c.set_attr(fn::acc, nm);
     }
+    s->fill_metas();
     std::lock_guard<std::mutex> lk(stores_mu);
     stores[key] = s;
     return s;
+}
+void reference_store::fill_metas() {
+    metas.resize(seqs.size());
+    for (size_t i = 0; i < seqs.size(); i++) {
+        const cseq &c = seqs[i];
+        metas[i] = ref_meta{(uint32_t)c.size(), c.size() ? c.getById(0).getPosition() : 0u,
+                            c.size() ? c.getById(c.size() - 1).getPosition() : 0u};
+    }
 }
 
 // Minimal aligned-FASTA reader ('>' name [description], sequence lines; '-'/'.' are gaps).
@@ -494,6 +503,7 @@ std::shared_ptr<reference_store> reference_store::open(const std::string &path, 
     }
     for (const auto &c : s->seqs) s->width = std::max(s->width, c.getWidth());
     for (auto &c : s->seqs) c.setWidth(s->width);
+    s->fill_metas();
     std::lock_guard<std::mutex> lk(stores_mu);
     stores[path] = s;
     return s;
@@ -847,11 +857,12 @@ void kmer_search::find_batch(const std::vector<const cseq *> &queries, std::vect
     const unsigned kk = pimpl->k;
     const bool count_all = pimpl->nofast;
     parallel_for(queries.size(), [&](size_t i) {
-        const auto &b = queries[i]->getAlignedBases();
         uint8_t *dst = qmask + qoff[i];
+        const size_t nb = queries[i]->size();
         static_assert(sizeof(aligned_base) == 4, "packed words");
-        masks_of_packed(dst, reinterpret_cast<const uint32_t *>(b.data()), b.size());
-        if (kmer_counts) (*kmer_counts)[i] = count_query_kmers(dst, b.size(), kk, count_all);
+        if (const uint8_t *dense = queries[i]->denseMasks()) memcpy(dst, dense, nb);  // (an unaligned query as its reader left it)
+        else masks_of_packed(dst, queries[i]->packed(), nb);
+        if (kmer_counts) (*kmer_counts)[i] = count_query_kmers(dst, nb, kk, count_all);
     });
     auto dev = st.worker_device(reference_store::dev_search);
     sina_hip_ctx *ctx = dev.get();
@@ -1141,17 +1152,22 @@ namespace {
 struct match_state {
     size_t have = 0, have_full = 0, have_cover_left = 0, have_cover_right = 0;
 };
-bool match_pass(search::result_vector &results, const cseq &query, match_state &st) {
+bool match_pass(search::result_vector &results, const cseq &query, match_state &st, const reference_store *store) {
     const ff_options &o = ff_opts;
     const size_t range_begin = 0, range_end = 0;
     st = match_state();
     auto remove = [&](const search::result_item &r) {
         const cseq &s = *r.sequence;
-        const bool is_full = s.size() >= o.fs_full_len;
-        const bool is_left = s.size() && s.begin()->getPosition() <= range_begin;
-        const bool is_right = s.size() && s.getById(s.size() - 1).getPosition() >= range_end;
-        if (s.size() < o.fs_min_len) return true;
-        if (o.fs_leave_query_out && query.getName() == s.getName()) return true;
+        // (size, first and last column: out of the store's table for its own sequences)
+        reference_store::ref_meta m;
+        if (store && store->owns(r.sequence)) m = store->meta(store->id_of(r.sequence));
+        else m = reference_store::ref_meta{(uint32_t)s.size(), s.size() ? s.begin()->getPosition() : 0u,
+                                           s.size() ? s.getById(s.size() - 1).getPosition() : 0u};
+        const bool is_full = m.size >= o.fs_full_len;
+        const bool is_left = m.size && m.first_pos <= range_begin;
+        const bool is_right = m.size && m.last_pos >= range_end;
+        if (m.size < o.fs_min_len) return true;
+        if (o.fs_leave_query_out && query.name_ref() == s.name_ref()) return true;
         if (o.fs_msc_max <= 2 && o.fs_msc_max < 1 && identity_cover_query(query, s) > o.fs_msc_max) return true;
         const bool min_reached = st.have >= o.fs_min, max_reached = st.have >= o.fs_max;
         const bool score_good = r.score < o.fs_msc;  // sic (src/famfinder.cpp:565-567)
@@ -1165,21 +1181,39 @@ bool match_pass(search::result_vector &results, const cseq &query, match_state &
         if (o.fs_cover_gene && is_left) ++st.have_cover_left;
         return false;
     };
-    // (41 candidates = 41 reference objects and their first and last bases, all over a 100 000-sequence store:
-    // three dependent cache misses each unless they are asked for ahead of the pass)
-    for (const auto &r : results) __builtin_prefetch(r.sequence);
-    for (const auto &r : results) {
-        const cseq &s = *r.sequence;
-        if (s.size()) {
-            __builtin_prefetch(&*s.begin());
-            __builtin_prefetch(&s.getById(s.size() - 1));
-        }
-    }
+    // (41 candidates out of a 100 000-sequence store: their records are asked for ahead of the pass)
+    if (store)
+        for (const auto &r : results)
+            if (store->owns(r.sequence)) __builtin_prefetch(&store->meta(store->id_of(r.sequence)));
     results.erase(std::remove_if(results.begin(), results.end(), remove), results.end());
     return !(st.have < o.fs_max || st.have_full < o.fs_req_full || st.have_cover_left < o.fs_cover_gene ||
              st.have_cover_right < o.fs_cover_gene);
 }
 }  // namespace
+
+// The text of align_family_slv from the list famfinder left in its place (cseq.h lazy_text): items are
+// reference id << 32 | whole-number score, owner the store.  The text is sized first and then written through a
+// pointer (forty relatives were eighty checked appends).
+void render_family_list(const void *owner, const uint64_t *items, size_t n, std::string &out) {
+    reference_store *st = const_cast<reference_store *>(static_cast<const reference_store *>(owner));
+    size_t total = 0;
+    for (size_t x = 0; x < n; x++) {
+        const uint32_t v = (uint32_t)items[x];
+        const size_t digits = v < 10 ? 1 : v < 100 ? 2 : v < 1000 ? 3 : v < 10000 ? 4 : v < 100000 ? 5 : v < 1000000 ? 6 : v < 10000000 ? 7 : 8;
+        total += st->family_label((uint32_t)(items[x] >> 32)).size() + 1 + digits + 4;
+    }
+    out.resize(total);
+    char *w = out.data();
+    for (size_t x = 0; x < n; x++) {
+        const std::string &label = st->family_label((uint32_t)(items[x] >> 32));
+        memcpy(w, label.data(), label.size());
+        w += label.size();
+        *w++ = ':';
+        w = std::to_chars(w, w + 10, (uint32_t)items[x]).ptr;
+        memcpy(w, ".00 ", 4);
+        w += 4;
+    }
+}
 
 // src/famfinder.cpp:439-494 for a batch; the k-mer search of every escalation
 // round is ONE launch over all queries still looking for relatives.
@@ -1229,7 +1263,7 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
                 return;
             }
             match_state st;
-            const bool enough = match_pass(res, *todo[i]->input_sequence, st);
+            const bool enough = match_pass(res, *todo[i]->input_sequence, st, arb.get());
             done[i] = (enough || max_results >= isize) ? 1 : 0;
         });
         std::vector<tray *> next;
@@ -1248,39 +1282,24 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
         auto &vc = *t.alignment_reference;
         cseq &c = *t.input_sequence;
         uint64_t tk = host_tsc();
-        std::string &fam = c.string_slot(fn::family);  // (written in place, into the sequence's recycled block)
-        // "<acc>.<start>:<score> " per relative (famfinder.cpp:462-470), ":%.2f " for the score.  The text is
-        // sized first and then written through a pointer: forty relatives were eighty checked appends.
-        // (the members' labels are 40 random reads into a 100 000-entry table: ask for all of them first)
-        for (auto &r : vc)
-            if (arb->owns(r.sequence)) __builtin_prefetch(&arb->family_label(arb->id_of(r.sequence)));
-        bool plain = true;  // every relative is of the store and has a whole-number score (k-mer counts are)
-        size_t total = 0;
+        // "<acc>.<start>:<score> " per relative (famfinder.cpp:462-470), ":%.2f " for the score.  Where every
+        // relative is of the store and has a whole-number score (k-mer counts are) the attribute is kept as the
+        // list of (id, score) and the text made when it is read (cseq.h lazy_text, render_family_list below).
+        bool plain = true;
         for (auto &r : vc) {
             const float sc = r.score;
             if (!(arb->owns(r.sequence) && sc >= 0.f && sc < 16777216.f && sc == (float)(uint32_t)sc)) {
                 plain = false;
                 break;
             }
-            const uint32_t v = (uint32_t)sc;
-            const size_t digits = v < 10 ? 1 : v < 100 ? 2 : v < 1000 ? 3 : v < 10000 ? 4 : v < 100000 ? 5 : v < 1000000 ? 6 : v < 10000000 ? 7 : 8;
-            total += arb->family_label(arb->id_of(r.sequence)).size() + 1 + digits + 4;
         }
         if (plain) {
-            fam.resize(total);
-            char *w = fam.data();
-            for (auto &r : vc) {
-                const std::string &label = arb->family_label(arb->id_of(r.sequence));
-                memcpy(w, label.data(), label.size());
-                w += label.size();
-                *w++ = ':';
-                w = std::to_chars(w, w + 10, (uint32_t)r.score).ptr;
-                memcpy(w, ".00 ", 4);
-                w += 4;
-            }
+            std::vector<uint64_t> &items = c.set_lazy_attr(fn::family, arb.get(), &render_family_list);
+            items.resize(vc.size());
+            for (size_t x = 0; x < vc.size(); x++) items[x] = ((uint64_t)arb->id_of(vc[x].sequence) << 32) | (uint32_t)vc[x].score;
         } else {
+            std::string &fam = c.string_slot(fn::family);  // (written in place, into the sequence's recycled block)
             char buf[64];
-            fam.clear();
             fam.reserve(vc.size() * 24);
             for (auto &r : vc) {
                 snprintf(buf, sizeof(buf), ":%.2f ", (double)r.score);
@@ -1297,6 +1316,10 @@ void famfinder::impl::run(std::vector<tray *> &batch) {
         tk = host_tick("ff.post: family string", tk);
         if (o.fs_req_gaps != 0) {  // :472-480
             auto too_few_gaps = [&](search::result_item &it) {
+                if (arb->owns(it.sequence)) {
+                    const reference_store::ref_meta &m = arb->meta(arb->id_of(it.sequence));
+                    return 0 == m.size || m.last_pos - m.size + 1 < o.fs_req_gaps;
+                }
                 return 0 == it.sequence->size() ||
                        it.sequence->rbegin()->getPosition() - it.sequence->size() + 1 < o.fs_req_gaps;
             };
@@ -1577,9 +1600,19 @@ std::string upper_copy(const std::string &s) {
 }
 
 struct dp_job {
-    tray *t;
-    cseq *c;                           // working copy (becomes aligned_sequence)
-    std::vector<const cseq *> family;  // mseq input order
+    tray *t = nullptr;
+    cseq *c = nullptr;  // working copy (becomes aligned_sequence)
+    // the family in mseq input order IS the tray's alignment_reference as the preparation left it (a list of its
+    // own per job was 9216 heap blocks per batch)
+    const search::result_vector *fam = nullptr;
+    size_t family_size() const { return fam->size(); }
+    const cseq *member(size_t y) const { return (*fam)[y].sequence; }
+    std::vector<const cseq *> family() const {
+        std::vector<const cseq *> v;
+        v.reserve(fam->size());
+        for (const auto &r : *fam) v.push_back(r.sequence);
+        return v;
+    }
 };
 }  // namespace
 
@@ -1631,10 +1664,8 @@ void aligner::operator()(std::vector<tray> &batch) {
             return;
         }
         uint64_t tk = host_tsc();
-        // (the working copy starts without bases: they are written once, below or when the DP is back)
-        cseq &c = *object_cache<cseq>::take();
-        c.copy_meta(*t.input_sequence);
-        tk = host_tick("prepare: working copy", tk);
+        // (the working copy -- src/align.cpp:320-326 -- is made where its bases are known: below for a copied
+        // alignment, when the DP is back for the rest; it never holds the query's own bases)
         search::result_vector &vc = *t.alignment_reference;
         // (the query's upper-case base string: only built if a family member passes the k-mer-count
         // test below and has to be searched for it -- exact relatives only)
@@ -1677,7 +1708,6 @@ void aligner::operator()(std::vector<tray> &batch) {
                 vc.erase(holders, vc.end());
                 if (vc.empty()) {
                     t.log << "that's ALL of them. skipping sequence;";
-                    object_cache<cseq>::give(&c);
                     return;
                 }
             } else {  // :349-388 steal the alignment
@@ -1686,6 +1716,8 @@ void aligner::operator()(std::vector<tray> &batch) {
                     return ref_ubases(item.sequence, tmp) == ubases_of_query();
                 };
                 auto exact = std::find_if(holders, vc.end(), is_query_itself);
+                cseq &c = *object_cache<cseq, cache_aligned_seq>::take();
+                c.copy_meta(*t.input_sequence);
                 if (exact != vc.end()) {
                     c.setAlignedBases(exact->sequence->getAlignedBases());
                     t.log << "copied alignment from identical template sequence "
@@ -1713,8 +1745,7 @@ void aligner::operator()(std::vector<tray> &batch) {
             }
         }
         jobs[i].t = &t;
-        jobs[i].c = &c;
-        for (auto &r : vc) jobs[i].family.push_back(r.sequence);
+        jobs[i].fam = &vc;
         need_dp[i] = 1;
         host_tick("prepare: family list", tk);
     });
@@ -1732,7 +1763,7 @@ void aligner::operator()(std::vector<tray> &batch) {
     for (size_t i = 0; i < batch.size(); i++)
         if (need_dp[i]) {
             if (o.fs_no_graph) groups[{std::vector<float>(), false}].push_back(i);
-            else groups[{batch[i].astats->getWeights(), o.device_graph && jobs[i].family.size() <= kDeviceFamilyMax}].push_back(i);
+            else groups[{batch[i].astats->getWeights(), o.device_graph && jobs[i].family_size() <= kDeviceFamilyMax}].push_back(i);
         }
 
     std::shared_ptr<reference_store> store;
@@ -1765,10 +1796,11 @@ void aligner::operator()(std::vector<tray> &batch) {
         thread_local batch_scratch<uint8_t> qmask_buf;
         uint8_t *const qmask = qmask_buf.get(qoff.back() + 1);
         parallel_for(nq, [&](size_t x) {  // (the DP looks at the four base bits only: case does not matter)
-            const uint32_t *b = jobs[idx[x]].t->input_sequence->packed();
-            const size_t nb = jobs[idx[x]].t->input_sequence->size();
+            const cseq &qs = *jobs[idx[x]].t->input_sequence;
+            const size_t nb = qs.size();
             uint8_t *dst = qmask + qoff[x];
-            masks_of_packed(dst, b, nb);
+            if (const uint8_t *dense = qs.denseMasks()) memcpy(dst, dense, nb);
+            else masks_of_packed(dst, qs.packed(), nb);
         });
         // Repeated queries -- the same bases in the same case against the same ordered family: amplicon runs are
         // full of them -- are aligned ONCE (one DAG, one DP, one walk); every tray then finishes from the device
@@ -1777,12 +1809,20 @@ void aligner::operator()(std::vector<tray> &batch) {
         const size_t dnq = group_equal_items(
             nq,
             [&](size_t x) {
-                const auto &fam = jobs[idx[x]].family;
-                return hash_bytes(qmask + qoff[x], qoff[x + 1] - qoff[x], hash_bytes(fam.data(), fam.size() * sizeof(fam[0]), fam.size()));
+                const dp_job &jb = jobs[idx[x]];
+                uint64_t hf = 0xcbf29ce484222325ull ^ jb.family_size();
+                for (size_t y = 0; y < jb.family_size(); y++) {
+                    hf = (hf ^ (uint64_t)reinterpret_cast<uintptr_t>(jb.member(y))) * 0x100000001b3ull;
+                    hf ^= hf >> 29;
+                }
+                return hash_bytes(qmask + qoff[x], qoff[x + 1] - qoff[x], hf);
             },
             [&](size_t a, size_t b) {
-                return qoff[a + 1] - qoff[a] == qoff[b + 1] - qoff[b] && jobs[idx[a]].family == jobs[idx[b]].family &&
-                       memcmp(qmask + qoff[a], qmask + qoff[b], qoff[a + 1] - qoff[a]) == 0;
+                const dp_job &ja = jobs[idx[a]], &jb = jobs[idx[b]];
+                if (qoff[a + 1] - qoff[a] != qoff[b + 1] - qoff[b] || ja.family_size() != jb.family_size()) return false;
+                for (size_t y = 0; y < ja.family_size(); y++)
+                    if (ja.member(y) != jb.member(y)) return false;
+                return memcmp(qmask + qoff[a], qmask + qoff[b], qoff[a + 1] - qoff[a]) == 0;
             },
             rep);
         std::vector<uint32_t> slot_of(nq);       // device slot of group member x
@@ -1828,11 +1868,12 @@ void aligner::operator()(std::vector<tray> &batch) {
         const uint8_t *const qmask = dqmask;
         if (graph_on_device) {
             std::vector<uint64_t> foff(nq + 1, 0);
-            for (size_t x = 0; x < nq; x++) foff[x + 1] = foff[x] + jobs[idx[x]].family.size();
+            for (size_t x = 0; x < nq; x++) foff[x + 1] = foff[x] + jobs[idx[x]].family_size();
             std::vector<uint32_t> fids(foff.back() ? foff.back() : 1);
-            for (size_t x = 0; x < nq; x++)
-                for (size_t y = 0; y < jobs[idx[x]].family.size(); y++)
-                    fids[foff[x] + y] = store->id_of(jobs[idx[x]].family[y]);
+            parallel_for(nq, [&](size_t x) {
+                const dp_job &jb = jobs[idx[x]];
+                for (size_t y = 0; y < jb.family_size(); y++) fids[foff[x] + y] = store->id_of(jb.member(y));
+            });
             width = store->getAlignmentWidth();
             ph.reset(), ph.reset(new scoped_phase("al.align_families(C-ABI)"));  // (the old phase ends first: the new one names the pool jobs)
             hip_check(sina_hip_align_families(ctx, fids.data(), foff.data(), (uint32_t)nq, qmask, qoff.data(),
@@ -1843,10 +1884,10 @@ void aligner::operator()(std::vector<tray> &batch) {
             ph.reset(), ph.reset(new scoped_phase("al.host_graph_build"));  // (the old phase ends first: the new one names the pool jobs)
             parallel_for(nq, [&](size_t x) {
                 if (o.fs_no_graph)
-                    build_family_profile(jobs[idx[x]].family, -o.match_score, -o.mismatch_score, o.gap_penalty,
+                    build_family_profile(jobs[idx[x]].family(), -o.match_score, -o.mismatch_score, o.gap_penalty,
                                          o.gap_ext_penalty, &gs[x]);
                 else
-                    build_family_graph(jobs[idx[x]].family, o.fs_weight, &gs[x]);
+                    build_family_graph(jobs[idx[x]].family(), o.fs_weight, &gs[x]);
             });
             ph.reset(), ph.reset(new scoped_phase("al.host_graph_concat"));  // (the old phase ends first: the new one names the pool jobs)
             sina_hip_graph_batch gb;
@@ -1897,10 +1938,30 @@ void aligner::operator()(std::vector<tray> &batch) {
         parallel_for(nq, [&](size_t x) {
             dp_job &jb = jobs[idx[x]];
             tray &t = *jb.t;
-            cseq &c = *jb.c;
             const sina_hip_align_out &r = out[slot_of[x]];
-            if (r.status != 0) throw std::runtime_error("device alignment failed for " + c.getName());
+            if (r.status != 0) throw std::runtime_error("device alignment failed for " + t.input_sequence->getName());
             uint64_t tk = host_tsc();
+            // the working copy: name and attributes of the input plus do_align's own (src/align.cpp:507-509,455-457),
+            // made in one pass (cseq.h copy_meta_with); its bases follow
+            const float score_q = r.raw / r.sum_weight;
+            const std::string &date_text = make_datetime();
+            const std::string &filter_name = t.astats->getName();
+            struct keys_t {
+                const std::string *head = cseq::attr_key(fn::head), *tail = cseq::attr_key(fn::tail), *filter = cseq::attr_key(fn::filter),
+                                  *qual = cseq::attr_key(fn::qual), *date = cseq::attr_key(fn::date);
+            };
+            static const keys_t keys;  // ("align_cutoff_head_slv" < "align_cutoff_tail_slv" < "align_filter_slv" < "align_quality_slv" < "aligned_slv")
+            const cseq::attr_init extra[5] = {
+                cseq::attr_init::of(keys.head, (int)r.cutoff_head),
+                cseq::attr_init::of(keys.tail, (int)r.cutoff_tail),
+                cseq::attr_init::of(keys.filter, std::string_view(filter_name)),
+                cseq::attr_init::of(keys.qual, (int)std::min(100.f, std::max(0.f, 100.f * score_q))),
+                cseq::attr_init::of(keys.date, std::string_view(date_text)),
+            };
+            cseq &c = *object_cache<cseq, cache_aligned_seq>::take();
+            jb.c = &c;
+            c.copy_meta_with(*t.input_sequence, extra, 5);
+            tk = host_tick("finish: working copy + attributes", tk);
             const uint32_t L = (uint32_t)t.input_sequence->size();
             const uint32_t *pos = staged_pos + dqoff[slot_of[x]];
             if (r.assembled) {
@@ -1908,8 +1969,10 @@ void aligner::operator()(std::vector<tray> &batch) {
                 // in which every insertion fitted its gap: the finished bases, and the fix-up's log line
                 c.clearSequence();
                 std::vector<aligned_base> &fin = c.mutableAlignedBases();  // (a recycled sequence: no allocation)
-                fin.resize(r.n_out);
-                memcpy(static_cast<void *>(fin.data()), pos, sizeof(aligned_base) * (size_t)r.n_out);
+                // (one pass: resize() would zero the block first; blocks in steps of 4 KB, so that a recycled
+                // sequence's block fits its next, slightly longer, occupant)
+                fin.reserve(((size_t)r.n_out + 1023) & ~(size_t)1023);
+                fin.assign(reinterpret_cast<const aligned_base *>(pos), reinterpret_cast<const aligned_base *>(pos) + r.n_out);
                 c.setWidth(width);
                 tk = host_tick("finish: assemble", tk);
                 if (o.insertion == INSERTION_REMOVE) t.log << "insertion=remove not implemented, using shift; ";
@@ -1994,16 +2057,11 @@ void aligner::operator()(std::vector<tray> &batch) {
                 t.log.write(line, w - line);
             }
             tk = host_tick("finish: score log text", tk);
-            c.set_attr(fn::head, r.cutoff_head);
-            c.set_attr(fn::tail, r.cutoff_tail);
-            c.set_attr(fn::qual, (int)std::min(100.f, std::max(0.f, 100.f * score)));
             if (o.write_used_rels) {
                 std::string s;
-                for (const cseq *f : jb.family) s += f->getName() + " ";
+                for (size_t y = 0; y < jb.family_size(); y++) s += jb.member(y)->getName() + " ";
                 c.set_attr(fn::used_rels, s);
             }
-            c.set_attr(fn::date, make_datetime());
-            c.set_attr(fn::filter, t.astats->getName());
             t.aligned_sequence = &c;
             host_tick("finish: attributes", tk);
         });
@@ -2015,14 +2073,14 @@ void aligner::operator()(std::vector<tray> &batch) {
             std::vector<uint64_t> qoff(nq + 1, 0), coff(nq + 1, 0);
             for (size_t x = 0; x < nq; x++) {
                 qoff[x + 1] = qoff[x] + jobs[idx[x]].c->size();
-                coff[x + 1] = coff[x] + jobs[idx[x]].family.size();
+                coff[x + 1] = coff[x] + jobs[idx[x]].family_size();
             }
             std::vector<uint32_t> qab(qoff.back() ? qoff.back() : 1), cids(coff.back() ? coff.back() : 1);
             for (size_t x = 0; x < nq; x++) {
                 const cseq &c = *jobs[idx[x]].c;
                 memcpy(qab.data() + qoff[x], c.packed(), 4 * (size_t)c.size());
-                for (size_t y = 0; y < jobs[idx[x]].family.size(); y++)
-                    cids[coff[x] + y] = store->id_of(jobs[idx[x]].family[y]);
+                for (size_t y = 0; y < jobs[idx[x]].family_size(); y++)
+                    cids[coff[x] + y] = store->id_of(jobs[idx[x]].member(y));
             }
             std::vector<sina_hip_match_counts> counts(coff.back() ? coff.back() : 1);
             auto dev = store->worker_device(reference_store::dev_compare);

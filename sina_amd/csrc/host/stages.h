@@ -92,7 +92,11 @@ private:
 // queries a second: the allocator's locks were a third of the host's CPU time.  Objects that trays
 // own go back to a per-thread free list instead (tray::destroy) and are handed out again in their
 // default state WITH their heap blocks (the 6 KB base list above all), by the stages and the driver.
-template <typename T> struct object_cache {
+// (Role: sequences that arrive as queries and sequences that leave as alignments keep different heap blocks -- mask
+// bytes there, packed words here -- and each kind goes back to a cache of its own, so that an object's next life
+// finds the blocks it needs)
+enum { cache_any = 0, cache_query_seq = 1, cache_aligned_seq = 2 };
+template <typename T, int Role = cache_any> struct object_cache {
     static T *take() {
         auto &f = mine().free;
         if (f.empty() && !from_depot(f)) return new T();
@@ -214,6 +218,13 @@ public:
     // "<acc>.<start>" of reference `id` as famfinder's family attribute lists it (computed once; a
     // later set_attr of acc / start on a reference is not picked up)
     const std::string &family_label(unsigned int id);
+    // what famfinder's cascade reads of a candidate (src/famfinder.cpp:527-533,474-480) -- number of bases, first and
+    // last column -- in one 12-byte record per reference: forty candidates per query out of a 100 000-sequence store
+    // were forty sequence objects and their first and last bases, three cache misses each
+    struct ref_meta {
+        uint32_t size, first_pos, last_pos;
+    };
+    const ref_meta &meta(unsigned int id) const { return metas[id]; }
     std::vector<std::string> getSequenceNames() const;
     void loadKey(const cseq &c, const std::string &key) const;  // acc := name, start := "0" if absent
     std::vector<alignment_stats> &getAlignmentStats() { return vastats; }
@@ -270,6 +281,8 @@ private:
     reference_store() = default;
     std::string path;
     std::vector<cseq> seqs;
+    std::vector<ref_meta> metas;
+    void fill_metas();
     unsigned int width{0};
     std::vector<alignment_stats> vastats;
     int device_id{0};
@@ -501,6 +514,9 @@ public:
     void commit(const report &r, std::ostream &log);  // in sequence order
     summary totals() const;
 };
+
+// text of a family attribute kept as a list (annotated_cseq::lazy_text; famfinder sets it, sinks may keep the list)
+void render_family_list(const void *store, const uint64_t *items, size_t n, std::string &out);
 
 // ---------------------------------------------------------------- batching shim
 // SINA calls a stage once per tray from many TBB workers (function_node with
