@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SINA_HIP_ABI_VERSION 4  /* 4: sina_hip_stats grew the row-skip counters (dp_rows ... dp_prune_rho); sina_hip_debug_dp_info, _rgain */
+#define SINA_HIP_ABI_VERSION 5  /* 5: sina_hip_stats grew scout_ms, scout_launches; 4: the row-skip counters, sina_hip_debug_dp_info, _rgain */
 
 typedef struct sina_hip_ctx sina_hip_ctx;
 
@@ -326,6 +326,9 @@ typedef struct sina_hip_stats {
     uint64_t graph_bytes;        /* device DAG build, algorithmic bytes: the families' packed bases read once, the DAGs
                                     (row records, columns, row-skip bounds, predecessor lists) written once          */
     uint32_t graph_launches, kmer_queries; /* DAG-build launches; queries searched by the k-mer count kernel           */
+    double scout_ms;             /* the scout pass (a bound on the optimum per query from a banded sweep, one lane per
+                                    query): launch to end, on the context's own stream beside other batches' kernels    */
+    uint32_t scout_launches, pad_;
 } sina_hip_stats;
 int sina_hip_get_stats(sina_hip_ctx *ctx, sina_hip_stats *s);
 

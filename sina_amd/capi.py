@@ -74,7 +74,8 @@ class Stats(C.Structure):
                 ("dags_used", C.c_uint64), ("dp_rows", C.c_uint64), ("dp_rows_swept", C.c_uint64),
                 ("dp_cells_swept", C.c_uint64), ("dp_queries_pruned", C.c_uint64), ("dp_second_attempts", C.c_uint64),
                 ("dp_full_sweeps", C.c_uint64), ("dp_prune_rho", C.c_double), ("graph_bytes", C.c_uint64),
-                ("graph_launches", C.c_uint32), ("kmer_queries", C.c_uint32)]
+                ("graph_launches", C.c_uint32), ("kmer_queries", C.c_uint32), ("scout_ms", C.c_double),
+                ("scout_launches", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 class DpInfo(C.Structure):

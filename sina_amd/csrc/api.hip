@@ -282,6 +282,31 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         for (uint32_t q = 0; q < bq; q++) max_n = std::max<uint32_t>(max_n, qd_host[q].N);
         a.below_init = (!weighted && !forbid && dp_below_init(max_n, a.gp, a.gpe)) ? 1 : 0;
     }
+    // The scout pass (scout.hip): every query's own bound U -- the cost of a real path -- instead of the store's
+    // guess.  On the context's own stream, beside whatever device-filling kernels the other batches have resident;
+    // the host waits for it HERE, before it asks for its DP launch's place in the FIFO: a DP launch admitted with
+    // its scout still running would hold one of the FIFO's two streams for milliseconds.  A fixed guess
+    // (SINA_HIP_TEST=rho=) or SINA_HIP_TEST=scout=0 leaves it out.
+    a.scout_u = nullptr;
+    a.scout_bias = (float)atof(test_knob("scout_add").c_str());
+    c->last_scout = false;
+    if (pp.on && !rho_fixed && a.below_init && a.gp >= a.gpe && pl.geom.T > 64 && test_knob("scout") != "0") {
+        const uint64_t tb_rows = tb_cells / (uint64_t)Lp;
+        if (c->scout.reserve(4 * scout_scratch_floats(tb_rows)) || c->scout_u.reserve(4 * (size_t)bq)) return 1;
+        SH_CHECK(hipEventRecord(c->ev[3], s));
+        if (launch_mesh_scout(a, bq, (uint32_t)Lp, c->scout.as<float>(), c->scout_u.as<float>(), s)) return 1;
+        SH_CHECK(hipEventRecord(c->ev[4], s));
+        SH_CHECK(wait_event(c->ev[4]));
+        float sms = 0;
+        SH_CHECK(hipEventElapsedTime(&sms, c->ev[3], c->ev[4]));
+        {
+            std::lock_guard<std::mutex> slk(c->st->stats_mu);
+            c->st->stats.scout_ms += sms;
+            c->st->stats.scout_launches++;
+        }
+        a.scout_u = c->scout_u.as<float>();
+        c->last_scout = true;
+    }
 
     BtArgs b;
     b.qd = a.qd;

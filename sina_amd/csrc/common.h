@@ -26,7 +26,7 @@ void set_error(const std::string &msg);
 //   SINA_HIP_CHAIN=0|1                   chained launches off / on under a counter-collecting profiler (ctx.h)
 //   SINA_HIP_NO_RUNTIME_DEFAULTS         the load-time constructor leaves the process environment alone (api.hip)
 //   SINA_HIP_TRACE_ALLOC                 one line per device / pinned allocation
-//   SINA_HIP_TEST="key=value;..."        test hooks (tests/ only): geom=T,B  generic=1  dense_div=N  lds_kb=N  rho=X  kmer_rows=1  bt_lanes=0/1
+//   SINA_HIP_TEST="key=value;..."        test hooks (tests/ only): geom=T,B  generic=1  dense_div=N  lds_kb=N  rho=X  kmer_rows=1  bt_lanes=0/1  scout=0  scout_add=X
 // The experiment switches of rounds 1-4 (SINA_HIP_SERIALIZE, _DP_BURST, _GRAPH_DRY, _BT_ON_FIFO, _STREAM_PRIO,
 // _SHARE_DAGS, _DP_ROUNDS, _DEBUG_SYNC) exist only in a build made with -DSINA_EXPERIMENTS
 // (make -C sina_amd/csrc VARIANT=exp EXTRA=-DSINA_EXPERIMENTS): the production library does not look at them.
@@ -340,6 +340,8 @@ struct DpArgs {
     int prune;
     float prune_rho;
     uint32_t prune_amax;
+    float scout_bias;           // test hook (SINA_HIP_TEST=scout_add=<x>): added to every scout value -- a scout forced wrong
+    const float *scout_u;       // per query: the cost of a real path (scout.hip), the first attempt's bound U; nullptr: the guess rho
 };
 
 struct BtArgs {
@@ -376,6 +378,10 @@ int dp_max_ring(const DpGeom &g);  // deepest LDS ring the slot allocators suppo
 size_t dp_default_lds_budget(const DpGeom &g);  // LDS per workgroup that keeps the register-limited occupancy
 int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
                    size_t lds_bytes, hipStream_t s);
+// the scout pass (scout.hip): per query the value of a path found in a band of kScoutBand columns per DAG row
+constexpr int kScoutBand = 16;
+size_t scout_scratch_floats(uint64_t tb_rows);  // floats of scratch for a launch of that many DAG rows (sum of N)
+int launch_mesh_scout(const DpArgs &a, uint32_t nq, uint32_t Lp, float *scratch, float *out_u, hipStream_t s);
 int launch_backtrack(const BtArgs &a, hipStream_t s);
 bool backtrack_by_lanes(const BtArgs &a);  // one lane per query (large launches of 16S-long queries), else one wave per query
 int launch_assemble(const BtArgs &a, hipStream_t s);  // (after launch_backtrack, same stream)

@@ -114,10 +114,12 @@ struct sina_hip_ctx {
     sina_hip::DevBuf qd, order, rec, node_pos, pred, succ_minpos, qmask, spill, edge, res, weights, out, out_pos, dbg;
     sina_hip::DevBuf prof16, self16;  // --fs-no-graph: match-term tables of a profile batch (sina_hip_graph_batch)
     sina_hip::DevBuf rgain;           // per DAG node: bound on the gain still to come (the DP kernel's row skip, common.h)
+    sina_hip::DevBuf scout, scout_u;  // the scout pass (scout.hip): its band rows, and its result -- a bound U per query
     sina_hip::HostBuf h_res;          // pinned copy of a launch's DpResults (row-skip statistics, the next launch's guess)
     bool profile_batch = false;       // the launch being prepared is one (set by sina_hip_align_graphs)
     void *last_tb = nullptr;  // the plane of the last launch (debug read-back: sina_hip_debug_mesh)
     bool dbg_planes = false;  // the launch being prepared is sina_hip_debug_mesh's: its planes are unpacked cell by cell
+    bool last_scout = false;  // the last launch's bounds came from the scout pass
     uint32_t last_bq = 0, last_prune_step = 0;  // queries / assumed largest step gain of the last launch (sina_hip_debug_dp_info)
     sina_hip::DevBuf k_qoff, k_scores, k_out_ids, k_out_scores, k_out_n, k_tmp0, k_tmp1, k_tmp2;
     sina_hip::DevBuf g_fam_ids, g_fam_off, g_tmp0, g_tmp1, g_tmp2, g_tmp3, g_sizes, g_wtab;
@@ -131,14 +133,15 @@ struct sina_hip_ctx {
 
     size_t lds_budget = 0;  // LDS per DP workgroup; 0 = what keeps the register-limited occupancy (dp_default_lds_budget)
 
-    static constexpr int kNumScratch = 37;
+    static constexpr int kNumScratch = 39;
     static_assert(kNumScratch <= 64, "sina_hip_store::cap_hint is too short");
     void scratch(sina_hip::DevBuf **all) {
         sina_hip::DevBuf *list[kNumScratch] = {&qd, &rec, &node_pos, &pred, &succ_minpos, &qmask, &spill, &res,
                                                &weights, &out, &out_pos, &k_qoff, &k_scores, &k_out_ids,
                                                &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2, &g_fam_ids,
                                                &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab, &order,
-                                               &s_qab, &s_qoff, &s_cand, &s_coff, &s_out, &edge, &prof16, &self16, &rgain};
+                                               &s_qab, &s_qoff, &s_cand, &s_coff, &s_out, &edge, &prof16, &self16, &rgain,
+                                               &scout, &scout_u};
         for (int i = 0; i < kNumScratch; i++) all[i] = list[i];
     }
     void publish_hints() {  // after a call: remember how big my buffers had to be
@@ -165,7 +168,7 @@ struct sina_hip_ctx {
     int prewarm(int kind) {
         sina_hip::DevBuf *search[] = {&k_qoff, &k_scores, &k_out_ids, &k_out_scores, &k_out_n, &k_tmp0, &k_tmp1, &k_tmp2, &qmask};
         sina_hip::DevBuf *align[] = {&qd, &order, &rec, &node_pos, &pred, &succ_minpos, &qmask, &spill, &edge, &res, &weights, &out,
-                                     &out_pos, &g_fam_ids, &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab, &rgain};
+                                     &out_pos, &g_fam_ids, &g_fam_off, &g_tmp0, &g_tmp1, &g_tmp2, &g_tmp3, &g_sizes, &g_wtab, &rgain, &scout, &scout_u};
         sina_hip::DevBuf *compare[] = {&s_qab, &s_qoff, &s_cand, &s_coff, &s_out};
         sina_hip::DevBuf **list = kind == 0 ? search : (kind == 1 ? align : compare);
         const size_t n = kind == 0 ? sizeof search / sizeof *search : (kind == 1 ? sizeof align / sizeof *align : sizeof compare / sizeof *compare);

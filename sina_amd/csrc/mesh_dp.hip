@@ -1007,7 +1007,8 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                       const uint32_t *__restrict__ predv, const uint8_t *__restrict__ qmaskv, void *__restrict__ tbv,
                       float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev, uint64_t edge_stride,
                       uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe, DryArgs dry,
-                      const uint2 *__restrict__ reachv, float prune_rho, uint32_t prune_amax, uint32_t n_slots) {
+                      const uint2 *__restrict__ reachv, float prune_rho, uint32_t prune_amax, uint32_t n_slots,
+                      const float *__restrict__ scout_uv, float scout_bias) {
     static_assert(B % 4 == 0, "16-byte accesses per array");
     constexpr int kStrip = 64 * B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1064,6 +1065,17 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         const uint32_t g0 = g_cols < g_len ? g_cols : g_len;
         gain0 = (float)g0 * kPruneUnit;
         U64 = -(int32_t)uniform((uint32_t)(int32_t)(prune_rho * (float)g0));  // (rounded towards zero: the looser side)
+        // ... or, better than any guess, what the scout pass found: the cost of a real path of THIS query (scout.hip),
+        // rounded up to a unit.  (Beyond +-1e5 the units leave float32's exact integers: the guess stands.)
+        if (scout_uv != nullptr) {
+            const float su = __uint_as_float(uniform(__float_as_uint(scout_uv[qi]))) + scout_bias;  // (bias: a test hook, 0)
+            if (su > -100000.0f && su < 100000.0f) {
+                const float up = su * 64.0f;
+                int32_t u = (int32_t)up;
+                if ((float)u < up) u++;
+                U64 = u;
+            }
+        }
     }
     uint32_t rows_done = 0, cells_done = 0, attempt = 0;
     const float gmin_f = (float)gmin * kPruneUnit;
@@ -1729,7 +1741,8 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     }
     if constexpr (!PRUNE) break;
     // ---- the certificate: an end cell at or below U is the full sweep's, and so is its path
-    if (res_status != 0 || res_v <= U_f) break;
+    // (a third attempt runs without a bound: it is the last whatever it finds -- a NaN fails every comparison)
+    if (res_status != 0 || res_v <= U_f || attempt >= 3) break;
     // not certified: sweep again.  What attempt 1 found under too tight a bound is still the cost of a path (or
     // kDead-ish if everything was cut off): the optimum is at most that -- and if some quirk of the recurrence
     // (mesh.h:340: a gap is only extended where it IS the cell's value) makes even that wrong, attempt 2's own
@@ -2265,7 +2278,7 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
         if (allow_full_lds(reinterpret_cast<const void *>(kfn))) return 1;
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.qmask, a.tb, a.dbg_value, a.spill,
                            a.edge, a.edge_stride, n_strips, a.res, a.ms, a.mms, a.gp, a.gpe, a.dry, a.reach, a.prune_rho,
-                           a.prune_amax, (uint32_t)(lds / dp_slot_bytes(DpGeom{64 * (int)n_strips, B})));
+                           a.prune_amax, (uint32_t)(lds / dp_slot_bytes(DpGeom{64 * (int)n_strips, B})), prune ? a.scout_u : nullptr, a.scout_bias);
     } else if (!weighted && !forbid && a.below_init) SH_LAUNCH(false, false, true);
     else if (!weighted && !forbid) SH_LAUNCH(false, false, false);
     else if (weighted && !forbid) SH_LAUNCH(true, false, false);

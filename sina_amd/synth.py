@@ -106,7 +106,8 @@ def make_refs(n_refs, length=1500, width=50000, seed=1, n_clades=20, clade_div=0
 
 def make_queries(refs, n_queries, seed=2, sub=0.03, dele=0.005, ins=0.003, window=None,
                  amb_rate=0.0, lower_rate=0.0):
-    """window=(start_frac, length) cuts each derived query to a sub-window."""
+    """window=(start_frac, length) cuts each derived query to a sub-window.  sub / dele / ins may be sequences:
+    query i then gets rate[i % len(rate)] (a launch that mixes near-identical and distant queries)."""
     rng = np.random.default_rng(seed)
     src = rng.integers(0, refs.n, size=n_queries)
     lens = (refs.off[src + 1] - refs.off[src]).astype(np.int64)
@@ -122,6 +123,10 @@ def make_queries(refs, n_queries, seed=2, sub=0.03, dele=0.005, ins=0.003, windo
     mm = m & 15
     for c in range(4):
         code[mm == (1 << c)] = c
+    def per_base(rate):  # a rate per query, spread over the query's bases
+        r = np.atleast_1d(np.asarray(rate, dtype=np.float64))
+        return r[0] if len(r) == 1 else np.repeat(r[np.arange(n_queries) % len(r)], lens)
+    sub, dele, ins = per_base(sub), per_base(dele), per_base(ins)
     s = rng.random(total) < sub
     code_s = (code + rng.integers(1, 4, size=total, dtype=np.uint8)) & 3
     newm = np.where(s, CODE_TO_MASK[code_s] | lowbit, m).astype(np.uint8)

@@ -25,7 +25,7 @@ def test_abi_library_exports_every_declared_symbol():
     L = capi.load()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.sina_hip_abi_version() == 4
+    assert L.sina_hip_abi_version() == 5
 
 
 def test_abi_rejects_bad_arguments_without_gpu():
