@@ -276,6 +276,7 @@ typedef struct sina_hip_dp_info {
     uint32_t rows_swept, cells_swept, attempts;
     float gain0, ubound;
     uint32_t prune_step, prune_gmin;
+    float scout;  /* what the scout pass found for this query (the first attempt's bound U); NaN: the launch had none */
 } sina_hip_dp_info;
 int sina_hip_debug_dp_info(sina_hip_ctx *ctx, uint32_t q, sina_hip_dp_info *out);
 int sina_hip_debug_rgain(sina_hip_ctx *ctx, uint32_t n, uint32_t *out, uint32_t *cols_right /* C(m), may be NULL */);

@@ -81,7 +81,8 @@ class Stats(C.Structure):
 class DpInfo(C.Structure):
     _fields_ = [("end_m", C.c_uint32), ("end_s", C.c_uint32), ("raw", C.c_float), ("status", C.c_int32),
                 ("rows_swept", C.c_uint32), ("cells_swept", C.c_uint32), ("attempts", C.c_uint32),
-                ("gain0", C.c_float), ("ubound", C.c_float), ("prune_step", C.c_uint32), ("prune_gmin", C.c_uint32)]
+                ("gain0", C.c_float), ("ubound", C.c_float), ("prune_step", C.c_uint32), ("prune_gmin", C.c_uint32),
+                ("scout", C.c_float)]
 
 
 _lib = None

@@ -1,6 +1,7 @@
 // C-ABI entry points of include/sina_hip.h: context, reference store, alignment.
 // (k-mer entry points live in kmer.hip, the device DAG build in graph_build.hip.)
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -211,23 +212,12 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     uint64_t edge_entries = 0;
     for (uint32_t q = 0; q < bq; q++) edge_entries += dp_edge_entries(qd_host[q].N);
     (void)n_node_entries;
-    // The trace-back plane is the one buffer whose size follows the batch (tens of GB for 16S): borrowed
-    // from the device's pool of two (ctx.h) until this launch's results are on the host.
-    const uint64_t tb_bytes = tb_cell_bytes(forbid) * tb_cells;
-    tb_plane_lease plane;
-    if (plane.acquire(c, std::max<uint64_t>(tb_bytes, 16))) return 1;
-    c->last_tb = plane.ptr;
     if (c->spill.reserve(std::max<uint64_t>(spill_rows, 1) * 8 * (uint64_t)Lp) ||
         c->edge.reserve(std::max<uint64_t>(1, (uint64_t)(pl.geom.T / 64 - 1) * edge_entries) * sizeof(EdgeRec)) ||
         c->res.reserve(sizeof(DpResult) * bq) || c->out.reserve(sizeof(sina_hip_align_out) * bq) ||
         c->out_pos.reserve(4 * std::max<uint64_t>(nqm, 1)))
         return 1;
     if (want_dbg_value && c->dbg.reserve(4 * tb_cells)) return 1;
-    // (rows the kernel never visits show the value a skipped row shows its successors)
-    if (want_dbg_value && pp.on) SH_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->dbg.p), 0x49742400 /* 1e6f */, tb_cells, s));
-    // (debug read-back of the planes: rows the kernel skips leave their trace-back cells unwritten -- "untouched cell"
-    // everywhere first, so that unpacking them stays inside the DAG)
-    if (c->dbg_planes && !forbid) SH_CHECK(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(plane.ptr), (unsigned short)kTbNone, tb_cells, s));
     // longest queries first (workgroups start in index order; see mesh_dp_kernel)
     std::vector<uint32_t> order(bq);
     for (uint32_t q = 0; q < bq; q++) order[q] = q;
@@ -245,7 +235,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     a.node_pos = c->node_pos.as<uint32_t>();
     a.succ_minpos = c->succ_minpos.as<uint32_t>();
     a.qmask = c->qmask.as<uint8_t>();
-    a.tb = plane.ptr;
+    a.tb = nullptr;  // (the plane is borrowed below, once the scout is back)
     a.dbg_value = want_dbg_value ? c->dbg.as<float>() : nullptr;
     a.spill = c->spill.as<float>();
     a.edge = c->edge.as<EdgeRec>();
@@ -288,13 +278,14 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     // its scout still running would hold one of the FIFO's two streams for milliseconds.  A fixed guess
     // (SINA_HIP_TEST=rho=) or SINA_HIP_TEST=scout=0 leaves it out.
     a.scout_u = nullptr;
+    a.scout_nq = 0;
     a.scout_bias = (float)atof(test_knob("scout_add").c_str());
     c->last_scout = false;
     if (pp.on && !rho_fixed && a.below_init && a.gp >= a.gpe && pl.geom.T > 64 && test_knob("scout") != "0") {
         const uint64_t tb_rows = tb_cells / (uint64_t)Lp;
-        if (c->scout.reserve(4 * scout_scratch_floats(tb_rows)) || c->scout_u.reserve(4 * (size_t)bq)) return 1;
+        if (c->scout.reserve(4 * scout_scratch_floats(tb_rows)) || c->scout_u.reserve(8 * (size_t)bq)) return 1;
         SH_CHECK(hipEventRecord(c->ev[3], s));
-        if (launch_mesh_scout(a, bq, (uint32_t)Lp, c->scout.as<float>(), c->scout_u.as<float>(), s)) return 1;
+        if (launch_mesh_scout(a, bq, (uint32_t)Lp, tb_rows, c->scout.as<float>(), c->scout_u.as<float>(), s)) return 1;
         SH_CHECK(hipEventRecord(c->ev[4], s));
         SH_CHECK(wait_event(c->ev[4]));
         float sms = 0;
@@ -305,8 +296,22 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
             c->st->stats.scout_launches++;
         }
         a.scout_u = c->scout_u.as<float>();
+        a.scout_nq = bq;
         c->last_scout = true;
     }
+    // The trace-back plane is the one buffer whose size follows the batch (tens of GB for 16S): borrowed
+    // from the device's pool of two (ctx.h) until this launch's results are on the host -- and not before the scout
+    // is back: a launch waiting for its scout does not hold a plane another launch could fill meanwhile.
+    const uint64_t tb_bytes = tb_cell_bytes(forbid) * tb_cells;
+    tb_plane_lease plane;
+    if (plane.acquire(c, std::max<uint64_t>(tb_bytes, 16))) return 1;
+    c->last_tb = plane.ptr;
+    a.tb = plane.ptr;
+    // (rows the kernel never visits show the value a skipped row shows its successors)
+    if (want_dbg_value && pp.on) SH_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->dbg.p), 0x49742400 /* 1e6f */, tb_cells, s));
+    // (debug read-back of the planes: rows the kernel skips leave their trace-back cells unwritten -- "untouched cell"
+    // everywhere first, so that unpacking them stays inside the DAG)
+    if (c->dbg_planes && !forbid) SH_CHECK(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(plane.ptr), (unsigned short)kTbNone, tb_cells, s));
 
     BtArgs b;
     b.qd = a.qd;
@@ -852,6 +857,13 @@ int sina_hip_debug_dp_info(sina_hip_ctx *c, uint32_t q, sina_hip_dp_info *out) {
     QDesc d;
     SH_CHECK(hipMemcpy(&d, c->qd.as<QDesc>() + q, sizeof d, hipMemcpyDeviceToHost));
     out->prune_gmin = d.gmin;
+    out->scout = NAN;
+    if (c->last_scout && c->scout_u.p) {  // (the smaller of the two sweeps' values)
+        float two[2];
+        SH_CHECK(hipMemcpy(&two[0], c->scout_u.as<float>() + q, sizeof(float), hipMemcpyDeviceToHost));
+        SH_CHECK(hipMemcpy(&two[1], c->scout_u.as<float>() + c->last_bq + q, sizeof(float), hipMemcpyDeviceToHost));
+        out->scout = std::min(two[0], two[1]);
+    }
     return 0;
 }
 

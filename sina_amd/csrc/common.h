@@ -341,6 +341,7 @@ struct DpArgs {
     float prune_rho;
     uint32_t prune_amax;
     float scout_bias;           // test hook (SINA_HIP_TEST=scout_add=<x>): added to every scout value -- a scout forced wrong
+    uint32_t scout_nq;          // queries of the launch (scout_u holds two values per query: [2][scout_nq])
     const float *scout_u;       // per query: the cost of a real path (scout.hip), the first attempt's bound U; nullptr: the guess rho
 };
 
@@ -381,7 +382,7 @@ int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a,
 // the scout pass (scout.hip): per query the value of a path found in a band of kScoutBand columns per DAG row
 constexpr int kScoutBand = 16;
 size_t scout_scratch_floats(uint64_t tb_rows);  // floats of scratch for a launch of that many DAG rows (sum of N)
-int launch_mesh_scout(const DpArgs &a, uint32_t nq, uint32_t Lp, float *scratch, float *out_u, hipStream_t s);
+int launch_mesh_scout(const DpArgs &a, uint32_t nq, uint32_t Lp, uint64_t tb_rows, float *scratch, float *out_u /* [2][nq] */, hipStream_t s);
 int launch_backtrack(const BtArgs &a, hipStream_t s);
 bool backtrack_by_lanes(const BtArgs &a);  // one lane per query (large launches of 16S-long queries), else one wave per query
 int launch_assemble(const BtArgs &a, hipStream_t s);  // (after launch_backtrack, same stream)

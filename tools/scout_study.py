@@ -20,7 +20,7 @@ from tests import util  # noqa: E402
 DEAD = np.float32(1e6)
 
 
-def scout(g, qmask, K, ms=-2.0, mms=1.0, gp=5.0, gpe=2.0):
+def scout(g, qmask, K, ms=-2.0, mms=1.0, gp=5.0, gpe=2.0, a_credit=0.0, rate_frac=0.0):
     """Banded recurrence (float32, the reference's operators); returns (value, centre column per row)."""
     f = np.float32
     ms, mms, gp, gpe = f(ms), f(mms), f(gp), f(gpe)
@@ -31,6 +31,7 @@ def scout(g, qmask, K, ms=-2.0, mms=1.0, gp=5.0, gpe=2.0):
     G = np.full((N, K), DEAD, np.float32)
     amin = np.zeros(N, np.int64)
     vmin = np.full(N, DEAD, np.float32)
+    vraw = np.full(N, DEAD, np.float32)
     snk = np.zeros(N, bool)
     snk[g["snk"]] = True
     best = np.float32(np.inf)
@@ -41,7 +42,10 @@ def scout(g, qmask, K, ms=-2.0, mms=1.0, gp=5.0, gpe=2.0):
         if len(preds) == 0:
             c = c_prev
         else:
-            pb = preds[np.argmin(vmin[preds])]
+            # (which predecessor to follow: rows that have consumed different numbers of query bases compare by value
+            # plus what the bases one of them is behind would have gained at a fraction of the path's own rate so far)
+            rate = rate_frac * max(0.0, -float(vraw[m - 1])) / max(1.0, float(amin[m - 1])) if m > 0 else 0.0
+            pb = preds[np.argmin(vraw[preds] + np.float32(rate) * amin[preds])]
             c = int(amin[pb]) + 1 - K // 2
         c = max(0, min(c, max(0, L - K)))
         cols = c + kk
@@ -86,8 +90,11 @@ def scout(g, qmask, K, ms=-2.0, mms=1.0, gp=5.0, gpe=2.0):
             e_prev = bool(ins)
         fv = np.where(inside, fv, DEAD)
         V[m], G[m], c_of[m] = fv, np.where(inside, gm, DEAD), c
-        a = int(np.argmin(fv))
-        amin[m], vmin[m] = c + a, fv[a]
+        # (the row's "minimum": by value plus a credit per query base not yet consumed -- cells of one row, and rows
+        # of one set of predecessors, have consumed different numbers of bases; a_credit = 0: the plain minimum)
+        fcred = fv + np.float32(a_credit) * (c + kk).astype(np.float32)
+        a = int(np.argmin(fcred))
+        amin[m], vmin[m], vraw[m] = c + a, fcred[a], fv[a]
         c_prev = c
         if c <= L - 1 < c + K:
             best = min(best, fv[L - 1 - c])
