@@ -202,7 +202,8 @@ static int prep_range(const sina_hip_graph_batch *g, const uint64_t *qoff, uint3
 // query masks are already in the context's device buffers; copies results back.
 int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint32_t bq, uint64_t n_node_entries,
                   uint64_t tb_cells, uint64_t spill_rows, uint64_t cells, uint64_t nqm, const sina_hip_align_params *p, uint32_t width,
-                  sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value, const PrunePlan &pp) {
+                  sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value, const PrunePlan &pp,
+                  const uint32_t *chain_ref) {
     hipStream_t s = c->stream;
     const int Lp = pl.geom.Lp();
     const bool weighted = p->weights != nullptr && p->n_weights > 0;
@@ -272,20 +273,21 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         for (uint32_t q = 0; q < bq; q++) max_n = std::max<uint32_t>(max_n, qd_host[q].N);
         a.below_init = (!weighted && !forbid && dp_below_init(max_n, a.gp, a.gpe)) ? 1 : 0;
     }
-    // The scout pass (scout.hip): every query's own bound U -- the cost of a real path -- instead of the store's
-    // guess.  On the context's own stream, beside whatever device-filling kernels the other batches have resident;
-    // the host waits for it HERE, before it asks for its DP launch's place in the FIFO: a DP launch admitted with
-    // its scout still running would hold one of the FIFO's two streams for milliseconds.  A fixed guess
-    // (SINA_HIP_TEST=rho=) or SINA_HIP_TEST=scout=0 leaves it out.
+    // The scout pass (scout.hip): every query's own bound U -- the cost of a real path, its alignment against the chain
+    // of its family's first member -- instead of the store's guess alone.  On the context's own stream (150 waves, a
+    // lane per query: not a device-filling kernel), before the launch borrows a trace-back plane and asks for its place
+    // in the FIFO.  A fixed guess (SINA_HIP_TEST=rho=) or SINA_HIP_TEST=scout=0 leaves it out, and so does a caller
+    // that brought its own DAGs (sina_hip_align_graphs: no family to take a chain from).
     a.scout_u = nullptr;
-    a.scout_nq = 0;
     a.scout_bias = (float)atof(test_knob("scout_add").c_str());
     c->last_scout = false;
-    if (pp.on && !rho_fixed && a.below_init && a.gp >= a.gpe && pl.geom.T > 64 && test_knob("scout") != "0") {
-        const uint64_t tb_rows = tb_cells / (uint64_t)Lp;
-        if (c->scout.reserve(4 * scout_scratch_floats(tb_rows)) || c->scout_u.reserve(8 * (size_t)bq)) return 1;
+    if (chain_ref != nullptr && pp.on && !rho_fixed && a.below_init && a.gp >= a.gpe && pl.geom.T > 64 && test_knob("scout") != "0") {
+        if (c->scout.reserve(4 * (size_t)bq) || c->scout_u.reserve(4 * (size_t)bq)) return 1;
+        if (upload(c, 7, c->scout.p, chain_ref, 4 * (size_t)bq, s)) return 1;
         SH_CHECK(hipEventRecord(c->ev[3], s));
-        if (launch_mesh_scout(a, bq, (uint32_t)Lp, tb_rows, c->scout.as<float>(), c->scout_u.as<float>(), s)) return 1;
+        if (launch_chain_scout(a, bq, c->st->ref_ab.as<uint32_t>(), c->st->ref_off.as<uint64_t>(), c->scout.as<uint32_t>(),
+                               c->scout_u.as<float>(), s))
+            return 1;
         SH_CHECK(hipEventRecord(c->ev[4], s));
         SH_CHECK(wait_event(c->ev[4]));
         float sms = 0;
@@ -296,7 +298,6 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
             c->st->stats.scout_launches++;
         }
         a.scout_u = c->scout_u.as<float>();
-        a.scout_nq = bq;
         c->last_scout = true;
     }
     // The trace-back plane is the one buffer whose size follows the batch (tens of GB for 16S): borrowed
@@ -858,12 +859,7 @@ int sina_hip_debug_dp_info(sina_hip_ctx *c, uint32_t q, sina_hip_dp_info *out) {
     SH_CHECK(hipMemcpy(&d, c->qd.as<QDesc>() + q, sizeof d, hipMemcpyDeviceToHost));
     out->prune_gmin = d.gmin;
     out->scout = NAN;
-    if (c->last_scout && c->scout_u.p) {  // (the smaller of the two sweeps' values)
-        float two[2];
-        SH_CHECK(hipMemcpy(&two[0], c->scout_u.as<float>() + q, sizeof(float), hipMemcpyDeviceToHost));
-        SH_CHECK(hipMemcpy(&two[1], c->scout_u.as<float>() + c->last_bq + q, sizeof(float), hipMemcpyDeviceToHost));
-        out->scout = std::min(two[0], two[1]);
-    }
+    if (c->last_scout && c->scout_u.p) SH_CHECK(hipMemcpy(&out->scout, c->scout_u.as<float>() + q, sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -341,7 +341,6 @@ struct DpArgs {
     float prune_rho;
     uint32_t prune_amax;
     float scout_bias;           // test hook (SINA_HIP_TEST=scout_add=<x>): added to every scout value -- a scout forced wrong
-    uint32_t scout_nq;          // queries of the launch (scout_u holds two values per query: [2][scout_nq])
     const float *scout_u;       // per query: the cost of a real path (scout.hip), the first attempt's bound U; nullptr: the guess rho
 };
 
@@ -379,10 +378,11 @@ int dp_max_ring(const DpGeom &g);  // deepest LDS ring the slot allocators suppo
 size_t dp_default_lds_budget(const DpGeom &g);  // LDS per workgroup that keeps the register-limited occupancy
 int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a, uint32_t nq,
                    size_t lds_bytes, hipStream_t s);
-// the scout pass (scout.hip): per query the value of a path found in a band of kScoutBand columns per DAG row
+// the scout pass (scout.hip): per query the cost of its banded alignment (kScoutBand columns per row) against the chain
+// of its family's first member -- a real path of the mesh, the first attempt's bound U
 constexpr int kScoutBand = 16;
-size_t scout_scratch_floats(uint64_t tb_rows);  // floats of scratch for a launch of that many DAG rows (sum of N)
-int launch_mesh_scout(const DpArgs &a, uint32_t nq, uint32_t Lp, uint64_t tb_rows, float *scratch, float *out_u /* [2][nq] */, hipStream_t s);
+int launch_chain_scout(const DpArgs &a, uint32_t nq, const uint32_t *ref_ab, const uint64_t *ref_off,
+                       const uint32_t *chain_ref /* device: [nq] reference ids */, float *out_u /* [nq] */, hipStream_t s);
 int launch_backtrack(const BtArgs &a, hipStream_t s);
 bool backtrack_by_lanes(const BtArgs &a);  // one lane per query (large launches of 16S-long queries), else one wave per query
 int launch_assemble(const BtArgs &a, hipStream_t s);  // (after launch_backtrack, same stream)
@@ -403,9 +403,11 @@ struct sina_hip_ctx;
 namespace sina_hip {
 int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl);
 int upload_weights(sina_hip_ctx *c, const sina_hip_align_params *p);
+// chain_ref: per query the reference id of its family's first member (host; nullptr: the DAGs are the caller's, no scout)
 int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint32_t bq, uint64_t n_node_entries,
                   uint64_t tb_cells, uint64_t spill_rows, uint64_t cells, uint64_t nqm, const sina_hip_align_params *p, uint32_t width,
-                  sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value, const PrunePlan &pp);
+                  sina_hip_align_out *out, uint32_t *out_pos, bool want_dbg_value, const PrunePlan &pp,
+                  const uint32_t *chain_ref = nullptr);
 // What a launch may skip rows with (api.hip): the scoring of `p` (non-negative gap costs, the simple scheme), the
 // largest and smallest node weight it will see, its longest query.  SINA_HIP_DP_PRUNE=0: never.
 PrunePlan prune_plan(const sina_hip_align_params *p, float wmax, float wmin, uint32_t maxL, bool profile_batch);

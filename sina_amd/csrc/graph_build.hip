@@ -990,6 +990,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
             uint64_t tbc = 0, sprows = 0, cells = 0;
             uint32_t erec_cursor = 0;
             std::vector<QDesc> qd;
+            std::vector<uint32_t> chain_ref;  // per query: its family's first member (the scout's chain, scout.hip)
             while (r1 < bq) {
                 const uint32_t u = dag_of[r1];  // (this query's DAG among the chunk's distinct ones)
                 const uint32_t N = bg.sizes[kSz * u];
@@ -1008,6 +1009,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
                 d.erec_off = erec_cursor;
                 erec_cursor += dp_edge_entries(N);
                 qd.push_back(d);
+                chain_ref.push_back(fam_ids[fam_off[q0 + r1]]);
                 tbc += (uint64_t)N * Lp;
                 sprows += d.n_spill;
                 cells += (uint64_t)N * d.L;
@@ -1021,6 +1023,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
                     cells -= (uint64_t)qd[r - r0].N * qd[r - r0].L;
                 }
                 qd.resize(r1r - r0);
+                chain_ref.resize(r1r - r0);
                 r1 = r1r;
             }
             const uint32_t rq = r1 - r0;
@@ -1031,7 +1034,7 @@ int sina_hip_align_families(sina_hip_ctx *c, const uint32_t *fam_ids, const uint
             c->profile_batch = false;  // (device-built DAGs: never a profile)
             c->out_pos_base = qbase - qoff[0];
             if (run_dp_device(c, pl, qd.data(), rq, (uint64_t)n_dags * bg.ncap, tbc, sprows, cells, nqm, p, c->st->width,
-                              out + q0 + r0, out_pos ? out_pos + qbase : nullptr, false, pp))
+                              out + q0 + r0, out_pos ? out_pos + qbase : nullptr, false, pp, chain_ref.data()))
                 return 1;
             r0 = r1;
         }

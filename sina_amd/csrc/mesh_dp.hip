@@ -1008,7 +1008,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                       float *__restrict__ dbg_value, float *spillv, EdgeRec *edgev, uint64_t edge_stride,
                       uint32_t n_strips, DpResult *__restrict__ resv, float ms, float mms, float gp, float gpe, DryArgs dry,
                       const uint2 *__restrict__ reachv, float prune_rho, uint32_t prune_amax, uint32_t n_slots,
-                      const float *__restrict__ scout_uv, float scout_bias, uint32_t scout_nq) {
+                      const float *__restrict__ scout_uv, float scout_bias) {
     static_assert(B % 4 == 0, "16-byte accesses per array");
     constexpr int kStrip = 64 * B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1065,16 +1065,15 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         const uint32_t g0 = g_cols < g_len ? g_cols : g_len;
         gain0 = (float)g0 * kPruneUnit;
         U64 = -(int32_t)uniform((uint32_t)(int32_t)(prune_rho * (float)g0));  // (rounded towards zero: the looser side)
-        // ... or, better than any guess, what the scout pass found: the cost of a real path of THIS query (scout.hip;
-        // the smaller of its two sweeps' values), rounded up to a unit.  (Beyond +-1e5 the units leave float32's exact
+        // ... or, better than any guess, what the scout pass found: the cost of a real path of THIS query (scout.hip:
+        // its alignment against the chain of its nearest relative), rounded up to a unit.  (Beyond +-1e5 the units leave float32's exact
         // integers: the guess stands.)  The store's guess stays as a guard, six per cent looser than it is used alone:
-        // a scout that lost the optimum (a path found, but a poor one: one query in a few hundred) would have its query
-        // sweep twice the rows of the others, and a launch ends with its slowest wave.  If the guard is too bold for
+        // a scout that lost the query (a long gap its relative does not share: a path found, but a poor one) would have
+        // its query sweep twice the rows of the others, and a launch ends with its slowest wave.  If the guard is too bold for
         // this query -- a query much further from its family than the store's others -- the first attempt dies early
         // and cheaply, and the second runs under the scout's value (below).
         if (scout_uv != nullptr) {
-            const float su = fminf(__uint_as_float(uniform(__float_as_uint(scout_uv[qi]))),
-                                   __uint_as_float(uniform(__float_as_uint(scout_uv[scout_nq + qi])))) + scout_bias;  // (bias: a test hook, 0)
+            const float su = __uint_as_float(uniform(__float_as_uint(scout_uv[qi]))) + scout_bias;  // (bias: a test hook, 0)
             if (su > -100000.0f && su < 100000.0f) {
                 const float up = su * 64.0f;
                 int32_t u = (int32_t)up;
@@ -2287,7 +2286,7 @@ int launch_tb(bool weighted, bool forbid, const DpArgs &a, uint32_t nq, uint32_t
         if (allow_full_lds(reinterpret_cast<const void *>(kfn))) return 1;
         hipLaunchKernelGGL(kfn, dim3(nq), dim3(64), lds, s, a.qd, a.order, a.rec, a.pred, a.qmask, a.tb, a.dbg_value, a.spill,
                            a.edge, a.edge_stride, n_strips, a.res, a.ms, a.mms, a.gp, a.gpe, a.dry, a.reach, a.prune_rho,
-                           a.prune_amax, (uint32_t)(lds / dp_slot_bytes(DpGeom{64 * (int)n_strips, B})), prune ? a.scout_u : nullptr, a.scout_bias, a.scout_nq);
+                           a.prune_amax, (uint32_t)(lds / dp_slot_bytes(DpGeom{64 * (int)n_strips, B})), prune ? a.scout_u : nullptr, a.scout_bias);
     } else if (!weighted && !forbid && a.below_init) SH_LAUNCH(false, false, true);
     else if (!weighted && !forbid) SH_LAUNCH(false, false, false);
     else if (weighted && !forbid) SH_LAUNCH(true, false, false);

@@ -3,25 +3,31 @@
 // The certified row skip of mesh_dp_simple_kernel (mesh_dp.hip) needs a number U that the optimum's
 // value does not exceed: rows that provably hold no cell of a path ending at U or below are not swept, and the
 // tighter U, the fewer are.  Until round 5 U was a guess -- one ratio optimum / bound per store, learnt from the
-// launches before, aimed below the smallest ratio seen: 3 % more rows than the queries' own optima would need on the
-// bench's homogeneous queries, and everybody's band as wide as the most distant query's on mixed input.  Any REAL
-// path's cost is a valid U.  This kernel finds one per query: the same recurrence (mesh.h:307-374, the reference's
-// operators and tie rules, as restated in mesh_dp.hip) over a band of K query columns per DAG row, the band
-// re-centred, row by row, on the column where the best predecessor row has its minimum; cells outside a row's band
-// count as unreached (1e6, the reference's own initial value, mesh.h:290).  What comes out is the value of a path
-// the full mesh also contains -- on the bench's queries (3 % substitutions, indels) and on queries four times as
-// distant it IS the optimum, bit for bit, already at K = 8 (tools/scout_study.py).  Nothing depends on that: the
-// skipping kernel certifies its result against U whatever U is, and sweeps again if the certificate fails.
+// launches before, aimed below the smallest ratio seen.  Any REAL path's cost is a valid U, and a query's own.
 //
-// How it maps to the hardware: ONE LANE PER QUERY.  A band of 16 cells per row is a dozen instructions per cell
-// -- as a wave per query it would be 3000 rows x 200 wave-instructions of mostly idle lanes (a tenth of the main
-// sweep); a lane per query shares every instruction among 64 queries: 150 waves for a 9216-query launch, a per
-// cent of the main kernel's instruction issue.  The price is latency -- a row is a chain of dependent loads (row
-// record -> predecessor headers -> predecessor bands, each lane its own addresses) -- which nobody waits for: the
-// kernel runs on the context's own stream beside the device-filling kernels of the other batches in flight, like
-// the lane walk of the trace-back (mesh_dp.hip backtrack_lanes_kernel).  Finished rows go to a scratch array in
-// HBM (header {band start, column of the minimum, minimum} + K values + K gapm values: 144 bytes per row at
-// K = 16), read back by their successors at whatever offset the two bands have to each other.
+// The path: the query against the CHAIN of its family's first member -- the reference famfinder ranked first, the
+// query's nearest relative by shared k-mers.  Every member of a family is a path through the family's DAG (its
+// bases' nodes, consecutive ones linked: mseq.cpp:47-118), so the query's banded alignment against that chain, scored
+// with the DAG's node weights and the reference's operators (mesh.h:307-374 restricted to one predecessor per row),
+// is the cost of a path the full mesh also contains.  It is not the optimum: where the query differs from its
+// nearest relative and another member agrees with it, the DAG's best path gains what the chain's path loses -- 50 to
+// 100 units of a 4000-unit optimum on the bench's queries (tools/scout_study.py), a fifth of what the store-wide
+// guess leaves.  Nothing depends on how good it is: the skipping kernel certifies its result against U whatever U
+// is, the store's guess stays as a guard against a chain that lost the query (a long gap the relative does not
+// share), and a failed certificate costs a second sweep, never a different result.
+//
+// Round 6 first built the obvious scout -- the same band swept over the whole DAG, re-centred row by row on the
+// best predecessor's minimum (credited for the bases it is behind) -- which finds the optimum ITSELF for 64 of 64
+// bench queries (profiles/history/r06_scout_dag_band.hip.txt).  Measured and dropped: a row of the DAG is a chain of
+// dependent scattered loads (its predecessors' bands, 64 different cache lines per instruction with a lane per
+// query), 30 ms per launch at 16 columns; the waves doing it take the registers of two of a SIMD's three DP waves for
+// as long; in the pipeline the rows saved (0.435 -> 0.376) bought nothing and everything beside it ran a sixth slower
+// (258 k -> 215 k sequences/s).  The chain needs no memory for rows at all -- one predecessor, the row before, in
+// registers -- and half the rows.
+//
+// How it maps to the hardware: ONE LANE PER QUERY, 64 queries per wave, 144 waves for a 9216-query launch; the band
+// (16 columns) and the previous row in registers; per row one packed base of the member, the DAG rows of its column
+// (node_pos, row record: a merge walk, the DAG is in column order) and, every fourth row, a word of query bases.
 #include <algorithm>
 
 #include "common.h"
@@ -32,103 +38,83 @@ namespace {
 
 constexpr float kScoutDead = 1000000.0f;  // "unreached": the reference's initial cell value (mesh.h:290)
 
-typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load at a 4-byte aligned address
-
-constexpr int kScoutRing = 32;  // rows whose headers {band start, column of the minimum, minimum} are kept in LDS
-
 template <int K>
-__global__ void __launch_bounds__(64) mesh_scout_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ orderv,
-                                                        const uint4 *__restrict__ recv, const uint32_t *__restrict__ predv,
-                                                        const uint8_t *__restrict__ qmaskv, float *scratch,
-                                                        uint32_t Lp, uint32_t nq, float ms, float mms, float gp, float gpe,
-                                                        float *__restrict__ out_u, uint64_t rows_total) {
+__global__ void __launch_bounds__(64) chain_scout_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict__ orderv,
+                                                         const uint4 *__restrict__ recv, const uint32_t *__restrict__ node_posv,
+                                                         const uint8_t *__restrict__ qmaskv, const uint32_t *__restrict__ ref_ab,
+                                                         const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ chain_ref,
+                                                         uint32_t nq, float ms, float mms, float gp, float gpe,
+                                                         float *__restrict__ out_u) {
     static_assert(K % 4 == 0 && K >= 8 && K <= 32, "band width");
-    constexpr int kRow = 4 + 2 * K;  // floats per stored row
-    // headers of the last kScoutRing rows of every lane's query: what a row needs of its predecessors BEFORE it can
-    // ask for their bands (where its own band goes, at which offset theirs lie) comes out of LDS, not out of a
-    // second round trip to memory -- a row is one round trip: the predecessors' bands
-    __shared__ uint2 ring[kScoutRing][64];
-    const int lane = threadIdx.x;
-    // Two sweeps per query, in different waves: they differ in how much a predecessor row that is AHEAD in the query
-    // is held back when a row chooses whom to follow (below) -- 0.5 and 0.9 of the sweep's own gain per base.  Either
-    // value is the cost of a real path; the skipping kernel takes the smaller.  (One setting loses the optimum behind
-    // a long gap early in the query, the other one on a stretch of weak matches: tools/scout_study.py.)
-    const uint32_t blocks_per_sweep = (nq + 63u) / 64u;
-    const uint32_t variant = blockIdx.x / blocks_per_sweep;
-    const float rate_frac = variant ? 0.9f : 0.5f;
-    const uint32_t slot = (blockIdx.x - variant * blocks_per_sweep) * 64u + threadIdx.x;
+    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
     if (slot >= nq) return;
     const uint32_t qi = orderv[slot];  // (longest first: the lanes of a wave run about equally long)
     const QDesc d = qdv[qi];
     const uint32_t N = d.N, L = d.L;
     const uint4 *__restrict__ rec = recv + d.node_off;
-    const uint32_t *__restrict__ pred = predv + d.edge_off;
-    // (rows of this query: the launch's trace-back rows are numbered the same way, tb_off = rows before it * Lp;
-    // K + 8 floats of slack in front of the array: a band read at an offset may start before its row.  NOT
-    // restrict: a row is written and, a row later, read through this one pointer)
-    float *rows = scratch + (K + 8) + ((size_t)variant * rows_total + (size_t)(d.tb_off / Lp)) * kRow;
+    const uint32_t *__restrict__ node_pos = node_posv + d.node_off;
+    const uint32_t member = chain_ref[qi];
+    const uint64_t b0 = ref_off[member], b1 = ref_off[member + 1];
     const int c_max = L > (uint32_t)K ? (int)(L - (uint32_t)K) : 0;
+    const float credit = (float)d.gmin * kPruneUnit;  // the smallest "best gain of a column" of this DAG
 
     float best = __builtin_inff();
-    int c_prev = 0;
-    const float credit = (float)d.gmin * kPruneUnit;  // the smallest "best gain of a column" of this DAG
-    float last_v = 0.f;  // the row before: value and column of its (credited) minimum
-    int last_a = 0;
-    // row record and first four predecessor entries, fetched a row ahead (they do not depend on the sweep)
-    uint4 r = rec[0];
-    uint4 pe4 = *reinterpret_cast<const uint4 *>(pred + (r.x & ~3u));
-    for (uint32_t m = 0; m < N; ++m) {
-        const uint4 r_next = rec[m + 1 < N ? m + 1 : m];
-        const uint32_t npred = r.z & 0xffu, mmask = (r.z >> 8) & 0xfu;
+    float pv[K], pg[K];  // the row before: value and gapm_val of its band
+#pragma unroll
+    for (int k = 0; k < K; k++) pv[k] = pg[k] = kScoutDead;
+    int c = 0;          // band start of the row before
+    int a_rel = K / 2;  // ... and where in its band its (credited) minimum sat
+    bool have_prev = false;
+    uint32_t m = 0;  // merge cursor into the DAG's rows (column order)
+    // query mask bytes [w_at, w_at + 4 (K/4 + 1)) as words, reloaded when the band leaves them
+    uint32_t w[K / 4 + 1];
+#pragma unroll
+    for (int i = 0; i <= K / 4; i++) w[i] = 0u;
+    uint64_t w_at = ~(uint64_t)0 - 16;
+    for (uint64_t bi = b0; bi < b1; ++bi) {
+        const uint32_t ab = ref_ab[bi];
+        const uint32_t col = ab & 0xFFFFFFu, bmask = (ab >> 24) & 31u;
+        // ---- the member's node: the DAG row of this column that carries this character (mseq.cpp:83-100)
+        while (m < N && node_pos[m] < col) ++m;
+        uint32_t row = m;
+        uint4 r = rec[row < N ? row : 0];
+        while (row < N && ((r.z >> 8) & 31u) != bmask) {
+            ++row;
+            if (row < N) r = rec[row];
+        }
+        if (row >= N || node_pos[row] != col) break;  // (cannot happen for a member of the family: give up, keep what was found)
+        const uint32_t mmask = (r.z >> 8) & 0xfu;
         const float wgt = __uint_as_float(r.y);
         const float vM = ms * wgt, vX = mms * wgt;  // scoring_schemes.h:154
-        // predecessor e of this row (the first few out of the words fetched ahead)
-        const uint32_t pb = r.x;
-        auto pred_id = [&](uint32_t e) -> uint32_t {
-            const uint32_t at = (pb & 3u) + e;
-            const uint32_t w = at == 0 ? pe4.x : (at == 1 ? pe4.y : (at == 2 ? pe4.z : (at == 3 ? pe4.w : pred[pb + e])));
-            return w & 0xffffu;
-        };
-        // header of predecessor row p: {band start | column of its minimum << 16, minimum}
-        auto header = [&](uint32_t p) -> uint2 {
-            if (m - p <= (uint32_t)kScoutRing) return ring[p % kScoutRing][lane];
-            const float4_u h = *reinterpret_cast<const float4_u *>(rows + (size_t)p * kRow);
-            return uint2{(uint32_t)__float_as_int(h.x) | ((uint32_t)__float_as_int(h.y) << 16), __float_as_uint(h.z)};
-        };
-        // ---- where the band goes: a diagonal step behind the "minimum" of the predecessor row to follow.  Rows that
-        // have consumed different numbers of query bases do not compare by value alone: behind a long gap of the query
-        // (a family member with the same gap gives the DAG an edge across it) the rows just above hold cells that went
-        // on matching the query against the gap's columns -- lower values, a worse path.  Each candidate is credited
-        // with what the bases it is behind would gain at a fraction of the rate the sweep has gained so far.
-        int c = c_prev;
-        if (npred != 0) {
-            const float rate = rate_frac * fmaxf(0.f, -last_v) / fmaxf(1.f, (float)last_a);
-            float bv = __builtin_inff();
-            int ba = 0;
-            for (uint32_t e = 0; e < npred; ++e) {
-                const uint2 h = header(pred_id(e));
-                const int a = (int)(h.x >> 16);
-                const float score = __uint_as_float(h.y) + rate * (float)a;
-                if (score < bv) {
-                    bv = score;
-                    ba = a;
-                }
-            }
-            c = ba + 1 - K / 2;
+        // ---- where the band goes: a diagonal step, one column more or less where the minimum has drifted from the
+        // band's middle (the previous row stays in registers: only shifts of 0, 1 and 2 columns are wired)
+        int delta = 0;
+        if (have_prev) {
+            delta = a_rel + 1 - K / 2;
+            delta = delta < 0 ? 0 : (delta > 2 ? 2 : delta);
         }
-        c = c < 0 ? 0 : (c > c_max ? c_max : c);
-        c_prev = c;
-        // ---- match / mismatch score of my K columns against this row (comp(): aligned_base.h:153).  The K mask
-        // bytes from column c on as K/4 + 1 aligned words, shifted into place: a byte load per column would be K
-        // memory instructions of 64 cache lines each -- the kernel is bound by those, not by arithmetic
+        int cn = c + delta;
+        cn = cn > c_max ? c_max : cn;
+        delta = cn - c;
+        c = cn;
+        // ---- match / mismatch score of my K columns against this row (comp(): aligned_base.h:153)
         float csel[K];
         {
             const uint64_t at = d.q_off + (uint64_t)c;  // (the launch's mask array starts on an allocation boundary)
-            const uint32_t sh = ((uint32_t)at & 3u) * 8u;
-            const uint32_t *qw = reinterpret_cast<const uint32_t *>(qmaskv + (at & ~(uint64_t)3));
-            uint32_t w[K / 4 + 1];
+            const uint64_t at4 = at & ~(uint64_t)3;
+            if (at4 != w_at) {
+                const uint32_t *qw = reinterpret_cast<const uint32_t *>(qmaskv + at4);
+                if (at4 == w_at + 4) {  // (the usual step: one word further)
 #pragma unroll
-            for (int i = 0; i <= K / 4; i++) w[i] = qw[i];  // (up to K + 6 bytes past the last query: inside the buffer's slack, DevBuf::reserve)
+                    for (int i = 0; i < K / 4; i++) w[i] = w[i + 1];
+                    w[K / 4] = qw[K / 4];
+                } else {
+#pragma unroll
+                    for (int i = 0; i <= K / 4; i++) w[i] = qw[i];  // (up to K + 6 bytes past the last query: the buffer's slack, DevBuf::reserve)
+                }
+                w_at = at4;
+            }
+            const uint32_t sh = ((uint32_t)at & 3u) * 8u;
 #pragma unroll
             for (int i = 0; i < K / 4; i++) {
                 const uint32_t x = sh ? ((w[i] >> sh) | (w[i + 1] << (32u - sh))) : w[i];
@@ -143,66 +129,44 @@ __global__ void __launch_bounds__(64) mesh_scout_kernel(const QDesc *__restrict_
         }
         const bool col0 = c == 0;  // my cell 0 is query column 0: initial value 1, no match step, no insertion
         float loc[K], gm[K];
-        if (npred == 0) {  // a source row: every cell starts at 1 (init_edge) and stays untouched
+        if (!have_prev) {
+            // the chain's first node: a source row of the DAG starts at 1 everywhere (init_edge); any other row can
+            // be entered for free at column 0 only -- its predecessors are not of the chain
+            const bool source = (r.z & 0xffu) == 0u;
 #pragma unroll
-            for (int k = 0; k < K; k++) loc[k] = gm[k] = 1.0f;
+            for (int k = 0; k < K; k++) loc[k] = gm[k] = (source || (k == 0 && col0)) ? 1.0f : kScoutDead;
         } else {
-            float dv[K], mt[K];
-            // the band of predecessor p at my columns: sv[k] = value[p][c + k - 1], sg[k] = gapm_val[p][c + k]
-            // (loaded at the offset the two bands have to each other; cells outside p's band: unreached)
-            auto load_band = [&](uint32_t p, float (&sv)[K + 1], float (&sg)[K], int &delta) {
-                const float *prow = rows + (size_t)p * kRow;
-                delta = c - (int)(header(p).x & 0xffffu);  // my cell k is the predecessor's cell k + delta
-                delta = delta < -(K + 1) ? -(K + 1) : (delta > K + 1 ? K + 1 : delta);
-                const float *pv = prow + 4 + delta - 1;
-                const float *pg = prow + 4 + K + delta;
+            // the previous row at my columns: sv[k] = value[p][c + k - 1], sg[k] = gapm_val[p][c + k]
+            float sv[K + 1], sg[K];
 #pragma unroll
-                for (int i = 0; i < K / 4; i++) {
-                    const float4_u a = *reinterpret_cast<const float4_u *>(pv + 4 * i);
-                    const float4_u b = *reinterpret_cast<const float4_u *>(pg + 4 * i);
-                    sv[4 * i] = a.x, sv[4 * i + 1] = a.y, sv[4 * i + 2] = a.z, sv[4 * i + 3] = a.w;
-                    sg[4 * i] = b.x, sg[4 * i + 1] = b.y, sg[4 * i + 2] = b.z, sg[4 * i + 3] = b.w;
-                }
-                sv[K] = pv[K];
-            };
-            auto relax = [&](float (&sv)[K + 1], float (&sg)[K], int delta, bool first) {
-#pragma unroll
-                for (int k = 0; k <= K; k++) sv[k] = (uint32_t)(k - 1 + delta) < (uint32_t)K ? sv[k] : kScoutDead;
-#pragma unroll
-                for (int k = 0; k < K; k++) sg[k] = (uint32_t)(k + delta) < (uint32_t)K ? sg[k] : kScoutDead;
-#pragma unroll
-                for (int k = 0; k < K; k++) {
-                    const float v = sv[k + 1] + gp;  // deletion (mesh.h:307-330): open ...
-                    const float g = sg[k] + gpe;     // ... or extend the predecessor's gap
-                    const float cand = v < g ? v : g;
-                    gm[k] = cand;                    // (the LAST predecessor defines gapm)
-                    float mv = sv[k] + csel[k];      // match from (p, s-1) (:360-374)
-                    if (k == 0 && col0) mv = __builtin_inff();
-                    if (first) {
-                        dv[k] = (k == 0 && col0) ? (cand < 1.0f ? cand : 1.0f) : cand;
-                        mt[k] = mv;
-                    } else {
-                        dv[k] = cand < dv[k] ? cand : dv[k];
-                        mt[k] = mv < mt[k] ? mv : mt[k];
-                    }
-                }
-            };
-            // (two predecessors' bands asked for at a time: a row is a wave's LONGEST predecessor list -- 64 queries --
-            // of round trips to memory if they go one by one)
-            for (uint32_t e = 0; e < npred; e += 2) {
-                float sv0[K + 1], sg0[K], sv1[K + 1], sg1[K];
-                int d0 = 0, d1 = 0;
-                const bool two = e + 1 < npred;
-                load_band(pred_id(e), sv0, sg0, d0);
-                if (two) load_band(pred_id(e + 1), sv1, sg1, d1);
-                relax(sv0, sg0, d0, e == 0);
-                if (two) relax(sv1, sg1, d1, false);
+            for (int k = 0; k <= K; k++) {
+                const float d0 = k >= 1 ? pv[k - 1] : kScoutDead;     // delta 0: the previous band's cell k - 1
+                const float d1 = k < K ? pv[k] : kScoutDead;          // delta 1: cell k
+                const float d2 = k + 1 < K ? pv[k + 1] : kScoutDead;  // delta 2: cell k + 1
+                sv[k] = delta == 0 ? d0 : (delta == 1 ? d1 : d2);
             }
 #pragma unroll
-            for (int k = 0; k < K; k++) loc[k] = mt[k] < dv[k] ? mt[k] : dv[k];
+            for (int k = 0; k < K; k++) {
+                const float d0 = pg[k];
+                const float d1 = k + 1 < K ? pg[k + 1] : kScoutDead;
+                const float d2 = k + 2 < K ? pg[k + 2] : kScoutDead;
+                sg[k] = delta == 0 ? d0 : (delta == 1 ? d1 : d2);
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const float v = sv[k + 1] + gp;  // deletion (mesh.h:307-330): open ...
+                const float g = sg[k] + gpe;     // ... or extend the predecessor's gap
+                const float cand = v < g ? v : g;
+                gm[k] = cand;
+                float mv = sv[k] + csel[k];      // match from (p, s-1) (:360-374)
+                float dv = cand;
+                if (k == 0 && col0) {
+                    mv = __builtin_inff();
+                    dv = cand < 1.0f ? cand : 1.0f;
+                }
+                loc[k] = mv < dv ? mv : dv;
+            }
         }
-        // (the next row's predecessor entries: asked for now, needed a row from here)
-        const uint4 pe4_next = *reinterpret_cast<const uint4 *>(pred + (r_next.x & ~3u));
         // ---- the insertion chain (mesh.h:332-358): nothing enters the band from its left
         float fv[K];
         fv[0] = loc[0];
@@ -214,62 +178,40 @@ __global__ void __launch_bounds__(64) mesh_scout_kernel(const QDesc *__restrict_
             fv[k] = ins ? gsx : loc[k];
             e_prev = ins;
         }
-        // ---- publish: the row for its successors, its minimum for their bands, the end-cell candidates
-        // (the row's "minimum": by value plus a credit per query base consumed -- the cells of a row have consumed
-        // different numbers; the credit is the smallest gain a column offers, so a matching step still lowers it)
+        // ---- the row's "minimum" (by value plus a credit per query base consumed: the cells of a row have consumed
+        // different numbers; the credit is the smallest gain a column offers, so a matching step still lowers it),
+        // the end-cell candidates (mesh.h:569-592), and the row becomes the previous one
         float vmin = __builtin_inff(), vcred = __builtin_inff();
-        int amin = c;
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const bool real = (uint32_t)c + (uint32_t)k < L;
             fv[k] = real ? fv[k] : kScoutDead;
             gm[k] = real ? gm[k] : kScoutDead;
             vmin = fv[k] < vmin ? fv[k] : vmin;
-            const float cr = fv[k] + credit * (float)(c + k);
+            const float cr = fv[k] + credit * (float)k;
             if (cr < vcred) {
                 vcred = cr;
-                amin = c + k;
-                last_v = fv[k];
+                a_rel = k;
             }
-            if ((uint32_t)c + (uint32_t)k == L - 1u) best = fv[k] < best ? fv[k] : best;  // rows x the last column (mesh.h:569-575)
+            if ((uint32_t)c + (uint32_t)k == L - 1u) best = fv[k] < best ? fv[k] : best;
+            pv[k] = fv[k];
+            pg[k] = gm[k];
         }
-        if (r.z & kRecSink) best = vmin < best ? vmin : best;  // sink rows x every column (:577-592)
-        last_a = amin;
-        ring[m % kScoutRing][lane] = uint2{(uint32_t)c | ((uint32_t)amin << 16), __float_as_uint(last_v)};
-        float *mine = rows + (size_t)m * kRow;
-        {
-            // (a row's successors are rows of this same lane: its own stores and loads, which the memory pipeline keeps
-            // in order -- no wait, no fence)
-            float4_u h;
-            h.x = __int_as_float(c);
-            h.y = __int_as_float(amin);
-            h.z = last_v;
-            h.w = 0.f;
-            *reinterpret_cast<float4_u *>(mine) = h;
-#pragma unroll
-            for (int i = 0; i < K / 4; i++) {
-                float4_u a, b;
-                a.x = fv[4 * i], a.y = fv[4 * i + 1], a.z = fv[4 * i + 2], a.w = fv[4 * i + 3];
-                b.x = gm[4 * i], b.y = gm[4 * i + 1], b.z = gm[4 * i + 2], b.w = gm[4 * i + 3];
-                *reinterpret_cast<float4_u *>(mine + 4 + 4 * i) = a;
-                *reinterpret_cast<float4_u *>(mine + 4 + K + 4 * i) = b;
-            }
-        }
-        r = r_next;
-        pe4 = pe4_next;
+        if (r.z & kRecSink) best = vmin < best ? vmin : best;
+        have_prev = true;
+        m = row;  // (the next base sits in a later column)
     }
-    out_u[(size_t)variant * nq + qi] = best;
+    out_u[qi] = best;
 }
 
 }  // namespace
 
-size_t scout_scratch_floats(uint64_t tb_rows) { return (size_t)(2 * tb_rows + 2) * (4 + 2 * kScoutBand) + 2 * (kScoutBand + 8); }
-
-// out_u: [2][nq] (the two sweeps' values)
-int launch_mesh_scout(const DpArgs &a, uint32_t nq, uint32_t Lp, uint64_t tb_rows, float *scratch, float *out_u, hipStream_t s) {
-    const uint32_t blocks = 2u * ((nq + 63u) / 64u);
-    hipLaunchKernelGGL((mesh_scout_kernel<kScoutBand>), dim3(blocks), dim3(64), 0, s, a.qd, a.order, a.rec, a.pred, a.qmask,
-                       scratch, Lp, nq, a.ms, a.mms, a.gp, a.gpe, out_u, tb_rows);
+// chain_ref: per query the reference id of its family's first member (device); out_u: [nq]
+int launch_chain_scout(const DpArgs &a, uint32_t nq, const uint32_t *ref_ab, const uint64_t *ref_off,
+                       const uint32_t *chain_ref, float *out_u, hipStream_t s) {
+    const uint32_t blocks = (nq + 63u) / 64u;
+    hipLaunchKernelGGL((chain_scout_kernel<kScoutBand>), dim3(blocks), dim3(64), 0, s, a.qd, a.order, a.rec, a.node_pos,
+                       a.qmask, ref_ab, ref_off, chain_ref, nq, a.ms, a.mms, a.gp, a.gpe, out_u);
     SH_CHECK(hipGetLastError());
     return 0;
 }

@@ -1,6 +1,9 @@
-"""CPU study for the scout pass: a banded copy of the recurrence -- K columns per DAG
-row, re-centred on the best predecessor's minimum -- whose end value is the cost of a real path and serves the
-certified row skip as its bound U.  For a handful of bench-shaped queries: the oracle's optimum V*, the scout's
+"""CPU study for the scout pass.  Two candidates for the bound U of the certified row skip,
+both costs of real paths: (a) scout(): a banded copy of the recurrence over the WHOLE DAG -- K columns per row,
+re-centred on the best predecessor's minimum (a_credit, rate_frac: how rows that have consumed different numbers of
+query bases are compared) -- which finds the optimum itself (built on the GPU, measured, dropped: scout.hip's
+header); (b) chain(): the query against the chain of ONE family member (--chain: members 0, 1, 2), what scout.hip
+does now.  For a handful of bench-shaped queries: the oracle's optimum V*, the scout's
 value at several K, and how wide the run of cells at or below T(m, s) is per row at U = scout (what a single
 band-following sweep would have to hold).  Test infrastructure: uses the oracle.
 
@@ -103,8 +106,49 @@ def scout(g, qmask, K, ms=-2.0, mms=1.0, gp=5.0, gpe=2.0, a_credit=0.0, rate_fra
     return best, c_of
 
 
+def chain(g, fam_member, qmask, ms=-2.0, mms=1.0, gp=5.0, gpe=2.0):
+    """Full (unbanded) pairwise recurrence of the query against the chain of one family member's nodes."""
+    f = np.float32
+    ab = fam_member.packed()
+    key = {(int(p), int(m)): r for r, (p, m) in enumerate(zip(g["pos"], g["mask"]))}
+    nodes = [key[(int(c), int(m) & 31)] for c, m in zip(ab & 0xFFFFFF, (ab >> 24) & 0xff)]
+    L = len(qmask)
+    snk = set(g["snk"].tolist())
+    V = G = None
+    best = np.inf
+    for r, m in enumerate(nodes):
+        w = g["weight"][m]
+        csel = np.where((qmask & g["mask"][m] & 0xf) != 0, f(ms * w), f(mms * w)).astype(np.float32)
+        if r == 0:
+            src = g["pred_off"][m] == g["pred_off"][m + 1]
+            loc = np.ones(L, np.float32) if src else np.full(L, DEAD, np.float32)
+            loc[0] = 1.0
+            gm = loc.copy()
+        else:
+            v, gg = V + f(gp), G + f(gpe)
+            gm = np.where(v < gg, v, gg)
+            mv = np.concatenate([[np.inf], V[:-1] + csel[1:]]).astype(np.float32)
+            dv = gm.copy()
+            dv[0] = min(gm[0], 1.0)
+            loc = np.where(mv < dv, mv, dv)
+        fv = loc.copy()
+        e_prev = fv[0] == 1.0
+        for k in range(1, L):
+            gsx = f(fv[k - 1] + (gpe if e_prev else gp))
+            ins = gsx <= loc[k]
+            if ins:
+                fv[k] = gsx
+            e_prev = bool(ins)
+        V, G = fv, gm
+        best = min(best, fv[L - 1])
+        if m in snk:
+            best = min(best, fv.min())
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--chain", action="store_true", help="the chain of family members 0, 1, 2 instead of the DAG band")
     ap.add_argument("--refs", type=int, default=20000)
     ap.add_argument("--queries", type=int, default=6)
     ap.add_argument("--length", type=int, default=1500)
@@ -139,6 +183,9 @@ def main():
         r = (L - 1 - np.arange(L)).astype(np.float64)
         Tm = np.minimum(amax * r[None, :], R[:, None] - gmin * np.maximum(0.0, C[:, None] - r[None, :]))
         line = "query %d: N %d L %d  V* %.2f |" % (qi, N, L, vstar)
+        if a.chain:
+            print(line + "  chain of member 0 / 1 / 2: U - V* = " + " / ".join("%.1f" % (chain(g, fam[j], qmask) - vstar) for j in (0, 1, 2)), flush=True)
+            continue
         for K in (8, 16, 32):
             u, c_of = scout(g, qmask, K)
             alive = val <= u + Tm
