@@ -281,7 +281,15 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     a.scout_u = nullptr;
     a.scout_bias = (float)atof(test_knob("scout_add").c_str());
     c->last_scout = false;
-    if (chain_ref != nullptr && pp.on && !rho_fixed && a.below_init && a.gp >= a.gpe && pl.geom.T > 64 && test_knob("scout") != "0") {
+    if (const std::string fixed = test_knob("scout_set"); !fixed.empty() && pp.on && !rho_fixed) {
+        // (test hook: every query's scout value is this number -- lets a caller-built DAG, which has no family to take
+        // a chain from, run under a chosen bound: tests/test_gpu_prune.py)
+        std::vector<float> vals(bq, (float)atof(fixed.c_str()));
+        if (c->scout_u.reserve(4 * (size_t)bq)) return 1;
+        if (upload(c, 7, c->scout_u.p, vals.data(), 4 * (size_t)bq, s)) return 1;
+        a.scout_u = c->scout_u.as<float>();
+        c->last_scout = true;
+    } else if (chain_ref != nullptr && pp.on && !rho_fixed && a.below_init && a.gp >= a.gpe && pl.geom.T > 64 && test_knob("scout") != "0") {
         if (c->scout.reserve(4 * (size_t)bq) || c->scout_u.reserve(4 * (size_t)bq)) return 1;
         if (upload(c, 7, c->scout.p, chain_ref, 4 * (size_t)bq, s)) return 1;
         SH_CHECK(hipEventRecord(c->ev[3], s));

@@ -26,7 +26,7 @@ void set_error(const std::string &msg);
 //   SINA_HIP_CHAIN=0|1                   chained launches off / on under a counter-collecting profiler (ctx.h)
 //   SINA_HIP_NO_RUNTIME_DEFAULTS         the load-time constructor leaves the process environment alone (api.hip)
 //   SINA_HIP_TRACE_ALLOC                 one line per device / pinned allocation
-//   SINA_HIP_TEST="key=value;..."        test hooks (tests/ only): geom=T,B  generic=1  dense_div=N  lds_kb=N  rho=X  kmer_rows=1  bt_lanes=0/1  scout=0  scout_add=X
+//   SINA_HIP_TEST="key=value;..."        test hooks (tests/ only): geom=T,B  generic=1  dense_div=N  lds_kb=N  rho=X  kmer_rows=1  bt_lanes=0/1  scout=0  scout_add=X  scout_set=X
 // The experiment switches of rounds 1-4 (SINA_HIP_SERIALIZE, _DP_BURST, _GRAPH_DRY, _BT_ON_FIFO, _STREAM_PRIO,
 // _SHARE_DAGS, _DP_ROUNDS, _DEBUG_SYNC) exist only in a build made with -DSINA_EXPERIMENTS
 // (make -C sina_amd/csrc VARIANT=exp EXTRA=-DSINA_EXPERIMENTS): the production library does not look at them.

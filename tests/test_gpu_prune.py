@@ -300,3 +300,44 @@ def test_row_skip_partial_queries_equal_oracle(oracle, monkeypatch, frac, rho, l
         pl.close()
     finally:
         st.close()
+
+
+def _bench_like_cases(oracle, n):
+    refs = synth.make_refs(1200, length=1500, width=50000, seed=91)
+    qs = synth.make_queries(refs, n, seed=92)
+    cs = util.cseqs_from_refs(refs)
+    idx = oracle.Index(cs, k=10)
+    for qi in range(n):
+        q = util.query_cseq(qs, qi)
+        ids, sc, _ = idx.famfinder(q, oracle.ff_opts())
+        fam = [cs[i] for i in ids]
+        yield fam, q, (q.packed() >> 24).astype(np.uint8), refs.width
+
+
+@pytest.mark.parametrize("slack", [0.0, 60.0, 1500.0, -30.0])
+def test_scout_value_planes_equal_oracle(oracle, gpu_ctx, monkeypatch, slack):
+    """Full-length 16S queries whose scout value is forced (SINA_HIP_TEST=scout_set) to the optimum plus a slack --
+    exact (0), what the chain scout leaves (60), very loose (1500) and refuted (-30: below the optimum, the certificate
+    fails and the query is swept again under what the first attempt found).  Whatever the value, every cell at or
+    below the bound the final attempt used is the oracle's (value bits, value_midx, value_sidx), every other cell above
+    its bound, and the tighter the value the fewer rows are swept."""
+    swept = 0
+    for fam, q, qm, width in _bench_like_cases(oracle, 4):
+        cells = oracle.mesh_compute(fam, q, oracle.align_opts())
+        g = util.graph_dict(fam)
+        gb = gpu_ctx.graph_batch([g], width)
+        util.set_knobs(monkeypatch, scout_set=None)
+        vm, vs, val = gpu_ctx.debug_mesh(gb, qm, gpu_ctx.params(), prune=True)
+        base = gpu_ctx.dp_info(0)
+        optimum = base["raw"]
+        util.set_knobs(monkeypatch, scout_set=repr(float(optimum) + slack))
+        vm, vs, val = gpu_ctx.debug_mesh(gb, qm, gpu_ctx.params(), prune=True)
+        info, alive = _check_planes(gpu_ctx, cells, vm, vs, val)
+        assert util.f32_bits(np.float32(info["raw"])) == util.f32_bits(np.float32(optimum))
+        if slack in (0.0, 60.0):
+            assert info["attempts"] == 1
+            assert info["rows_swept"] <= base["rows_swept"], (info["rows_swept"], base["rows_swept"])
+        if slack == -30.0:
+            assert info["attempts"] == 2
+        swept += info["rows_swept"]
+    util.set_knobs(monkeypatch, scout_set=None)
