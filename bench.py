@@ -61,6 +61,9 @@ def parse():
                     help="fraction of every step's queries that repeat another query of the same step (amplicon-like "
                          "input; identical queries of a batch are searched and aligned once).  Default 0: the headline "
                          "workload has no repeats")
+    ap.add_argument("--divergence-mix", action="store_true",
+                    help="queries at 0.5 / 3 / 10 / 20 %% substitutions (indels in proportion), interleaved: every launch "
+                         "mixes near-identical and distant queries (default: 3 %% throughout, the headline workload)")
     ap.add_argument("--confined-cpus", type=int, default=2,
                     help="N = 1 only: after the timed region the same number of steps runs once more with every thread of "
                          "the process confined to this many CPUs (an 8-rank node inside a 16-CPU quota leaves a rank two) "
@@ -268,7 +271,8 @@ def main():
     prime_n = a.sub_batch * 2 * max(1, a.inflight)
     n_q = a.batch * (a.steps + a.warmup + 1) + prime_n
     window = (1.0 / 3.0, a.window) if a.window else None
-    qs = synth.make_queries(refs, n_q, seed=3 + 1000 * rank, window=window)
+    mix = dict(sub=[0.005, 0.03, 0.10, 0.20], dele=[0.001, 0.005, 0.015, 0.03], ins=[0.001, 0.003, 0.01, 0.02]) if a.divergence_mix else {}
+    qs = synth.make_queries(refs, n_q, seed=3 + 1000 * rank, window=window, **mix)
     if a.dup_rate > 0:
         qs = synth.with_repeats(qs, a.dup_rate, a.batch, seed=17 + rank)
 
@@ -440,26 +444,28 @@ def main():
     achieved = DP_BYTES_PER_CELL * dp_cells_swept / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
 
     # HBM bytes per DP launch from the PMC passes of this same command (tools/prof_bench.sh ->
-    # profiles/r05_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), and the DP kernel's VALU
-    # wave-instructions per COMPUTED cell from its SQ pass (tools/prof_dp_pmc.sh -> profiles/r05_dp_valu.json);
+    # profiles/r06_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), and the DP kernel's VALU
+    # wave-instructions per COMPUTED cell from its SQ pass (tools/prof_dp_pmc.sh -> profiles/r06_dp_valu.json);
     # both only if they were recorded on this kernel source revision, else null
     dp_kernel_name = "mesh_dp_simple_kernel"  # (SINA defaults: simple scheme, gap_open >= gap_extend; mesh_dp.hip)
     dp_traffic, traffic_note = None, "no PMC profile recorded for this kernel source + configuration"
+    other_traffic = {}
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r06_traffic.json")))
         meta = tj.get("_meta", {})
         if (meta.get("kernel_source_rev") == kernel_source_rev() and meta.get("batch") == a.batch and
                 meta.get("sub_batch") == a.sub_batch and meta.get("refs") == a.refs and
                 meta.get("length") == a.length and meta.get("window") == a.window):
             dp_traffic = tj[dp_kernel_name]["hbm_bytes"]
+            other_traffic = {k: tj[k] for k in ("family_graph_kernel", "kmer_count_kernel") if k in tj}
             traffic_note = ("HBM bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from the separate "
-                            "--pmc passes of this same command recorded in profiles/r05_traffic.json (same kernel "
+                            "--pmc passes of this same command recorded in profiles/r06_traffic.json (same kernel "
                             "source revision and configuration as this run; not measured by this run)")
     except Exception:
         pass
     valu_per_cell = None
     try:
-        vj = json.load(open(os.path.join(ROOT, "profiles", "r05_dp_valu.json")))
+        vj = json.load(open(os.path.join(ROOT, "profiles", "r06_dp_valu.json")))
         if vj.get("kernel_source_rev") == kernel_source_rev():
             valu_per_cell = float(vj["valu_wave_instructions_per_cell"])
     except Exception:
@@ -511,7 +517,7 @@ def main():
                                 ("configs[3] shape: full-length 16S, large reference" if a.refs >= 400000 else
                                  "configs[1]: full-length 16S")),
                                a.length, (", cut to %d" % a.window) if a.window else "", a.refs, a.width),
-                "refs": a.refs, "length": a.length, "width": a.width, "window": a.window, "dup_rate": a.dup_rate,
+                "refs": a.refs, "length": a.length, "width": a.width, "window": a.window, "dup_rate": a.dup_rate, "divergence_mix": bool(a.divergence_mix),
                 "queries_per_step_per_gpu": a.batch,
                 "queries_per_launch": a.sub_batch,
                 "inflight_batches": a.inflight,
@@ -545,8 +551,13 @@ def main():
                     "second_attempts": s1["dp_second_attempts"] - s0["dp_second_attempts"],
                     "full_sweeps": s1["dp_full_sweeps"] - s0["dp_full_sweeps"],
                     "guess_rho": s1["dp_prune_rho"],
+                    "scout_launches": s1["scout_launches"] - s0["scout_launches"],
+                    "scout_ms_per_launch": ((s1["scout_ms"] - s0["scout_ms"]) / (s1["scout_launches"] - s0["scout_launches"])
+                                            if s1["scout_launches"] > s0["scout_launches"] else 0.0),
                     "what": "certified-exact: a (row, 512-column strip) is swept only if a cell in it can still lie on a "
-                            "path ending at or below the query's bound U (value <= U + bound on the gain still to come); "
+                            "path ending at or below the query's bound U (value <= U + bound on the gain still to come; U = "
+                            "the cost of the query's alignment against the chain of its family's first member -- the scout "
+                            "pass, a real path of the mesh -- guarded by the store's learnt guess); "
                             "certificate: the end cell found has value <= U, else the query is swept again (second_attempts: "
                             "under the bound the first attempt found; full_sweeps: without one).  cells_computed counts "
                             "every sweep; results are bit-identical to the full sweep (tests/test_gpu_prune.py, verify)",
@@ -588,31 +599,33 @@ def main():
                         "per wave-instruction and SIMD, it takes ~2.4 -- the rest is dependency stalls and scalar work that "
                         "three waves per SIMD do not hide (DESIGN.md 3.1, 8)",
             },
-            # the other device-filling kernels against the same HBM roofline (SURVEY 8d's algorithmic bytes): the DAG build
-            # -- the families' packed bases read once, the DAGs written once -- and the k-mer count -- 4 B per posting of
-            # the query's k-mers + the int16 score row cleared and read (2 x 2 B per reference)
+            # the other device-filling kernels against the HBM roofline: what they MOVE (FETCH_SIZE x2 + WRITE_SIZE of the
+            # PMC passes recorded on this kernel source revision, profiles/r06_traffic.json; null without such a record)
+            # over their time alone (the untimed step with one batch in flight) -- a fraction of what the memory system can
+            # deliver, never above 1.  SURVEY 8d's algorithmic bytes are reported beside it: the k-mer count moves LESS than
+            # those (dense lists are read as bitmaps, the score rows never leave LDS), the DAG build more (2.3 x).  Both are
+            # bound by instruction issue, not bytes.
             "roofline_other": {
-                "family_graph_kernel": (lambda b, ms: None if ms <= 0 else {
-                    "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": b / (ms * 1e-3) / 1e9,
-                    "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b / max(1, s1["graph_launches"] - s0["graph_launches"]),
-                    "ms_per_launch": ms / max(1, s1["graph_launches"] - s0["graph_launches"]),
-                    "note": "bound by instruction issue (integer / LDS-atomic work in barrier-separated phases, four workgroups per "
-                            "CU: DESIGN 3.3, profiles/r05_graph_sq_counters.txt), not by bytes; this is its start-to-end time in "
-                            "the chained pipeline, where the build starts in the DP launch's drain -- "
-                            "kernels_ms_per_step_isolated has it alone"})(
-                    s1["graph_bytes"] - s0["graph_bytes"], s1["graph_ms"] - s0["graph_ms"]),
-                "kmer_count_kernel": (lambda b, ms: None if ms <= 0 else {
-                    "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": b / (ms * 1e-3) / 1e9,
-                    "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_launch": b / max(1, s1["kmer_launches"] - s0["kmer_launches"]),
-                    "ms_per_launch": ms / max(1, s1["kmer_launches"] - s0["kmer_launches"]),
-                    "note": "SURVEY 8d's accounting (4 B per posting of the query's k-mers + 2 x 2 B per reference for the score "
-                            "row); the kernel moves LESS than that -- dense lists are read as bitmaps (n/8 B per list instead "
-                            "of 4 B per posting) and, with candidate lists (stores of 65 536 references and more), the score "
-                            "row never leaves LDS -- so the fraction can exceed 1; measured HBM bytes per launch: "
-                            "profiles/r05_bench_summary.txt (26 GB per 9216 queries at 100 k references); what bounds it is the bitmap path streaming out of the MALL (profiles/r05_kmer_ablation.txt)"})(
-                    4.0 * (s1["postings"] - s0["postings"]) + 4.0 * a.refs * (s1["kmer_queries"] - s0["kmer_queries"]),
-                    s1["kmer_count_ms"] - s0["kmer_count_ms"]),
+                name: (lambda tr, alg, ms_alone, ms_pipe, launches, note: None if launches <= 0 else {
+                    "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                    "measured_bytes_per_launch": tr["hbm_bytes"] if tr else None,
+                    "achieved": (tr["hbm_bytes"] / (ms_alone * 1e-3) / 1e9) if tr and ms_alone > 0 else None,
+                    "frac": (tr["hbm_bytes"] / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr and ms_alone > 0 else None,
+                    "ms_per_launch_alone": ms_alone, "ms_per_launch_in_pipeline": ms_pipe / launches,
+                    "algorithmic_bytes_per_launch": alg / launches,
+                    "algorithmic_over_measured": (alg / launches / tr["hbm_bytes"]) if tr and tr["hbm_bytes"] > 0 else None,
+                    "note": note})(
+                    other_traffic.get(name), alg, ms_alone, ms_pipe, launches, note)
+                for name, alg, ms_alone, ms_pipe, launches, note in (
+                    ("family_graph_kernel", s1["graph_bytes"] - s0["graph_bytes"], iso["graph_ms"] / max(1, iso["graph_launches"]), s1["graph_ms"] - s0["graph_ms"],
+                     s1["graph_launches"] - s0["graph_launches"],
+                     "algorithmic: the families' packed bases read once, the DAGs written once; in the chained pipeline the build "
+                     "starts in a DP launch's drain, so its start-to-end time there is longer than alone"),
+                    ("kmer_count_kernel", 4.0 * (s1["postings"] - s0["postings"]) + 4.0 * a.refs * (s1["kmer_queries"] - s0["kmer_queries"]),
+                     iso["kmer_count_ms"] / max(1, iso["kmer_launches"]), s1["kmer_count_ms"] - s0["kmer_count_ms"], s1["kmer_launches"] - s0["kmer_launches"],
+                     "algorithmic: 4 B per posting of the query's k-mers + 2 x 2 B per reference for the score row; measured bytes are "
+                     "fabric traffic (the bitmaps of dense lists come out of the MALL); VALU at 0.90 of the pipe "
+                     "(profiles/r05_kmer_sq_counters.txt)"))
             },
             "kernels_ms_per_step_isolated": {
                 "kmer_count_kernel": iso["kmer_count_ms"],

@@ -259,10 +259,12 @@ int sina_hip_align_families(sina_hip_ctx *ctx, const uint32_t *fam_ids, const ui
                             uint32_t *out_pos);
 
 /* Test hook: DP planes of ONE query for bit-exact comparison with the oracle.
- * tb_vm/tb_vs: [N*L] value_midx / value_sidx; value: [N*L] float (may be NULL). */
+ * tb_vm/tb_vs: [N*L] value_midx / value_sidx; value: [N*L] float (may be NULL).
+ * prune: 0 = every row of every strip is swept (the planes are the reference's cell for cell), 1 = the launch as
+ * production makes it, certified row skip included (cells it proved irrelevant hold what it left there). */
 int sina_hip_debug_mesh(sina_hip_ctx *ctx, const sina_hip_graph_batch *g, const uint8_t *qmask,
                         uint32_t qlen, const sina_hip_align_params *p, uint32_t *tb_vm,
-                        uint32_t *tb_vs, float *value);
+                        uint32_t *tb_vs, float *value, int prune);
 
 /* Test hooks for the certified row skip: what the DP kernel reported for query q of the context's LAST launch
  * (attempts 0: that launch swept everything), and the first n entries of the per-node bound R(m) the last launch /

@@ -124,7 +124,7 @@ def load():
     L.sina_hip_align_families.argtypes = [vp, u32p, u64p, C.c_uint32, u8p, u64p, C.POINTER(AlignParams),
                                           C.POINTER(AlignOut), u32p]
     L.sina_hip_debug_mesh.argtypes = [vp, C.POINTER(GraphBatch), u8p, C.c_uint32, C.POINTER(AlignParams),
-                                      u32p, u32p, f32p]
+                                      u32p, u32p, f32p, C.c_int]
     L.sina_hip_debug_family_graph.argtypes = [vp, u32p, C.c_uint32, C.c_float, C.c_uint32, u32p, u32p, u32p, u8p,
                                               f32p, u32p, u32p, u32p, u8p, u32p, C.c_uint32, C.c_uint32]
     L.sina_hip_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -325,19 +325,9 @@ class Context:
         vm = np.zeros((n, L), np.uint32)
         vs = np.zeros((n, L), np.uint32)
         val = np.zeros((n, L), np.float32) if want_value else None
-        old = os.environ.get("SINA_HIP_DP_PRUNE")  # (read by the library per launch)
-        if not prune:
-            os.environ["SINA_HIP_DP_PRUNE"] = "0"
-        try:
-            self._check(self.L.sina_hip_debug_mesh(self.h, C.byref(gb), _ptr(qmask, u8p), L, C.byref(params),
-                                                   _ptr(vm, u32p), _ptr(vs, u32p),
-                                                   _ptr(val, f32p) if want_value else None))
-        finally:
-            if not prune:
-                if old is None:
-                    os.environ.pop("SINA_HIP_DP_PRUNE", None)
-                else:
-                    os.environ["SINA_HIP_DP_PRUNE"] = old
+        self._check(self.L.sina_hip_debug_mesh(self.h, C.byref(gb), _ptr(qmask, u8p), L, C.byref(params),
+                                               _ptr(vm, u32p), _ptr(vs, u32p),
+                                               _ptr(val, f32p) if want_value else None, 1 if prune else 0))
         return vm, vs, val
 
     def debug_family_graph(self, fam_ids, fs_weight=1.0, ring_depth=4):

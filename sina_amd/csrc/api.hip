@@ -32,6 +32,7 @@ int plan_dp(sina_hip_ctx *c, uint32_t maxL, DpPlan *pl) {
 // query takes the second attempt; 0.01 = nearly no bound).  Read per launch.
 PrunePlan prune_plan(const sina_hip_align_params *p, float wmax, float wmin, uint32_t maxL, bool profile_batch) {
     PrunePlan pp;
+    if (!std::isfinite(wmax) || !std::isfinite(wmin)) return pp;  // (a NaN weight: no bound holds)
     const char *off = getenv("SINA_HIP_DP_PRUNE");
     if (off && off[0] == '0') return pp;
     if (profile_batch || (p->weights != nullptr && p->n_weights > 0) || p->insertion == SINA_INSERTION_FORBID) return pp;
@@ -250,7 +251,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     a.gpe = p->gap_ext_penalty;
     a.prof16 = c->profile_batch ? c->prof16.as<float>() : nullptr;
     // certified row skip (mesh_dp.hip): the guess the launch's queries start with -- what the store has learnt
-    // from the queries before, or SINA_HIP_DP_PRUNE_RHO
+    // from the queries before, or SINA_HIP_TEST=rho=<x>
     c->last_bq = bq;
     c->last_prune_step = pp.on ? pp.amax : 0u;
     a.reach = pp.on ? c->rgain.as<uint2>() : nullptr;
@@ -440,8 +441,15 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     // The launch's smallest optimum / bound, less a margin: a query whose first bound fails pays a second sweep, and
     // the launch ends with its slowest wave -- one such query among the last to start costs the whole device a sweep's
     // time, so the guess aims at NO failures among queries like the ones seen (a wider band costs a few per cent).
+    // (round 6: the 2 % point of the launch's ratios, not their minimum -- one poorly aligning query among 9216 must not
+    // widen everybody's band; the few below it pay a second sweep.  With the scout pass the guess is only the guard
+    // of the scout's values, six per cent looser still: mesh_dp.hip)
     float rho_seen = -1.f;
-    if (!ratios.empty()) rho_seen = *std::min_element(ratios.begin(), ratios.end()) - 0.015f;
+    if (!ratios.empty()) {
+        const size_t at = ratios.size() / 50;
+        std::nth_element(ratios.begin(), ratios.begin() + (std::ptrdiff_t)at, ratios.end());
+        rho_seen = ratios[at] - 0.015f;
+    }
     std::lock_guard<std::mutex> slk(c->st->stats_mu);
     c->st->stats.dp_ms += ms;
     c->st->stats.dp_busy_ms += ms - shared;
@@ -524,11 +532,14 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         const uint64_t n_all = g->node_off[nq] - g->node_off[0];
         for (uint64_t i = 0; i < n_all; i++) {
             const float w = g->node_weight[g->node_off[0] + i];
+            if (!(w == w)) wmax = wmin = NAN;  // (a NaN compares false both ways and would slip through: it switches the row skip off)
+            if (!(wmax == wmax)) break;
             wmax = (i == 0 || w > wmax) ? w : wmax;
             wmin = (i == 0 || w < wmin) ? w : wmin;
         }
     }
-    const PrunePlan pp = prune_plan(p, wmax, wmin, maxL, g->node_score16 != nullptr);
+    PrunePlan pp = prune_plan(p, wmax, wmin, maxL, g->node_score16 != nullptr);
+    if (c->no_prune) pp.on = 0;  // (sina_hip_debug_mesh, prune = 0)
 
     const uint64_t tb_budget_cells = tb_plane_budget(c) / tb_cell_bytes(forbid);
     HostPrep hp;
@@ -634,6 +645,7 @@ static int align_graphs_impl(sina_hip_ctx *c, const sina_hip_graph_batch *g, con
         }
         q0 = q1;
     }
+    c->dbg_planes = false;  // (only this call's launches were the debug entry's: a later launch must not clear a plane)
     return 0;
 }
 
@@ -837,9 +849,14 @@ int sina_hip_align_graphs(sina_hip_ctx *c, const sina_hip_graph_batch *g, const 
 }
 
 int sina_hip_debug_mesh(sina_hip_ctx *c, const sina_hip_graph_batch *g, const uint8_t *qmask, uint32_t qlen,
-                        const sina_hip_align_params *p, uint32_t *tb_vm, uint32_t *tb_vs, float *value) {
+                        const sina_hip_align_params *p, uint32_t *tb_vm, uint32_t *tb_vs, float *value, int prune) {
     if (!c || !g || g->nq != 1 || !tb_vm || !tb_vs) SH_FAIL("debug_mesh: needs exactly one query");
     std::lock_guard<std::mutex> lk(c->mu);
+    struct no_prune_scope {  // (this call's launches only; the context is locked)
+        sina_hip_ctx *c;
+        ~no_prune_scope() { c->no_prune = false; }
+    } scope{c};
+    c->no_prune = prune == 0;
     const uint64_t qoff[2] = {0, qlen};
     sina_hip_align_out o;
     std::vector<uint32_t> pos(qlen);

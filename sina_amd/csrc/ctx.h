@@ -47,6 +47,10 @@ struct sina_hip_store {
     // what the HIP header documents for that call); dry_mem: the launches' counters of started workgroups, plain memory
     uint32_t *dry_flag = nullptr;
     uint32_t *dry_mem = nullptr;
+    // a launch did not end within kChainTimeoutS: its kernels and wait-value operations are still queued and still
+    // refer to the contexts' buffers.  From then on every launch fails at once, and nothing of the store or its
+    // contexts is freed (hipFree would block on the wedged queue, or a stale kernel would run over reused memory)
+    std::atomic<bool> wedged{false};
     std::atomic<bool> chain_broken{false};  // a chained wait timed out once (heavy_launch::done): launches wait for ends from now on
     static constexpr uint32_t kDryCounters = 64;
     uint32_t heavy_seq = 0;          // launches queued so far (guarded by heavy_mu, like everything below)
@@ -119,6 +123,7 @@ struct sina_hip_ctx {
     bool profile_batch = false;       // the launch being prepared is one (set by sina_hip_align_graphs)
     void *last_tb = nullptr;  // the plane of the last launch (debug read-back: sina_hip_debug_mesh)
     bool dbg_planes = false;  // the launch being prepared is sina_hip_debug_mesh's: its planes are unpacked cell by cell
+    bool no_prune = false;    // ... and it asked for a sweep of every row (sina_hip_debug_mesh, prune = 0)
     bool last_scout = false;  // the last launch's bounds came from the scout pass
     uint32_t last_bq = 0, last_prune_step = 0;  // queries / assumed largest step gain of the last launch (sina_hip_debug_dp_info)
     sina_hip::DevBuf k_qoff, k_scores, k_out_ids, k_out_scores, k_out_n, k_tmp0, k_tmp1, k_tmp2;
@@ -179,6 +184,7 @@ struct sina_hip_ctx {
         return 0;
     }
     void free_all() {
+        if (st && st->wedged.load(std::memory_order_relaxed)) return;  // (see sina_hip_store::wedged: leaked on purpose)
         sina_hip::DevBuf *all[kNumScratch];
         scratch(all);
         for (auto *b : all) b->release();
@@ -363,14 +369,18 @@ constexpr double kChainTimeoutS = 120.0;
 // (timeout_s > 0: gives up with hipErrorNotReady after that long)
 inline hipError_t wait_event(hipEvent_t ev, double timeout_s = 0.0) {
     long ns = 50000;  // 50 us, growing to 1 ms: short waits are answered fast, a 17 ms DP kernel costs ~25 wake-ups
-    double waited = 0.0;
+    timespec t0;
+    if (timeout_s > 0.0) clock_gettime(CLOCK_MONOTONIC, &t0);
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
-        if (timeout_s > 0.0 && waited > timeout_s) return hipErrorNotReady;
+        if (timeout_s > 0.0) {  // (wall time, not the sum of the sleeps asked for)
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s) return hipErrorNotReady;
+        }
         timespec ts{0, ns};
         nanosleep(&ts, nullptr);
-        waited += ns * 1e-9;
         if (ns < 1000000) ns += ns / 2;
     }
 }
@@ -467,6 +477,10 @@ struct heavy_launch {
     heavy_launch(sina_hip_ctx *c_, hipStream_t own_, int kind_ = kHeavyKmer) : c(c_), own(own_), hs(own_), kind(kind_) {
         if (!serialize_kernels() || !c->st->heavy) return;
         sina_hip_store *st = c->st;
+        if (st->wedged.load(std::memory_order_relaxed)) {
+            failed = true;
+            return;
+        }
         failed = hipEventRecord(c->ev[10], own) != hipSuccess;
         lk = std::unique_lock<std::mutex>(st->heavy_mu);
         const bool chain = chain_kernels() && st->heavy2 && st->dry_mem && !st->chain_broken.load(std::memory_order_relaxed);
@@ -553,9 +567,10 @@ struct heavy_launch {
         const hipError_t we = wait_event(c->ev[11], chained ? kChainTimeoutS : 0.0);
         if (we == hipErrorNotReady) {
             c->st->chain_broken.store(true, std::memory_order_relaxed);
+            c->st->wedged.store(true, std::memory_order_relaxed);
             leave();
             set_error("heavy_launch: a chained launch did not end within 120 s -- a tool that serialises kernels across "
-                      "queues? (set SINA_HIP_CHAIN=0); the store waits for launch ends from now on");
+                      "queues? (set SINA_HIP_CHAIN=0); the store takes no further launches, its buffers stay allocated");
             return 1;
         }
         failed = failed || we != hipSuccess;

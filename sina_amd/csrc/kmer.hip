@@ -21,7 +21,9 @@
 //           (reductions over 16-byte loads; an LDS histogram serialises on the few low bins every
 //           lane hits) -> ordered compaction (ties keep the LARGEST ids) -> bitonic sort of the
 //           <= 4096 survivors.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <cstring>
@@ -1003,24 +1005,24 @@ int sina_hip_build_index(sina_hip_ctx *c, unsigned k, int nofast) {
                                c->st->ref_off.as<uint64_t>(), c->st->n_refs, k, nofast == 0, keys_in.as<uint64_t>());
         size_t tb = 0;
         const int end_bit = 32 + 2 * (int)k;
-        if (hipcub::DeviceRadixSort::SortKeys(nullptr, tb, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(),
-                                              (int)n, 0, 64, s) != hipSuccess)
+        // (rocPRIM directly; only the bits a key can have: k-mer << 32 | reference id)
+        if (rocprim::radix_sort_keys(nullptr, tb, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), (size_t)n, 0u,
+                                     (unsigned)end_bit, s) != hipSuccess)
             break;
-        (void)end_bit;
         if (tmp.reserve(tb + 16)) break;
-        if (n && hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(),
-                                                   (int)n, 0, 64, s) != hipSuccess)
+        if (n && rocprim::radix_sort_keys(tmp.p, tb, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), (size_t)n, 0u,
+                                          (unsigned)end_bit, s) != hipSuccess)
             break;
         const unsigned blocks = (unsigned)((n + 255) / 256);
         if (n) hipLaunchKernelGGL(mark_unique, dim3(blocks), dim3(256), 0, s, keys_out.as<uint64_t>(), n,
                                   flag.as<uint32_t>());
         size_t tb2 = 0;
-        if (hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, flag.as<uint32_t>(), pos.as<uint32_t>(), (int)n, s) !=
-            hipSuccess)
+        if (rocprim::exclusive_scan(nullptr, tb2, flag.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)n,
+                                    rocprim::plus<uint32_t>(), s) != hipSuccess)
             break;
         if (tmp.reserve(tb2 + 16)) break;
-        if (n && hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, flag.as<uint32_t>(), pos.as<uint32_t>(), (int)n, s) !=
-                     hipSuccess)
+        if (n && rocprim::exclusive_scan(tmp.p, tb2, flag.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)n,
+                                         rocprim::plus<uint32_t>(), s) != hipSuccess)
             break;
         uint32_t last_flag = 0, last_pos = 0;
         if (n) {
@@ -1042,11 +1044,11 @@ int sina_hip_build_index(sina_hip_ctx *c, unsigned k, int nofast) {
                                flag.as<uint32_t>(), pos.as<uint32_t>(), n, c->st->idx_ids.as<uint32_t>(),
                                counts.as<uint32_t>());
         size_t tb3 = 0;
-        ok = ok && hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, counts.as<uint32_t>(), c->st->idx_off.as<uint32_t>(),
-                                                    (int)(nk + 1), s) == hipSuccess;
+        ok = ok && rocprim::exclusive_scan(nullptr, tb3, counts.as<uint32_t>(), c->st->idx_off.as<uint32_t>(), 0u,
+                                           (size_t)(nk + 1), rocprim::plus<uint32_t>(), s) == hipSuccess;
         ok = ok && tmp.reserve(tb3 + 16) == 0;
-        ok = ok && hipcub::DeviceScan::ExclusiveSum(tmp.p, tb3, counts.as<uint32_t>(), c->st->idx_off.as<uint32_t>(),
-                                                    (int)(nk + 1), s) == hipSuccess;
+        ok = ok && rocprim::exclusive_scan(tmp.p, tb3, counts.as<uint32_t>(), c->st->idx_off.as<uint32_t>(), 0u,
+                                           (size_t)(nk + 1), rocprim::plus<uint32_t>(), s) == hipSuccess;
         ok = ok && hipStreamSynchronize(s) == hipSuccess;
         counts.release();
         if (!ok) break;

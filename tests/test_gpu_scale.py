@@ -266,9 +266,13 @@ def _oracle_run(oracle, cs, idx, qs, qi):
     return r
 
 
-def _pipeline_equals_oracle(oracle, refs, qs, key, min_dp):
-    cs = util.cseqs_from_refs(refs)
-    idx = oracle.Index(cs, k=10)
+def _pipeline_equals_oracle(oracle, refs, qs, key, min_dp, world=None):
+    """world: (cs, idx) of `refs` if the caller has them already (the oracle's index of 100 000 references takes a
+    while to build: two tests share one)."""
+    cs, idx = world if world is not None else (None, None)
+    if cs is None:
+        cs = util.cseqs_from_refs(refs)
+        idx = oracle.Index(cs, k=10)
     st = pipeline.Store(key, refs)
     try:
         st.build_index(10, False)
@@ -312,14 +316,32 @@ def test_23s_vs_33k_references(oracle):
     _pipeline_equals_oracle(oracle, refs, qs, ":mem:23s-33k", min_dp=8)
 
 
-def test_16s_full_length_vs_100k_references(oracle):
-    """configs[1] itself, end to end: 32 full-length 16S queries against the bench's 100 000-sequence reference
-    (synthetic SILVA-NR-like clade model, width 50 000, seed 2 -- what bench.py builds): four reference tiles,
-    dense bitmaps, the three-strip 8-column DP geometry, device DAG build, backtrack, device-side assembly.
-    Family, aligned columns + case bits, head / tail / quality and the full log text equal the oracle's."""
+@pytest.fixture(scope="module")
+def refs_100k(oracle):
+    """The bench's 100 000-sequence reference (synthetic SILVA-NR-like clade model, width 50 000, seed 2 -- what
+    bench.py builds) with the oracle's sequences and index of it: configs[1] and configs[2] both name it."""
     refs = synth.make_refs(100000, length=1500, width=50000, seed=2)
+    cs = util.cseqs_from_refs(refs)
+    return refs, (cs, oracle.Index(cs, k=10))
+
+
+def test_16s_full_length_vs_100k_references(oracle, refs_100k):
+    """configs[1] itself, end to end: 32 full-length 16S queries against the bench's 100 000-sequence reference: four
+    reference tiles, dense bitmaps, the three-strip 8-column DP geometry, device DAG build, scout, backtrack,
+    device-side assembly.  Family, aligned columns + case bits, head / tail / quality and the full log text equal
+    the oracle's."""
+    refs, world = refs_100k
     qs = synth.make_queries(refs, 32, seed=3)
-    _pipeline_equals_oracle(oracle, refs, qs, ":mem:16s-100k", min_dp=30)
+    _pipeline_equals_oracle(oracle, refs, qs, ":mem:16s-100k", min_dp=30, world=world)
+
+
+def test_v4_amplicons_vs_100k_references(oracle, refs_100k):
+    """configs[2] at the reference count it names: 250-base windows (what `bench.py --window 250` cuts) against the
+    same 100 000 references -- one DP strip of four columns per lane, no row skip, the candidate lists of the k-mer
+    search at four tiles."""
+    refs, world = refs_100k
+    qs = synth.make_queries(refs, 48, seed=33, window=(1.0 / 3.0, 250))
+    _pipeline_equals_oracle(oracle, refs, qs, ":mem:v4-100k", min_dp=40, world=world)
 
 
 def test_16s_full_length_vs_500k_references(oracle):
