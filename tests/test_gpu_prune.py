@@ -336,6 +336,7 @@ def test_scout_value_planes_equal_oracle(oracle, gpu_ctx, monkeypatch, slack):
         assert util.f32_bits(np.float32(info["raw"])) == util.f32_bits(np.float32(optimum))
         if slack in (0.0, 60.0):
             assert info["attempts"] == 1
+        if slack == 0.0:     # (no bound is tighter than the optimum itself)
             assert info["rows_swept"] <= base["rows_swept"], (info["rows_swept"], base["rows_swept"])
         if slack == -30.0:
             assert info["attempts"] == 2
