@@ -380,7 +380,7 @@ int launch_mesh_dp(const DpGeom &g, bool weighted, bool forbid, const DpArgs &a,
                    size_t lds_bytes, hipStream_t s);
 // the scout pass (scout.hip): per query the cost of its banded alignment (kScoutBand columns per row) against the chain
 // of its family's first member -- a real path of the mesh, the first attempt's bound U
-constexpr int kScoutBand = 16;
+constexpr int kScoutBand = 8;
 int launch_chain_scout(const DpArgs &a, uint32_t nq, const uint32_t *ref_ab, const uint64_t *ref_off,
                        const uint32_t *chain_ref /* device: [nq] reference ids */, float *out_u /* [nq] */, hipStream_t s);
 int launch_backtrack(const BtArgs &a, hipStream_t s);

@@ -27,4 +27,10 @@ python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --dup-rate 0.5 > $O/ben
 SINA_HIP_CHAIN=0 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --confined-cpus 0 > $O/bench_line_chain0.json 2> $O/bench_chain0.err
 python3 bench.py --steps 20 --warmup 5 > $O/bench_line_plain.json 2> $O/bench_plain.err
 python3 bench.py > $O/bench_line_default.json 2> $O/bench_default.err
+# round 6: the scout pass alone and against the store's guess, a launch that mixes divergences (with and without the scout)
+python3 tools/perf_scout.py 9216 > $O/perf_scout.txt 2>&1
+SINA_HIP_TEST="scout=0" python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --confined-cpus 0 > $O/bench_line_noscout.json 2> $O/bench_noscout.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --confined-cpus 0 --divergence-mix > $O/bench_line_mix.json 2> $O/bench_mix.err
+SINA_HIP_TEST="scout=0" python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --confined-cpus 0 --divergence-mix > $O/bench_line_mix_noscout.json 2> $O/bench_mix_noscout.err
+SINA_HOST_PROFILE=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --confined-cpus 0 > $O/bench_line_hostprof.json 2> $O/host_profile.txt
 ls -la $O
