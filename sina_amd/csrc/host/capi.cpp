@@ -56,7 +56,7 @@ struct result {
     // goes back to its cache with this record's previous block, so neither allocates in steady state).  Until
     // round 5 the sink copied them into an arena of the pipeline's -- the fifth time a query's 6 KB went through
     // a core; what a real sink does with them (format, write) it does from the sequence itself.
-    std::vector<aligned_base> own;
+    base_vector own;
     std::string log;
     // align_family_slv: as text, or as the list famfinder left (rendered by sina_host_result_family; the store is
     // kept alive by the pipeline's stages)
@@ -1161,7 +1161,7 @@ int sina_host_fix_duplicates(uint32_t *ab, uint32_t n, uint32_t width, int lower
                              uint32_t log_cap) {
     try {
         cseq c("");
-        std::vector<aligned_base> v;
+        base_vector v;
         for (uint32_t i = 0; i < n; i++) v.push_back(aligned_base::from_raw(ab[i]));
         c.setAlignedBases(v);
         c.setWidth(width);

@@ -10,7 +10,164 @@
 
 #include <algorithm>
 
+#include <immintrin.h>
+#include <sys/mman.h>
+#include <vector>
+
 namespace sina {
+
+__attribute__((target("avx2"))) static void stream_copy_avx2(unsigned char *d, const unsigned char *s, size_t n) {
+    const size_t head = (32 - (reinterpret_cast<uintptr_t>(d) & 31)) & 31;  // (bytes up to the destination's next 32-byte boundary)
+    if (head) {
+        memcpy(d, s, head);
+        d += head, s += head, n -= head;
+    }
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i + 64));
+        const __m256i e = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(d + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(d + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(d + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(d + i + 96), e);
+    }
+    _mm_sfence();
+    if (i < n) memcpy(d + i, s + i, n - i);
+}
+void stream_copy(void *dst, const void *src, size_t bytes) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (!avx2 || bytes < 1024) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    stream_copy_avx2(static_cast<unsigned char *>(dst), static_cast<const unsigned char *>(src), bytes);
+}
+
+// ---- the pool behind base_block_allocator (cseq.h)
+namespace {
+constexpr size_t kMinClass = 12, kMaxClass = 16;  // 4 KB .. 64 KB
+constexpr size_t kRegion = (size_t)2 << 20;
+struct block_pool {
+    struct depot_t {
+        std::mutex mu;
+        std::vector<void *> free[kMaxClass - kMinClass + 1];
+        unsigned char *region = nullptr;
+        size_t left = 0;
+    };
+    static depot_t &depot() {
+        static depot_t *d = new depot_t();  // (never destroyed: blocks outlive static destruction order)
+        return *d;
+    }
+    struct local_t {
+        std::vector<void *> free[kMaxClass - kMinClass + 1];
+    };
+    // A thread's free lists.  Other thread-local objects (the stages' object caches) free base lists from THEIR
+    // destructors, possibly after this one has run: from then on the thread goes to the depot directly.
+    struct holder {
+        local_t *p = nullptr;
+        bool dead = false;
+        ~holder() {
+            dead = true;
+            if (!p) return;
+            depot_t &d = depot();
+            {
+                std::lock_guard<std::mutex> lk(d.mu);
+                for (size_t c = 0; c <= kMaxClass - kMinClass; c++)
+                    for (void *b : p->free[c]) d.free[c].push_back(b);
+            }
+            delete p;
+            p = nullptr;
+        }
+    };
+    static local_t *mine() {
+        thread_local holder h;
+        if (h.dead) return nullptr;
+        if (!h.p) h.p = new local_t();
+        return h.p;
+    }
+    static size_t class_of(size_t bytes) {
+        size_t c = kMinClass;
+        while (((size_t)1 << c) < bytes) c++;
+        return c;
+    }
+    static void *take(size_t c) {
+        local_t *l = mine();
+        if (l) {
+            auto &f = l->free[c - kMinClass];
+            if (!f.empty()) {
+                void *p = f.back();
+                f.pop_back();
+                return p;
+            }
+        }
+        depot_t &d = depot();
+        std::lock_guard<std::mutex> lk(d.mu);
+        auto &df = d.free[c - kMinClass];
+        if (!df.empty()) {
+            void *p = df.back();
+            df.pop_back();
+            // (a batch at a time: the thread that frees blocks and the one that takes them are rarely the same)
+            if (l)
+                for (int i = 0; i < 63 && !df.empty(); i++) {
+                    l->free[c - kMinClass].push_back(df.back());
+                    df.pop_back();
+                }
+            return p;
+        }
+        const size_t sz = (size_t)1 << c;
+        if (d.left < sz) {
+            void *m = nullptr;
+            if (posix_memalign(&m, kRegion, kRegion) != 0) throw std::bad_alloc();
+            (void)madvise(m, kRegion, MADV_HUGEPAGE);
+            d.region = static_cast<unsigned char *>(m);
+            d.left = kRegion;
+        }
+        void *p = d.region;
+        d.region += sz;
+        d.left -= sz;
+        return p;
+    }
+    static void give(void *p, size_t c) {
+        local_t *l = mine();
+        if (!l) {
+            depot_t &d = depot();
+            std::lock_guard<std::mutex> lk(d.mu);
+            d.free[c - kMinClass].push_back(p);
+            return;
+        }
+        auto &f = l->free[c - kMinClass];
+        f.push_back(p);
+        if (f.size() >= 512) {  // (a thread that only frees: half of its list goes to the depot)
+            depot_t &d = depot();
+            std::lock_guard<std::mutex> lk(d.mu);
+            for (int i = 0; i < 256; i++) {
+                d.free[c - kMinClass].push_back(f.back());
+                f.pop_back();
+            }
+        }
+    }
+};
+}  // namespace
+void *base_block_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    if (bytes > ((size_t)1 << kMaxClass)) {
+        void *p = malloc(bytes);
+        if (!p) throw std::bad_alloc();
+        return p;
+    }
+    return block_pool::take(block_pool::class_of(bytes));
+}
+void base_block_free(void *p, size_t bytes) {
+    if (p == nullptr) return;
+    if (bytes == 0) bytes = 1;
+    if (bytes > ((size_t)1 << kMaxClass)) {
+        free(p);
+        return;
+    }
+    block_pool::give(p, block_pool::class_of(bytes));
+}
 
 namespace fn {
 const char *turn = "turn";

@@ -7,6 +7,7 @@
 
 #include <cstdint>
 #include <map>
+#include <new>
 #include <ostream>
 #include <sstream>
 #include <stdexcept>
@@ -28,6 +29,11 @@ __attribute__((target_clones("avx2", "default"))) inline void packed_of_masks(ui
     for (size_t i = 0; i < n; i++) dst[i] = (uint32_t)i | ((uint32_t)src[i] << 24);
 }
 
+
+// A copy whose destination nobody reads soon (a finished alignment on its way to a sink): non-temporal stores, so that
+// the destination's lines are not first read into the cache to be overwritten -- a third of the copy's memory traffic --
+// and do not push anything out of it.  Plain memcpy where AVX2 is missing or the block is small.
+void stream_copy(void *dst, const void *src, size_t bytes);
 
 enum base_types { BASE_A = 0, BASE_G = 1, BASE_C = 2, BASE_TU = 3, BASE_MAX = 4, BASE_LC = 4 };
 
@@ -74,7 +80,7 @@ class aligned_base {
 public:
     using idx_type = uint32_t;
     using base_type = base_iupac;
-    aligned_base() : raw(0) {}  // column 0, no base ('-'): a plain zero, so that vectors of them start as a memset
+    aligned_base() = default;  // (trivial: `aligned_base()` / `{}` is column 0 without a base, a default-initialised one is not set at all)
     explicit aligned_base(idx_type pos, unsigned char c = '-') : raw((pos & 0xFFFFFFu) | ((uint32_t)base_iupac::from_char(c) << 24)) {}
     aligned_base(idx_type pos, base_iupac b) : raw((pos & 0xFFFFFFu) | ((uint32_t)b.mask() << 24)) {}
     static aligned_base from_raw(uint32_t r) {
@@ -100,14 +106,37 @@ public:
 };
 static_assert(sizeof(aligned_base) == 4, "aligned_base must stay 4 bytes");
 
+// The heap blocks of base lists.  A pipeline moves a 6 KB block per query from stage to stage and thread to thread;
+// out of the general allocator that was, per query, a page fault or two (fresh top-of-heap memory, 4 KB pages) and a
+// zero fill by resize() before the real contents arrived.  Base lists therefore come out of a process-wide pool of
+// blocks in power-of-two size classes (4 KB .. 64 KB; larger ones from malloc), carved from 2 MB regions that ask for
+// transparent huge pages, kept on per-thread free lists with a shared depot behind them; and resize() leaves new
+// elements as they are (every writer fills what it sizes).
+void *base_block_alloc(size_t bytes);
+void base_block_free(void *p, size_t bytes);
+template <class T> struct base_block_allocator {
+    using value_type = T;
+    base_block_allocator() = default;
+    template <class U> base_block_allocator(const base_block_allocator<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(base_block_alloc(n * sizeof(T))); }
+    void deallocate(T *p, size_t n) { base_block_free(p, n * sizeof(T)); }
+    template <class U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }  // (default-, not value-initialised)
+    template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) {
+        ::new (static_cast<void *>(p)) U(std::forward<A0>(a0), std::forward<A>(a)...);
+    }
+    template <class U> bool operator==(const base_block_allocator<U> &) const { return true; }
+    template <class U> bool operator!=(const base_block_allocator<U> &) const { return false; }
+};
+using base_vector = std::vector<aligned_base, base_block_allocator<aligned_base>>;
+
 class cseq_base {
 public:
     using idx_type = unsigned int;
     using vidx_type = aligned_base::idx_type;
     using value_type = aligned_base;
-    using iterator = std::vector<aligned_base>::iterator;
-    using const_iterator = std::vector<aligned_base>::const_iterator;
-    using const_reverse_iterator = std::vector<aligned_base>::const_reverse_iterator;
+    using iterator = base_vector::iterator;
+    using const_iterator = base_vector::const_iterator;
+    using const_reverse_iterator = base_vector::const_reverse_iterator;
 
     cseq_base() = default;
     cseq_base(const char *_name, const char *_data = nullptr);
@@ -135,12 +164,13 @@ public:
     const uint8_t *denseMasks() const { return dmask.empty() ? nullptr : dmask.data(); }
 
     vidx_type size() const { return (vidx_type)(unpacked ? dmask.size() : bases.size()); }
-    const std::vector<aligned_base> &getAlignedBases() const { unpack(); return bases; }
-    void setAlignedBases(const std::vector<aligned_base> &vab) { drop_masks(); bases = vab; }
-    void setAlignedBases(std::vector<aligned_base> &&vab) { drop_masks(); bases = std::move(vab); }
-    std::vector<aligned_base> takeAlignedBases() { touch(); return std::move(bases); }  // leaves the sequence empty
+    const base_vector &getAlignedBases() const { unpack(); return bases; }
+    void setAlignedBases(const base_vector &vab) { drop_masks(); bases = vab; }
+    void setAlignedBases(base_vector &&vab) { drop_masks(); bases = std::move(vab); }
+    void setAlignedBases(const aligned_base *first, size_t n) { drop_masks(); bases.assign(first, first + n); }
+    base_vector takeAlignedBases() { touch(); return std::move(bases); }  // leaves the sequence empty
     // the base list itself, for writing it in place (a recycled sequence keeps its heap block: resize, fill)
-    std::vector<aligned_base> &mutableAlignedBases() { touch(); return bases; }
+    base_vector &mutableAlignedBases() { touch(); return bases; }
     vidx_type getWidth() const { return alignment_width; }
     void setWidth(vidx_type newWidth);
     void fix_duplicate_positions(std::ostream &log, bool lowercase, bool remove);
@@ -187,7 +217,7 @@ private:
         dmask.clear();
     }
     std::string name;
-    mutable std::vector<aligned_base> bases;
+    mutable base_vector bases;
     std::vector<uint8_t> dmask;     // iupac masks of a dense sequence (empty: not dense, or changed since)
     mutable bool unpacked{false};   // dense and `bases` not made yet
     unsigned int alignment_width{0};

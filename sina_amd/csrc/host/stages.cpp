@@ -441,7 +441,7 @@ std::shared_ptr<reference_store> reference_store::from_packed(const std::string 
     s->path = key;
     s->width = width;
     s->seqs.reserve(n);
-    std::vector<aligned_base> tmp;
+    base_vector tmp;
     for (uint32_t i = 0; i < n; i++) {
         std::string nm = names ? std::string(names[i]) : ("ref" + std::to_string(i));
         s->seqs.emplace_back(nm.c_str());
@@ -1736,8 +1736,7 @@ void aligner::operator()(std::vector<tray> &batch) {
                     const auto &refal = holders->sequence->getAlignedBases();
                     std::string tmp;
                     const size_t at = ref_ubases(holders->sequence, tmp).find(ubases_of_query());
-                    std::vector<aligned_base> sub(refal.begin() + at, refal.begin() + at + n_bases);
-                    c.setAlignedBases(sub);
+                    c.setAlignedBases(refal.data() + at, n_bases);
                     t.log << "copied alignment from (longer) template sequence "
                           << holders->sequence->get_attr<std::string>(fn::acc) << ":"
                           << holders->sequence->get_attr<std::string>(fn::start, "0") << "; ";
@@ -1977,11 +1976,11 @@ void aligner::operator()(std::vector<tray> &batch) {
                 // the device did the container steps (append rule, setWidth, reverse) and a NAST fix-up
                 // in which every insertion fitted its gap: the finished bases, and the fix-up's log line
                 c.clearSequence();
-                std::vector<aligned_base> &fin = c.mutableAlignedBases();  // (a recycled sequence: no allocation)
-                // (one pass: resize() would zero the block first; blocks in steps of 4 KB, so that a recycled
-                // sequence's block fits its next, slightly longer, occupant)
-                fin.reserve(((size_t)r.n_out + 1023) & ~(size_t)1023);
-                fin.assign(reinterpret_cast<const aligned_base *>(pos), reinterpret_cast<const aligned_base *>(pos) + r.n_out);
+                base_vector &fin = c.mutableAlignedBases();  // (a recycled sequence: no allocation)
+                // (one pass, past the cache: base lists are not zeroed by resize() -- cseq.h, base_block_allocator -- and
+                // nobody reads the finished list before a sink takes it)
+                fin.resize(r.n_out);
+                stream_copy(static_cast<void *>(fin.data()), pos, sizeof(aligned_base) * (size_t)r.n_out);
                 c.setWidth(width);
                 tk = host_tick("finish: assemble", tk);
                 if (o.insertion == INSERTION_REMOVE) t.log << "insertion=remove not implemented, using shift; ";
@@ -2006,7 +2005,7 @@ void aligner::operator()(std::vector<tray> &batch) {
             // src/cseq.cpp:79-95), then the sequence is reversed (order and columns, :283-289).  The
             // columns after the rule never decrease, so the result is written back to front directly.
             c.clearSequence();
-            std::vector<aligned_base> &fin = c.mutableAlignedBases();  // (a recycled sequence: no allocation)
+            base_vector &fin = c.mutableAlignedBases();  // (a recycled sequence: no allocation)
             fin.resize(n_out);
             uint32_t reach = 0;  // alignment_width while appending (clearSequence: 0)
             bool direct = true;
