@@ -264,7 +264,7 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
             a.prune_rho = (float)atof(r.c_str());
             rho_fixed = a.prune_rho > 0.f;
         }
-        if (!rho_fixed) {
+        if (!rho_fixed) {  // (the guess a launch without a scout starts from; one WITH a scout takes the guard, below)
             std::lock_guard<std::mutex> slk(c->st->stats_mu);
             a.prune_rho = c->st->prune_rho;
         }
@@ -308,6 +308,10 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         }
         a.scout_u = c->scout_u.as<float>();
         c->last_scout = true;
+    }
+    if (a.scout_u != nullptr && !rho_fixed) {
+        std::lock_guard<std::mutex> slk(c->st->stats_mu);
+        a.prune_rho = c->st->prune_rho_guard;
     }
     // The trace-back plane is the one buffer whose size follows the batch (tens of GB for 16S): borrowed
     // from the device's pool of two (ctx.h) until this launch's results are on the host -- and not before the scout
@@ -441,14 +445,17 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
     // The launch's smallest optimum / bound, less a margin: a query whose first bound fails pays a second sweep, and
     // the launch ends with its slowest wave -- one such query among the last to start costs the whole device a sweep's
     // time, so the guess aims at NO failures among queries like the ones seen (a wider band costs a few per cent).
-    // (round 6: the 2 % point of the launch's ratios, not their minimum -- one poorly aligning query among 9216 must not
-    // widen everybody's band; the few below it pay a second sweep.  With the scout pass the guess is only the guard
-    // of the scout's values, six per cent looser still: mesh_dp.hip)
-    float rho_seen = -1.f;
+    // Two guesses per store.  Alone (a launch without a scout pass: caller-built DAGs) a guess that fails ONE query costs
+    // the whole launch a sweep's time -- it ends with its slowest wave -- so it aims below the smallest ratio seen
+    // (round 5; the 2 % point, tried in round 6: 95 second attempts in 184 320 queries, DP launches 30.1 instead of
+    // 26.4 ms).  As the GUARD of the scout's values it only has to catch a scout that lost its query: the 2 % point,
+    // six per cent looser still in the kernel -- one poorly aligning query among 9216 does not widen everybody's guard.
+    float rho_seen = -1.f, rho_guard_seen = -1.f;
     if (!ratios.empty()) {
+        rho_seen = *std::min_element(ratios.begin(), ratios.end()) - 0.015f;
         const size_t at = ratios.size() / 50;
         std::nth_element(ratios.begin(), ratios.begin() + (std::ptrdiff_t)at, ratios.end());
-        rho_seen = ratios[at] - 0.015f;
+        rho_guard_seen = ratios[at] - 0.015f;
     }
     std::lock_guard<std::mutex> slk(c->st->stats_mu);
     c->st->stats.dp_ms += ms;
@@ -467,6 +474,9 @@ int run_dp_device(sina_hip_ctx *c, const DpPlan &pl, const QDesc *qd_host, uint3
         float &rho = c->st->prune_rho;
         rho = rho_seen < rho ? rho_seen : 0.5f * (rho + rho_seen);
         rho = std::min(0.99f, std::max(0.05f, rho));
+        float &rg = c->st->prune_rho_guard;
+        rg = rho_guard_seen < rg ? rho_guard_seen : 0.5f * (rg + rho_guard_seen);
+        rg = std::min(0.99f, std::max(0.05f, rg));
     }
     c->st->stats.dp_prune_rho = c->st->prune_rho;
     return 0;

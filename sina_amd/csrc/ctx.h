@@ -82,7 +82,8 @@ struct sina_hip_store {
     // the next launch starts its queries with, learnt from the queries aligned so far (run_dp_device; under stats_mu).
     // Results never depend on it: a guess that is too bold costs the queries it fails a second sweep, a timid one
     // a wider band.
-    float prune_rho = 0.80f;
+    float prune_rho = 0.80f;        // the guess a launch WITHOUT a scout pass starts from (below the smallest ratio seen)
+    float prune_rho_guard = 0.80f;  // ... and the guard of the scout's values (the 2 % point of the ratios seen)
     sina_hip_stats stats;
     // Trace-back planes -- tens of GB each, the one allocation whose size follows the launch -- belong
     // to the DEVICE, not to a context: only one DP kernel runs at a time, so two planes serve any number
@@ -501,7 +502,12 @@ struct heavy_launch {
                 if (st->heavy_last_kind == kHeavyDp && heavy_order_policy() > 0) {
                     pick = oldest_of(kHeavyDp);
                     if (!pick) pick = oldest_of(kHeavyGraph);
-                } else if (st->heavy_last_kind == kHeavyDp && heavy_order_policy() < 0) {
+                } else if (heavy_order_policy() < 0) {
+                    // (round 6: a DAG build, then a k-mer search, goes before a DP launch WHENEVER one waits, not only
+                    // behind a DP launch: a batch's scout pass runs between its DAG build and its DP launch, on the
+                    // context's own stream -- with the build scheduled right in front of the batch's own DP launch the
+                    // FIFO sat idle for the scout's 4.5 ms every step (profiles/r06_heavy_gaps_before.txt); built a DP
+                    // launch earlier, the scout runs beside the DP launch of the batch before)
                     pick = oldest_of(kHeavyGraph);
                     if (!pick) pick = oldest_of(kHeavyKmer);
                 }

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 
+#include <atomic>
 #include <immintrin.h>
 #include <sys/mman.h>
 #include <vector>
@@ -53,6 +54,7 @@ struct block_pool {
     struct depot_t {
         std::mutex mu;
         std::vector<void *> free[kMaxClass - kMinClass + 1];
+        std::atomic<size_t> n_free[kMaxClass - kMinClass + 1] = {};  // (sizes of the lists above, readable without the lock)
         unsigned char *region = nullptr;
         size_t left = 0;
     };
@@ -62,6 +64,8 @@ struct block_pool {
     }
     struct local_t {
         std::vector<void *> free[kMaxClass - kMinClass + 1];
+        unsigned char *region = nullptr;  // what is left of the 2 MB region this thread is carving
+        size_t left = 0;
     };
     // A thread's free lists.  Other thread-local objects (the stages' object caches) free base lists from THEIR
     // destructors, possibly after this one has run: from then on the thread goes to the depot directly.
@@ -74,8 +78,10 @@ struct block_pool {
             depot_t &d = depot();
             {
                 std::lock_guard<std::mutex> lk(d.mu);
-                for (size_t c = 0; c <= kMaxClass - kMinClass; c++)
+                for (size_t c = 0; c <= kMaxClass - kMinClass; c++) {
                     for (void *b : p->free[c]) d.free[c].push_back(b);
+                    d.n_free[c].store(d.free[c].size(), std::memory_order_relaxed);
+                }
             }
             delete p;
             p = nullptr;
@@ -103,30 +109,39 @@ struct block_pool {
             }
         }
         depot_t &d = depot();
-        std::lock_guard<std::mutex> lk(d.mu);
-        auto &df = d.free[c - kMinClass];
-        if (!df.empty()) {
-            void *p = df.back();
-            df.pop_back();
-            // (a batch at a time: the thread that frees blocks and the one that takes them are rarely the same)
-            if (l)
-                for (int i = 0; i < 63 && !df.empty(); i++) {
-                    l->free[c - kMinClass].push_back(df.back());
-                    df.pop_back();
-                }
-            return p;
+        if (d.n_free[c - kMinClass].load(std::memory_order_relaxed) != 0) {
+            std::lock_guard<std::mutex> lk(d.mu);
+            auto &df = d.free[c - kMinClass];
+            if (!df.empty()) {
+                void *p = df.back();
+                df.pop_back();
+                // (a batch at a time: the thread that frees blocks and the one that takes them are rarely the same)
+                if (l)
+                    for (int i = 0; i < 63 && !df.empty(); i++) {
+                        l->free[c - kMinClass].push_back(df.back());
+                        df.pop_back();
+                    }
+                d.n_free[c - kMinClass].store(df.size(), std::memory_order_relaxed);
+                return p;
+            }
         }
+        // fresh memory: every thread carves its own 2 MB regions (no lock, and a region's pages are first touched by
+        // the thread that asked for it)
         const size_t sz = (size_t)1 << c;
-        if (d.left < sz) {
+        unsigned char *&region = l ? l->region : d.region;
+        size_t &left = l ? l->left : d.left;
+        std::unique_lock<std::mutex> lk(d.mu, std::defer_lock);
+        if (!l) lk.lock();
+        if (left < sz) {
             void *m = nullptr;
             if (posix_memalign(&m, kRegion, kRegion) != 0) throw std::bad_alloc();
             (void)madvise(m, kRegion, MADV_HUGEPAGE);
-            d.region = static_cast<unsigned char *>(m);
-            d.left = kRegion;
+            region = static_cast<unsigned char *>(m);
+            left = kRegion;
         }
-        void *p = d.region;
-        d.region += sz;
-        d.left -= sz;
+        void *p = region;
+        region += sz;
+        left -= sz;
         return p;
     }
     static void give(void *p, size_t c) {
@@ -135,6 +150,7 @@ struct block_pool {
             depot_t &d = depot();
             std::lock_guard<std::mutex> lk(d.mu);
             d.free[c - kMinClass].push_back(p);
+            d.n_free[c - kMinClass].store(d.free[c - kMinClass].size(), std::memory_order_relaxed);
             return;
         }
         auto &f = l->free[c - kMinClass];
@@ -146,6 +162,7 @@ struct block_pool {
                 d.free[c - kMinClass].push_back(f.back());
                 f.pop_back();
             }
+            d.n_free[c - kMinClass].store(d.free[c - kMinClass].size(), std::memory_order_relaxed);
         }
     }
 };

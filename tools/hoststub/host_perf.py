@@ -28,6 +28,7 @@ ap.add_argument("--batch", type=int, default=9216)
 ap.add_argument("--inflight", type=int, default=4)
 ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--repeat", type=int, default=3)
+ap.add_argument("--window", type=int, default=0, help="cut queries to this many bases (V4: 250)")
 a = ap.parse_args()
 
 C.CDLL(os.path.join(HERE, "libsina_hip.so"), mode=C.RTLD_GLOBAL)  # (its soname satisfies the host library's NEEDED)
@@ -37,7 +38,7 @@ capi.load = lambda: None  # (the stub is in; the real library must not be)
 pipeline.HOST_LIB_PATH = os.path.join(HERE, "libsina_host.so")
 
 refs = synth.make_refs(a.refs, length=a.length, width=50000, seed=1)
-qs = synth.make_queries(refs, a.queries, seed=2)
+qs = synth.make_queries(refs, a.queries, seed=2, window=(1.0 / 3.0, a.window) if a.window else None)
 st = pipeline.Store(":mem:hostperf", refs, device=0)
 pl = pipeline.Pipeline(st, host_threads=a.threads or None)
 pl.run(qs.mask, qs.off, batch=a.batch, inflight=a.inflight)  # warm-up: object caches, arenas
