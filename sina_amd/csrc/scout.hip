@@ -26,7 +26,7 @@
 // registers -- and half the rows.
 //
 // How it maps to the hardware: ONE LANE PER QUERY, 64 queries per wave, 144 waves for a 9216-query launch; the band
-// (16 columns) and the previous row in registers; per row one packed base of the member, the DAG rows of its column
+// (8 columns) and the previous row in registers; per row one packed base of the member, the DAG rows of its column
 // (node_pos, row record: a merge walk, the DAG is in column order) and, every fourth row, a word of query bases.
 #include <algorithm>
 
