@@ -71,18 +71,48 @@ __global__ void __launch_bounds__(64) chain_scout_kernel(const QDesc *__restrict
 #pragma unroll
     for (int i = 0; i <= K / 4; i++) w[i] = 0u;
     uint64_t w_at = ~(uint64_t)0 - 16;
+    // The member's next base and the DAG rows it can sit in are asked for a row AHEAD: a row of the sweep is then
+    // arithmetic on what is already there instead of a chain of three dependent loads (base -> column -> node_pos ->
+    // row record), each of them a few microseconds beside the device-filling kernels of the other batches.
+    uint32_t ab_next = b0 < b1 ? ref_ab[b0] : 0u;
+    uint32_t wpos[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // node_pos and records of rows m .. m + 2
+    uint4 wrec[3] = {};
+    auto load_window = [&](uint32_t at) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const uint32_t x = at + (uint32_t)i;
+            wpos[i] = x < N ? node_pos[x] : 0xFFFFFFFFu;
+            wrec[i] = rec[x < N ? x : 0];
+        }
+    };
+    load_window(0);
     for (uint64_t bi = b0; bi < b1; ++bi) {
-        const uint32_t ab = ref_ab[bi];
+        const uint32_t ab = ab_next;
+        if (bi + 1 < b1) ab_next = ref_ab[bi + 1];
         const uint32_t col = ab & 0xFFFFFFu, bmask = (ab >> 24) & 31u;
         // ---- the member's node: the DAG row of this column that carries this character (mseq.cpp:83-100)
-        while (m < N && node_pos[m] < col) ++m;
-        uint32_t row = m;
-        uint4 r = rec[row < N ? row : 0];
-        while (row < N && ((r.z >> 8) & 31u) != bmask) {
-            ++row;
-            if (row < N) r = rec[row];
+        uint32_t row = N;
+        uint4 r = wrec[0];
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < 3; i++)  // (the usual case: one of the three rows behind the previous base's)
+            if (!found && wpos[i] == col && ((wrec[i].z >> 8) & 31u) == bmask) {
+                found = true;
+                row = m + (uint32_t)i;
+                r = wrec[i];
+            }
+        if (!found) {  // a column with more nodes, or columns the member skips: the walk itself
+            while (m < N && node_pos[m] < col) ++m;
+            row = m;
+            r = rec[row < N ? row : 0];
+            while (row < N && ((r.z >> 8) & 31u) != bmask) {
+                ++row;
+                if (row < N) r = rec[row];
+            }
+            if (row >= N || node_pos[row] != col) break;  // (cannot happen for a member of the family: give up, keep what was found)
         }
-        if (row >= N || node_pos[row] != col) break;  // (cannot happen for a member of the family: give up, keep what was found)
+        m = row + 1;  // (the next base sits in a later column: behind this row)
+        load_window(m);
         const uint32_t mmask = (r.z >> 8) & 0xfu;
         const float wgt = __uint_as_float(r.y);
         const float vM = ms * wgt, vX = mms * wgt;  // scoring_schemes.h:154
@@ -199,7 +229,6 @@ __global__ void __launch_bounds__(64) chain_scout_kernel(const QDesc *__restrict
         }
         if (r.z & kRecSink) best = vmin < best ? vmin : best;
         have_prev = true;
-        m = row;  // (the next base sits in a later column)
     }
     out_u[qi] = best;
 }
