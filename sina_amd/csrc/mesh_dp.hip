@@ -1246,6 +1246,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         // flag the strip to the left stored with its edge record (EdgeRec::gmax).
         bool edge_dead = false;
         uint2 cur_reach = {0u, 0u};
+        float Bm_row = 0.f, nc_row = 0.f;
         if constexpr (PRUNE) {
             // (edge records of rows at or beyond edge_end may be stale: the strip to the left was cut before them)
             edge_dead = m >= edge_end || (have_left_strip && cur_edge.w == 0u);
@@ -1300,6 +1301,9 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                 sload_wait(cur_pe);
             }
             cur_reach = reach[m];
+            // (U + R(m)) and C(m) of this row, as floats: every term a multiple of 1/64 below 2^18 -- exact in float32
+            Bm_row = (float)(U64 + (int32_t)cur_reach.x) * kPruneUnit;
+            nc_row = (float)(cur_reach.y >> 16);
         }
 
         // ---- match / mismatch score of my cells against this row: comp() = (row mask & query mask) != 0
@@ -1517,7 +1521,14 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             float left_v = lane_shr1(sx_v);
             if (lane0) left_v = sl_v;
             float g0 = left_v + (mask((sx_em << 1) | sl_e) ? gpev : gpv);
-            uint64_t enter = __builtin_amdgcn_ballot_w64(g0 <= loc[0]);  // (column 0: left_v = +inf)
+            // (row skip: a gap that enters my cells ABOVE the bound of my first cell -- the largest of my cells' bounds
+            // -- is not followed.  Whatever it would set is above its bound, and stays so to the right: bounds fall
+            // with the column by more than a gap costs nothing.  The invariant asks of such cells only that they stay
+            // above their bounds; dropping a candidate can only raise them.  Right of a query's band every lane is
+            // entered by the chain running out of the band: half the rows' chain phases were spent on cells nobody reads.)
+            float t_first = __builtin_inff();
+            if constexpr (PRUNE) t_first = min2_raw(A_lane, __builtin_fmaf(-gmin_f, __builtin_fmaxf(nc_row - r_lane, 0.f), Bm_row));
+            uint64_t enter = __builtin_amdgcn_ballot_w64(g0 <= loc[0] && g0 <= t_first);  // (column 0: left_v = +inf)
             if (enter != 0) {
                 float g[B];
                 uint64_t pass[B];
@@ -1565,7 +1576,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                     left_v = lane_shr1(ex_v);
                     if (lane0) left_v = sl_v;
                     g0 = left_v + (mask((ex_em << 1) | sl_e) ? gpev : gpv);
-                    enter = __builtin_amdgcn_ballot_w64(g0 <= loc[0]);
+                    enter = __builtin_amdgcn_ballot_w64(g0 <= loc[0] && g0 <= t_first);
                 }
                 // 3. the cells the entering gap wins (a prefix of mine) become insertion cells
 #pragma unroll
@@ -1586,8 +1597,8 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         bool row_dead = false;
         if constexpr (PRUNE) {
             // (U + R(m)) - gmin * max(0, C(m) - r): every term a multiple of 1/64 below 2^18 -- exact in float32
-            Bm_f = (float)(U64 + (int32_t)cur_reach.x) * kPruneUnit;
-            nc_f = (float)(cur_reach.y >> 16);
+            Bm_f = Bm_row;
+            nc_f = nc_row;
             float lm = fv[0];
 #pragma unroll
             for (int k = 1; k + 1 < B; k += 2) lm = min3_raw(lm, fv[k], fv[k + 1]);
