@@ -17,6 +17,7 @@
 #include <fstream>
 #include <map>
 #include <sstream>
+#include <thread>
 #include <memory>
 
 using namespace sina;
@@ -1116,6 +1117,120 @@ int sina_host_compare(const char *a_aligned, const char *b_aligned, int iupac, i
         return 0;
     } catch (const std::exception &e) {
         return fail(e);
+    }
+}
+
+// Self-checks of the host containers' round-6 machinery, for the CPU suite (no GPU, no store): a "dense" sequence
+// (mask bytes only) against the same sequence built base by base, under every operation that must make its packed
+// words first; a lazily rendered attribute against the eagerly set one, through copies; base lists out of the block
+// pool across threads.  Returns 0, or 1 with the first failed check in err.
+int sina_host_selftest(char *err, uint32_t err_cap) {
+    auto fail = [&](const char *what) {
+        if (err && err_cap) snprintf(err, err_cap, "%s", what);
+        return 1;
+    };
+    try {
+        // ---- dense == packed
+        const char *bases = "ACGUNRYacguKMSWBDHV";
+        const size_t n = strlen(bases);
+        std::vector<uint8_t> masks;
+        cseq eager("x");
+        for (size_t i = 0; i < n; i++) {
+            masks.push_back(base_iupac::from_char((unsigned char)bases[i]));
+            eager.append(aligned_base((uint32_t)i, (unsigned char)bases[i]));
+        }
+        eager.setWidth((uint32_t)n);
+        auto fresh = [&] {
+            cseq d("x");
+            d.setDenseMasks(masks.data(), masks.size());
+            return d;
+        };
+        {
+            cseq d = fresh();
+            if (d.size() != n || d.getWidth() != n || d.denseMasks() == nullptr) return fail("dense: size / width / masks");
+            if (d.getBases() != eager.getBases()) return fail("dense: getBases");
+            if (d.denseMasks() == nullptr) return fail("dense: getBases must not drop the masks");
+            if (!(d == eager)) return fail("dense: operator==");
+            if (memcmp(d.packed(), eager.packed(), 4 * n) != 0) return fail("dense: packed words");
+            if (d.denseMasks() == nullptr) return fail("dense: a const read must keep the masks");
+            if (d.getAligned() != eager.getAligned()) return fail("dense: getAligned");
+        }
+        for (int op = 0; op < 5; op++) {
+            cseq d = fresh(), e = eager;
+            switch (op) {
+            case 0: d.setWidth(40), e.setWidth(40); break;
+            case 1: d.reverse(), e.reverse(); break;
+            case 2: d.complement(), e.complement(); break;
+            case 3: d.upperCaseAll(), e.upperCaseAll(); break;
+            default: d.append(aligned_base(30, 'A')), e.append(aligned_base(30, 'A')); break;
+            }
+            if (!(d == e) || d.getWidth() != e.getWidth()) return fail("dense: a changing operation differs from the packed sequence");
+            if (op >= 1 && d.denseMasks() != nullptr) return fail("dense: a changed sequence still offers its old masks");
+            if (op == 0 && d.denseMasks() == nullptr) return fail("dense: a wider alignment must keep the masks");
+        }
+        {
+            cseq d = fresh(), copy(d);
+            copy.complement();
+            if (!(d == eager)) return fail("dense: a copy's change reached the original");
+            d.clearSequence();
+            if (d.size() != 0 || d.denseMasks() != nullptr) return fail("dense: clearSequence");
+        }
+        // ---- lazy attribute == eager attribute
+        {
+            auto render = [](const void *owner, const uint64_t *items, size_t cnt, std::string &out) {
+                out = *static_cast<const std::string *>(owner);
+                for (size_t i = 0; i < cnt; i++) out += std::to_string(items[i]) + " ";
+            };
+            const std::string prefix = "p:";
+            cseq c("y");
+            c.set_attr("aaa", 1);
+            std::vector<uint64_t> &it = c.set_lazy_attr(fn::family, &prefix, +render);
+            it = {3, 1, 4};
+            c.set_attr("zzz", std::string("z"));
+            if (c.lazy_attr(fn::family) == nullptr) return fail("lazy: not pending after set");
+            cseq copy;
+            copy.copy_meta(c);
+            const cseq::attr_init extra[1] = {cseq::attr_init::of(cseq::attr_key(fn::qual), 77)};
+            cseq merged;
+            merged.copy_meta_with(c, extra, 1);
+            if (copy.lazy_attr(fn::family) == nullptr || merged.lazy_attr(fn::family) == nullptr) return fail("lazy: not carried by copy_meta");
+            if (c.get_attr<std::string>(fn::family) != "p:3 1 4 ") return fail("lazy: rendered text");
+            if (c.lazy_attr(fn::family) != nullptr) return fail("lazy: still pending after a read");
+            if (copy.get_attr<std::string>(fn::family) != "p:3 1 4 " || merged.get_attr<std::string>(fn::family) != "p:3 1 4 ")
+                return fail("lazy: a copy renders differently");
+            if (merged.get_attr<int>(fn::qual) != 77 || merged.get_attr<int>("aaa") != 1 || merged.get_attr<std::string>("zzz") != "z")
+                return fail("copy_meta_with: merged attributes");
+            std::string keys;
+            for (const auto &a : merged.get_attrs()) keys += a.key() + ",";
+            if (keys != std::string("aaa,") + fn::family + "," + fn::qual + ",zzz,") return fail("copy_meta_with: key order");
+            c.set_attr(fn::family, std::string("plain"));
+            if (c.get_attr<std::string>(fn::family) != "plain") return fail("lazy: overwritten by set_attr");
+        }
+        // ---- the block pool across threads
+        {
+            std::atomic<int> bad{0};
+            std::vector<base_vector> handed(64);
+            std::vector<std::thread> th;
+            for (int t = 0; t < 4; t++)
+                th.emplace_back([&, t] {
+                    for (int round = 0; round < 200; round++)
+                        for (int i = t; i < 64; i += 4) {
+                            base_vector v;
+                            v.resize((size_t)(500 + 37 * i + round));
+                            for (size_t k = 0; k < v.size(); k++) v[k] = aligned_base::from_raw((uint32_t)(k * 2654435761u + (uint32_t)i));
+                            handed[i].swap(v);  // (the old block is freed by this thread, the new one possibly by another)
+                        }
+                });
+            for (auto &x : th) x.join();
+            for (int i = 0; i < 64; i++)
+                for (size_t k = 0; k < handed[i].size(); k++)
+                    if (handed[i][k].raw != (uint32_t)(k * 2654435761u + (uint32_t)i)) bad++;
+            if (bad.load()) return fail("block pool: a block was handed out twice");
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        if (err && err_cap) snprintf(err, err_cap, "exception: %s", e.what());
+        return 1;
     }
 }
 

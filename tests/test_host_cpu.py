@@ -46,6 +46,16 @@ def _op(aligned, op=0, arg=0, what=0):
     return rc, buf.value.decode(), n.value, w.value
 
 
+def test_host_container_selftest():
+    """Round 6's host machinery, checked inside the library (sina_host_selftest): a sequence kept as its mask bytes
+    against the same sequence built base by base under every operation; an attribute kept as the list it is rendered
+    from, through copies and the merged working copy; base lists out of the block pool handed between threads."""
+    H = pipeline.load_host()
+    err = C.create_string_buffer(256)
+    H.sina_host_selftest.argtypes = [C.c_char_p, C.c_uint32]
+    assert H.sina_host_selftest(err, 256) == 0, err.value.decode()
+
+
 def test_host_cseq_matches_reference_kats():
     k = json.load(open(os.path.join(GOLD, "cseq_kat.json")))
     rc, s, n, w = _op(k["rna_aligned"])
