@@ -1206,6 +1206,21 @@ int sina_host_selftest(char *err, uint32_t err_cap) {
             c.set_attr(fn::family, std::string("plain"));
             if (c.get_attr<std::string>(fn::family) != "plain") return fail("lazy: overwritten by set_attr");
         }
+        // ---- find_bases == std::string::find
+        {
+            uint64_t x = 88172645463325252ull;
+            auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+            for (int round = 0; round < 4000; round++) {
+                const size_t h = 1 + rnd() % 200, n = 1 + rnd() % 40;
+                std::string hay(h, 'A'), needle;
+                for (auto &ch : hay) ch = "ACGU"[rnd() % (round % 3 ? 4 : 2)];
+                if (rnd() % 3 && n <= h) needle = hay.substr(rnd() % (h - n + 1), n);  // (present: anywhere, the very end included)
+                else { needle.assign(n, 'A'); for (auto &ch : needle) ch = "ACGU"[rnd() % 4]; }
+                if (round % 7 == 0 && n <= h) needle = hay.substr(h - n, n);
+                const size_t want = hay.find(needle);
+                if (find_bases(hay, needle, 0) != want || find_bases(hay, needle, 1) != want) return fail("find_bases differs from std::string::find");
+            }
+        }
         // ---- the block pool across threads
         {
             std::atomic<int> bad{0};

@@ -594,6 +594,8 @@ private:
 
 // ---------------------------------------------------------------- helpers
 // parallel for over [0, n) on a process-wide pool (stands in for TBB's workers)
+// first occurrence of `needle` in `hay`, like std::string::find (the aligner's exact-relative test; stages.cpp)
+size_t find_bases(const std::string &hay, const std::string &needle, int force_scalar = 0);
 void parallel_for(size_t n, const std::function<void(size_t)> &fn);
 void set_host_threads(unsigned n);
 // identical queries of a batch go to the device once (k-mer search; DAG + DP when the family is the same too):
