@@ -213,6 +213,13 @@ __device__ __forceinline__ float sel(bool c, float a, float b) {
     return __uint_as_float(c ? __float_as_uint(a) : bu);
 }
 
+// (the same with the empty asm on `a`: for a `b` that has further uses -- hiding that one costs a register copy)
+__device__ __forceinline__ float sel_a(bool c, float a, float b) {
+    uint32_t au = __float_as_uint(a);
+    asm("" : "+v"(au));
+    return __uint_as_float(c ? au : __float_as_uint(b));
+}
+
 // "is the predicate true in any lane": the wave mask itself (HIP's __any() goes through a 0 / 1 VGPR and
 // a second compare)
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
@@ -1280,6 +1287,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                     }
                 }
                 prev_dead = true;
+                SH_PROF_CNT(28, 1)
                 if constexpr (DBG) {
                     if (qi == 0) {
                         float dead_cells[B];
@@ -1365,9 +1373,12 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         // previous row left it in, or loaded INTO them -- the previous row is needed by nothing else then
         auto last_pred = [&](uint32_t pe, float &left_of_strip) {
             if (PRUNE && prev_dead && (pe & 0xffffu) + 1 == m) {  // the previous row was not swept: it shows kDead
+                // (an opaque value: as a plain constant the compiler filled 17 registers with it IN FRONT of this
+                // test, on every row, and copied the previous row's 16 into place behind it for all the others)
+                const float kd = opaque_v(kDead);
 #pragma unroll
-                for (int i = 0; i < B / 4; i++) prev_v.v[i] = prev_g.v[i] = typename Cells<B>::V{kDead, kDead, kDead, kDead};
-                left_of_strip = kDead;
+                for (int i = 0; i < B / 4; i++) prev_v.v[i] = prev_g.v[i] = typename Cells<B>::V{kd, kd, kd, kd};
+                left_of_strip = kd;
             } else if ((pe & 0xffffu) + 1 == m) {
                 left_of_strip = prev_edge_val;
             } else {
@@ -1396,7 +1407,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                 const float mv = ((k == 0) ? svl : prev_v[k - 1]) + csel[k];  // match from (p, s-1) (:360-374)
                 if (k > 0) {  // below_init: the deletion candidate always beats the 1e6 initial value
                     const bool mwin = mv < cand;
-                    loc[k] = sel(mwin, mv, cand);
+                    loc[k] = sel_a(mwin, mv, cand);  // (cand lives on as gm[k]: hiding IT cost a copy per cell)
                     ltag[k] = mwin ? kTbMatch : ts;
                 } else {      // ... but my cell 0 may be column 0: initial value 1, no match step
                     const bool better = !col0_mine || cand < 1.0f;
@@ -1530,9 +1541,12 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             if constexpr (PRUNE) t_first = min2_raw(A_lane, __builtin_fmaf(-gmin_f, __builtin_fmaxf(nc_row - r_lane, 0.f), Bm_row));
             uint64_t enter = __builtin_amdgcn_ballot_w64(g0 <= loc[0] && g0 <= t_first);  // (column 0: left_v = +inf)
             if (enter != 0) {
+                SH_PROF_CNT(12, 1)
                 float g[B];
                 uint64_t pass[B];
                 for (int guard = 0; guard < (1 << 20); ++guard) {
+                    SH_PROF_CNT(13, 1)
+                    SH_PROF_CNT(16 + (guard < 8 ? guard : 8), 1)
                     g[0] = g0;
                     pass[0] = enter;
 #pragma unroll
@@ -1547,10 +1561,14 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                     ex_em = ne;
                     if (changed == 0) break;
                     if (guard == 0) {
+                        SH_PROF_CNT(14, 1)
                         // a gap runs through a whole lane: GUESS all exit states with a log-step scan, the
                         // iterations then verify the guess (mesh_dp_kernel; single fused multiply-adds
                         // stand for the cells' repeated adds -- a guess may be off at a rounding)
-                        float th = loc[0];
+                        // (the guess follows the rule above too: a lane is only entered at or below its first cell's bound --
+                        // without it the guess ran gaps on through the dead lanes right of the band, and seven in ten of the
+                        // rows that come here paid an iteration to take them back)
+                        float th = PRUNE ? min2_raw(loc[0], t_first) : loc[0];
 #pragma unroll
                         for (int k = 1; k < B; k++) th = min2_raw(th, __builtin_fmaf(-(float)k, gpe, loc[k]));
                         const float th1 = lane_shr1(th);
@@ -1702,6 +1720,10 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         }
         SH_PROF(7)
         SH_PROF_CNT(8, 1)
+        SH_PROF_CNT(15, npred >= 2 ? 1 : 0)
+        SH_PROF_CNT(25, npred)
+        SH_PROF_CNT(26, r_keep != kRowNone ? 1 : 0)
+        SH_PROF_CNT(27, is_sink ? 1 : 0)
         cur = nrec;
         cur_edge = nedge;
         cur_pe = npe;

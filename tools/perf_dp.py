@@ -70,7 +70,9 @@ if prof:
         print("%-14s %5.1f%%  %8.0f ticks/row" % (n, 100 * a[i] / tot, a[i] / rows))
     print("wave-rows %d  far preds/row %.3f  rerun iters/row %.3f  spill rows/row %.3f" % (
         rows, a[9] / rows, a[10] / rows, a[11] / rows))
-    print("rerun iterations/row histogram [0,1,2,3,4,5-8,9-16,17-32,33+]:",
+    print("simple kernel: rows with an entering gap %.3f, chain iterations/row %.3f, log-step scans/row %.3f, rows with >= 2 predecessors %.3f, predecessors/row %.3f, rows kept in a slot %.3f, sink rows %.4f, skipped rows visited per swept row %.3f" % (
+        a[12] / rows, a[13] / rows, a[14] / rows, a[15] / rows, a[25] / rows, a[26] / rows, a[27] / rows, a[28] / rows))
+    print("(simple kernel: rows that reached chain iteration 1, 2, ... 8, 9+, per row / general kernel:) rerun iterations/row histogram [0,1,2,3,4,5-8,9-16,17-32,33+]:",
           " ".join("%.3f" % (a[16 + i] / rows) for i in range(9)))
 # ... and the launch's drain: when the waves of the last launch started and ended (100 MHz clock)
 if prof and hasattr(lib, "sina_hip_debug_dp_spans") and nq <= 16384:
