@@ -181,6 +181,14 @@ __device__ int g_dp_abl;  // ablation mask (timing experiments only, results are
 #define SH_PROF_FLUSH
 #endif
 
+// The insertion chain's log-step guess (mesh_dp_simple_kernel, phase 2) is made after this many plain iterations have
+// failed to settle the row's exit states.  Of the rows whose first iteration changes something (0.53 per swept row), a
+// third are settled by the second (a gap that runs one lane further and dies there); guessing only behind it: 0.53 ->
+// 0.37 guesses per row for 0.21 more iterations (a third of a guess's price each), and a guess made from two steps'
+// states is almost never off -- rows that needed four and more iterations fell from 0.12 to 0.01 per row.
+#ifndef SINA_DP_SCAN_AT
+#define SINA_DP_SCAN_AT 1
+#endif
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 // 16 bytes through the scalar cache from a wave-uniform address (see uniform()).  A load from the
 // CONSTANT address space, so that the compiler emits s_load_dwordx4 and keeps track of it being in
@@ -1560,7 +1568,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                     ex_v = nv;
                     ex_em = ne;
                     if (changed == 0) break;
-                    if (guard == 0) {
+                    if (guard == SINA_DP_SCAN_AT) {
                         SH_PROF_CNT(14, 1)
                         // a gap runs through a whole lane: GUESS all exit states with a log-step scan, the
                         // iterations then verify the guess (mesh_dp_kernel; single fused multiply-adds
