@@ -1547,7 +1547,14 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             // entered by the chain running out of the band: half the rows' chain phases were spent on cells nobody reads.)
             float t_first = __builtin_inff();
             if constexpr (PRUNE) t_first = min2_raw(A_lane, __builtin_fmaf(-gmin_f, __builtin_fmaxf(nc_row - r_lane, 0.f), Bm_row));
-            uint64_t enter = __builtin_amdgcn_ballot_w64(g0 <= loc[0] && g0 <= t_first);  // (column 0: left_v = +inf)
+            // (two wave masks ANDed on the scalar unit: the ballot of the conjunction went through a 0 / 1 register
+            // and a second compare)
+            auto enters = [&](float gin) -> uint64_t {
+                uint64_t e = __builtin_amdgcn_ballot_w64(gin <= loc[0]);
+                if constexpr (PRUNE) e &= __builtin_amdgcn_ballot_w64(gin <= t_first);
+                return e;
+            };
+            uint64_t enter = enters(g0);  // (column 0: left_v = +inf)
             if (enter != 0) {
                 SH_PROF_CNT(12, 1)
                 float g[B];
@@ -1602,7 +1609,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                     left_v = lane_shr1(ex_v);
                     if (lane0) left_v = sl_v;
                     g0 = left_v + (mask((ex_em << 1) | sl_e) ? gpev : gpv);
-                    enter = __builtin_amdgcn_ballot_w64(g0 <= loc[0] && g0 <= t_first);
+                    enter = enters(g0);
                 }
                 // 3. the cells the entering gap wins (a prefix of mine) become insertion cells
 #pragma unroll
