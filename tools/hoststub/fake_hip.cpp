@@ -6,6 +6,7 @@
 // without a GPU (tools/hoststub/host_perf.py).  It computes nothing: k-mer "results" are hash-picked
 // reference ids with descending scores, "alignments" put query base i in column 3 i.  Anything that checks
 // results against the oracle must use the real library.
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -56,7 +57,11 @@ int sina_hip_kmer_topk(sina_hip_ctx *c, const uint8_t *qmask, const uint64_t *qo
         const uint32_t base = (uint32_t)(h % n);
         for (uint32_t x = 0; x < max; x++) {
             out_ids[(size_t)q * max + x] = (base + x * 97u) % n;  // (distinct while 97 x < n)
-            out_scores[(size_t)q * max + x] = (float)(300 - (int)(x % 200));
+            // (below the query's own k-mer count -- about a quarter of its bases in "fast" mode -- as the scores of a real
+            // search nearly always are: a member that carries EVERY k-mer of the query sends the aligner into its
+            // exact-relative test, a string search per member)
+            const int top = (int)((qoff[q + 1] - qoff[q]) / 6);
+            out_scores[(size_t)q * max + x] = (float)std::max(1, top - (int)(x % 200));
         }
         out_n[q] = max;
     }
