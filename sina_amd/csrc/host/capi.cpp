@@ -39,6 +39,7 @@ struct result {
         n_ab = 0;
         own.clear();
         log.clear();
+        note.set = false;
         family.clear();
         family_items.clear();
         family_render = nullptr;
@@ -58,7 +59,8 @@ struct result {
     // round 5 the sink copied them into an arena of the pipeline's -- the fifth time a query's 6 KB went through
     // a core; what a real sink does with them (format, write) it does from the sequence itself.
     base_vector own;
-    std::string log;
+    mutable std::string log;          // (the tray's log; its score line is put in when the log is asked for)
+    mutable tray::score_note note;
     // align_family_slv: as text, or as the list famfinder left (rendered by sina_host_result_family; the store is
     // kept alive by the pipeline's stages)
     mutable std::string family;
@@ -134,6 +136,7 @@ void extract_tray(pipeline *p, tray &t, result &r, uint32_t query_bases) {
     r.reset();
     uint64_t tk = host_tsc();
     r.log.assign(t.log.view());  // (no temporary: the result's string keeps its block between runs)
+    r.note = t.pending_score;
     if (const cseq::lazy_text *lz = t.input_sequence->lazy_attr(fn::family)) {  // (the list; the text when it is asked for)
         r.family_items.assign(lz->items.begin(), lz->items.end());
         r.family_owner = lz->owner;
@@ -189,8 +192,7 @@ void fill_query_tray(tray &t, uint32_t q, const uint8_t *qmask, const uint64_t *
     t.seqno = q;
     // (trays are reused from batch to batch: a fresh log -- destroy() frees the sequences but leaves the
     // text, and the previous occupant's would lead this one's)
-    t.log.str(std::string());
-    t.log.clear();
+    t.clear_log();
     t.input_sequence = object_cache<cseq, cache_query_seq>::take();
     {
         char name[24] = "query";
@@ -1017,7 +1019,14 @@ int sina_host_result(void *pp, uint32_t q, int *status, int *head, int *tail, in
 const uint32_t *sina_host_result_bases(void *pp, uint32_t q) {
     return reinterpret_cast<const uint32_t *>(result_at(pp, q).ab);
 }
-const char *sina_host_result_log(void *pp, uint32_t q) { return result_at(pp, q).log.c_str(); }
+const char *sina_host_result_log(void *pp, uint32_t q) {
+    const result &r = result_at(pp, q);
+    if (r.note.set) {  // (rendered once, in place)
+        r.note.merge_into(r.log);
+        r.note.set = false;
+    }
+    return r.log.c_str();
+}
 const char *sina_host_result_family(void *pp, uint32_t q) {
     const result &r = result_at(pp, q);
     if (r.family_render && r.family.empty()) r.family_render(r.family_owner, r.family_items.data(), r.family_items.size(), r.family);

@@ -703,7 +703,7 @@ void log_printer::render(tray &t, report &out) const {
     log += "sequence_number: " + std::to_string(t.seqno) + "\n";
     log += "sequence_identifier: " + t.input_sequence->getName() + "\n";
     if (t.aligned_sequence == nullptr) {
-        log += std::string(fn::align_log) + ": " + t.log.str() + "\n";
+        log += std::string(fn::align_log) + ": " + t.log_text() + "\n";
         log += std::string(fn::fullname) + ": " + t.input_sequence->get_attr<std::string>(fn::fullname) + "\n";
         log += "alignment failed!\n";
         return;
@@ -712,7 +712,7 @@ void log_printer::render(tray &t, report &out) const {
     cseq &aligned = *t.aligned_sequence;
     // (helix pairing comes from the ARB database: no pairs, bp score 0)
     aligned.set_attr("align_bp_score_slv", 0);
-    aligned.set_attr(fn::align_log, t.log.str());
+    aligned.set_attr(fn::align_log, t.log_text());
     aligned.set_attr("nuc", (int)aligned.size());
     if (aligned.size() != 0u) {
         aligned.set_attr("align_startpos_slv", (int)aligned.begin()->getPosition());

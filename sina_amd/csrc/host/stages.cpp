@@ -386,6 +386,40 @@ tray::tray(const tray &o)
       family_scores_kmer_k(o.family_scores_kmer_k), query_kmer_count(o.query_kmer_count) {
     log.str(o.log.str());
     log.seekp(0, std::ios_base::end);
+    pending_score = o.pending_score;
+}
+// (the stream's default float format is printf's %g = to_chars(general, 6) -- checked on 2e7 floats)
+size_t tray::score_note::render(char *line, size_t cap) const {
+    char *w = line, *const end = line + cap;
+    auto lit = [&](const char *txt) {
+        const size_t n = std::min(strlen(txt), (size_t)(end - w));  // (the line is 130 characters at most)
+        memcpy(w, txt, n);
+        w += n;
+    };
+    auto flt = [&](float v) { w = std::to_chars(w, end, v, std::chars_format::general, 6).ptr; };
+    lit("scoring: raw=");
+    flt(raw);
+    lit(", weight=");
+    flt(weight);
+    lit(", query-len=");
+    w = std::to_chars(w, end, len).ptr;
+    lit(", aligned-bases=");
+    w = std::to_chars(w, end, aligned).ptr;
+    lit(", score=");
+    flt(score);
+    lit("; ");
+    return (size_t)(w - line);
+}
+void tray::score_note::merge_into(std::string &text) const {
+    if (!set) return;
+    char line[192];
+    const size_t n = render(line, sizeof line);
+    text.insert(std::min<size_t>(at, text.size()), line, n);
+}
+std::string tray::log_text() const {
+    std::string s(log.view());
+    pending_score.merge_into(s);
+    return s;
 }
 tray &tray::operator=(const tray &o) {
     seqno = o.seqno;
@@ -395,6 +429,7 @@ tray &tray::operator=(const tray &o) {
     search_result = o.search_result;
     log.str(o.log.str());
     log.seekp(0, std::ios_base::end);
+    pending_score = o.pending_score;
     astats = o.astats;
     family_scores_kmer_k = o.family_scores_kmer_k;
     query_kmer_count = o.query_kmer_count;
@@ -2090,28 +2125,8 @@ void aligner::operator()(std::vector<tray> &batch) {
             if (c.getWidth() > width) t.log << "warning: result sequence too wide!";
             const float rval = r.raw, sum_weight = r.sum_weight;
             const float score = rval / sum_weight;
-            {   // (the stream's default float format is printf's %g = to_chars(general, 6) -- checked on 2e7 floats,
-                // a third of snprintf's time; one write instead of nine inserts)
-                char line[192], *w = line, *const end = line + sizeof line;
-                auto lit = [&](const char *txt) {
-                    const size_t len = std::min(strlen(txt), (size_t)(end - w));  // (the line is 130 characters at most)
-                    memcpy(w, txt, len);
-                    w += len;
-                };
-                auto flt = [&](float v) { w = std::to_chars(w, end, v, std::chars_format::general, 6).ptr; };
-                lit("scoring: raw=");
-                flt(rval);
-                lit(", weight=");
-                flt(sum_weight);
-                lit(", query-len=");
-                w = std::to_chars(w, end, L).ptr;
-                lit(", aligned-bases=");
-                w = std::to_chars(w, end, r.aligned_bases).ptr;
-                lit(", score=");
-                flt(score);
-                lit("; ");
-                t.log.write(line, w - line);
-            }
+            // (the line itself is rendered when the log is read: tray::score_note)
+            t.pending_score = tray::score_note{rval, sum_weight, score, L, (int32_t)r.aligned_bases, (uint32_t)t.log.view().size(), true};
             tk = host_tick("finish: score log text", tk);
             if (o.write_used_rels) {
                 std::string s;

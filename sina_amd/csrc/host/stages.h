@@ -179,6 +179,27 @@ public:
     int family_scores_kmer_k{0};
     // with it: the query's own k-mer count under that k / filter, or -1 = not counted
     int query_kmer_count{-1};
+    // The aligner's "scoring: raw=..., score=...;" line (src/align.cpp:455-457), kept as the five numbers it is made
+    // of and the place in `log` where it belongs: three floats to text and a stream insert were 0.6 us per query, and
+    // the text is only read when a sink asks for the log.  Readers take the log through log_text().
+    struct score_note {
+        float raw = 0.f, weight = 0.f, score = 0.f;
+        uint32_t len = 0;
+        int32_t aligned = 0;
+        uint32_t at = 0;
+        bool set = false;
+        // the line as text (at most 160 characters); returns its length
+        size_t render(char *line, size_t cap) const;
+        // `log` with the line put in at `at`
+        void merge_into(std::string &log_text) const;
+    };
+    score_note pending_score;
+    std::string log_text() const;   // log, with a pending score line rendered in its place
+    void clear_log() {
+        log.str(std::string());
+        log.clear();
+        pending_score.set = false;
+    }
 
     tray() = default;
     tray(const tray &o);
