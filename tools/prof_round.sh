@@ -22,6 +22,10 @@ rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt_v4 -o kt -- python
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt_23s -o kt -- python3 bench.py --no-cpu-baseline --confined-cpus 0 --length 3000 --width 150000 --batch 6144 --sub-batch 3072 --inflight 2 --steps 6 --warmup 1 > $O/23s_bench.json 2> $O/23s.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt_500k -o kt -- python3 bench.py --no-cpu-baseline --confined-cpus 0 --refs 500000 > $O/500k_bench.json 2> $O/500k.err
 rm -f $O/kt_*/kt_kernel_trace.csv
+# (the same three without the profiler: its interception costs a core of kernel-mode time -- host_cores_busy of the lines above is not the pipeline's)
+python3 bench.py --no-cpu-baseline --confined-cpus 0 --window 250 --batch 16384 --sub-batch 5120 > $O/v4_bench_plain.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --confined-cpus 0 --length 3000 --width 150000 --batch 6144 --sub-batch 3072 --inflight 2 --steps 6 --warmup 1 > $O/23s_bench_plain.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --confined-cpus 0 --refs 500000 > $O/500k_bench_plain.json 2>/dev/null
 python3 tools/perf_fasta.py align 40000 100000 > $O/perf_fasta.txt 2>&1
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --dup-rate 0.5 > $O/bench_line_dup50.json 2> $O/bench_dup50.err
 SINA_HIP_CHAIN=0 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --confined-cpus 0 > $O/bench_line_chain0.json 2> $O/bench_chain0.err
