@@ -1191,6 +1191,10 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
     u32x4 cur_pe = sload16(pred_addr + (uint64_t)cur.x * 4);
     u32x4 cur_edge = {0, 0, 0, 0};
     if (have_left_strip) cur_edge = sload16(e_in + (uint64_t)(m_begin < N ? m_begin : 0u) * sizeof(EdgeRec));
+    // (the row's {R(m), last successor | C(m)}: fetched a row ahead like its record -- loaded where it is used, the
+    // wait for it was a wait for every scalar load in flight, the next row's record and edge record included)
+    uint2 reach_cur = {0u, 0u};
+    if constexpr (PRUNE) reach_cur = reach[m_begin < N ? m_begin : 0u];
     sload_wait(cur_pe);
     sload_wait(cur_edge);
     Cells<B> prev_v, prev_g;  // the row just finished (common.h: a row whose only successor is the next row is kept nowhere else)
@@ -1234,6 +1238,8 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         if ((m & 127u) == 0) issue_priority_by_progress(strip * N + m, S * N);
         const uint32_t m_next = m + 1 < N ? m + 1 : m;
         const uint4 nrec = rec[m_next];
+        uint2 nreach = {0u, 0u};
+        if constexpr (PRUNE) nreach = reach[m_next];
         u32x4 nedge = {0, 0, 0, 0};
         if (have_left_strip) nedge = sload16(e_in + (uint64_t)m_next * sizeof(EdgeRec));
 
@@ -1308,6 +1314,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                 if (have_left_strip) sload_wait(nedge);
                 cur = nrec;
                 cur_edge = nedge;
+                reach_cur = nreach;
                 pe_valid = false;
                 continue;
             }
@@ -1316,7 +1323,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                 cur_pe = sload16(pred_addr + (uint64_t)r_pb * 4);
                 sload_wait(cur_pe);
             }
-            cur_reach = reach[m];
+            cur_reach = reach_cur;
             // (U + R(m)) and C(m) of this row, as floats: every term a multiple of 1/64 below 2^18 -- exact in float32
             Bm_row = (float)(U64 + (int32_t)cur_reach.x) * kPruneUnit;
             nc_row = (float)(cur_reach.y >> 16);
@@ -1324,8 +1331,10 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
 
         // ---- match / mismatch score of my cells against this row: comp() = (row mask & query mask) != 0
         // (aligned_base.h:153), one class test per set bit of the row's mask (an empty mask: NaN, in no class mask)
+        // (computed BEHIND the first predecessor row's LDS reads, in each of the branches below: the reads' round trip
+        // then runs under these twenty instructions instead of in front of the first candidate)
         float csel[B];
-        {
+        auto match_scores = [&]() {
             auto base_float = [](uint32_t bit) -> float {  // class of the lowest set bit of `bit`
                 return __uint_as_float((bit & 1u) ? 0u : ((bit & 2u) ? 0x3f800000u : ((bit & 4u) ? 0x7f800000u : ((bit & 8u) ? 0xbf800000u : 0x7fc00000u))));
             };
@@ -1337,7 +1346,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
 #pragma unroll
                 for (int k = 0; k < B; k++) csel[k] = __builtin_amdgcn_classf(rf2, (int)qcls[k]) ? vM : csel[k];
             }
-        }
+        };
 
         SH_PROF(1)
         // ---- phase 1: deletion / match candidates from the predecessor rows, in ascending id order
@@ -1402,6 +1411,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
             // ---- one predecessor (60 % of the rows): its candidates ARE the best ones
             float los;
             last_pred(cur_pe.x, los);
+            match_scores();
             const float svl = left_value(prev_v, los);
 #pragma unroll
             for (int k = 0; k < B; k++) {
@@ -1482,6 +1492,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
                 Cells<B> sv, sg;
                 float los;
                 load_pred(cur_pe.x, sv, sg, los);
+                match_scores();
                 relax(std::true_type{}, std::false_type{}, 0u, sv, sg, left_value(sv, los));
                 for (uint32_t e = 1; e + 1 < npred; ++e) {
                     const uint32_t pe = e == 1 ? cur_pe.y : (e == 2 ? cur_pe.z : (e == 3 ? cur_pe.w : pred[r_pb + e]));
@@ -1742,6 +1753,7 @@ mesh_dp_simple_kernel(const QDesc *__restrict__ qdv, const uint32_t *__restrict_
         cur = nrec;
         cur_edge = nedge;
         cur_pe = npe;
+        reach_cur = nreach;
 #pragma unroll
         for (int i = 0; i < B / 4; i++) {
             prev_v.v[i] = typename Cells<B>::V{fv[4 * i], fv[4 * i + 1], fv[4 * i + 2], fv[4 * i + 3]};
