@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--length", type=int, default=1500)
     ap.add_argument("--width", type=int, default=50000)
     ap.add_argument("--window", type=int, default=0, help="cut queries to this many bases (V4: 250)")
-    ap.add_argument("--inflight", type=int, default=4, help="batches worked on concurrently per rank")
+    ap.add_argument("--inflight", type=int, default=6, help="batches worked on concurrently per rank")
     ap.add_argument("--sub-batch", type=int, default=9216,
                     help="queries per GPU launch inside a step (one DP wave per query; an MI355X has 3072 wave slots "
                          "at three waves per SIMD: 9216 = three rounds.  Every DP launch ends with ~4.4 ms in which its "

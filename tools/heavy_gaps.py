@@ -12,11 +12,11 @@ def short(n):
     return n[:24]
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in rows)
 hv = [x for x in iv if x[2] in HEAVY]
-# the timed region: the run's longest stretch without a gap of more than 25 ms between device-filling kernels
+# the timed region: the run's longest stretch without a gap of more than 12 ms between device-filling kernels
 # (tools/kt_union.py picks the same window), from its second DP launch to its last
 runs, cur, reach = [], [hv[0]], hv[0][1]
 for x in hv[1:]:
-    if x[0] - reach > 25e6:
+    if x[0] - reach > 12e6:
         runs.append(cur)
         cur = []
     cur.append(x)

@@ -33,12 +33,12 @@ iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel
             if short(r["Kernel_Name"]))
 dp = [x for x in iv if x[2] == "mesh_dp_"]
 # the timed region: the longest stretch of the run in which no two consecutive device-filling kernels are more than
-# 25 ms apart (between bench.py's set-up pass, warm-up, timed steps and isolated step the host counts results for
+# 12 ms apart (between bench.py's set-up pass, warm-up, timed steps and isolated step the host counts results for
 # hundreds of milliseconds); the stretch's first and last DP launch bound the window
 runs, cur = [], [iv[0]]
 reach = iv[0][1]
 for x in iv[1:]:
-    if x[0] - reach > 25e6:
+    if x[0] - reach > 12e6:
         runs.append(cur)
         cur = []
     cur.append(x)
