@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--width", type=int, default=50000)
     ap.add_argument("--window", type=int, default=0, help="cut queries to this many bases (V4: 250)")
     ap.add_argument("--inflight", type=int, default=6, help="batches worked on concurrently per rank")
+    ap.add_argument("--exact-rate", type=float, default=0.0,
+                    help="this share of the queries are UNMUTATED copies (windows) of their source reference: an amplicon run "
+                         "against the database its organisms are in.  The aligner copies such a query's alignment from a "
+                         "family member that contains it (src/align.cpp:349-388) -- no DP, but a string search per member")
     ap.add_argument("--sub-batch", type=int, default=9216,
                     help="queries per GPU launch inside a step (one DP wave per query; an MI355X has 3072 wave slots "
                          "at three waves per SIMD: 9216 = three rounds.  Every DP launch ends with ~4.4 ms in which its "
@@ -272,6 +276,9 @@ def main():
     n_q = a.batch * (a.steps + a.warmup + 1) + prime_n
     window = (1.0 / 3.0, a.window) if a.window else None
     mix = dict(sub=[0.005, 0.03, 0.10, 0.20], dele=[0.001, 0.005, 0.015, 0.03], ins=[0.001, 0.003, 0.01, 0.02]) if a.divergence_mix else {}
+    if a.exact_rate > 0 and not mix:  # (query i of every hundred: exact if i < 100 x the rate)
+        k = int(round(100 * min(1.0, a.exact_rate)))
+        mix = dict(sub=[0.0] * k + [0.03] * (100 - k), dele=[0.0] * k + [0.005] * (100 - k), ins=[0.0] * k + [0.003] * (100 - k))
     qs = synth.make_queries(refs, n_q, seed=3 + 1000 * rank, window=window, **mix)
     if a.dup_rate > 0:
         qs = synth.with_repeats(qs, a.dup_rate, a.batch, seed=17 + rank)
@@ -517,7 +524,7 @@ def main():
                                 ("configs[3] shape: full-length 16S, large reference" if a.refs >= 400000 else
                                  "configs[1]: full-length 16S")),
                                a.length, (", cut to %d" % a.window) if a.window else "", a.refs, a.width),
-                "refs": a.refs, "length": a.length, "width": a.width, "window": a.window, "dup_rate": a.dup_rate, "divergence_mix": bool(a.divergence_mix),
+                "refs": a.refs, "length": a.length, "width": a.width, "window": a.window, "dup_rate": a.dup_rate, "exact_rate": a.exact_rate, "divergence_mix": bool(a.divergence_mix),
                 "queries_per_step_per_gpu": a.batch,
                 "queries_per_launch": a.sub_batch,
                 "inflight_batches": a.inflight,

@@ -37,4 +37,7 @@ SINA_HIP_TEST="scout=0" python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --confined-cpus 0 --divergence-mix > $O/bench_line_mix.json 2> $O/bench_mix.err
 SINA_HIP_TEST="scout=0" python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --confined-cpus 0 --divergence-mix > $O/bench_line_mix_noscout.json 2> $O/bench_mix_noscout.err
 SINA_HOST_PROFILE=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --confined-cpus 0 > $O/bench_line_hostprof.json 2> $O/host_profile.txt
+# exact relatives (the aligner's copy short-cut: no DP for them, a string search per family member on the host)
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --confined-cpus 0 --exact-rate 0.3 > $O/bench_line_exact30.json 2> $O/bench_exact30.err
+python3 bench.py --no-cpu-baseline --confined-cpus 0 --window 250 --batch 16384 --sub-batch 5120 --exact-rate 0.3 > $O/v4_bench_exact30.json 2> $O/v4_exact30.err
 ls -la $O

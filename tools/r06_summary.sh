@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/r06_summary.sh <dir>  -- one line per bench JSON of a tools/prof_round.sh session
 cd ${1:-gpurun_out/r06}
-for f in bench_line_default bench_line_plain bench_line_noscout bench_line_mix bench_line_mix_noscout bench_line_dup50 bench_line_chain0 v4_bench 23s_bench 500k_bench v4_bench_plain 23s_bench_plain 500k_bench_plain bench_line_hostprof; do python3 -c "
+for f in bench_line_default bench_line_plain bench_line_noscout bench_line_mix bench_line_mix_noscout bench_line_dup50 bench_line_chain0 v4_bench 23s_bench 500k_bench v4_bench_plain 23s_bench_plain 500k_bench_plain bench_line_exact30 v4_bench_exact30 bench_line_hostprof; do python3 -c "
 import json,sys
 try:
     d=json.load(open(sys.argv[1]+'.json'))
