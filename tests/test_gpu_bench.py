@@ -14,8 +14,8 @@ def test_bench_line_and_rank_confined_to_two_cpus():
     """A short bench run (smaller launches, 20 000 references: seconds, not the headline configuration): the line
     carries what the contract asks for, and the confined leg -- every thread of the process on TWO CPUs, what a
     rank of an 8-rank node gets of a 16-CPU quota (src/sina.cpp:241-243,450: the reference sizes its pipeline by
-    --threads) -- keeps most of the unconfined rate.  (One MI355X, full-size steps, round 6: 0.90-0.93 at two CPUs at
-    6 us of host CPU per query; the floor asserted here leaves a shared test box some room.)"""
+    --threads) -- keeps most of the unconfined rate.  (One MI355X, full-size steps, round 6: 0.86-0.93 at two CPUs at
+    5 us of host CPU per query; the floor asserted here leaves a shared test box some room.)"""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
            "--refs", "20000", "--batch", "3072", "--sub-batch", "3072"]
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
@@ -32,8 +32,8 @@ def test_bench_line_and_rank_confined_to_two_cpus():
     c = j["confined"]
     assert c["cpus"] == 2 and j["confined_rate_frac"] == c["rate_frac"]
     assert c["host_cores_busy"] <= 2.05
-    assert c["rate_frac"] >= 0.8, c   # (the review's mark for this floor was 0.85: see the measured 3072-query numbers in DESIGN 5)
-    assert j["host_cores_busy"] <= 2.4, j["host_cores_busy"]   # (round 5: 2.85 at full-size steps; small launches cost more per query)
+    assert c["rate_frac"] >= 0.85, c   # (measured in this configuration, four runs on one box: 0.908-0.937)
+    assert j["host_cores_busy"] <= 1.8, j["host_cores_busy"]   # (measured here: 0.94-1.02; round 5: 2.85 at full-size steps)
 
 
 _CHILD = r"""
