@@ -465,6 +465,10 @@ def main():
                 meta.get("length") == a.length and meta.get("window") == a.window):
             dp_traffic = tj[dp_kernel_name]["hbm_bytes"]
             other_traffic = {k: tj[k] for k in ("family_graph_kernel", "kmer_count_kernel") if k in tj}
+            for short, key in (("chain_scout_kernel", "chain_scou"), ("backtrack_kernel", "backtrack_")):  # (the trace's truncated names)
+                for k in tj:
+                    if key in k:
+                        other_traffic[short] = tj[k]
             traffic_note = ("HBM bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from the separate "
                             "--pmc passes of this same command recorded in profiles/r06_traffic.json (same kernel "
                             "source revision and configuration as this run; not measured by this run)")
@@ -619,8 +623,8 @@ def main():
                     "achieved": (tr["hbm_bytes"] / (ms_alone * 1e-3) / 1e9) if tr and ms_alone > 0 else None,
                     "frac": (tr["hbm_bytes"] / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr and ms_alone > 0 else None,
                     "ms_per_launch_alone": ms_alone, "ms_per_launch_in_pipeline": ms_pipe / launches,
-                    "algorithmic_bytes_per_launch": alg / launches,
-                    "algorithmic_over_measured": (alg / launches / tr["hbm_bytes"]) if tr and tr["hbm_bytes"] > 0 else None,
+                    "algorithmic_bytes_per_launch": (alg / launches) if alg is not None else None,
+                    "algorithmic_over_measured": (alg / launches / tr["hbm_bytes"]) if alg is not None and tr and tr["hbm_bytes"] > 0 else None,
                     "note": note})(
                     other_traffic.get(name), alg, ms_alone, ms_pipe, launches, note)
                 for name, alg, ms_alone, ms_pipe, launches, note in (
@@ -632,7 +636,17 @@ def main():
                      iso["kmer_count_ms"] / max(1, iso["kmer_launches"]), s1["kmer_count_ms"] - s0["kmer_count_ms"], s1["kmer_launches"] - s0["kmer_launches"],
                      "algorithmic: 4 B per posting of the query's k-mers + 2 x 2 B per reference for the score row; measured bytes are "
                      "fabric traffic (the bitmaps of dense lists come out of the MALL); VALU at 0.90 of the pipe "
-                     "(profiles/r05_kmer_sq_counters.txt)"))
+                     "(profiles/r05_kmer_sq_counters.txt)"),
+                    # the two kernels with ONE LANE per query (144 waves per 9216 queries): a chain of dependent loads per
+                    # lane, bound by latency -- they run beside the device-filling kernels, off the FIFO's critical path
+                    ("chain_scout_kernel", None, iso["scout_ms"] / max(1, iso["scout_launches"]), s1["scout_ms"] - s0["scout_ms"],
+                     s1["scout_launches"] - s0["scout_launches"],
+                     "one lane per query walking its nearest relative's chain (band of 8 columns in registers): latency-bound by "
+                     "construction, 144 waves per launch; its time in the pipeline is beside the other batches' kernels"),
+                    ("backtrack_kernel", None, iso["backtrack_ms"] / max(1, iso["dp_launches"]), s1["backtrack_ms"] - s0["backtrack_ms"],
+                     s1["dp_launches"] - s0["dp_launches"],
+                     "one lane per query walking its trace-back cells (a dependent 2-byte read per step; 74 MB of path cells per "
+                     "launch are useful, a 64-byte sector holds 32 columns of ONE row): latency-bound, runs beside the next launch"))
             },
             "kernels_ms_per_step_isolated": {
                 "kmer_count_kernel": iso["kmer_count_ms"],
