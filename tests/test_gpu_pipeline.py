@@ -174,6 +174,23 @@ def test_pipeline_copy_shortcut_and_realign(oracle, world):
         pl.close()
 
 
+def test_pipeline_exact_relatives_among_mutated_queries(oracle, world):
+    """One batch in which every third query is an exact copy of its reference, every third an exact window of it and
+    the rest are mutated (bench.py --exact-rate): copies and DP alignments side by side, short windows that several
+    family members hold (the aligner's containment search, host/stages.cpp find_bases) -- all against the oracle."""
+    refs, cs, idx, st = world
+    full = synth.make_queries(refs, 60, seed=91, sub=[0.0, 0.03, 0.03], dele=[0.0, 0.005, 0.005], ins=[0.0, 0.003, 0.003])
+    wins = synth.make_queries(refs, 60, seed=92, sub=[0.03, 0.0, 0.03], dele=[0.005, 0.0, 0.005], ins=[0.003, 0.0, 0.003],
+                              window=(0.3, 60))
+    ff = {"fs-min-len": 40, "fs-full-len": 250}
+    for queries, min_copy in ((full, 18), (wins, 15)):
+        pl = pipeline.Pipeline(st, famfinder=ff)
+        pl.run(queries.mask, queries.off, batch=32, inflight=2)
+        n_dp, n_copy = _check(oracle, refs, queries, pl, cs, idx, ff=dict(fs_min_len=40, fs_full_len=250))
+        assert n_copy >= min_copy and n_dp >= 20, (n_dp, n_copy)
+        pl.close()
+
+
 def test_pipeline_family_escalation_and_rejects(oracle, world):
     """Default fs-min-len/full-len reject most of these short references: the candidate list
     escalates 41 -> 410 -> all (famfinder.cpp:591-608) and some queries end with no relatives."""
