@@ -96,6 +96,7 @@ struct result {
 struct pipeline {
     famfinder ff;
     aligner al;
+    pipeline() { al.defer_score_line = true; }  // (this driver's sink reads a tray's log through log_text())
     std::unique_ptr<search_filter> sf;  // only with sina_host_pipeline_create_search()
     std::shared_ptr<reference_store> search_store;
     double sf_s = 0;
@@ -935,7 +936,9 @@ int sina_host_pipeline_run_single_trays(void *pp, const uint8_t *qmask, const ui
         if (failed) memset(failed, 0, nq);
         if (err && err_cap) err[0] = 0;
         batched<famfinder> bff(p->ff, max_batch, linger_us);
-        batched<aligner> bal(p->al, max_batch, linger_us);
+        aligner whole_log = p->al;  // (the callers of the shim read their trays' logs themselves)
+        whole_log.defer_score_line = false;
+        batched<aligner> bal(whole_log, max_batch, linger_us);
         std::unique_ptr<batched<search_filter>> bsf;
         if (p->sf) bsf.reset(new batched<search_filter>(*p->sf, max_batch, linger_us));
         // (a sequence of the store's width that is not one of the store's: what a stale tray would carry)

@@ -2125,8 +2125,17 @@ void aligner::operator()(std::vector<tray> &batch) {
             if (c.getWidth() > width) t.log << "warning: result sequence too wide!";
             const float rval = r.raw, sum_weight = r.sum_weight;
             const float score = rval / sum_weight;
-            // (the line itself is rendered when the log is read: tray::score_note)
-            t.pending_score = tray::score_note{rval, sum_weight, score, L, (int32_t)r.aligned_bases, (uint32_t)t.log.view().size(), true};
+            // (the line itself is rendered when the log is read: tray::score_note -- or at once, for a caller that
+            // reads the stream itself)
+            {
+                const tray::score_note note{rval, sum_weight, score, L, (int32_t)r.aligned_bases, (uint32_t)t.log.view().size(), true};
+                if (defer_score_line) {
+                    t.pending_score = note;
+                } else {
+                    char line[192];
+                    t.log.write(line, (std::streamsize)note.render(line, sizeof line));
+                }
+            }
             tk = host_tick("finish: score log text", tk);
             if (o.write_used_rels) {
                 std::string s;

@@ -400,6 +400,11 @@ public:
         std::string database;  // reference store the DAGs are built from (same as famfinder "db")
     };
     static options *opts;
+    // The "scoring: ..." line of a tray's log as a note to be rendered by tray::log_text() instead of text in `log`
+    // (tray::score_note).  Off by default: a tray handed back to code that reads `log` itself -- SINA's own stages
+    // behind batched<aligner> -- carries the whole text; the pipeline driver of host/capi.cpp, whose sink reads the
+    // log through log_text(), switches it on.
+    bool defer_score_line = false;
     aligner();
     aligner(const aligner &rhs);
     ~aligner();
