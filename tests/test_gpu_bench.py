@@ -50,6 +50,20 @@ def test_bench_line_and_rank_confined_to_two_cpus():
     assert cores <= 1.8, cores   # (measured here: 0.94-1.02; round 5: 2.85 at full-size steps)
 
 
+@pytest.mark.parametrize("flags", [["--exact-rate", "0.3"], ["--divergence-mix"], ["--dup-rate", "0.5"]])
+def test_bench_workload_flags(flags):
+    """The bench's other workloads -- exact relatives (the aligner's copy short-cut), mixed divergence, repeated
+    queries -- at a small size: the line comes out, every query is aligned, the verify leg finds nothing."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--refs", "20000", "--batch", "2048",
+           "--sub-batch", "2048", "--inflight", "2", "--confined-cpus", "0", "--cpu-sample", "1", "--verify", "16"] + flags
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert j["value"] > 10000 and j["verify"]["checked"] > 0 and j["verify"]["identical"] == j["verify"]["checked"], j["verify"]
+    if flags[0] == "--exact-rate":
+        assert j["config"]["exact_rate"] == 0.3
+
+
 _CHILD = r"""
 import hashlib, sys
 sys.path.insert(0, %r)
