@@ -281,8 +281,18 @@ def test_device_family_graph_fuzz(oracle, gpu_ctx, seed):
     for F in (int(pick([1, 2, 3, 5])), int(pick([17, 40, 64])), int(pick([100, 127, 128]))):
         ids = rng.choice(refs.n, size=F, replace=False).astype(np.uint32)
         fsw, ring = float(pick([1.0, 0.0, 2.5])), int(pick([1, 3, 4, 8]))
-        g = gpu_ctx.debug_family_graph(ids, fsw, ring)
         o = util.graph_dict([cs[i] for i in ids], fsw)
+        try:
+            g = gpu_ctx.debug_family_graph(ids, fsw, ring)
+        except Exception as e:  # noqa: BLE001
+            # the one documented refusal a random family can run into (32 768 spill rows per query -- a
+            # family of 128 half-ambiguous members on a ring of one slot; seed 138 of a 400-seed run): it has to be
+            # that limit, and the model has to agree that the DAG is beyond it
+            if "too many spill rows" not in str(e):
+                raise
+            model = util.row_store_model(o["pred_off"], o["pred"], ring)
+            assert int(((model != 0xFFFFFFFF) & (model >= 0x80000000)).sum()) > 32768, (seed, F)
+            continue
         assert g["n"] == o["n"], (seed, F)
         assert (g["pos"] == o["pos"]).all() and (g["mask"] == o["mask"]).all(), (seed, F)
         assert (util.f32_bits(g["weight"]) == util.f32_bits(o["weight"])).all(), (seed, F)
