@@ -2,6 +2,8 @@
 guesses, (a) every cell whose reference value is at or below the bound the kernel ended up using is the reference's
 bit for bit -- value, value_midx, value_sidx -- and every other cell is above its bound, (b) the finished alignments
 are the oracle's, (c) a guess that is too bold is caught by the certificate and the query is swept again."""
+import os
+
 import numpy as np
 import pytest
 
@@ -200,7 +202,7 @@ def test_row_skip_narrow_band_after_wide_ones(oracle, gpu_ctx, monkeypatch, rho)
             assert (got_cols == own).mean() > 0.97
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SINA_FUZZ_SEEDS", "12"))))
 def test_row_skip_plane_fuzz(oracle, monkeypatch, seed):
     """The mesh plane fuzz of test_gpu_edges.py with the row skip in play: seeded random families (1 - 60 members,
     divergence, long deletions, ambiguity codes, lower case), scoring parameters, fs-weight, LDS budget, a forced
